@@ -1,0 +1,16 @@
+"""midi-vae_amd: MI355X-native engine for the MIDI-VAE train / inference step.
+
+The directory name carries a hyphen (it mirrors the reference repo's name), so it is imported
+through the repo-root shim ``midi_vae_amd.py`` which registers this directory as the package
+``midi_vae_amd``.  Sub-modules:
+
+  config    settings surface (reference settings.py names)
+  packers   host packers + argmax decode (reference vae_definition.py:770-1235)
+  layout    parameter layout of the model (names, shapes, offsets in the flat fp32 buffer)
+  hiplib    ctypes binding of the C-ABI library built from csrc/ (include/midivae_hip.h)
+  engine    device engine: resident buffers, train step, encode / decode
+  model     ``VAE`` facade with the reference's ``create`` / ``fit`` / ``evaluate`` / ``predict`` surface
+  synth     synthetic piano-roll windows
+  dp        data-parallel sharding over torch.distributed (RCCL)
+"""
+__version__ = "0.1.0"
