@@ -1,0 +1,212 @@
+/*
+ * midivae_hip.h  --  C ABI of libmidivae_hip.so (gfx950 / MI355X).
+ *
+ * The reference (brunnergino/MIDI-VAE) has no FFI: its hot path is reached through four Keras Model
+ * methods called from Python --
+ *     autoencoder.fit       reference vae_training.py:804-809
+ *     autoencoder.evaluate  reference vae_training.py:300
+ *     encoder.predict       reference vae_training.py:289,795 ; vae_evaluation.py:2180-2181
+ *     decoder.predict       reference vae_evaluation.py:2482
+ * and everything below those calls is Keras/recurrentshop graph code (reference vae_definition.py:15-761).
+ * This header is the operator set those four calls decompose into on the device.  Each entry names the
+ * reference construct it replaces.  The Python host (midi-vae_amd/engine.py) binds it with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, in order;
+ *   - return value: 0 = enqueued, negative = rejected (MVAE_E_*), nothing enqueued; never throws;
+ *   - sequences are TIME-MAJOR: element (t, b, c) of a (T, B, C) array lives at (t*B + b)*C + c;
+ *   - `dtype` selects the MFMA operand type AND the storage type of sequence activations:
+ *         MVAE_F32  : f32 operands (v_mfma_f32_16x16x4_f32), f32 storage  -- parity mode
+ *         MVAE_BF16 : bf16 operands (v_mfma_f32_16x16x32_bf16), f32 accumulate, bf16 storage
+ *     recurrent state, gate arithmetic, losses, gradients of parameters and the optimizer are always f32;
+ *   - gate blocks along a 'G*H' axis: [z|r|h] GRU, [i|f|g|o] LSTM, [h] SimpleRNN.
+ */
+#ifndef MIDIVAE_HIP_H
+#define MIDIVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVAE_ABI_VERSION 1
+
+enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3 };
+enum { MVAE_GRU = 0, MVAE_LSTM = 1, MVAE_RNN = 2 };
+enum { MVAE_F32 = 0, MVAE_BF16 = 1 };
+/* where x_t W + b comes from in a recurrent layer */
+enum {
+    MVAE_X_DENSE = 0,  /* xp (T,B,G*H) precomputed by mvae_gemm (layers fed by another layer)              */
+    MVAE_X_INDEX = 1,  /* one-hot rows: xp = table[idx[t,b]], table (K,G*H) f32 = W + b  (notes, instruments) */
+    MVAE_X_SCALAR = 2, /* 1-wide input: xp = xs[t,b]*w + bias                              (velocity roll)  */
+    MVAE_X_CONST = 3   /* the same row every step: xp = xp0[b]                  (decoder cells, Appendix A.6) */
+};
+
+int mvae_abi_version(void);
+/* human-readable build string (arch, compile date) */
+const char* mvae_build_info(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Recurrent layer, forward.  Replaces keras.layers.{GRU,LSTM,SimpleRNN} (encoder, reference
+ * vae_definition.py:448-480) and recurrentshop {GRU,LSTM,SimpleRNN}Cell stepped by RecurrentModel (decoder,
+ * :533-546,584-594,622-632).  One workgroup owns 16 batch rows for all T steps; no inter-workgroup traffic.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t cell, dtype, xmode;
+    int32_t T, B, H;
+    const void* u_pack;    /* recurrent kernel packed by mvae_pack_recurrent (direction 0)                    */
+    const void* xp;        /* DENSE: (T,B,G*H) dtype                                                          */
+    const uint8_t* idx;    /* INDEX: (T,B)                                                                    */
+    const float* table;    /* INDEX: (K,G*H)                                                                  */
+    const float* xs;       /* SCALAR: (T,B)                                                                   */
+    const float* w_row;    /* SCALAR: (G*H)                                                                   */
+    const float* bias;     /* SCALAR: (G*H)                                                                   */
+    const float* xp0;      /* CONST: (B,G*H)                                                                  */
+    const float* h0;       /* (B,H) or NULL = zeros                                                           */
+    const float* c0;       /* LSTM: (B,H) or NULL = zeros                                                     */
+    void* hs;              /* (T+1,B,H) dtype or NULL; slot 0 receives h0, slot t+1 receives h_t              */
+    void* cs;              /* LSTM: (T+1,B,H) dtype or NULL                                                   */
+    void* acts;            /* (T,B,G*H) dtype post-activation gates, or NULL (inference)                      */
+    float* h_last;         /* (B,H) or NULL                                                                   */
+} mvae_rnn_fwd_args;
+int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
+
+/* Recurrent layer, backward through time (the autodiff of the above that Keras/TF derives).
+ * Produces d(xp) for every step; parameter gradients follow from it with mvae_gemm / mvae_colsum. */
+typedef struct {
+    int32_t cell, dtype;
+    int32_t T, B, H;
+    const void* ut_pack;   /* recurrent kernel packed by mvae_pack_recurrent (direction 1)                    */
+    const void* hs;        /* (T+1,B,H) dtype, from forward                                                   */
+    const void* cs;        /* LSTM: (T+1,B,H) dtype                                                           */
+    const void* acts;      /* (T,B,G*H) dtype                                                                 */
+    const void* dhs_ext;   /* (T,B,H) dtype gradient arriving at h_t from the layer above, or NULL            */
+    const float* dh_last;  /* (B,H) gradient arriving at the final state, or NULL                             */
+    void* da;              /* (T,B,G*H) dtype: gradient w.r.t. xp                                             */
+    void* rh;              /* GRU: (T,B,H) dtype r_t*h_{t-1} (left operand of the candidate-kernel gradient)  */
+    float* dh0;            /* (B,H) or NULL                                                                   */
+    float* dc0;            /* LSTM: (B,H) or NULL                                                             */
+} mvae_rnn_bwd_args;
+int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream);
+
+/* Pack a recurrent kernel U (H, G*H) f32 row-major into MFMA A-fragment order.
+ * direction 0: forward  (rows of A = gate columns, contraction over h)      -> G*H*H elements
+ * direction 1: backward (rows of A = hidden units, contraction over gate columns) -> G*H*H elements */
+int mvae_pack_recurrent(const float* U, void* out, int32_t cell, int32_t H, int32_t dtype, int32_t direction,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GEMM  C = alpha * opA(A) * opB(B) [+ bias] [-> tanh]   (Dense layers :484,487,506-507,563-567; input
+ * projections of stacked layers; all parameter gradients).  Row-major with leading dimensions.
+ *   a_kind: MVAE_F32 / MVAE_BF16, or MVAE_A_ONEHOT: A is never stored - opA(A)[m,k] = (idx[k] == m)
+ *           (requires trans_a = 1), used for the gradient of an X_INDEX table.
+ *   c_kind: MVAE_F32 / MVAE_BF16.   accumulate: 0 store, 1 atomic add into f32 C (split-K allowed).
+ * --------------------------------------------------------------------------------------------------------- */
+enum { MVAE_A_ONEHOT = 2 };
+enum { MVAE_ACT_NONE = 0, MVAE_ACT_TANH = 1 };
+typedef struct {
+    int32_t M, N, K;
+    int32_t trans_a, trans_b;     /* 0: stored (M,K)/(K,N); 1: stored (K,M)/(N,K)                             */
+    int32_t a_kind, b_kind, c_kind;
+    int32_t lda, ldb, ldc;
+    int32_t accumulate, act, split_k;
+    float alpha;
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;            /* (N) or NULL                                                              */
+} mvae_gemm_args;
+int mvae_gemm(const mvae_gemm_args* a, void* stream);
+
+/* out[n] (+)= sum_r X[r, n]  for X (R, N) of `kind`; ldx elements between rows; atomic f32 accumulate */
+int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream);
+/* out[b, n] = sum_t X[t, b, n]   (gradient of an X_CONST row) */
+int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Output heads: Dense(H -> N) + activation + Keras weighted loss + metric + d(logits), fused, over all
+ * (t, b) rows at once.  Replaces Dense(softmax)+categorical_crossentropy (:542,:593 with :338,:367),
+ * Dense(sigmoid)+mse (:631,:374) and the per-output 'accuracy' metric (:339).
+ *   kind 0: softmax + categorical cross-entropy (targets as class index per row, or -1 = all-zero target)
+ *   kind 1: sigmoid + squared error (targets f32 per row), N must be 1
+ * Row weights: rw[row] multiplies the row's score (already divided by the Keras normalisers on the host).
+ * scalars[0] += sum rw*score, scalars[1] += number of rows whose argmax (or rounding) matches the target.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t kind, dtype;
+    int32_t R, H, N;              /* R = T*B rows                                                            */
+    int32_t want_grad;
+    const void* hs;               /* (R,H) dtype                                                             */
+    const void* wt;               /* (NP,H) dtype: W^T zero-padded to NP rows (mvae_transpose_convert)       */
+    const float* bias;            /* (N)                                                                     */
+    const uint8_t* target_idx;    /* kind 0: (R) class index, 255 = all-zero target row                      */
+    const float* target_val;      /* kind 1: (R)                                                             */
+    const float* row_weight;      /* (R) or NULL = 1                                                         */
+    float grad_scale;             /* multiplies d(logits) (loss weight of the head)                          */
+    float* probs;                 /* (R,N) f32 or NULL                                                       */
+    uint8_t* argmax;              /* (R) or NULL: first-max index (kind 0), round(p) (kind 1)                */
+    void* dlogits;                /* (R,NP) dtype, NP = N rounded up to 16; required if want_grad            */
+    float* scalars;               /* (2) accumulated atomically                                              */
+} mvae_head_args;
+int mvae_head(const mvae_head_args* a, void* stream);
+/* padded column count NP used for `wt` rows and `dlogits` columns of an N-wide head (16/32/64/128; <0 = too wide) */
+int mvae_head_np(int32_t N);
+
+/* Latent block: KL term + reparameterisation + style classifier on z[:, :C], forward and backward
+ * (reference vae_definition.py:29-37, 498-502, 514-515, 730-734 and their gradients). */
+typedef struct {
+    int32_t B, Z, C;
+    float beta, prior_mean, prior_std, inv_batch;
+    const float* mu;              /* (B,Z)                                                                   */
+    const float* logvar;          /* (B,Z)                                                                   */
+    const float* eps;             /* (B,Z) already scaled by epsilon_std                                     */
+    const uint8_t* style_target;  /* (B) class index or NULL (no style head)                                 */
+    const float* style_row_weight;/* (B) Keras sample weight / normalisers, or NULL = inv_batch              */
+    float* z;                     /* (B,Z) out                                                               */
+    float* style_probs;           /* (B,C) out or NULL                                                       */
+    float* scalars;               /* (3): += inv_batch*sum_b kl_b, += sum_b rw*style CE, += style argmax hits */
+} mvae_latent_fwd_args;
+int mvae_latent_fwd(const mvae_latent_fwd_args* a, void* stream);
+
+typedef struct {
+    int32_t B, Z, C;
+    float beta, prior_mean, prior_std, style_weight, inv_batch;
+    const float* mu;
+    const float* logvar;
+    const float* eps;
+    const float* dz;              /* (B,Z) gradient arriving from the decoder's initial-state Denses          */
+    const float* style_probs;     /* (B,C) or NULL                                                           */
+    const uint8_t* style_target;
+    const float* style_row_weight;
+    float* dmu;                   /* (B,Z)                                                                   */
+    float* dlogvar;               /* (B,Z)                                                                   */
+} mvae_latent_bwd_args;
+int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
+
+/* elementwise helpers */
+int mvae_tanh_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream);      /* dx = dy*(1-y^2) */
+int mvae_convert(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, size_t n, void* stream);
+/* table (K,N) = W (K,N) + bias (N): the X_INDEX lookup table of a one-hot input layer */
+int mvae_make_table(const float* W, const float* bias, float* table, int32_t K, int32_t N, void* stream);
+/* out (N_pad,K) dst_kind = transpose of W (K,N) f32, rows N..N_pad-1 zero */
+int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int32_t N_pad, int32_t dst_kind,
+                           void* stream);
+
+/* Keras-2.0.8 optimizers on a flat f32 parameter buffer (reference vae_definition.py:174-175).
+ * Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)   (epsilon outside the correction) */
+int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                   float eps, int32_t t, float grad_scale, void* stream);
+/* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph */
+int mvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t* t_done, float grad_scale, void* stream);
+int mvae_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps,
+                      float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDIVAE_HIP_H */

@@ -1,0 +1,121 @@
+// Shared device helpers for the gfx950 kernels of libmidivae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/midivae_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+#define MVAE_WAVE 64
+
+// ---- scalar conversions (round-to-nearest-even; NaN not special-cased: inputs are finite) -----------------
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// ---- storage-type traits ---------------------------------------------------------------------------------
+template <typename T> struct st;   // storage traits
+template <> struct st<float> {
+    typedef f32x4 vec4;            // 4 consecutive elements
+    static __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct st<bf16_t> {
+    static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+        u16x4 r = *reinterpret_cast<const u16x4*>(p);
+        f32x4 v = {bf2f(r[0]), bf2f(r[1]), bf2f(r[2]), bf2f(r[3])};
+        return v;
+    }
+    static __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+        u16x4 r = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<u16x4*>(p) = r;
+    }
+    static __device__ __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- activations (Keras semantics) ---------------------------------------------------
+__device__ __forceinline__ float hard_sigmoid(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
+// derivative from the OUTPUT y: 0.2 strictly inside (0,1)
+__device__ __forceinline__ float dhard_sigmoid(float y) { return (y > 0.0f && y < 1.0f) ? 0.2f : 0.0f; }
+__device__ __forceinline__ float tanh_f(float x) { return tanhf(x); }   // ocml: accurate near 0 (parity mode)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- MFMA wrappers: D(16x16) = A(16xK) * B(Kx16) + C ------------------------------------------------------
+// lane l:  A[row = l&15][k-slot = l>>4],  B[k-slot = l>>4][col = l&15],  C[row = (l>>4)*4 + i][col = l&15]
+// bf16: a k-slot is 8 consecutive k (K = 32);   f32: a k-slot is ONE k (K = 4).
+__device__ __forceinline__ f32x4 mfma_bf16(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// One "k-group" of the contraction = 32 k for bf16 (one MFMA), 16 k for f32 (four MFMAs; lane slot q holds
+// k = 16 s + 4 q + i, i = 0..3, so both operands are read as 4 consecutive floats).
+template <typename T> struct op;
+template <> struct op<bf16_t> {
+    static constexpr int KG = 32;               // k per group
+    typedef u16x8 frag;                         // per-lane fragment: 8 consecutive k
+    static constexpr int FRAG_ELEMS = 8;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return mfma_bf16(a, b, c); }
+};
+template <> struct op<float> {
+    static constexpr int KG = 16;
+    typedef f32x4 frag;                         // 4 consecutive k
+    static constexpr int FRAG_ELEMS = 4;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        c = mfma_f32(a[0], b[0], c);
+        c = mfma_f32(a[1], b[1], c);
+        c = mfma_f32(a[2], b[2], c);
+        c = mfma_f32(a[3], b[3], c);
+        return c;
+    }
+};
+
+__host__ __device__ constexpr int mvae_gates(int cell) { return cell == MVAE_GRU ? 3 : (cell == MVAE_LSTM ? 4 : 1); }
+
+// 16-lane-group reductions (lanes sharing l>>4)
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ int group16_min_i(int v) {
+    v = min(v, __shfl_xor(v, 1));
+    v = min(v, __shfl_xor(v, 2));
+    v = min(v, __shfl_xor(v, 4));
+    v = min(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+#define MVAE_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return MVAE_E_LAUNCH;          \
+    } while (0)

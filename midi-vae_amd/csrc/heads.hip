@@ -1,0 +1,171 @@
+// Output heads of the MIDI-VAE decoder, fused over all (t, b) rows at once:
+//   Dense(H -> N) + softmax + Keras categorical cross-entropy + accuracy + argmax + d(logits)   (notes, instruments)
+//   Dense(H -> 1) + sigmoid + squared error + binary accuracy + d(logit)                         (velocity)
+// Replaces Dense(activation) on the top decoder cell (reference vae_definition.py:542,593,631), the losses
+// (:338,:367,:374) with Keras' weighted-objective semantics, the 'accuracy' metrics (:339)
+// and sample_vector(...,'argmax') of the decode path (reference vae_definition.py:1048-1067).
+//
+// One wave = 16 rows; logits come off the matrix cores with A = rows of h (read straight from HBM, k-contiguous)
+// and B = W^T (L2-resident), so a row's N logits sit across the 16 lanes of a lane group and the softmax is a
+// 4-step butterfly; nothing goes through LDS.  The (R, N) probability tensor is written only on request.
+#include "common.h"
+
+namespace {
+
+constexpr float CE_EPS = 1e-7f;
+
+template <typename WT, int NTL, int KIND>
+__global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
+    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
+    typedef typename op<WT>::frag frag;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int R = a.R, H = a.H, N = a.N, NP = NTL * 16;
+    const int row0 = (blockIdx.x * 4 + w) * 16;
+    if (row0 >= R) return;
+    const WT* __restrict__ hs = reinterpret_cast<const WT*>(a.hs);
+    const WT* __restrict__ wt = reinterpret_cast<const WT*>(a.wt);
+    const int ra = min(row0 + r, R - 1);
+
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int n = 0; n < NTL; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < H / KG; ++s) {
+        const frag fa = *reinterpret_cast<const frag*>(hs + (size_t)ra * H + s * KG + q * FE);
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) {
+            const frag fb = *reinterpret_cast<const frag*>(wt + (size_t)(n * 16 + r) * H + s * KG + q * FE);
+            acc[n] = op<WT>::mma(fa, fb, acc[n]);     // C[row = q*4+i][col = n*16 + r]
+        }
+    }
+    float bias[NTL];
+#pragma unroll
+    for (int n = 0; n < NTL; ++n) bias[n] = (n * 16 + r < N) ? a.bias[n * 16 + r] : 0.0f;
+
+    float loss_acc = 0.0f, hit_acc = 0.0f;
+    WT* __restrict__ dl = reinterpret_cast<WT*>(a.dlogits);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + q * 4 + i;
+        const bool rv = row < R;
+        const int rc = rv ? row : R - 1;
+        const float rw = a.row_weight ? a.row_weight[rc] : 1.0f;
+        if (KIND == 0) {
+            float lg[NTL], mx = -INFINITY;
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) {
+                lg[n] = (n * 16 + r < N) ? acc[n][i] + bias[n] : -INFINITY;
+                mx = fmaxf(mx, lg[n]);
+            }
+            mx = group16_max(mx);
+            float p[NTL], sum = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) {
+                p[n] = expf(lg[n] - mx);
+                sum += p[n];
+            }
+            sum = group16_sum(sum);
+            const float inv = 1.0f / sum;
+            const int tg = a.target_idx ? (int)a.target_idx[rc] : 255;
+            float pt = 0.0f, pm = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NTL; ++n) {
+                p[n] *= inv;
+                pm = fmaxf(pm, p[n]);
+                if (n * 16 + r == tg) pt = p[n];
+            }
+            pt = group16_sum(pt);
+            pm = group16_max(pm);
+            int am = 1 << 30;
+#pragma unroll
+            for (int n = 0; n < NTL; ++n)
+                if (p[n] == pm && n * 16 + r < N) am = min(am, n * 16 + r);
+            am = group16_min_i(am);                                    // first maximum (NumPy argmax tie rule)
+            const bool has_t = tg < N;
+            const bool inside = has_t && pt >= CE_EPS && pt <= 1.0f - CE_EPS;
+            const float ce = has_t ? -logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
+            if (rv && r == 0) {
+                loss_acc += rw * ce;
+                hit_acc += (am == (has_t ? tg : 0)) ? 1.0f : 0.0f;
+                if (a.argmax) a.argmax[row] = (uint8_t)am;
+            }
+            if (rv) {
+#pragma unroll
+                for (int n = 0; n < NTL; ++n) {
+                    const int col = n * 16 + r;
+                    if (a.probs && col < N) a.probs[(size_t)row * N + col] = p[n];
+                    if (a.want_grad) {
+                        const float g = inside ? a.grad_scale * rw * (p[n] - (col == tg ? 1.0f : 0.0f)) : 0.0f;
+                        st<WT>::store(dl + (size_t)row * NP + col, col < N ? g : 0.0f);
+                    }
+                }
+            }
+        } else {
+            // sigmoid + squared error: only column 0 is real
+            const float pr = sigmoid_f(acc[0][i] + bias[0]);
+            const float y = a.target_val ? a.target_val[rc] : 0.0f;
+            if (rv && r == 0) {
+                loss_acc += rw * (pr - y) * (pr - y);
+                const float rounded = rintf(pr);                          // Keras binary_accuracy: round half to even
+                hit_acc += (rounded == y) ? 1.0f : 0.0f;
+                if (a.probs) a.probs[row] = pr;
+                if (a.argmax) a.argmax[row] = (uint8_t)rounded;
+                if (a.want_grad) st<WT>::store(dl + (size_t)row * NP, a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr));
+            }
+        }
+    }
+    if (a.scalars) {
+        loss_acc = wave_sum(loss_acc);
+        hit_acc = wave_sum(hit_acc);
+        if (l == 0) {
+            atomicAdd(a.scalars, loss_acc);
+            atomicAdd(a.scalars + 1, hit_acc);
+        }
+    }
+}
+
+template <typename WT, int KIND>
+int launch(const mvae_head_args& a, hipStream_t s) {
+    const int ntl = (a.N + 15) / 16;
+    const dim3 grid((a.R + 63) / 64), block(256);
+    switch (ntl) {
+        case 1: hipLaunchKernelGGL((head_k<WT, 1, KIND>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((head_k<WT, 2, KIND>), grid, block, 0, s, a); break;
+        case 3:
+        case 4: hipLaunchKernelGGL((head_k<WT, 4, KIND>), grid, block, 0, s, a); break;
+        case 5: case 6: case 7:
+        case 8: hipLaunchKernelGGL((head_k<WT, 8, KIND>), grid, block, 0, s, a); break;
+        default: return MVAE_E_UNSUPPORTED;
+    }
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
+}  // namespace
+
+// NB: dlogits has NP = 16*ceil(N/16) columns for N<=16 / N in (32,64] / (64,128]; N in (16,32] uses 32; the
+// kernel instantiation for 3 tiles is the 4-tile one, so callers must size wt / dlogits with mvae_head_np().
+extern "C" int mvae_head_np(int32_t N) {
+    const int ntl = (N + 15) / 16;
+    if (ntl <= 1) return 16;
+    if (ntl == 2) return 32;
+    if (ntl <= 4) return 64;
+    if (ntl <= 8) return 128;
+    return -1;
+}
+
+extern "C" int mvae_head(const mvae_head_args* a, void* stream) {
+    if (!a || !a->hs || !a->wt || !a->bias || a->R <= 0 || a->N <= 0 || a->H <= 0) return MVAE_E_ARG;
+    if (a->want_grad && !a->dlogits) return MVAE_E_ARG;
+    if (a->kind == 1 && a->N != 1) return MVAE_E_ARG;
+    if (a->kind == 0 && a->N > 128) return MVAE_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->dtype == MVAE_F32) {
+        if (a->H % 16) return MVAE_E_UNSUPPORTED;
+        return a->kind == 0 ? launch<float, 0>(*a, s) : launch<float, 1>(*a, s);
+    }
+    if (a->dtype == MVAE_BF16) {
+        if (a->H % 32) return MVAE_E_UNSUPPORTED;
+        return a->kind == 0 ? launch<bf16_t, 0>(*a, s) : launch<bf16_t, 1>(*a, s);
+    }
+    return MVAE_E_ARG;
+}

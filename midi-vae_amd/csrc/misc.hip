@@ -1,0 +1,293 @@
+// Small kernels of the MIDI-VAE step: latent block (KL + reparameterisation + style classifier), reductions,
+// conversions / weight preparation, Keras optimizers.  All HBM-bound, one pass over their operands.
+#include "common.h"
+
+namespace {
+
+constexpr float CE_EPS = 1e-7f;
+
+// ---- latent block (reference vae_definition.py:29-37 KL, :498-502 sampling, :730-734 style softmax) -----------
+// one wave per batch row
+__global__ __launch_bounds__(256) void latent_fwd_k(const mvae_latent_fwd_args a) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= a.B) return;
+    const int Z = a.Z;
+    const float plv = 2.0f * logf(a.prior_std), pvar = a.prior_std * a.prior_std;
+    float kl = 0.0f;
+    for (int j = l; j < Z; j += 64) {
+        const float mu = a.mu[(size_t)b * Z + j], lv = a.logvar[(size_t)b * Z + j];
+        const float d = mu - a.prior_mean;
+        kl += 1.0f + lv - plv - (d * d + expf(lv)) / pvar;
+        a.z[(size_t)b * Z + j] = mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + j];
+    }
+    kl = wave_sum(kl);
+    if (l == 0) {
+        atomicAdd(a.scalars, a.inv_batch * a.beta * (-0.5f) * kl);
+        if (a.style_target && a.C > 0) {
+            const int C = a.C;
+            const float* zr = a.z + (size_t)b * Z;    // written by this wave's lanes j < C; C <= 64 -> same wave
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) {
+                const float mu = a.mu[(size_t)b * Z + c], lv = a.logvar[(size_t)b * Z + c];
+                mx = fmaxf(mx, mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + c]);
+            }
+            float sum = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float mu = a.mu[(size_t)b * Z + c], lv = a.logvar[(size_t)b * Z + c];
+                sum += expf(mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + c] - mx);
+            }
+            (void)zr;
+            const int tg = a.style_target[b];
+            float pt = 0.0f, pm = -1.0f;
+            int am = 0;
+            for (int c = 0; c < C; ++c) {
+                const float mu = a.mu[(size_t)b * Z + c], lv = a.logvar[(size_t)b * Z + c];
+                const float p = expf(mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + c] - mx) / sum;
+                if (a.style_probs) a.style_probs[(size_t)b * C + c] = p;
+                if (c == tg) pt = p;
+                if (p > pm) { pm = p; am = c; }
+            }
+            const float rw = a.style_row_weight ? a.style_row_weight[b] : a.inv_batch;
+            const float ce = tg < C ? -logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
+            atomicAdd(a.scalars + 1, rw * ce);
+            atomicAdd(a.scalars + 2, am == (tg < C ? tg : 0) ? 1.0f : 0.0f);
+        }
+    }
+}
+
+__global__ void latent_bwd_k(const mvae_latent_bwd_args a) {
+    const size_t n = (size_t)a.B * a.Z;
+    const float pvar = a.prior_std * a.prior_std;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / a.Z), j = (int)(e % a.Z);
+        float dz = a.dz[e];
+        if (a.style_probs && a.style_target && j < a.C) {
+            const int tg = a.style_target[b];
+            if (tg < a.C) {
+                const float pt = a.style_probs[(size_t)b * a.C + tg];
+                if (pt >= CE_EPS && pt <= 1.0f - CE_EPS) {
+                    const float rw = a.style_row_weight ? a.style_row_weight[b] : a.inv_batch;
+                    dz += a.style_weight * rw * (a.style_probs[(size_t)b * a.C + j] - (j == tg ? 1.0f : 0.0f));
+                }
+            }
+        }
+        const float mu = a.mu[e], lv = a.logvar[e];
+        a.dmu[e] = dz + a.beta * (mu - a.prior_mean) / pvar * a.inv_batch;
+        a.dlogvar[e] = dz * a.eps[e] * 0.5f * expf(0.5f * lv) + a.beta * (-0.5f) * (1.0f - expf(lv) / pvar) * a.inv_batch;
+    }
+}
+
+// ---- reductions -----------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ void colsum_k(const WT* __restrict__ X, int R, int N, int ldx, int rows_per_block, float* __restrict__ out) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.0f;
+        for (int rr = r0; rr < r1; ++rr) s += st<WT>::load(X + (size_t)rr * ldx + n);
+        atomicAdd(out + n, s);
+    }
+}
+
+template <typename WT>
+__global__ void sum_time_k(const WT* __restrict__ X, int T, int BN, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= BN) return;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s += st<WT>::load(X + (size_t)t * BN + e);
+    out[e] = s;
+}
+
+// ---- elementwise ----------------------------------------------------------------------------------------------
+__global__ void tanh_bwd_k(const float* y, const float* dy, float* dx, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        dx[e] = dy[e] * (1.0f - y[e] * y[e]);
+}
+
+template <typename S, typename D>
+__global__ void convert_k(const S* src, D* dst, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        st<D>::store(dst + e, st<S>::load(src + e));
+}
+
+__global__ void make_table_k(const float* W, const float* bias, float* table, int K, int N) {
+    const size_t n = (size_t)K * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        table[e] = W[e] + bias[e % N];
+}
+
+template <typename D>
+__global__ void transpose_convert_k(const float* W, D* out, int K, int N, int NPAD) {
+    const size_t n = (size_t)NPAD * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int nn = (int)(e / K), k = (int)(e % K);
+        st<D>::store(out + e, nn < N ? W[(size_t)k * N + nn] : 0.0f);
+    }
+}
+
+// ---- optimizers (Keras 2.0.8 formulas) ------------------------------------------------------
+__global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+                       float gs) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float ge = g[e] * gs;
+        const float me = b1 * m[e] + (1.0f - b1) * ge;
+        const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+        m[e] = me;
+        v[e] = ve;
+        p[e] -= lr_t * me / (sqrtf(ve) + eps);
+    }
+}
+// graph-replayable form: the step count lives in device memory (t_done = completed steps)
+__global__ void adam_dev_k(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                           float eps, float gs, const int* t_done) {
+    const float t = (float)(*t_done + 1);
+    const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float ge = g[e] * gs;
+        const float me = b1 * m[e] + (1.0f - b1) * ge;
+        const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+        m[e] = me;
+        v[e] = ve;
+        p[e] -= lr_t * me / (sqrtf(ve) + eps);
+    }
+}
+__global__ void bump_k(int* t) { *t += 1; }
+__global__ void rmsprop_k(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps, float gs) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float ge = g[e] * gs;
+        const float ve = rho * v[e] + (1.0f - rho) * ge * ge;
+        v[e] = ve;
+        p[e] -= lr * ge / (sqrtf(ve) + eps);
+    }
+}
+
+inline int nblocks(size_t n, int per = 256, int cap = 2048) {
+    size_t b = (n + per - 1) / per;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+extern "C" const char* mvae_build_info(void) { return "libmidivae_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
+
+extern "C" int mvae_latent_fwd(const mvae_latent_fwd_args* a, void* stream) {
+    if (!a || !a->mu || !a->logvar || !a->eps || !a->z || !a->scalars || a->B <= 0 || a->Z <= 0) return MVAE_E_ARG;
+    if (a->style_target && (a->C <= 0 || a->C > 64 || a->C > a->Z)) return MVAE_E_ARG;
+    hipLaunchKernelGGL(latent_fwd_k, dim3((a->B + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream) {
+    if (!a || !a->mu || !a->logvar || !a->eps || !a->dz || !a->dmu || !a->dlogvar || a->B <= 0 || a->Z <= 0)
+        return MVAE_E_ARG;
+    hipLaunchKernelGGL(latent_bwd_k, dim3(nblocks((size_t)a->B * a->Z)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), *a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
+extern "C" int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream) {
+    if (!X || !out || R <= 0 || N <= 0 || ldx < N) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rpb = (R + 1023) / 1024;
+    if (rpb < 8) rpb = 8;
+    const int blocks = (R + rpb - 1) / rpb;
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(colsum_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)X, R, N, ldx, rpb, out);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(colsum_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, R, N, ldx, rpb, out);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, void* stream) {
+    if (!X || !out || T <= 0 || BN <= 0) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(sum_time_k<float>, dim3((BN + 255) / 256), dim3(256), 0, s, (const float*)X, T, BN, out);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(sum_time_k<bf16_t>, dim3((BN + 255) / 256), dim3(256), 0, s, (const bf16_t*)X, T, BN, out);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
+extern "C" int mvae_tanh_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream) {
+    if (!y || !dy || !dx) return MVAE_E_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(tanh_bwd_k, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, dy, dx, n);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_convert(const void* src, int32_t sk, void* dst, int32_t dk, size_t n, void* stream) {
+    if (!src || !dst) return MVAE_E_ARG;
+    if (n == 0) return MVAE_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks(n)), b(256);
+    if (sk == MVAE_F32 && dk == MVAE_BF16)
+        hipLaunchKernelGGL((convert_k<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (sk == MVAE_BF16 && dk == MVAE_F32)
+        hipLaunchKernelGGL((convert_k<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (sk == MVAE_F32 && dk == MVAE_F32)
+        hipLaunchKernelGGL((convert_k<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+    else if (sk == MVAE_BF16 && dk == MVAE_BF16)
+        hipLaunchKernelGGL((convert_k<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_make_table(const float* W, const float* bias, float* table, int32_t K, int32_t N, void* stream) {
+    if (!W || !bias || !table || K <= 0 || N <= 0) return MVAE_E_ARG;
+    hipLaunchKernelGGL(make_table_k, dim3(nblocks((size_t)K * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W,
+                       bias, table, K, N);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int32_t N_pad, int32_t dk,
+                                      void* stream) {
+    if (!W || !out || K <= 0 || N <= 0 || N_pad < N) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks((size_t)K * N_pad)), b(256);
+    if (dk == MVAE_F32)
+        hipLaunchKernelGGL(transpose_convert_k<float>, g, b, 0, s, W, (float*)out, K, N, N_pad);
+    else if (dk == MVAE_BF16)
+        hipLaunchKernelGGL(transpose_convert_k<bf16_t>, g, b, 0, s, W, (bf16_t*)out, K, N, N_pad);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
+extern "C" int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                              float eps, int32_t t, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || t < 1) return MVAE_E_ARG;
+    if (n == 0) return MVAE_OK;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    hipLaunchKernelGGL(adam_k, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n,
+                       (float)lr_t, beta1, beta2, eps, grad_scale);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                                  float beta2, float eps, int32_t* t_done, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !t_done) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
+                              grad_scale, t_done);
+    hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps,
+                                 float grad_scale, void* stream) {
+    if (!p || !g || !v) return MVAE_E_ARG;
+    if (n == 0) return MVAE_OK;
+    hipLaunchKernelGGL(rmsprop_k, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, v, n, lr, rho,
+                       eps, grad_scale);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}

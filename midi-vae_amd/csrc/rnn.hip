@@ -1,0 +1,546 @@
+// Recurrent layers of the MIDI-VAE hot path on gfx950: forward recurrence, BPTT, weight packing.
+//
+// Replaces keras.layers.{GRU,LSTM,SimpleRNN} (reference vae_definition.py:448-480) and recurrentshop
+// {GRU,LSTM,SimpleRNN}Cell stepped by RecurrentModel (reference vae_definition.py:533-546 etc.).
+//
+// Mapping to the machine (generic kernel, any H in {64,128,256}):
+//   * the recurrence is independent across batch rows, so ONE workgroup (4 waves) owns 16 batch rows for all
+//     T steps: no inter-workgroup synchronisation exists anywhere in this file;
+//   * per step the gate pre-activations are  gates^T (G*H x 16) = U^T (G*H x H) * h^T (H x 16)  on MFMA with
+//     the WEIGHTS as the A operand (16 gate columns per tile) and the 16 batch rows as the N dimension, so a
+//     lane's 4 accumulator values are 4 CONSECUTIVE hidden units of one batch row: every global load / store
+//     of xp, gates, h, c is an 8- or 16-byte vector access on row-major (T,B,*) arrays;
+//   * wave w owns hidden units [w*H/4, (w+1)*H/4) for ALL gates, so the gate arithmetic, the cell state c and
+//     the f32 master copy of h stay in that lane's registers for all T steps; only the MFMA-operand copy of
+//     h_t goes through LDS (double buffered, one barrier per step; GRU needs a second for r*h);
+//   * U is pre-packed in A-fragment order (mvae_pack_recurrent) so each wave-load of U is 1 KiB contiguous;
+//     it is re-read from L2 every step here (the H=256 bf16 resident-U kernel lives in rnn_resident.hip).
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------
+// packing
+// ----------------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ void pack_recurrent_k(const float* __restrict__ U, WT* __restrict__ out, int H, int GH, int direction) {
+    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
+    const int rowsA = direction == 0 ? GH : H;   // A rows
+    const int K = direction == 0 ? H : GH;       // contraction length
+    const int S = K / KG;
+    const size_t total = (size_t)rowsA * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % FE);
+        const int l = (int)((e / FE) % 64);
+        const size_t f = e / (FE * 64);
+        const int s = (int)(f % S);
+        const int mt = (int)(f / S);
+        const int arow = mt * 16 + (l & 15);
+        const int k = s * KG + (l >> 4) * FE + j;
+        const float v = direction == 0 ? U[(size_t)k * GH + arow]      // A[gate col][h]   = U[h][gate col]
+                                       : U[(size_t)arow * GH + k];     // A[unit][gate col] = U[unit][gate col]
+        st<WT>::store(out + e, v);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// forward
+// ----------------------------------------------------------------------------------------------------------
+template <typename WT> struct lds_pad { static constexpr int value = 16 / sizeof(WT); };
+
+template <int CELL, typename WT, int XMODE, int NT>
+__global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
+    constexpr int G = mvae_gates(CELL);
+    constexpr int H = NT * 64, GH = G * H;
+    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS, S = H / KG;
+    constexpr int LDH = H + lds_pad<WT>::value;
+    typedef typename op<WT>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WT* hbuf = reinterpret_cast<WT*>(smem);                       // [2][16][LDH]
+    WT* rhbuf = hbuf + 2 * 16 * LDH;                              // [16][LDH]       (GRU only)
+    float* wb = reinterpret_cast<float*>(rhbuf + (CELL == MVAE_GRU ? 16 * LDH : 0));   // [2][GH] (SCALAR only)
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const bool valid = b < B;
+    const int bb = valid ? b : B - 1;
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
+    WT* __restrict__ hs = reinterpret_cast<WT*>(a.hs);
+    WT* __restrict__ cs = reinterpret_cast<WT*>(a.cs);
+    WT* __restrict__ acts = reinterpret_cast<WT*>(a.acts);
+    const WT* __restrict__ xp = reinterpret_cast<const WT*>(a.xp);
+
+    int ub[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) ub[n] = w * (H / 4) + n * 16 + q * 4;
+
+    // ---- initial state -------------------------------------------------------------------------------
+    f32x4 hreg[NT], creg[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)bb * H + ub[n]) : z4;
+        creg[n] = (CELL == MVAE_LSTM && a.c0) ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)bb * H + ub[n]) : z4;
+        st<WT>::store4(hbuf + r * LDH + ub[n], hreg[n]);
+        if (valid) {
+            if (hs) st<WT>::store4(hs + (size_t)b * H + ub[n], hreg[n]);
+            if (CELL == MVAE_LSTM && cs) st<WT>::store4(cs + (size_t)b * H + ub[n], creg[n]);
+        }
+    }
+    if (XMODE == MVAE_X_SCALAR) {
+        for (int i = tid; i < GH; i += 256) {
+            wb[i] = a.w_row[i];
+            wb[GH + i] = a.bias[i];
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * B + bb;
+        // ---- x_t W + b for this lane's (gate, unit) positions; consumed after the MFMAs ----------------
+        f32x4 xv[G][NT];
+        if (XMODE == MVAE_X_DENSE) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xv[g][n] = st<WT>::load4(xp + row * GH + g * H + ub[n]);
+        } else if (XMODE == MVAE_X_INDEX) {
+            const float* trow = a.table + (size_t)a.idx[row] * GH;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xv[g][n] = *reinterpret_cast<const f32x4*>(trow + g * H + ub[n]);
+        } else if (XMODE == MVAE_X_SCALAR) {
+            const float x = a.xs[row];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wb + g * H + ub[n]);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(wb + GH + g * H + ub[n]);
+                    xv[g][n] = x * w4 + b4;
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    xv[g][n] = *reinterpret_cast<const f32x4*>(a.xp0 + (size_t)bb * GH + g * H + ub[n]);
+        }
+
+        // ---- h_{t-1} U on the matrix cores -----------------------------------------------------------
+        constexpr int GA = (CELL == MVAE_GRU) ? 2 : G;   // gates whose recurrent input is h itself
+        f32x4 acc[G][NT];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const WT* hrow = hbuf + cur * 16 * LDH + r * LDH + q * FE;
+#pragma unroll 2
+        for (int s = 0; s < S; ++s) {
+            const frag bf = *reinterpret_cast<const frag*>(hrow + s * KG);
+#pragma unroll
+            for (int g = 0; g < GA; ++g)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int mt = g * (H / 16) + w * NT + n;
+                    acc[g][n] = op<WT>::mma(up[((size_t)mt * S + s) * 64 + l], bf, acc[g][n]);
+                }
+        }
+
+        f32x4 hnew[NT];
+        if (CELL == MVAE_GRU) {
+            f32x4 z[NT], rr[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    z[n][i] = hard_sigmoid(acc[0][n][i] + xv[0][n][i]);
+                    rr[n][i] = hard_sigmoid(acc[1][n][i] + xv[1][n][i]);
+                }
+                st<WT>::store4(rhbuf + r * LDH + ub[n], rr[n] * hreg[n]);
+            }
+            __syncthreads();
+            const WT* rhrow = rhbuf + r * LDH + q * FE;
+#pragma unroll 2
+            for (int s = 0; s < S; ++s) {
+                const frag bf = *reinterpret_cast<const frag*>(rhrow + s * KG);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int mt = 2 * (H / 16) + w * NT + n;
+                    acc[2][n] = op<WT>::mma(up[((size_t)mt * S + s) * 64 + l], bf, acc[2][n]);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 hh;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hh[i] = tanh_f(acc[2][n][i] + xv[2][n][i]);
+                    hnew[n][i] = z[n][i] * hreg[n][i] + (1.0f - z[n][i]) * hh[i];
+                }
+                if (acts && valid) {
+                    WT* ap = acts + ((size_t)t * B + b) * GH + ub[n];
+                    st<WT>::store4(ap, z[n]);
+                    st<WT>::store4(ap + H, rr[n]);
+                    st<WT>::store4(ap + 2 * H, hh);
+                }
+            }
+        } else if (CELL == MVAE_LSTM) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 ig, fg, gg, og;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ig[i] = hard_sigmoid(acc[0][n][i] + xv[0][n][i]);
+                    fg[i] = hard_sigmoid(acc[1][n][i] + xv[1][n][i]);
+                    gg[i] = tanh_f(acc[2][n][i] + xv[2][n][i]);
+                    og[i] = hard_sigmoid(acc[3][n][i] + xv[3][n][i]);
+                    creg[n][i] = fg[i] * creg[n][i] + ig[i] * gg[i];
+                    hnew[n][i] = og[i] * tanh_f(creg[n][i]);
+                }
+                if (valid) {
+                    if (acts) {
+                        WT* ap = acts + ((size_t)t * B + b) * GH + ub[n];
+                        st<WT>::store4(ap, ig);
+                        st<WT>::store4(ap + H, fg);
+                        st<WT>::store4(ap + 2 * H, gg);
+                        st<WT>::store4(ap + 3 * H, og);
+                    }
+                    if (cs) st<WT>::store4(cs + ((size_t)(t + 1) * B + b) * H + ub[n], creg[n]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hnew[n][i] = tanh_f(acc[0][n][i] + xv[0][n][i]);
+                if (acts && valid) st<WT>::store4(acts + ((size_t)t * B + b) * GH + ub[n], hnew[n]);
+            }
+        }
+
+        // ---- publish h_t: MFMA-operand copy to LDS, sequence copy to HBM ---------------------------------
+        WT* hnext = hbuf + (cur ^ 1) * 16 * LDH + r * LDH;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            hreg[n] = hnew[n];
+            st<WT>::store4(hnext + ub[n], hnew[n]);
+            if (hs && valid) st<WT>::store4(hs + ((size_t)(t + 1) * B + b) * H + ub[n], hnew[n]);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (a.h_last && valid) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + ub[n]) = hreg[n];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// backward through time
+// ----------------------------------------------------------------------------------------------------------
+template <int CELL, typename WT, int NT>
+__global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
+    constexpr int G = mvae_gates(CELL);
+    constexpr int H = NT * 64, GH = G * H;
+    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS, S2 = GH / KG;
+    constexpr int LDA = GH + lds_pad<WT>::value;
+    typedef typename op<WT>::frag frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WT* dabuf = reinterpret_cast<WT*>(smem);                      // [16][LDA]
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const bool valid = b < B;
+    const int bb = valid ? b : B - 1;
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    const WT* __restrict__ hs = reinterpret_cast<const WT*>(a.hs);
+    const WT* __restrict__ cs = reinterpret_cast<const WT*>(a.cs);
+    const WT* __restrict__ acts = reinterpret_cast<const WT*>(a.acts);
+    const WT* __restrict__ dext = reinterpret_cast<const WT*>(a.dhs_ext);
+    WT* __restrict__ da = reinterpret_cast<WT*>(a.da);
+    WT* __restrict__ rh = reinterpret_cast<WT*>(a.rh);
+
+    int ub[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) ub[n] = w * (H / 4) + n * 16 + q * 4;
+
+    f32x4 dh[NT], dc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bb * H + ub[n]) : z4;
+        dc[n] = z4;
+    }
+    WT* drow = dabuf + r * LDA;
+    const WT* brow = dabuf + r * LDA + q * FE;
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t row = (size_t)t * B + bb;
+        const WT* ap = acts + row * GH;
+        f32x4 d[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            d[n] = dh[n];
+            if (dext) d[n] += st<WT>::load4(dext + row * H + ub[n]);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (CELL == MVAE_LSTM) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 ig = st<WT>::load4(ap + ub[n]), fg = st<WT>::load4(ap + H + ub[n]);
+                const f32x4 gg = st<WT>::load4(ap + 2 * H + ub[n]), og = st<WT>::load4(ap + 3 * H + ub[n]);
+                const f32x4 c = st<WT>::load4(cs + ((size_t)(t + 1) * B + bb) * H + ub[n]);
+                const f32x4 cp = st<WT>::load4(cs + row * H + ub[n]);
+                f32x4 di, df, dg, dO;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float tc = tanh_f(c[i]);
+                    const float dct = dc[n][i] + d[n][i] * og[i] * (1.0f - tc * tc);
+                    di[i] = dct * gg[i] * dhard_sigmoid(ig[i]);
+                    df[i] = dct * cp[i] * dhard_sigmoid(fg[i]);
+                    dg[i] = dct * ig[i] * (1.0f - gg[i] * gg[i]);
+                    dO[i] = d[n][i] * tc * dhard_sigmoid(og[i]);
+                    dc[n][i] = dct * fg[i];
+                }
+                st<WT>::store4(drow + ub[n], di);
+                st<WT>::store4(drow + H + ub[n], df);
+                st<WT>::store4(drow + 2 * H + ub[n], dg);
+                st<WT>::store4(drow + 3 * H + ub[n], dO);
+                if (valid) {
+                    WT* gp = da + ((size_t)t * B + b) * GH + ub[n];
+                    st<WT>::store4(gp, di);
+                    st<WT>::store4(gp + H, df);
+                    st<WT>::store4(gp + 2 * H, dg);
+                    st<WT>::store4(gp + 3 * H, dO);
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < S2; ++s) {
+                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dh[n] = acc[n];
+        } else if (CELL == MVAE_GRU) {
+            f32x4 z[NT], rr[NT], hp[NT], hh[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                z[n] = st<WT>::load4(ap + ub[n]);
+                rr[n] = st<WT>::load4(ap + H + ub[n]);
+                hh[n] = st<WT>::load4(ap + 2 * H + ub[n]);
+                hp[n] = st<WT>::load4(hs + row * H + ub[n]);
+                f32x4 dah;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dah[i] = d[n][i] * (1.0f - z[n][i]) * (1.0f - hh[n][i] * hh[n][i]);
+                st<WT>::store4(drow + 2 * H + ub[n], dah);
+                if (valid) {
+                    st<WT>::store4(da + ((size_t)t * B + b) * GH + 2 * H + ub[n], dah);
+                    if (rh) st<WT>::store4(rh + ((size_t)t * B + b) * H + ub[n], rr[n] * hp[n]);
+                }
+            }
+            __syncthreads();
+            constexpr int SH = H / KG;
+#pragma unroll 4
+            for (int s = 2 * SH; s < 3 * SH; ++s) {
+                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
+            }
+            f32x4 drh[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                drh[n] = acc[n];
+                acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 daz, dar;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    daz[i] = d[n][i] * (hp[n][i] - hh[n][i]) * dhard_sigmoid(z[n][i]);
+                    dar[i] = drh[n][i] * hp[n][i] * dhard_sigmoid(rr[n][i]);
+                }
+                st<WT>::store4(drow + ub[n], daz);
+                st<WT>::store4(drow + H + ub[n], dar);
+                if (valid) {
+                    WT* gp = da + ((size_t)t * B + b) * GH + ub[n];
+                    st<WT>::store4(gp, daz);
+                    st<WT>::store4(gp + H, dar);
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < 2 * SH; ++s) {
+                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dh[n][i] = d[n][i] * z[n][i] + drh[n][i] * rr[n][i] + acc[n][i];
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 y = st<WT>::load4(ap + ub[n]);
+                f32x4 dy;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dy[i] = d[n][i] * (1.0f - y[i] * y[i]);
+                st<WT>::store4(drow + ub[n], dy);
+                if (valid) st<WT>::store4(da + ((size_t)t * B + b) * GH + ub[n], dy);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int s = 0; s < S2; ++s) {
+                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) dh[n] = acc[n];
+        }
+        __syncthreads();   // all waves done reading dabuf before the next step overwrites it
+    }
+    if (valid) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * H + ub[n]) = dh[n];
+            if (CELL == MVAE_LSTM && a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * H + ub[n]) = dc[n];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// dispatch
+// ----------------------------------------------------------------------------------------------------------
+template <int CELL, typename WT, int XMODE, int NT>
+int launch_fwd(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    constexpr int G = mvae_gates(CELL), H = NT * 64;
+    constexpr int LDH = H + lds_pad<WT>::value;
+    size_t lds = (size_t)(2 + (CELL == MVAE_GRU ? 1 : 0)) * 16 * LDH * sizeof(WT);
+    if (XMODE == MVAE_X_SCALAR) lds += (size_t)2 * G * H * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;   // gfx950 has 160 KiB of LDS per CU; anything above 64 KiB must be requested
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_k<CELL, WT, XMODE, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return MVAE_E_LAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((rnn_fwd_k<CELL, WT, XMODE, NT>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+template <int CELL, typename WT, int XMODE>
+int fwd_nt(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    switch (a.H) {
+        case 64: return launch_fwd<CELL, WT, XMODE, 1>(a, s);
+        case 128: return launch_fwd<CELL, WT, XMODE, 2>(a, s);
+        case 256: return launch_fwd<CELL, WT, XMODE, 4>(a, s);
+    }
+    return MVAE_E_UNSUPPORTED;
+}
+template <int CELL, typename WT>
+int fwd_xmode(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    switch (a.xmode) {
+        case MVAE_X_DENSE: return a.xp ? fwd_nt<CELL, WT, MVAE_X_DENSE>(a, s) : MVAE_E_ARG;
+        case MVAE_X_INDEX: return (a.idx && a.table) ? fwd_nt<CELL, WT, MVAE_X_INDEX>(a, s) : MVAE_E_ARG;
+        case MVAE_X_SCALAR: return (a.xs && a.w_row && a.bias) ? fwd_nt<CELL, WT, MVAE_X_SCALAR>(a, s) : MVAE_E_ARG;
+        case MVAE_X_CONST: return a.xp0 ? fwd_nt<CELL, WT, MVAE_X_CONST>(a, s) : MVAE_E_ARG;
+    }
+    return MVAE_E_ARG;
+}
+template <typename WT>
+int fwd_cell(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    switch (a.cell) {
+        case MVAE_GRU: return fwd_xmode<MVAE_GRU, WT>(a, s);
+        case MVAE_LSTM: return fwd_xmode<MVAE_LSTM, WT>(a, s);
+        case MVAE_RNN: return fwd_xmode<MVAE_RNN, WT>(a, s);
+    }
+    return MVAE_E_ARG;
+}
+
+template <int CELL, typename WT, int NT>
+int launch_bwd(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    constexpr int GH = mvae_gates(CELL) * NT * 64;
+    const size_t lds = (size_t)16 * (GH + lds_pad<WT>::value) * sizeof(WT);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_k<CELL, WT, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return MVAE_E_LAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((rnn_bwd_k<CELL, WT, NT>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+template <int CELL, typename WT>
+int bwd_nt(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    switch (a.H) {
+        case 64: return launch_bwd<CELL, WT, 1>(a, s);
+        case 128: return launch_bwd<CELL, WT, 2>(a, s);
+        case 256: return launch_bwd<CELL, WT, 4>(a, s);
+    }
+    return MVAE_E_UNSUPPORTED;
+}
+template <typename WT>
+int bwd_cell(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    switch (a.cell) {
+        case MVAE_GRU: return bwd_nt<MVAE_GRU, WT>(a, s);
+        case MVAE_LSTM: return a.cs ? bwd_nt<MVAE_LSTM, WT>(a, s) : MVAE_E_ARG;
+        case MVAE_RNN: return bwd_nt<MVAE_RNN, WT>(a, s);
+    }
+    return MVAE_E_ARG;
+}
+
+}  // namespace
+
+extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
+    if (!a || !a->u_pack || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->dtype == MVAE_F32) return fwd_cell<float>(*a, s);
+    if (a->dtype == MVAE_BF16) return fwd_cell<bf16_t>(*a, s);
+    return MVAE_E_ARG;
+}
+
+extern "C" int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream) {
+    if (!a || !a->ut_pack || !a->hs || !a->acts || !a->da || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->dtype == MVAE_F32) return bwd_cell<float>(*a, s);
+    if (a->dtype == MVAE_BF16) return bwd_cell<bf16_t>(*a, s);
+    return MVAE_E_ARG;
+}
+
+extern "C" int mvae_pack_recurrent(const float* U, void* out, int32_t cell, int32_t H, int32_t dtype,
+                                   int32_t direction, void* stream) {
+    if (!U || !out || (H % 64) != 0 || direction < 0 || direction > 1) return MVAE_E_ARG;
+    if (cell != MVAE_GRU && cell != MVAE_LSTM && cell != MVAE_RNN) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int GH = mvae_gates(cell) * H;
+    const size_t total = (size_t)GH * H;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (dtype == MVAE_F32)
+        hipLaunchKernelGGL(pack_recurrent_k<float>, dim3(blocks), dim3(256), 0, s, U, (float*)out, H, GH, direction);
+    else if (dtype == MVAE_BF16)
+        hipLaunchKernelGGL(pack_recurrent_k<bf16_t>, dim3(blocks), dim3(256), 0, s, U, (bf16_t*)out, H, GH, direction);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}

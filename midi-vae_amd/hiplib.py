@@ -1,0 +1,126 @@
+"""ctypes binding of libmidivae_hip.so (C ABI declared in include/midivae_hip.h).
+
+The library is built in-tree by ``make -C midi-vae_amd/csrc`` (or ``__graft_entry__.build()``).  Loading fails
+LOUDLY when it is missing: there is no CPU fallback anywhere in the product path.
+
+Device pointers are plain integers here (``tensor.data_ptr()``); streams are the raw ``hipStream_t`` value
+(``torch.cuda.current_stream().cuda_stream``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmidivae_hip.so")
+
+GRU, LSTM, RNN = 0, 1, 2
+F32, BF16, ONEHOT = 0, 1, 2
+X_DENSE, X_INDEX, X_SCALAR, X_CONST = 0, 1, 2, 3
+ACT_NONE, ACT_TANH = 0, 1
+CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
+GATES = {GRU: 3, LSTM: 4, RNN: 1}
+ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
+          -3: "MVAE_E_LAUNCH (HIP launch failed)"}
+
+_i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+
+
+class RnnFwdArgs(C.Structure):
+    _fields_ = [("cell", _i32), ("dtype", _i32), ("xmode", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
+                ("u_pack", _vp), ("xp", _vp), ("idx", _vp), ("table", _vp), ("xs", _vp), ("w_row", _vp),
+                ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
+                ("h_last", _vp)]
+
+
+class RnnBwdArgs(C.Structure):
+    _fields_ = [("cell", _i32), ("dtype", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
+                ("ut_pack", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp), ("dhs_ext", _vp), ("dh_last", _vp),
+                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("trans_a", _i32), ("trans_b", _i32),
+                ("a_kind", _i32), ("b_kind", _i32), ("c_kind", _i32), ("lda", _i32), ("ldb", _i32), ("ldc", _i32),
+                ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
+                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("kind", _i32), ("dtype", _i32), ("R", _i32), ("H", _i32), ("N", _i32), ("want_grad", _i32),
+                ("hs", _vp), ("wt", _vp), ("bias", _vp), ("target_idx", _vp), ("target_val", _vp),
+                ("row_weight", _vp), ("grad_scale", _f32), ("probs", _vp), ("argmax", _vp), ("dlogits", _vp),
+                ("scalars", _vp)]
+
+
+class LatentFwdArgs(C.Structure):
+    _fields_ = [("B", _i32), ("Z", _i32), ("C", _i32), ("beta", _f32), ("prior_mean", _f32), ("prior_std", _f32),
+                ("inv_batch", _f32), ("mu", _vp), ("logvar", _vp), ("eps", _vp), ("style_target", _vp),
+                ("style_row_weight", _vp), ("z", _vp), ("style_probs", _vp), ("scalars", _vp)]
+
+
+class LatentBwdArgs(C.Structure):
+    _fields_ = [("B", _i32), ("Z", _i32), ("C", _i32), ("beta", _f32), ("prior_mean", _f32), ("prior_std", _f32),
+                ("style_weight", _f32), ("inv_batch", _f32), ("mu", _vp), ("logvar", _vp), ("eps", _vp), ("dz", _vp),
+                ("style_probs", _vp), ("style_target", _vp), ("style_row_weight", _vp), ("dmu", _vp),
+                ("dlogvar", _vp)]
+
+
+# name -> (restype, argtypes); every symbol include/midivae_hip.h declares
+SIGNATURES = {
+    "mvae_abi_version": (_i32, []),
+    "mvae_build_info": (C.c_char_p, []),
+    "mvae_rnn_fwd": (_i32, [C.POINTER(RnnFwdArgs), _vp]),
+    "mvae_rnn_bwd": (_i32, [C.POINTER(RnnBwdArgs), _vp]),
+    "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
+    "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_head": (_i32, [C.POINTER(HeadArgs), _vp]),
+    "mvae_head_np": (_i32, [_i32]),
+    "mvae_latent_fwd": (_i32, [C.POINTER(LatentFwdArgs), _vp]),
+    "mvae_latent_bwd": (_i32, [C.POINTER(LatentBwdArgs), _vp]),
+    "mvae_tanh_bwd": (_i32, [_vp, _vp, _vp, _sz, _vp]),
+    "mvae_convert": (_i32, [_vp, _i32, _vp, _i32, _sz, _vp]),
+    "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "mvae_transpose_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_adam_step": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _vp]),
+    "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the C-ABI library once; raise HipLibraryMissing (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found - build it with `make -C midi-vae_amd/csrc` (or __graft_entry__.build()); "
+            "the MIDI-VAE engine has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvae_abi_version() != 1:
+        raise HipLibraryMissing("ABI version mismatch: library %d, binding 1" % lib.mvae_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s" % (what, ERRORS.get(code, code)))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()

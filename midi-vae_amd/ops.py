@@ -1,0 +1,150 @@
+"""Tensor-level wrappers over the C ABI (hiplib): argument marshalling only, no arithmetic.
+
+torch is used for what the task allows it for: device memory (tensors), streams.  Every function enqueues on
+torch's CURRENT stream and returns immediately.  Shapes follow include/midivae_hip.h (time-major sequences).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hiplib as hl
+
+_TORCH_DT = {hl.F32: torch.float32, hl.BF16: torch.bfloat16}
+
+
+def torch_dtype(kind):
+    return _TORCH_DT[kind]
+
+
+def kind_of(t):
+    if t.dtype == torch.float32:
+        return hl.F32
+    if t.dtype == torch.bfloat16:
+        return hl.BF16
+    raise TypeError("unsupported tensor dtype %s" % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+    return t.data_ptr()
+
+
+def pack_recurrent(U, cell, dtype, direction, out=None):
+    """U (H, G*H) f32 -> fragment-ordered copy (flat, dtype)."""
+    H = U.shape[0]
+    if out is None:
+        out = torch.empty(U.numel(), dtype=_TORCH_DT[dtype], device=U.device)
+    hl.check(hl.load().mvae_pack_recurrent(_p(U), _p(out), cell, H, dtype, direction, _stream()), "mvae_pack_recurrent")
+    return out
+
+
+def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
+            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None):
+    if xp is not None:
+        xmode = hl.X_DENSE
+    elif idx is not None:
+        xmode = hl.X_INDEX
+    elif xs is not None:
+        xmode = hl.X_SCALAR
+    else:
+        xmode = hl.X_CONST
+    a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _p(xp), _p(idx), _p(table), _p(xs), _p(w_row),
+                      _p(bias), _p(xp0), _p(h0), _p(c0), _p(hs), _p(cs), _p(acts), _p(h_last))
+    hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
+
+
+def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, rh=None, dh0=None,
+            dc0=None):
+    a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _p(hs), _p(cs), _p(acts), _p(dhs_ext), _p(dh_last), _p(da),
+                      _p(rh), _p(dh0), _p(dc0))
+    hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
+
+
+def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
+         accumulate=False, split_k=1, alpha=1.0, a_kind=None):
+    """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths."""
+    a_kind = kind_of(A) if a_kind is None else a_kind
+    if lda is None:
+        lda = (M if trans_a else K)
+    if ldb is None:
+        ldb = (K if trans_b else N)
+    if ldc is None:
+        ldc = N
+    g = hl.GemmArgs(M, N, K, int(trans_a), int(trans_b), a_kind, kind_of(B), kind_of(C), lda, ldb, ldc,
+                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias))
+    hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
+
+
+def colsum(X, R, N, out, ldx=None):
+    hl.check(hl.load().mvae_colsum(X.data_ptr(), kind_of(X), R, N, N if ldx is None else ldx, _p(out), _stream()),
+             "mvae_colsum")
+
+
+def sum_over_time(X, T, BN, out):
+    hl.check(hl.load().mvae_sum_over_time(_p(X), kind_of(X), T, BN, _p(out), _stream()), "mvae_sum_over_time")
+
+
+def head_np(N):
+    return hl.load().mvae_head_np(N)
+
+
+def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None, row_weight=None, grad_scale=1.0,
+         probs=None, argmax=None, dlogits=None, scalars=None):
+    a = hl.HeadArgs(kind, dtype, R, H, N, int(dlogits is not None), hs.data_ptr(), _p(wt), _p(bias), _p(target_idx),
+                    _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars))
+    hl.check(hl.load().mvae_head(a, _stream()), "mvae_head")
+
+
+def latent_fwd(B, Z, C, beta, prior_mean, prior_std, inv_batch, mu, logvar, eps, z, scalars, *, style_target=None,
+               style_row_weight=None, style_probs=None):
+    a = hl.LatentFwdArgs(B, Z, C, beta, prior_mean, prior_std, inv_batch, _p(mu), _p(logvar), _p(eps),
+                         _p(style_target), _p(style_row_weight), _p(z), _p(style_probs), _p(scalars))
+    hl.check(hl.load().mvae_latent_fwd(a, _stream()), "mvae_latent_fwd")
+
+
+def latent_bwd(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, mu, logvar, eps, dz, dmu, dlogvar, *,
+               style_probs=None, style_target=None, style_row_weight=None):
+    a = hl.LatentBwdArgs(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, _p(mu), _p(logvar), _p(eps),
+                         _p(dz), _p(style_probs), _p(style_target), _p(style_row_weight), _p(dmu), _p(dlogvar))
+    hl.check(hl.load().mvae_latent_bwd(a, _stream()), "mvae_latent_bwd")
+
+
+def tanh_bwd(y, dy, dx):
+    hl.check(hl.load().mvae_tanh_bwd(_p(y), _p(dy), _p(dx), y.numel(), _stream()), "mvae_tanh_bwd")
+
+
+def convert(src, dst):
+    hl.check(hl.load().mvae_convert(_p(src), kind_of(src), _p(dst), kind_of(dst), src.numel(), _stream()),
+             "mvae_convert")
+
+
+def make_table(W, bias, table):
+    K, N = W.shape
+    hl.check(hl.load().mvae_make_table(_p(W), _p(bias), _p(table), K, N, _stream()), "mvae_make_table")
+
+
+def transpose_convert(W, out, n_pad=None):
+    K, N = W.shape
+    hl.check(hl.load().mvae_transpose_convert(_p(W), _p(out), K, N, N if n_pad is None else n_pad, kind_of(out),
+                                              _stream()), "mvae_transpose_convert")
+
+
+def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    hl.check(hl.load().mvae_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, t, grad_scale,
+                                      _stream()), "mvae_adam_step")
+
+
+def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    hl.check(hl.load().mvae_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(t_done),
+                                          grad_scale, _stream()), "mvae_adam_step_dev")
+
+
+def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0):
+    hl.check(hl.load().mvae_rmsprop_step(_p(p), _p(g), _p(v), p.numel(), lr, rho, eps, grad_scale, _stream()),
+             "mvae_rmsprop_step")

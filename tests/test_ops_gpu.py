@@ -1,0 +1,357 @@
+"""Operator-level parity: every C-ABI kernel vs the float64 oracle on seeded inputs (GPU box only).
+
+Tolerances: f32 mode (exact-f32 MFMA, f32 storage) rtol/atol 2e-4 class against float64; bf16 mode (bf16 MFMA
+operands + bf16 sequence storage, f32 accumulate/state) 3e-2 class.  Integer outputs (argmax) are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd import hiplib as hl
+from midi_vae_amd import ops
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+CELLS = [("GRU", hl.GRU), ("LSTM", hl.LSTM), ("SimpleRNN", hl.RNN)]
+DTYPES = [(hl.F32, 3e-4), (hl.BF16, 4e-2)]
+
+
+def dev(a, dt=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV).to(dt).contiguous()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def close(got, want, tol, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want)
+    bound = tol * (1.0 + np.abs(want))
+    assert np.all(err <= bound), "%s: max err %.3e (tol %.1e) at %s" % (
+        what, err.max(), tol, np.unravel_index(np.argmax(err - bound), err.shape))
+
+
+def _rnn_problem(cellname, H, T, B, seed, K=7):
+    rng = np.random.default_rng(seed)
+    G = vo.GATES[cellname]
+    U = rng.standard_normal((H, G * H)) * (0.5 / np.sqrt(H))
+    W = rng.standard_normal((K, G * H)) * 0.4
+    b = rng.standard_normal((G * H,)) * 0.2
+    h0 = rng.standard_normal((B, H)) * 0.3
+    c0 = rng.standard_normal((B, H)) * 0.3
+    return rng, G, U, W, b, h0, c0
+
+
+@pytest.mark.parametrize("cellname,cell", CELLS)
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("xmode", ["dense", "index", "scalar", "const"])
+@pytest.mark.parametrize("H,B", [(64, 5), (128, 37)])
+def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
+    T = 9
+    rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=H + B)
+    GH = G * H
+    td = ops.torch_dtype(dtype)
+    kw = {}
+    if xmode == "dense":
+        xp = rng.standard_normal((T, B, GH)) * 0.5
+        if dtype == hl.BF16:
+            xp = host(dev(xp, td))       # the kernel sees bf16-rounded inputs; give the oracle the same
+        kw["xp"] = dev(xp, td)
+    elif xmode == "index":
+        idx = rng.integers(0, 7, (T, B))
+        table = W + b
+        xp = table[idx]
+        kw["idx"], kw["table"] = dev(idx, torch.uint8), dev(table)
+    elif xmode == "scalar":
+        xs = rng.random((T, B))
+        xp = xs[..., None] * W[0] + b
+        kw["xs"], kw["w_row"], kw["bias"] = dev(xs), dev(W[0]), dev(b)
+    else:
+        xp0 = rng.standard_normal((B, GH)) * 0.5
+        xp = np.broadcast_to(xp0[None], (T, B, GH)).copy()
+        kw["xp0"] = dev(xp0)
+    hs_o, cs_o, acts_o = vo.rnn_forward(cellname, xp, U, h0, c0 if cellname == "LSTM" else None)
+
+    up = ops.pack_recurrent(dev(U), cell, dtype, 0)
+    hs = torch.zeros((T + 1, B, H), dtype=td, device=DEV)
+    cs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if cellname == "LSTM" else None
+    acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
+    h_last = torch.zeros((B, H), device=DEV)
+    ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
+                acts=acts, h_last=h_last, **kw)
+    torch.cuda.synchronize()
+    close(host(hs), hs_o, tol, "hs")
+    close(host(acts), acts_o, tol, "acts")
+    close(host(h_last), hs_o[-1], tol, "h_last")
+    if cs is not None:
+        close(host(cs), cs_o, tol, "cs")
+
+
+def test_rnn_forward_zero_initial_state_and_inference_mode():
+    """h0/c0 NULL = zeros; hs/cs/acts NULL = inference: only the final state is produced."""
+    rng, G, U, W, b, h0, c0 = _rnn_problem("LSTM", 64, 6, 16, seed=3)
+    xp = rng.standard_normal((6, 16, G * 64)) * 0.5
+    hs_o, _, _ = vo.rnn_forward("LSTM", xp, U, np.zeros((16, 64)), np.zeros((16, 64)))
+    h_last = torch.zeros((16, 64), device=DEV)
+    ops.rnn_fwd(hl.LSTM, hl.F32, 6, 16, 64, ops.pack_recurrent(dev(U), hl.LSTM, hl.F32, 0), xp=dev(xp), h_last=h_last)
+    torch.cuda.synchronize()
+    close(host(h_last), hs_o[-1], 3e-4)
+
+
+@pytest.mark.parametrize("cellname,cell", CELLS)
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False)])
+def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
+    T = 8
+    rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=11 + H)
+    GH = G * H
+    td = ops.torch_dtype(dtype)
+    rnd = (lambda a: host(dev(a, td))) if dtype == hl.BF16 else (lambda a: a)
+    xp = rng.standard_normal((T, B, GH)) * 0.5
+    hs_o, cs_o, acts_o = vo.rnn_forward(cellname, xp, U, h0, c0 if cellname == "LSTM" else None)
+    hs_o, acts_o = rnd(hs_o), rnd(acts_o)
+    if cs_o is not None:
+        cs_o = rnd(cs_o)
+    dext = rnd(rng.standard_normal((T, B, H)) * 0.1) if ext else None
+    dlast = rng.standard_normal((B, H)) * 0.1
+    da_o, dU_o, dh0_o, dc0_o = vo.rnn_backward(cellname, hs_o, cs_o, acts_o, U, dext, dlast)
+
+    ut = ops.pack_recurrent(dev(U), cell, dtype, 1)
+    da = torch.zeros((T, B, GH), dtype=td, device=DEV)
+    rh = torch.zeros((T, B, H), dtype=td, device=DEV)
+    dh0 = torch.zeros((B, H), device=DEV)
+    dc0 = torch.zeros((B, H), device=DEV)
+    ops.rnn_bwd(cell, dtype, T, B, H, ut, dev(hs_o, td), dev(cs_o, td) if cs_o is not None else None, dev(acts_o, td), da,
+                dhs_ext=dev(dext, td) if ext else None, dh_last=dev(dlast), rh=rh, dh0=dh0, dc0=dc0)
+    torch.cuda.synchronize()
+    close(host(da), da_o, tol, "da")
+    close(host(dh0), dh0_o, tol, "dh0")
+    if cellname == "LSTM":
+        close(host(dc0), dc0_o, tol, "dc0")
+    if cellname == "GRU":
+        close(host(rh), acts_o[:, :, H:2 * H] * hs_o[:-1], tol, "rh")
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(50, 61, 33), (300, 192, 256), (128, 128, 1000)])
+def test_gemm(ta, tb, dtype, tol, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    td = ops.torch_dtype(dtype)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    bias = rng.standard_normal((N,))
+    Ad, Bd = dev(A, td), dev(B, td)
+    A, B = host(Ad), host(Bd)
+    want = (A.T if ta else A) @ (B.T if tb else B)
+    C = torch.zeros((M, N), device=DEV)
+    ops.gemm(Ad, Bd, C, M, N, K, trans_a=ta, trans_b=tb, bias=dev(bias), act=hl.ACT_TANH, alpha=0.05)
+    torch.cuda.synchronize()
+    close(host(C), np.tanh(0.05 * want + bias), tol * 10, "tanh epilogue")
+    # split-K atomic accumulate into an f32 C that already holds data
+    C2 = torch.ones((M, N), device=DEV)
+    ops.gemm(Ad, Bd, C2, M, N, K, trans_a=ta, trans_b=tb, accumulate=True, split_k=3)
+    torch.cuda.synchronize()
+    close(host(C2), 1.0 + want, tol * np.sqrt(K), "split-k")
+    if dtype == hl.BF16:
+        C3 = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(Ad, Bd, C3, M, N, K, trans_a=ta, trans_b=tb)
+        torch.cuda.synchronize()
+        close(host(C3), want, 2e-2 * np.sqrt(K), "bf16 out")
+
+
+def test_gemm_leading_dimensions_and_column_blocks():
+    """GRU candidate-kernel gradient: dU[:, 2H:] = rh^T da[:, 2H:] written into a column block of dU."""
+    rng = np.random.default_rng(5)
+    R, H = 200, 64
+    rh, da = rng.standard_normal((R, H)), rng.standard_normal((R, 3 * H))
+    dU = torch.zeros((H, 3 * H), device=DEV)
+    rh_d, da_d = dev(rh), dev(da)
+    ops.gemm(rh_d, da_d[:, 2 * H:], dU[:, 2 * H:], H, H, R, trans_a=True, ldb=3 * H, ldc=3 * H, accumulate=True, split_k=2)
+    torch.cuda.synchronize()
+    want = np.zeros((H, 3 * H))
+    want[:, 2 * H:] = rh.T @ da[:, 2 * H:]
+    close(host(dU), want, 1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(hl.F32, 1e-5), (hl.BF16, 1e-2)])
+def test_gemm_onehot_table_gradient(dtype, tol):
+    rng = np.random.default_rng(9)
+    R, D, N = 700, 61, 192
+    idx = rng.integers(0, D, (R,))
+    da = rng.standard_normal((R, N))
+    dad = dev(da, ops.torch_dtype(dtype))
+    da = host(dad)
+    want = np.zeros((D, N))
+    np.add.at(want, idx, da)
+    out = torch.zeros((D, N), device=DEV)
+    ops.gemm(dev(idx, torch.uint8), dad, out, D, N, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=4)
+    torch.cuda.synchronize()
+    close(host(out), want, tol * 10)
+
+
+@pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
+@pytest.mark.parametrize("N", [61, 16, 3])
+def test_softmax_head(dtype, tol, N):
+    rng = np.random.default_rng(N)
+    R, H = 333, 64
+    td = ops.torch_dtype(dtype)
+    hs = dev(rng.standard_normal((R, H)), td)
+    W = rng.standard_normal((H, N)) * 0.3
+    bias = rng.standard_normal((N,)) * 0.1
+    tgt = rng.integers(0, N, (R,))
+    tgt[5] = 255                                  # all-zero target row
+    rw = rng.random((R,)) / R
+    NP = ops.head_np(N)
+    wt = torch.zeros((NP, H), dtype=td, device=DEV)
+    ops.transpose_convert(dev(W), wt, n_pad=NP)
+    Wq = host(wt)[:N].T
+    logits = host(hs) @ Wq + bias
+    p = vo.softmax(logits)
+    y = np.zeros((R, N))
+    ok = tgt < N
+    y[np.nonzero(ok)[0], tgt[ok]] = 1
+    want_loss = np.sum(rw * vo._cce(p, y) * ok)
+    want_dl = 0.7 * rw[:, None] * vo._cce_grad_logits(p, y)
+    probs = torch.zeros((R, N), device=DEV)
+    am = torch.zeros((R,), dtype=torch.uint8, device=DEV)
+    dl = torch.zeros((R, NP), dtype=td, device=DEV)
+    sc = torch.zeros((2,), device=DEV)
+    ops.head(0, dtype, R, H, N, hs, wt, dev(bias), target_idx=dev(tgt, torch.uint8), row_weight=dev(rw), grad_scale=0.7,
+             probs=probs, argmax=am, dlogits=dl, scalars=sc)
+    torch.cuda.synchronize()
+    close(host(probs), p, tol, "probs")
+    close(host(dl)[:, :N], want_dl, tol, "dlogits")
+    assert np.all(host(dl)[:, N:] == 0)
+    close(host(sc)[0], want_loss, tol * 5, "loss")
+    # argmax is bit-exact w.r.t. the probabilities the kernel itself returned (first maximum)
+    assert np.array_equal(am.cpu().numpy(), np.argmax(probs.cpu().numpy(), axis=1).astype(np.uint8))
+    hits = np.sum(np.argmax(probs.cpu().numpy(), 1) == np.where(ok, tgt, 0))
+    assert host(sc)[1] == hits
+
+
+@pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
+def test_sigmoid_head(dtype, tol):
+    rng = np.random.default_rng(2)
+    R, H = 150, 64
+    td = ops.torch_dtype(dtype)
+    hs = dev(rng.standard_normal((R, H)), td)
+    W = rng.standard_normal((H, 1)) * 0.3
+    bias = np.array([0.1])
+    y = np.where(rng.random(R) < 0.5, 0.0, 0.5 + 0.5 * rng.random(R))
+    y[:10] = 1.0
+    rw = rng.random((R,)) / R
+    wt = torch.zeros((16, H), dtype=td, device=DEV)
+    ops.transpose_convert(dev(W), wt, n_pad=16)
+    p = vo.sigmoid(host(hs) @ host(wt)[:1].T + bias)[:, 0]
+    probs = torch.zeros((R,), device=DEV)
+    dl = torch.zeros((R, 16), dtype=td, device=DEV)
+    sc = torch.zeros((2,), device=DEV)
+    ops.head(1, dtype, R, H, 1, hs, wt, dev(bias), target_val=dev(y), row_weight=dev(rw), grad_scale=1.0, probs=probs,
+             dlogits=dl, scalars=sc)
+    torch.cuda.synchronize()
+    close(host(probs), p, tol)
+    close(host(dl)[:, 0], rw * 2 * (p - y) * p * (1 - p), tol)
+    close(host(sc)[0], np.sum(rw * (p - y) ** 2), tol * 5)
+    assert host(sc)[1] == np.sum(np.round(probs.cpu().numpy()) == y.astype(np.float32))
+
+
+def test_latent_block():
+    rng = np.random.default_rng(4)
+    B, Z, Cn = 37, 24, 4
+    mu, lv = rng.standard_normal((B, Z)) * 0.5, rng.standard_normal((B, Z)) * 0.3
+    eps = rng.standard_normal((B, Z)) * 0.01
+    tgt = rng.integers(0, Cn, (B,))
+    beta, pm, ps, sw = 0.1, 0.2, 1.5, 0.3
+    z_o = mu + np.exp(lv / 2) * eps
+    kl = np.mean(beta * (-0.5 * np.sum(1 + lv - 2 * np.log(ps) - ((mu - pm) ** 2 + np.exp(lv)) / ps ** 2, 1)))
+    p = vo.softmax(z_o[:, :Cn])
+    y = np.eye(Cn)[tgt]
+    ce = np.mean(vo._cce(p, y))
+    z = torch.zeros((B, Z), device=DEV)
+    sp = torch.zeros((B, Cn), device=DEV)
+    sc = torch.zeros((3,), device=DEV)
+    ops.latent_fwd(B, Z, Cn, beta, pm, ps, 1.0 / B, dev(mu), dev(lv), dev(eps), z, sc, style_target=dev(tgt, torch.uint8),
+                   style_probs=sp)
+    torch.cuda.synchronize()
+    close(host(z), z_o, 1e-5)
+    close(host(sp), p, 1e-5)
+    close(host(sc)[:2], [kl, ce], 1e-4)
+    assert host(sc)[2] == np.sum(np.argmax(p, 1) == tgt)
+    dz = rng.standard_normal((B, Z)) * 0.1
+    dzt = dz.copy()
+    dzt[:, :Cn] += sw * vo._cce_grad_logits(p, y) / B
+    dmu_o = dzt + beta * (mu - pm) / ps ** 2 / B
+    dlv_o = dzt * eps * 0.5 * np.exp(lv / 2) + beta * (-0.5) * (1 - np.exp(lv) / ps ** 2) / B
+    dmu, dlv = torch.zeros((B, Z), device=DEV), torch.zeros((B, Z), device=DEV)
+    ops.latent_bwd(B, Z, Cn, beta, pm, ps, sw, 1.0 / B, dev(mu), dev(lv), dev(eps), dev(dz), dmu, dlv, style_probs=sp,
+                   style_target=dev(tgt, torch.uint8))
+    torch.cuda.synchronize()
+    close(host(dmu), dmu_o, 1e-5)
+    close(host(dlv), dlv_o, 1e-5)
+
+
+def test_reductions_and_elementwise():
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((1000, 192))
+    out = torch.zeros((192,), device=DEV)
+    ops.colsum(dev(X), 1000, 192, out)
+    Xt = rng.standard_normal((11, 500))
+    out2 = torch.zeros((500,), device=DEV)
+    ops.sum_over_time(dev(Xt, torch.bfloat16), 11, 500, out2)
+    y, dy = np.tanh(rng.standard_normal(777)), rng.standard_normal(777)
+    dx = torch.zeros((777,), device=DEV)
+    ops.tanh_bwd(dev(y), dev(dy), dx)
+    W, b = rng.standard_normal((7, 48)), rng.standard_normal(48)
+    tab = torch.zeros((7, 48), device=DEV)
+    ops.make_table(dev(W), dev(b), tab)
+    torch.cuda.synchronize()
+    close(host(out), X.sum(0), 1e-4)
+    close(host(out2), host(dev(Xt, torch.bfloat16)).sum(0), 1e-5)
+    close(host(dx), dy * (1 - y * y), 1e-6)
+    close(host(tab), W + b, 1e-6)
+
+
+def test_keras_adam_and_rmsprop_match_oracle():
+    rng = np.random.default_rng(8)
+    n = 5000
+    p0, m = rng.standard_normal(n), vo.OracleVAE(vo.make_cfg(lr=1e-3))
+    p_o = {"w": p0.copy()}
+    st = m.new_opt_state(p_o)
+    p = dev(p0)
+    mm, vv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    t_done = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for t in range(1, 4):
+        g = rng.standard_normal(n)
+        m.opt_step(p_o, {"w": g}, st)
+        if t < 3:
+            ops.adam_step(p, dev(g), mm, vv, 1e-3, t)
+            t_done += 1
+        else:
+            ops.adam_step_dev(p, dev(g), mm, vv, 1e-3, t_done)
+    torch.cuda.synchronize()
+    close(host(p), p_o["w"], 1e-5)
+    assert int(t_done.item()) == 3
+    m2 = vo.OracleVAE(vo.make_cfg(lr=1e-3, optimizer="RMSprop"))
+    p_o = {"w": p0.copy()}
+    st = m2.new_opt_state(p_o)
+    p, vv = dev(p0), torch.zeros(n, device=DEV)
+    g = rng.standard_normal(n)
+    m2.opt_step(p_o, {"w": g}, st)
+    ops.rmsprop_step(p, dev(g), vv, 1e-3)
+    torch.cuda.synchronize()
+    close(host(p), p_o["w"], 1e-5)
+
+
+def test_rejects_bad_arguments_without_launching():
+    lib = hl.load()
+    assert lib.mvae_rnn_fwd(None, None) == -1
+    a = hl.RnnFwdArgs()
+    assert lib.mvae_rnn_fwd(a, None) == -1
+    with pytest.raises(RuntimeError):
+        ops.rnn_fwd(hl.GRU, hl.F32, 4, 4, 96, torch.zeros(8, device=DEV), xp=torch.zeros(8, device=DEV))   # H=96 unsupported
