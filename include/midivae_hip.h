@@ -72,6 +72,8 @@ typedef struct {
     void* cs;              /* LSTM: (T+1,B,H) dtype or NULL                                                   */
     void* acts;            /* (T,B,G*H) dtype post-activation gates, or NULL (inference)                      */
     float* h_last;         /* (B,H) or NULL                                                                   */
+    int32_t h0_ld;         /* row stride of h0 / c0 in floats (0 = H): states may be column blocks of a wider buffer */
+    int32_t h_last_ld;     /* row stride of h_last (0 = H)                                                     */
 } mvae_rnn_fwd_args;
 int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
 
@@ -90,6 +92,8 @@ typedef struct {
     void* rh;              /* GRU: (T,B,H) dtype r_t*h_{t-1} (left operand of the candidate-kernel gradient)  */
     float* dh0;            /* (B,H) or NULL                                                                   */
     float* dc0;            /* LSTM: (B,H) or NULL                                                             */
+    int32_t dh_last_ld;    /* row stride of dh_last (0 = H)                                                   */
+    int32_t dh0_ld;        /* row stride of dh0 / dc0 (0 = H)                                                 */
 } mvae_rnn_bwd_args;
 int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream);
 
@@ -169,6 +173,7 @@ typedef struct {
     float* z;                     /* (B,Z) out                                                               */
     float* style_probs;           /* (B,C) out or NULL                                                       */
     float* scalars;               /* (3): += inv_batch*sum_b kl_b, += sum_b rw*style CE, += style argmax hits */
+    int32_t ldz;                  /* row stride of z (0 = Z): z may be the left block of [z | history]       */
 } mvae_latent_fwd_args;
 int mvae_latent_fwd(const mvae_latent_fwd_args* a, void* stream);
 
@@ -184,6 +189,7 @@ typedef struct {
     const float* style_row_weight;
     float* dmu;                   /* (B,Z)                                                                   */
     float* dlogvar;               /* (B,Z)                                                                   */
+    int32_t lddz;                 /* row stride of dz (0 = Z)                                                */
 } mvae_latent_bwd_args;
 int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
 

@@ -19,14 +19,13 @@ __global__ __launch_bounds__(256) void latent_fwd_k(const mvae_latent_fwd_args a
         const float mu = a.mu[(size_t)b * Z + j], lv = a.logvar[(size_t)b * Z + j];
         const float d = mu - a.prior_mean;
         kl += 1.0f + lv - plv - (d * d + expf(lv)) / pvar;
-        a.z[(size_t)b * Z + j] = mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + j];
+        a.z[(size_t)b * (a.ldz ? a.ldz : Z) + j] = mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + j];
     }
     kl = wave_sum(kl);
     if (l == 0) {
         atomicAdd(a.scalars, a.inv_batch * a.beta * (-0.5f) * kl);
         if (a.style_target && a.C > 0) {
             const int C = a.C;
-            const float* zr = a.z + (size_t)b * Z;    // written by this wave's lanes j < C; C <= 64 -> same wave
             float mx = -INFINITY;
             for (int c = 0; c < C; ++c) {
                 const float mu = a.mu[(size_t)b * Z + c], lv = a.logvar[(size_t)b * Z + c];
@@ -37,7 +36,6 @@ __global__ __launch_bounds__(256) void latent_fwd_k(const mvae_latent_fwd_args a
                 const float mu = a.mu[(size_t)b * Z + c], lv = a.logvar[(size_t)b * Z + c];
                 sum += expf(mu + expf(0.5f * lv) * a.eps[(size_t)b * Z + c] - mx);
             }
-            (void)zr;
             const int tg = a.style_target[b];
             float pt = 0.0f, pm = -1.0f;
             int am = 0;
@@ -61,7 +59,7 @@ __global__ void latent_bwd_k(const mvae_latent_bwd_args a) {
     const float pvar = a.prior_std * a.prior_std;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / a.Z), j = (int)(e % a.Z);
-        float dz = a.dz[e];
+        float dz = a.dz[(size_t)b * (a.lddz ? a.lddz : a.Z) + j];
         if (a.style_probs && a.style_target && j < a.C) {
             const int tg = a.style_target[b];
             if (tg < a.C) {

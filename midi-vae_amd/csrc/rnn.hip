@@ -75,14 +75,15 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
     int ub[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) ub[n] = w * (H / 4) + n * 16 + q * 4;
+    const int ld0 = a.h0_ld ? a.h0_ld : H, ldl = a.h_last_ld ? a.h_last_ld : H;
 
     // ---- initial state -------------------------------------------------------------------------------
     f32x4 hreg[NT], creg[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)bb * H + ub[n]) : z4;
-        creg[n] = (CELL == MVAE_LSTM && a.c0) ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)bb * H + ub[n]) : z4;
+        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)bb * ld0 + ub[n]) : z4;
+        creg[n] = (CELL == MVAE_LSTM && a.c0) ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)bb * ld0 + ub[n]) : z4;
         st<WT>::store4(hbuf + r * LDH + ub[n], hreg[n]);
         if (valid) {
             if (hs) st<WT>::store4(hs + (size_t)b * H + ub[n], hreg[n]);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
     }
     if (a.h_last && valid) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * H + ub[n]) = hreg[n];
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hreg[n];
     }
 }
 
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bb * H + ub[n]) : z4;
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bb * (a.dh_last_ld ? a.dh_last_ld : H) + ub[n]) : z4;
         dc[n] = z4;
     }
     WT* drow = dabuf + r * LDA;
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
     if (valid) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * H + ub[n]) = dh[n];
-            if (CELL == MVAE_LSTM && a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * H + ub[n]) = dc[n];
+            const int ldd = a.dh0_ld ? a.dh0_ld : H;
+            if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub[n]) = dh[n];
+            if (CELL == MVAE_LSTM && a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * ldd + ub[n]) = dc[n];
         }
     }
 }

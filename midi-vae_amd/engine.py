@@ -1,0 +1,656 @@
+"""Device engine of the MIDI-VAE train / inference step (one GPU, one process).
+
+Owns every resident buffer in HBM (parameters + optimizer state, packed weight copies, saved activations, gradient
+workspaces, input staging) and sequences the C-ABI kernels of libmidivae_hip.so for
+    train_step   = what ``autoencoder.fit`` does per minibatch     (reference vae_training.py:804-809)
+    eval_step    = ``autoencoder.evaluate`` per minibatch           (reference vae_training.py:300)
+    encode       = ``encoder.predict``                              (reference vae_training.py:289,795)
+    decode       = ``decoder.predict`` (+ fused argmax decode)      (reference vae_evaluation.py:2482-2483)
+torch supplies device memory, streams / events and graph capture only; every arithmetic operation of the step is a
+kernel of the in-tree HIP library.  There is no CPU fallback: constructing an Engine without the library or without
+a GPU raises.
+
+Graph structure and the semantics it follows are documented in DESIGN.md; reference citations are on the methods.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import hiplib as hl
+from . import ops
+from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
+
+# slots of the scalar accumulator
+S_NOTES_LOSS, S_NOTES_HITS, S_INSTR_LOSS, S_INSTR_HITS, S_VEL_LOSS, S_VEL_HITS, S_KL, S_STYLE_LOSS, S_STYLE_HITS = range(9)
+N_SCALARS = 16
+
+
+class _Rec(object):
+    """One recurrent layer: its parameter prefix, geometry, input mode and (per batch size) its buffers."""
+
+    def __init__(self, prefix, T, xmode, K, init_block=None, lower=None):
+        self.prefix, self.T, self.xmode, self.K = prefix, T, xmode, K
+        self.init_block = init_block      # first column block of dec.init holding this cell's initial state(s)
+        self.lower = lower                # the layer whose h sequence feeds this one (X_DENSE)
+
+
+class Engine(object):
+    def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
+                 training: bool = True, use_graphs: bool = False):
+        hl.load()          # raises HipLibraryMissing - no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("the MIDI-VAE engine needs an MI355X (torch.cuda.is_available() is False)")
+        self.spec, self.device, self.training = spec, torch.device(device), training
+        self.kind = {"bf16": hl.BF16, "f32": hl.F32}[dtype]
+        self.dt = ops.torch_dtype(self.kind)
+        self.cell = hl.CELL_CODE[spec.cell]
+        self.maxB = int(max_batch)
+        self.layout = ParamLayout.build(spec)
+        self.use_graphs = use_graphs
+        self._graphs = {}
+        L, dev = self.layout, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.params = torch.zeros(L.total, **f32)
+        self.grads = torch.zeros(L.total, **f32)
+        self.opt_m = torch.zeros(L.total, **f32)
+        self.opt_v = torch.zeros(L.total, **f32)
+        self.t_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.P = {n: L.view(self.params, n) for n in L.entries}
+        self.G = {n: L.view(self.grads, n) for n in L.entries}
+        self.scal = torch.zeros(N_SCALARS, **f32)
+        self.set_params(init_params(spec, seed))
+        self._build_graph_description()
+        self._alloc(self.maxB)
+        self._views_cache = {}
+
+    # ------------------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------------------
+    def set_params(self, named: dict):
+        self.params.copy_(torch.from_numpy(self.layout.pack(named)).to(self.device))
+        self._weights_dirty = True
+
+    def get_params(self) -> "OrderedDict[str, np.ndarray]":
+        return self.layout.unpack(self.params.cpu().numpy())
+
+    def get_grads(self) -> "OrderedDict[str, np.ndarray]":
+        return self.layout.unpack(self.grads.cpu().numpy())
+
+    def reset_optimizer(self):
+        self.opt_m.zero_()
+        self.opt_v.zero_()
+        self.t_done.zero_()
+
+    # ------------------------------------------------------------------------------------------------------
+    # static description of the recurrent layers
+    # ------------------------------------------------------------------------------------------------------
+    def _build_graph_description(self):
+        s = self.spec
+        self.enc_notes = []
+        for l in range(s.Le):
+            self.enc_notes.append(_Rec("enc.notes.%d" % l, s.T, hl.X_INDEX if l == 0 else hl.X_DENSE,
+                                       s.Din if l == 0 else s.H, lower=self.enc_notes[-1] if l else None))
+        self.enc_instr = _Rec("enc.instr", s.V, hl.X_INDEX, s.ID) if s.meta_instrument else None
+        self.enc_vel = _Rec("enc.vel", s.T, hl.X_SCALAR, 1) if s.meta_velocity else None
+        blocks = dec_init_blocks(s)
+        self.n_init = len(blocks)
+        self.dec_notes = []
+        for l in range(s.Ld):
+            self.dec_notes.append(_Rec("dec.notes.%d" % l, s.T, hl.X_CONST if l == 0 else hl.X_DENSE,
+                                       s.Dout if l == 0 else s.H, init_block=blocks.index("dec.notes.init.%d.0" % l),
+                                       lower=self.dec_notes[-1] if l else None))
+        self.dec_instr = (_Rec("dec.instr.cell", s.V, hl.X_CONST, s.ID, init_block=blocks.index("dec.instr.init.0"))
+                          if s.meta_instrument else None)
+        self.dec_vel = (_Rec("dec.vel.cell", s.T, hl.X_CONST, 1, init_block=blocks.index("dec.vel.init.0"))
+                        if s.meta_velocity else None)
+        self.all_rec = (self.enc_notes + [r for r in (self.enc_instr, self.enc_vel) if r] + self.dec_notes +
+                        [r for r in (self.dec_instr, self.dec_vel) if r])
+        self.ncat = 1 + int(s.meta_instrument) + int(s.meta_velocity)
+        self.has_pack = s.meta_instrument or s.meta_velocity
+
+    # ------------------------------------------------------------------------------------------------------
+    # buffers (sized for max_batch; smaller batches reinterpret the same storage with a smaller row stride)
+    # ------------------------------------------------------------------------------------------------------
+    def _alloc(self, B):
+        s, dev, dt = self.spec, self.device, self.dt
+        H, GH, Z, T, V = s.H, s.GH, s.Z, s.T, s.V
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        st = self.store = {}
+
+        def buf(name, n, **kw):
+            st[name] = torch.zeros(int(n), **kw)
+
+        esz = dict(dtype=dt, device=dev)
+        for r in self.all_rec:
+            p = r.prefix
+            buf(p + ".u_pack", GH * H, **esz)
+            buf(p + ".ut_pack", GH * H, **esz)
+            buf(p + ".hs", (r.T + 1) * B * H, **esz)
+            if s.cell == "LSTM":
+                buf(p + ".cs", (r.T + 1) * B * H, **esz)
+            if self.training:
+                buf(p + ".acts", r.T * B * GH, **esz)
+                buf(p + ".da", r.T * B * GH, **esz)
+                if s.cell == "GRU":
+                    buf(p + ".rh", r.T * B * H, **esz)
+            if r.xmode == hl.X_INDEX:
+                buf(p + ".table", r.K * GH, **f32)
+            elif r.xmode == hl.X_DENSE:
+                buf(p + ".xp", r.T * B * GH, **esz)
+                buf(p + ".wt", GH * H, **esz)            # W^T (GH,H): forward projection, k-contiguous
+                if self.training:
+                    buf(p + ".wc", H * GH, **esz)        # W (H,GH) in dtype: backward dx, k-contiguous
+                    buf(p + ".dx", r.T * B * H, **esz)   # gradient w.r.t. the lower layer's h sequence
+            elif r.xmode == hl.X_CONST:
+                buf(p + ".xp0", B * GH, **f32)
+                if self.training:
+                    buf(p + ".dxp0", B * GH, **f32)
+        # heads
+        self.np_notes, self.np_instr = ops.head_np(s.Dout), ops.head_np(s.ID)
+        buf("notes.wt", self.np_notes * H, **esz)
+        buf("notes.argmax", T * B, **u8)
+        if self.training:
+            buf("notes.dl", T * B * self.np_notes, **esz)
+            buf("notes.dhs", T * B * H, **esz)
+        if s.meta_instrument:
+            buf("instr.wt", self.np_instr * H, **esz)
+            buf("instr.argmax", V * B, **u8)
+            if self.training:
+                buf("instr.dl", V * B * self.np_instr, **esz)
+                buf("instr.dhs", V * B * H, **esz)
+        if s.meta_velocity:
+            buf("vel.wt", 16 * H, **esz)
+            buf("vel.round", T * B, **u8)
+            if self.training:
+                buf("vel.dl", T * B * 16, **esz)
+                buf("vel.dhs", T * B * H, **esz)
+        # encoder tail / latent / decoder initial states (all f32, (B, .) row-major)
+        for name, n in (("cat", self.ncat * H), ("pack", H), ("extra", H), ("mu", Z), ("lv", Z), ("zh", s.zin),
+                        ("style_p", max(s.C, 1)), ("S", self.n_init * H)):
+            buf(name, B * n, **f32)
+        if self.training:
+            for name, n in (("dS", self.n_init * H), ("dzh", s.zin), ("dmu", Z), ("dlv", Z), ("dtail", H),
+                            ("dtail2", H), ("dcat", self.ncat * H)):
+                buf(name, B * n, **f32)
+        # inputs
+        buf("in.x_idx", T * B, **u8)
+        buf("in.y_idx", T * B, **u8)
+        buf("in.i_idx", V * B, **u8)
+        buf("in.vel", T * B, **f32)
+        buf("in.eps", B * Z, **f32)
+        buf("in.c_idx", B, **u8)
+        buf("in.rw_notes", T * B, **f32)
+        buf("in.rw_instr", V * B, **f32)
+        buf("in.rw_vel", T * B, **f32)
+        buf("in.rw_style", B, **f32)
+        buf("in.start_notes", B * s.Dout, **f32)
+        buf("in.start_instr", B * s.ID, **f32)
+        buf("in.start_vel", B, **f32)
+        # inference outputs on request
+        buf("out.notes_p", T * B * s.Dout, **f32)
+        buf("out.instr_p", V * B * s.ID, **f32)
+        buf("out.vel_p", T * B, **f32)
+
+    def bytes_resident(self):
+        return (sum(t.numel() * t.element_size() for t in self.store.values()) +
+                4 * self.params.numel() * 4)
+
+    def _v(self, name, *shape):
+        """View of buffer ``name`` with the given shape (the storage is sized for max_batch)."""
+        n = int(np.prod(shape))
+        return self.store[name][:n].view(*shape)
+
+    # ------------------------------------------------------------------------------------------------------
+    # input staging (host NumPy -> device).  Layout conversion to time-major happens here, once, on the host.
+    # ------------------------------------------------------------------------------------------------------
+    def _up(self, name, arr, tdtype):
+        a = np.ascontiguousarray(arr)
+        t = torch.from_numpy(a).to(self.device, non_blocking=False).to(tdtype)
+        self.store[name][:t.numel()].copy_(t.reshape(-1))
+
+    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None):
+        """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; eps (B,Z) f32 ALREADY scaled by
+        epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
+        B = x_idx.shape[0]
+        self._up("in.x_idx", np.asarray(x_idx, np.uint8).T, torch.uint8)
+        if self.spec.meta_instrument:
+            self._up("in.i_idx", np.asarray(i_idx, np.uint8).T, torch.uint8)
+        if self.spec.meta_velocity:
+            self._up("in.vel", np.asarray(vel, np.float32).T, torch.float32)
+        if eps is None:
+            self._v("in.eps", B, self.spec.Z).zero_()
+        else:
+            self._up("in.eps", np.asarray(eps, np.float32), torch.float32)
+        return B
+
+    def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None):
+        s = self.spec
+        zh = self._v("zh", B, s.zin)
+        if s.history:
+            if hist is None:
+                zh[:, s.Z:].zero_()
+            else:
+                zh[:, s.Z:].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
+        if z is not None:
+            zh[:, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
+        for name, val, shape in (("in.start_notes", start_notes, (B, s.Dout)), ("in.start_instr", start_instr, (B, s.ID)),
+                                 ("in.start_vel", start_vel, (B,))):
+            if val is None:
+                self._v(name, *shape).zero_()
+            else:
+                self._up(name, np.asarray(val, np.float32).reshape(shape), torch.float32)
+
+    def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None):
+        """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
+        (score*w / mean(w != 0), then the mean over the axes) into one factor per row."""
+        s = self.spec
+        T, V = s.T, s.V
+        self._up("in.y_idx", np.asarray(y_idx, np.uint8).T, torch.uint8)
+
+        def norm(w, n_other):
+            w = np.asarray(w, np.float64)
+            nz = np.mean(w != 0)
+            return w / (nz * w.size * n_other)
+
+        wn = np.ones((B, T)) if w_notes is None else w_notes
+        self._up("in.rw_notes", norm(wn, 1).T, torch.float32)
+        if s.meta_instrument:
+            wi = np.ones((B,)) if w_instr is None else w_instr
+            self._up("in.rw_instr", np.broadcast_to(norm(wi, V)[None, :], (V, B)), torch.float32)
+        if s.meta_velocity:
+            wv = np.ones((B,)) if w_vel is None else w_vel
+            self._up("in.rw_vel", np.broadcast_to(norm(wv, T)[None, :], (T, B)), torch.float32)
+        if s.style:
+            ws = np.ones((B,)) if w_style is None else w_style
+            self._up("in.rw_style", norm(ws, 1), torch.float32)
+            self._up("in.c_idx", np.asarray(c_idx, np.uint8), torch.uint8)
+
+    # ------------------------------------------------------------------------------------------------------
+    # weight preparation: packed / transposed / converted copies the kernels consume (once per optimizer step)
+    # ------------------------------------------------------------------------------------------------------
+    def prepare_weights(self):
+        s, P = self.spec, self.P
+        for r in self.all_rec:
+            p = r.prefix
+            ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 0, out=self.store[p + ".u_pack"])
+            if self.training:
+                ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 1, out=self.store[p + ".ut_pack"])
+            if r.xmode == hl.X_INDEX:
+                ops.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+            elif r.xmode == hl.X_DENSE:
+                ops.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
+                if self.training:
+                    ops.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
+        ops.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
+        if s.meta_instrument:
+            ops.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
+        if s.meta_velocity:
+            ops.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+        self._weights_dirty = False
+
+    # ------------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------------
+    def _rec_forward(self, r, B, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None, start=None):
+        s, P, p = self.spec, self.P, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        kw = {}
+        if r.xmode == hl.X_INDEX:
+            kw.update(idx=idx, table=self._v(p + ".table", r.K, GH))
+        elif r.xmode == hl.X_SCALAR:
+            kw.update(xs=xs, w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
+        elif r.xmode == hl.X_CONST:
+            xp0 = self._v(p + ".xp0", B, GH)
+            ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])      # start W + b (Appendix A.6)
+            kw.update(xp0=xp0)
+        else:
+            lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:]
+            xp = self._v(p + ".xp", T, B, GH)
+            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, T * B, GH, H, trans_b=True, bias=P[p + ".b"])
+            kw.update(xp=xp)
+        ops.rnn_fwd(self.cell, self.kind, T, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
+                    hs=self._v(p + ".hs", T + 1, B, H),
+                    cs=self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None,
+                    acts=self._v(p + ".acts", T, B, GH) if self.training else None,
+                    h_last=h_last, h_last_ld=h_last_ld, **kw)
+
+    def encoder_forward(self, B):
+        """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502."""
+        s, P = self.spec, self.P
+        H, Z = s.H, s.Z
+        cat = self._v("cat", B, self.ncat * H)
+        ldc = self.ncat * H
+        for i, r in enumerate(self.enc_notes):
+            last = i == len(self.enc_notes) - 1
+            self._rec_forward(r, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H] if last else None,
+                              h_last_ld=ldc if last else 0)
+        k = 1
+        if s.meta_instrument:
+            self._rec_forward(self.enc_instr, B, idx=self._v("in.i_idx", s.V, B), h_last=cat[:, k * H:(k + 1) * H],
+                              h_last_ld=ldc)
+            k += 1
+        if s.meta_velocity:
+            self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc)
+        h = cat
+        if self.has_pack:
+            pk = self._v("pack", B, H)
+            ops.gemm(cat, P["enc.pack.W"], pk, B, H, self.ncat * H, bias=P["enc.pack.b"], act=hl.ACT_TANH)
+            h = pk
+        if s.extra_layer:
+            ex = self._v("extra", B, H)
+            ops.gemm(h, P["enc.extra.W"], ex, B, H, H, bias=P["enc.extra.b"], act=hl.ACT_TANH)
+            h = ex
+        self._tail = h
+        h1w = H // 2 if s.split else H
+        h2 = h[:, h1w:] if s.split else h
+        mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
+        ops.gemm(h, P["enc.zmean.W"], mu, B, Z, h1w, lda=H, bias=P["enc.zmean.b"])
+        ops.gemm(h2, P["enc.zlogvar.W"], lv, B, Z, H - h1w if s.split else H, lda=H, bias=P["enc.zlogvar.b"])
+        zh = self._v("zh", B, s.zin)
+        ops.latent_fwd(B, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / B, mu, lv,
+                       self._v("in.eps", B, Z), zh, self.scal[S_KL:S_KL + 3],
+                       style_target=self._v("in.c_idx", B) if (s.style and self._have_targets) else None,
+                       style_row_weight=self._v("in.rw_style", B) if (s.style and self._have_targets) else None,
+                       style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
+
+    def decoder_forward(self, B, want_probs=False):
+        """reference vae_definition.py:519-645 (decoder heads) + losses :332-441 when targets are staged."""
+        s, P = self.spec, self.P
+        H, T, V = s.H, s.T, s.V
+        zh = self._v("zh", B, s.zin)
+        S = self._v("S", B, self.n_init * H)
+        ops.gemm(zh, P["dec.init.W"], S, B, self.n_init * H, s.zin, bias=P["dec.init.b"], act=hl.ACT_TANH)
+        ldS = self.n_init * H
+
+        def states(r):
+            k = r.init_block
+            h0 = S[:, k * H:(k + 1) * H]
+            c0 = S[:, (k + 1) * H:(k + 2) * H] if s.cell == "LSTM" else None
+            return dict(h0=h0, c0=c0, h0_ld=ldS)
+
+        tg = self._have_targets
+        for r in self.dec_notes:
+            self._rec_forward(r, B, start=self._v("in.start_notes", B, s.Dout), **states(r))
+        top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
+        ops.head(0, self.kind, T * B, H, s.Dout, top, self._v("notes.wt", self.np_notes, H), P["dec.notes.out.b"],
+                 target_idx=self._v("in.y_idx", T * B) if tg else None,
+                 row_weight=self._v("in.rw_notes", T * B) if tg else None, grad_scale=1.0,
+                 probs=self._v("out.notes_p", T * B, s.Dout) if want_probs else None,
+                 argmax=self._v("notes.argmax", T * B),
+                 dlogits=self._v("notes.dl", T * B, self.np_notes) if (self.training and tg) else None,
+                 scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2])
+        if s.meta_instrument:
+            r = self.dec_instr
+            self._rec_forward(r, B, start=self._v("in.start_instr", B, s.ID), **states(r))
+            top = self._v(r.prefix + ".hs", V + 1, B, H)[1:]
+            ops.head(0, self.kind, V * B, H, s.ID, top, self._v("instr.wt", self.np_instr, H), P["dec.instr.out.b"],
+                     target_idx=self._v("in.i_idx", V * B) if tg else None,
+                     row_weight=self._v("in.rw_instr", V * B) if tg else None, grad_scale=s.w_instr,
+                     probs=self._v("out.instr_p", V * B, s.ID) if want_probs else None,
+                     argmax=self._v("instr.argmax", V * B),
+                     dlogits=self._v("instr.dl", V * B, self.np_instr) if (self.training and tg) else None,
+                     scalars=self.scal[S_INSTR_LOSS:S_INSTR_LOSS + 2])
+        if s.meta_velocity:
+            r = self.dec_vel
+            self._rec_forward(r, B, start=self._v("in.start_vel", B, 1), **states(r))
+            top = self._v(r.prefix + ".hs", T + 1, B, H)[1:]
+            ops.head(1, self.kind, T * B, H, 1, top, self._v("vel.wt", 16, H), P["dec.vel.out.b"],
+                     target_val=self._v("in.vel", T * B) if tg else None,
+                     row_weight=self._v("in.rw_vel", T * B) if tg else None, grad_scale=s.w_vel,
+                     probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
+                     dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
+                     scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2])
+
+    # ------------------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------------------
+    def _split_k(self, K):
+        return int(min(64, max(1, K // 2048)))
+
+    def _rec_backward(self, r, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0, idx=None,
+                      xs=None, start=None):
+        """BPTT of one layer + its parameter gradients.  Returns the gradient w.r.t. the lower layer's h sequence
+        for X_DENSE layers (None otherwise)."""
+        s, P, G, p = self.spec, self.P, self.G, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        R = T * B
+        hs = self._v(p + ".hs", T + 1, B, H)
+        da = self._v(p + ".da", T, B, GH)
+        rh = self._v(p + ".rh", T, B, H) if s.cell == "GRU" else None
+        ops.rnn_bwd(self.cell, self.kind, T, B, H, self.store[p + ".ut_pack"], hs,
+                    self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None, self._v(p + ".acts", T, B, GH), da,
+                    dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld)
+        da2, hprev = da.view(R, GH), hs[:T].reshape(R, H)
+        sk = self._split_k(R)
+        # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
+        if s.cell == "GRU":
+            ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk)
+            ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
+                     accumulate=True, split_k=sk)
+        else:
+            ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+        dx = None
+        if r.xmode == hl.X_CONST:
+            dxp0 = self._v(p + ".dxp0", B, GH)
+            ops.sum_over_time(da, T, B * GH, dxp0)
+            ops.colsum(dxp0, B, GH, G[p + ".b"])
+            ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+        else:
+            ops.colsum(da2, R, GH, G[p + ".b"])
+            if r.xmode == hl.X_INDEX:
+                ops.gemm(idx.view(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True,
+                         split_k=sk)
+            elif r.xmode == hl.X_SCALAR:
+                ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk)
+            else:
+                lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
+                ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                dx = self._v(p + ".dx", T, B, H)
+                ops.gemm(da2, self._v(p + ".wc", H, GH), dx, R, H, GH, trans_b=True)
+        return dx
+
+    def _head_backward(self, B, name, r, N, NP, outW, outb):
+        """d(logits) -> gradient of the output Dense and of the top cell's h sequence."""
+        s, G = self.spec, self.G
+        H, T = s.H, r.T
+        R = T * B
+        dl = self._v(name + ".dl", R, NP)
+        top = self._v(r.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
+        ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
+        ops.colsum(dl, R, N, G[outb], ldx=NP)
+        dhs = self._v(name + ".dhs", T, B, H)
+        ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP)        # dl (R,NP) * W^T (NP,H); pad rows are zero
+        return dhs
+
+    def backward(self, B):
+        """Reverse of encoder_forward/decoder_forward; accumulates into self.grads (zeroed by the caller)."""
+        s, P, G = self.spec, self.P, self.G
+        H, Z, T, V = s.H, s.Z, s.T, s.V
+        dS = self._v("dS", B, self.n_init * H)
+        ldS = self.n_init * H
+
+        def dstates(r):
+            k = r.init_block
+            return dict(dh0=dS[:, k * H:(k + 1) * H], dc0=dS[:, (k + 1) * H:(k + 2) * H] if s.cell == "LSTM" else None,
+                        dh0_ld=ldS)
+
+        # ---- decoder -----------------------------------------------------------------------------------
+        dext = self._head_backward(B, "notes", self.dec_notes[-1], s.Dout, self.np_notes, "dec.notes.out.W",
+                                   "dec.notes.out.b")
+        for r in reversed(self.dec_notes):
+            dext = self._rec_backward(r, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), **dstates(r))
+        if s.meta_instrument:
+            dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
+                                       "dec.instr.out.b")
+            self._rec_backward(self.dec_instr, B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
+                               **dstates(self.dec_instr))
+        if s.meta_velocity:
+            dext = self._head_backward(B, "vel", self.dec_vel, 1, 16, "dec.vel.out.W", "dec.vel.out.b")
+            self._rec_backward(self.dec_vel, B, dhs_ext=dext, start=self._v("in.start_vel", B, 1), **dstates(self.dec_vel))
+        # initial-state Denses: S = tanh([z|hist] Winit + b)
+        S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
+        ops.tanh_bwd(S, dS, dS)
+        ops.gemm(zh, dS, G["dec.init.W"], s.zin, ldS, B, trans_a=True, accumulate=True)
+        ops.colsum(dS, B, ldS, G["dec.init.b"])
+        dzh = self._v("dzh", B, s.zin)
+        ops.gemm(dS, P["dec.init.W"], dzh, B, s.zin, ldS, trans_b=True)
+        # ---- latent ------------------------------------------------------------------------------------
+        mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
+        dmu, dlv = self._v("dmu", B, Z), self._v("dlv", B, Z)
+        ops.latent_bwd(B, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / B, mu, lv,
+                       self._v("in.eps", B, Z), dzh, dmu, dlv, style_probs=self._v("style_p", B, s.C) if s.style else None,
+                       style_target=self._v("in.c_idx", B) if s.style else None,
+                       style_row_weight=self._v("in.rw_style", B) if s.style else None, lddz=s.zin)
+        h = self._tail
+        h1w = H // 2 if s.split else H
+        h2w = H - h1w if s.split else H
+        dt = self._v("dtail", B, H)
+        ops.gemm(h, dmu, G["enc.zmean.W"], h1w, Z, B, trans_a=True, lda=H, accumulate=True)
+        ops.colsum(dmu, B, Z, G["enc.zmean.b"])
+        ops.gemm(h[:, h1w:] if s.split else h, dlv, G["enc.zlogvar.W"], h2w, Z, B, trans_a=True, lda=H, accumulate=True)
+        ops.colsum(dlv, B, Z, G["enc.zlogvar.b"])
+        if s.split:
+            ops.gemm(dmu, P["enc.zmean.W"], dt, B, h1w, Z, trans_b=True, ldc=H)
+            ops.gemm(dlv, P["enc.zlogvar.W"], dt[:, h1w:], B, h2w, Z, trans_b=True, ldc=H)
+        else:
+            ops.gemm(dmu, P["enc.zmean.W"], dt, B, H, Z, trans_b=True)
+            dt2 = self._v("dtail2", B, H)
+            ops.gemm(dlv, P["enc.zlogvar.W"], dt2, B, H, Z, trans_b=True)
+            dt.add_(dt2)
+        # ---- encoder tail ------------------------------------------------------------------------------
+        if s.extra_layer:
+            ex = self._v("extra", B, H)
+            src = self._v("pack", B, H) if self.has_pack else self._v("cat", B, H)
+            ops.tanh_bwd(ex, dt, dt)
+            ops.gemm(src, dt, G["enc.extra.W"], H, H, B, trans_a=True, accumulate=True)
+            ops.colsum(dt, B, H, G["enc.extra.b"])
+            dt2 = self._v("dtail2", B, H)
+            ops.gemm(dt, P["enc.extra.W"], dt2, B, H, H, trans_b=True)
+            dt = dt2
+        ldc = self.ncat * H
+        if self.has_pack:
+            pk, cat = self._v("pack", B, H), self._v("cat", B, ldc)
+            ops.tanh_bwd(pk, dt, dt)
+            ops.gemm(cat, dt, G["enc.pack.W"], ldc, H, B, trans_a=True, accumulate=True)
+            ops.colsum(dt, B, H, G["enc.pack.b"])
+            dcat = self._v("dcat", B, ldc)
+            ops.gemm(dt, P["enc.pack.W"], dcat, B, ldc, H, trans_b=True)
+        else:
+            dcat = dt
+        # ---- encoder recurrences -------------------------------------------------------------------------
+        k = 1
+        if s.meta_instrument:
+            self._rec_backward(self.enc_instr, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                               idx=self._v("in.i_idx", V, B))
+            k += 1
+        if s.meta_velocity:
+            self._rec_backward(self.enc_vel, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                               xs=self._v("in.vel", T, B))
+        dext, dlast, dld = None, dcat[:, 0:H], ldc
+        for r in reversed(self.enc_notes):
+            dext = self._rec_backward(r, B, dhs_ext=dext, dh_last=dlast, dh_last_ld=dld, idx=self._v("in.x_idx", T, B))
+            dlast, dld = None, 0
+
+    # ------------------------------------------------------------------------------------------------------
+    # steps
+    # ------------------------------------------------------------------------------------------------------
+    def optimizer_step(self, grad_scale=1.0):
+        s = self.spec
+        if s.optimizer == "Adam":
+            ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale)
+        else:
+            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale)
+        self._weights_dirty = True
+
+    def forward_backward(self, B):
+        """One pass of forward + losses + backward on the staged batch (gradients left in self.grads)."""
+        assert self.training
+        self._have_targets = True
+        self.scal.zero_()
+        self.grads.zero_()
+        if self._weights_dirty:
+            self.prepare_weights()
+        self.encoder_forward(B)
+        self.decoder_forward(B)
+        self.backward(B)
+
+    def train_step(self, B, allreduce=None):
+        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch."""
+        self.forward_backward(B)
+        gs = 1.0
+        if allreduce is not None:
+            gs = allreduce(self.grads)
+        self.optimizer_step(gs if gs is not None else 1.0)
+
+    def eval_step(self, B, want_probs=False):
+        """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""
+        self._have_targets = True
+        self.scal.zero_()
+        if self._weights_dirty:
+            self.prepare_weights()
+        self.encoder_forward(B)
+        self.decoder_forward(B, want_probs=want_probs)
+
+    def encode(self, B):
+        """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
+        self._have_targets = False
+        self.scal.zero_()
+        if self._weights_dirty:
+            self.prepare_weights()
+        self.encoder_forward(B)
+        return self._v("zh", B, self.spec.zin)[:, :self.spec.Z]
+
+    def decode(self, B, want_probs=True):
+        """``decoder.predict`` on the staged [z|history]; argmax note indices are always produced on device."""
+        self._have_targets = False
+        self.scal.zero_()
+        if self._weights_dirty:
+            self.prepare_weights()
+        self.decoder_forward(B, want_probs=want_probs)
+
+    # ------------------------------------------------------------------------------------------------------
+    # results
+    # ------------------------------------------------------------------------------------------------------
+    def metrics(self, B) -> "OrderedDict[str, float]":
+        """Losses / accuracies of the last step with the oracle's key names (one device->host copy)."""
+        s = self.spec
+        v = self.scal.cpu().numpy().astype(np.float64)
+        m = OrderedDict()
+        m["kl"] = v[S_KL]
+        m["notes_loss"], m["notes_acc"] = v[S_NOTES_LOSS], v[S_NOTES_HITS] / (B * s.T)
+        total = m["notes_loss"] + m["kl"]
+        if s.meta_instrument:
+            m["instr_loss"], m["instr_acc"] = v[S_INSTR_LOSS], v[S_INSTR_HITS] / (B * s.V)
+            total += s.w_instr * m["instr_loss"]
+        if s.meta_velocity:
+            m["vel_loss"], m["vel_acc"] = v[S_VEL_LOSS], v[S_VEL_HITS] / (B * s.T)
+            total += s.w_vel * m["vel_loss"]
+        if s.style:
+            m["style_loss"], m["style_acc"] = v[S_STYLE_LOSS], v[S_STYLE_HITS] / B
+            total += s.w_style * m["style_loss"]
+        m["loss"] = total
+        return m
+
+    def outputs(self, B):
+        """Batch-major NumPy copies of the decoder outputs of the last forward run with want_probs=True."""
+        s = self.spec
+        out = OrderedDict()
+        out["notes"] = self._v("out.notes_p", s.T, B, s.Dout).permute(1, 0, 2).cpu().numpy()
+        if s.meta_instrument:
+            out["instr"] = self._v("out.instr_p", s.V, B, s.ID).permute(1, 0, 2).cpu().numpy()
+        if s.meta_velocity:
+            out["vel"] = self._v("out.vel_p", s.T, B, 1).permute(1, 0, 2).cpu().numpy()
+        if s.style:
+            out["style"] = self._v("style_p", B, s.C).cpu().numpy()
+        return out
+
+    def note_indices(self, B):
+        """(B,T) uint8 argmax note index per row - the fused form of sample_vector(...,'argmax')."""
+        return self._v("notes.argmax", self.spec.T, B).t().contiguous().cpu().numpy()
+
+    def latent(self, B):
+        return self._v("zh", B, self.spec.zin)[:, :self.spec.Z].cpu().numpy()

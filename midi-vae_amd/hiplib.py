@@ -30,13 +30,13 @@ class RnnFwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("xmode", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("u_pack", _vp), ("xp", _vp), ("idx", _vp), ("table", _vp), ("xs", _vp), ("w_row", _vp),
                 ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
-                ("h_last", _vp)]
+                ("h_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32)]
 
 
 class RnnBwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("ut_pack", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp), ("dhs_ext", _vp), ("dh_last", _vp),
-                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp)]
+                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32)]
 
 
 class GemmArgs(C.Structure):
@@ -56,14 +56,14 @@ class HeadArgs(C.Structure):
 class LatentFwdArgs(C.Structure):
     _fields_ = [("B", _i32), ("Z", _i32), ("C", _i32), ("beta", _f32), ("prior_mean", _f32), ("prior_std", _f32),
                 ("inv_batch", _f32), ("mu", _vp), ("logvar", _vp), ("eps", _vp), ("style_target", _vp),
-                ("style_row_weight", _vp), ("z", _vp), ("style_probs", _vp), ("scalars", _vp)]
+                ("style_row_weight", _vp), ("z", _vp), ("style_probs", _vp), ("scalars", _vp), ("ldz", _i32)]
 
 
 class LatentBwdArgs(C.Structure):
     _fields_ = [("B", _i32), ("Z", _i32), ("C", _i32), ("beta", _f32), ("prior_mean", _f32), ("prior_std", _f32),
                 ("style_weight", _f32), ("inv_batch", _f32), ("mu", _vp), ("logvar", _vp), ("eps", _vp), ("dz", _vp),
                 ("style_probs", _vp), ("style_target", _vp), ("style_row_weight", _vp), ("dmu", _vp),
-                ("dlogvar", _vp)]
+                ("dlogvar", _vp), ("lddz", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/midivae_hip.h declares

@@ -35,6 +35,11 @@ def _p(t):
     return t.data_ptr()
 
 
+def _pv(t):
+    """pointer of a possibly strided VIEW (column block); the caller passes the row stride separately"""
+    return None if t is None else t.data_ptr()
+
+
 def pack_recurrent(U, cell, dtype, direction, out=None):
     """U (H, G*H) f32 -> fragment-ordered copy (flat, dtype)."""
     H = U.shape[0]
@@ -45,7 +50,7 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
-            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None):
+            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, h0_ld=0, h_last_ld=0):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -55,14 +60,14 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
     else:
         xmode = hl.X_CONST
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _p(xp), _p(idx), _p(table), _p(xs), _p(w_row),
-                      _p(bias), _p(xp0), _p(h0), _p(c0), _p(hs), _p(cs), _p(acts), _p(h_last))
+                      _p(bias), _p(xp0), _pv(h0), _pv(c0), _p(hs), _p(cs), _p(acts), _pv(h_last), h0_ld, h_last_ld)
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, rh=None, dh0=None,
-            dc0=None):
-    a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _p(hs), _p(cs), _p(acts), _p(dhs_ext), _p(dh_last), _p(da),
-                      _p(rh), _p(dh0), _p(dc0))
+            dc0=None, dh_last_ld=0, dh0_ld=0):
+    a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _p(hs), _p(cs), _p(acts), _p(dhs_ext), _pv(dh_last), _p(da),
+                      _p(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld)
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 
@@ -102,16 +107,16 @@ def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None
 
 
 def latent_fwd(B, Z, C, beta, prior_mean, prior_std, inv_batch, mu, logvar, eps, z, scalars, *, style_target=None,
-               style_row_weight=None, style_probs=None):
+               style_row_weight=None, style_probs=None, ldz=0):
     a = hl.LatentFwdArgs(B, Z, C, beta, prior_mean, prior_std, inv_batch, _p(mu), _p(logvar), _p(eps),
-                         _p(style_target), _p(style_row_weight), _p(z), _p(style_probs), _p(scalars))
+                         _p(style_target), _p(style_row_weight), _pv(z), _p(style_probs), _p(scalars), ldz)
     hl.check(hl.load().mvae_latent_fwd(a, _stream()), "mvae_latent_fwd")
 
 
 def latent_bwd(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, mu, logvar, eps, dz, dmu, dlogvar, *,
-               style_probs=None, style_target=None, style_row_weight=None):
+               style_probs=None, style_target=None, style_row_weight=None, lddz=0):
     a = hl.LatentBwdArgs(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, _p(mu), _p(logvar), _p(eps),
-                         _p(dz), _p(style_probs), _p(style_target), _p(style_row_weight), _p(dmu), _p(dlogvar))
+                         _pv(dz), _p(style_probs), _p(style_target), _p(style_row_weight), _p(dmu), _p(dlogvar), lddz)
     hl.check(hl.load().mvae_latent_bwd(a, _stream()), "mvae_latent_bwd")
 
 

@@ -1,0 +1,167 @@
+"""End-to-end parity of the device engine against the float64 oracle (GPU box only): losses, every parameter
+gradient, parameters after optimizer steps, encoder / decoder outputs, bit-exact argmax decode.
+
+f32 mode  : exact-f32 MFMA + f32 storage.  Tolerance 2e-4 relative (+2e-6 absolute on gradients).
+bf16 mode : bf16 MFMA operands and bf16 sequence storage.  Tolerance 3e-2 on losses / outputs; gradients are
+            compared by relative L2 error per tensor (< 6e-2).
+"""
+import numpy as np
+import pytest
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd.engine import Engine
+from midi_vae_amd.layout import ModelSpec, init_params
+from oracle.vae_oracle import OracleVAE, make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _onehot(idx, n):
+    out = np.zeros(idx.shape + (n,))
+    np.put_along_axis(out, idx[..., None].astype(np.int64), 1, -1)
+    return out
+
+
+def _problem(cell, B, seed=0, H=64, Z=32, T=12, V=4, C=2, **kw):
+    spec = ModelSpec(cell=cell, H=H, Z=Z, T=T, V=V, C=C, lr=1e-3, **kw)
+    rng = np.random.default_rng(seed)
+    params = init_params(spec, seed)
+    for k in params:                       # non-zero biases so every path carries signal
+        if k.endswith(".b"):
+            params[k] = (rng.standard_normal(params[k].shape) * 0.1).astype(np.float32)
+    x_idx = np.where(rng.random((B, T)) < 0.35, spec.Dout - 1, rng.integers(0, spec.Dout - 1, (B, T))).astype(np.uint8)
+    i_idx = rng.integers(0, spec.ID, (B, V)).astype(np.uint8)
+    vel = np.where((x_idx == spec.Dout - 1) | (rng.random((B, T)) < 0.5), 0.0, 0.5 + 0.5 * rng.random((B, T)))
+    vel = vel.astype(np.float32)
+    hist = (rng.standard_normal((B, Z)) * 0.1).astype(np.float32)
+    eps = (rng.standard_normal((B, Z)) * spec.epsilon_std).astype(np.float32)
+    c_idx = rng.integers(0, C, (B,)).astype(np.uint8)
+    w_notes = np.where(x_idx == spec.Dout - 1, 0.5, 1.0)
+    batch = dict(X=_onehot(x_idx, spec.Din), I=_onehot(i_idx, spec.ID), Vel=vel[..., None].astype(np.float64),
+                 Hist=hist.astype(np.float64), Y=_onehot(x_idx, spec.Dout), C=_onehot(c_idx, C), w_notes=w_notes)
+    raw = dict(x_idx=x_idx, i_idx=i_idx, vel=vel, hist=hist, eps=eps, c_idx=c_idx, w_notes=w_notes)
+    return spec, params, batch, raw
+
+
+def _stage(eng, raw, B):
+    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"])
+    eng.stage_decoder_inputs(B, hist=raw["hist"])
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"])
+
+
+def _rel_l2(a, b):
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "SimpleRNN"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B", [7, 32])
+def test_forward_backward_matches_oracle(cell, dtype, B):
+    spec, params, batch, raw = _problem(cell, B, seed=B)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+
+    eng = Engine(spec, max_batch=32, dtype=dtype, seed=0)
+    eng.set_params(params)
+    _stage(eng, raw, B)
+    eng.forward_backward(B)
+    m = eng.metrics(B)
+    g = eng.get_grads()
+    tol = 2e-4 if dtype == "f32" else 3e-2
+    for k in m_o:
+        if k.endswith("_acc"):
+            continue
+        assert abs(m[k] - m_o[k]) <= tol * (1 + abs(m_o[k])), (k, m[k], m_o[k])
+    if dtype == "f32":
+        for k in m_o:
+            if k.endswith("_acc"):
+                assert abs(m[k] - m_o[k]) < 1e-9, (k, m[k], m_o[k])
+    for k in g_o:
+        if dtype == "f32":
+            err = np.abs(g[k] - g_o[k])
+            assert np.all(err <= 2e-6 + 2e-4 * np.abs(g_o[k]) + 2e-4 * np.abs(g_o[k]).max()), (k, err.max())
+        else:
+            if np.linalg.norm(g_o[k]) < 1e-9:
+                assert np.linalg.norm(g[k]) < 1e-6, k
+            else:
+                assert _rel_l2(g[k], g_o[k]) < 6e-2, (k, _rel_l2(g[k], g_o[k]))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_three_train_steps_match_oracle_f32(cell):
+    """ELBO trajectory: same init / data / epsilon on both sides, equal steps (BASELINE target: |dELBO| <= 1e-3)."""
+    B = 16
+    spec, params, batch, raw = _problem(cell, B, seed=3)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    st = orc.new_opt_state(p64)
+    eng = Engine(spec, max_batch=B, dtype="f32")
+    eng.set_params(params)
+    _stage(eng, raw, B)
+    for step in range(3):
+        m_o = orc.train_step(p64, st, batch, raw["eps"].astype(np.float64))
+        eng.train_step(B)
+        m = eng.metrics(B)
+        assert abs(m["loss"] - m_o["loss"]) < 1e-3, (step, m["loss"], m_o["loss"])
+    got = eng.get_params()
+    for k in p64:
+        assert np.allclose(got[k], p64[k], rtol=1e-3, atol=2e-5), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_encode_decode_and_argmax(dtype):
+    B = 9
+    spec, params, batch, raw = _problem("GRU", B, seed=11)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    eng = Engine(spec, max_batch=16, dtype=dtype, training=False)
+    eng.set_params(params)
+    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"])
+    z = eng.encode(B).cpu().numpy()
+    z_o = orc.encode(p64, batch["X"], batch["I"], batch["Vel"], raw["eps"].astype(np.float64))
+    tol = 2e-4 if dtype == "f32" else 3e-2
+    assert np.allclose(z, z_o, rtol=tol, atol=tol)
+    # decoder alone, latent swap style: feed an arbitrary z
+    z_in = z_o.astype(np.float32)
+    z_in[:, [0, 1]] = z_in[:, [1, 0]]
+    eng.stage_decoder_inputs(B, hist=raw["hist"], z=z_in)
+    eng.decode(B, want_probs=True)
+    out = eng.outputs(B)
+    out_o = orc.decode(p64, z_in.astype(np.float64), raw["hist"].astype(np.float64),
+                       dict(notes=np.zeros((B, spec.Dout)), instr=np.zeros((B, spec.ID)), vel=np.zeros((B,))))
+    for k in ("notes", "instr", "vel"):
+        assert np.allclose(out[k], out_o[k], rtol=tol, atol=tol), k
+    # the fused argmax is bit-exact w.r.t. NumPy argmax of the probabilities the engine returned
+    assert np.array_equal(eng.note_indices(B), np.argmax(out["notes"], -1).astype(np.uint8))
+    if dtype == "f32":
+        assert np.array_equal(eng.note_indices(B), np.argmax(out_o["notes"], -1).astype(np.uint8))
+
+
+def test_ragged_batch_reuses_buffers():
+    """A smaller last minibatch (songs are not multiples of batch_size) runs in the same engine."""
+    spec, params, batch, raw = _problem("GRU", 5, seed=2)
+    eng = Engine(spec, max_batch=64, dtype="f32")
+    eng.set_params(params)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    for B in (5, 3):
+        sub = {k: v[:B] for k, v in raw.items()}
+        _stage(eng, sub, B)
+        eng.eval_step(B)
+        m_o, _ = orc.forward(p64, {k: v[:B] for k, v in batch.items()}, sub["eps"].astype(np.float64))
+        assert abs(eng.metrics(B)["loss"] - m_o["loss"]) < 2e-4 * (1 + abs(m_o["loss"]))
+
+
+def test_h256_one_step_bf16_runs_and_is_finite():
+    spec, params, batch, raw = _problem("LSTM", 32, seed=5, H=256, Z=64, T=16)
+    eng = Engine(spec, max_batch=32, dtype="bf16")
+    eng.set_params(params)
+    _stage(eng, raw, 32)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, _ = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    eng.train_step(32)
+    m = eng.metrics(32)
+    assert np.isfinite(m["loss"]) and abs(m["loss"] - m_o["loss"]) < 3e-2 * (1 + abs(m_o["loss"]))
