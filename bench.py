@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py - MIDI-VAE train-step throughput on N MI355X (one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: 2-style, seq_len=128 x voices=4 (T=512 interleaved rows), z=64, batch=256 per
+GPU, bf16 MFMA operands, LSTM cells (north_star; --cell GRU for the reference's shipped default), H=256, 2+2 layers,
+instrument + velocity + style heads.  A "step" = forward + all losses + backward + (gradient all-reduce) + Keras-Adam
+update on one minibatch of synthetic piano-roll windows already resident in HBM.  Weak scaling: 256 windows per GPU.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     dominant kernel (the T-step recurrent kernels) measured live with HIP events on the launch stream
+  cpu_baseline the oracle (NumPy port of the same step) timed on the host cores, rank 0 / N=1 only, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def cpu_baseline(spec, budget_s=20.0):
+    """Oracle train step (float32 NumPy, BLAS threads = all host cores) on a bounded sample of the same workload."""
+    from oracle.vae_oracle import OracleVAE, make_cfg
+    from midi_vae_amd.layout import init_params
+    from midi_vae_amd.synth import make_windows
+    Bs = 8
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()), dtype=np.float32)
+    p = {k: v.astype(np.float32) for k, v in init_params(spec, 1234).items()}
+    w = make_windows(Bs, spec.T, spec.Dout, spec.V, spec.ID, spec.C, spec.Z, seed=1234, epsilon_std=spec.epsilon_std)
+    oh = lambda idx, n: np.eye(n, dtype=np.float32)[idx.astype(np.int64)]
+    batch = dict(X=oh(w["x_idx"], spec.Din), I=oh(w["i_idx"], spec.ID), Vel=w["vel"][..., None], Hist=w["hist"],
+                 Y=oh(w["x_idx"], spec.Dout), C=oh(w["c_idx"], spec.C))
+    st = orc.new_opt_state(p)
+    t0 = time.perf_counter()
+    orc.train_step(p, st, batch, w["eps"])          # warm-up (BLAS thread pools, page faults)
+    first = time.perf_counter() - t0
+    n = int(max(1, min(5, (budget_s - first) // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        orc.train_step(p, st, batch, w["eps"])
+    dt = (time.perf_counter() - t0) / n
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": Bs / dt, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d windows x %d timed step(s) of the identical train step (T=%d,H=%d,%s) in float32 NumPy "
+                      "(oracle/vae_oracle.py), %.2f s/step" % (Bs, n, spec.T, spec.H, spec.cell, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--voices", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    import torch
+    import midi_vae_amd  # noqa: F401
+    from midi_vae_amd.engine import Engine
+    from midi_vae_amd.layout import ModelSpec
+    from midi_vae_amd.synth import make_windows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    T = args.seq_len * args.voices
+    spec = ModelSpec(cell=args.cell, H=256, Z=args.latent, Din=61, Dout=61, T=T, V=args.voices, ID=16, C=2, Le=2, Ld=2)
+    B = args.batch
+    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234)
+    w = make_windows(B, T, 61, args.voices, 16, 2, args.latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
+    eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
+    eng.stage_decoder_inputs(B, hist=w["hist"])
+    eng.stage_targets(B, w["x_idx"], w["c_idx"])
+
+    allreduce = None
+    if world > 1:
+        from midi_vae_amd.dp import make_allreduce
+        allreduce = make_allreduce(eng, dist, world)
+
+    def step():
+        eng.train_step(B, allreduce=allreduce)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    first_loss = eng.metrics(B)["loss"] if args.warmup else float("nan")
+
+    eng.prof = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = eng.prof_summary()
+    eng.prof = None
+    m = eng.metrics(B)
+
+    if rank == 0:
+        G, H = spec.G, spec.H
+        # dominant kernel: the long (T-step) recurrences.  Algorithmic work per launch = the recurrent GEMM only:
+        # 2*B*H*(G*H) flop per step (forward h U; backward da U^T), T steps per launch.
+        longk = {k: v for k, v in prof.items() if not k[1].endswith("instr") and "instr" not in k[1]}
+        by_kind = {}
+        for (kind, _), (n, ms) in longk.items():
+            by_kind.setdefault(kind, []).append((n, ms))
+        tot = {k: sum(n * ms for n, ms in v) for k, v in by_kind.items()}
+        dom = max(tot, key=tot.get)
+        launches = sum(n for n, _ in by_kind[dom])
+        avg_ms = tot[dom] / launches
+        flop = 2.0 * B * H * G * H * T
+        achieved = flop / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "MIDI roll windows/sec (train step)", "value": B * world * args.steps / elapsed,
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU %s "
+                                   "H=256 2+2 layers, notes+instrument+velocity+style heads, Keras-Adam"
+                                   % (args.seq_len, args.voices, T, args.latent, B, args.cell),
+                       "global_batch": B * world, "T": T, "cell": args.cell, "parallelism": "dp%d" % world},
+            "elbo": {"loss_after_warmup": first_loss, "loss_final": m["loss"], "kl": m["kl"],
+                     "notes_loss": m["notes_loss"]},
+            "roofline": {"bound": "mfma", "kernel": "%s_k<%s,%s,T=%d>" % (dom, args.cell, args.dtype, T),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                         "flop_per_launch": flop,
+                         "all_kernels_ms_per_step": {"%s:%s" % k: n * ms / args.steps for k, (n, ms) in prof.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

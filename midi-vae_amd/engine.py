@@ -51,6 +51,7 @@ class Engine(object):
         self.layout = ParamLayout.build(spec)
         self.use_graphs = use_graphs
         self._graphs = {}
+        self.prof = None       # dict -> per-kernel HIP-event pairs are recorded on the launch stream (bench.py)
         L, dev = self.layout, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         self.params = torch.zeros(L.total, **f32)
@@ -65,6 +66,22 @@ class Engine(object):
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
+
+    def _timed(self, key, fn):
+        """Run ``fn`` (one kernel launch); when profiling, bracket it with HIP events on the launch stream."""
+        if self.prof is None:
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.prof.setdefault(key, []).append((e0, e1))
+
+    def prof_summary(self):
+        """key -> (launches, mean ms) for the event pairs collected since ``self.prof = {}`` (sync first)."""
+        torch.cuda.synchronize()
+        return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b in v]))) for k, v in (self.prof or {}).items()}
 
     # ------------------------------------------------------------------------------------------------------
     # parameters
@@ -312,11 +329,10 @@ class Engine(object):
             xp = self._v(p + ".xp", T, B, GH)
             ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, T * B, GH, H, trans_b=True, bias=P[p + ".b"])
             kw.update(xp=xp)
-        ops.rnn_fwd(self.cell, self.kind, T, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
-                    hs=self._v(p + ".hs", T + 1, B, H),
-                    cs=self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None,
-                    acts=self._v(p + ".acts", T, B, GH) if self.training else None,
-                    h_last=h_last, h_last_ld=h_last_ld, **kw)
+        self._timed(("rnn_fwd", p), lambda: ops.rnn_fwd(
+            self.cell, self.kind, T, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
+            hs=self._v(p + ".hs", T + 1, B, H), cs=self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None,
+            acts=self._v(p + ".acts", T, B, GH) if self.training else None, h_last=h_last, h_last_ld=h_last_ld, **kw))
 
     def encoder_forward(self, B):
         """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502."""
@@ -421,9 +437,10 @@ class Engine(object):
         hs = self._v(p + ".hs", T + 1, B, H)
         da = self._v(p + ".da", T, B, GH)
         rh = self._v(p + ".rh", T, B, H) if s.cell == "GRU" else None
-        ops.rnn_bwd(self.cell, self.kind, T, B, H, self.store[p + ".ut_pack"], hs,
-                    self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None, self._v(p + ".acts", T, B, GH), da,
-                    dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld)
+        self._timed(("rnn_bwd", p), lambda: ops.rnn_bwd(
+            self.cell, self.kind, T, B, H, self.store[p + ".ut_pack"], hs,
+            self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None, self._v(p + ".acts", T, B, GH), da,
+            dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld))
         da2, hprev = da.view(R, GH), hs[:T].reshape(R, H)
         sk = self._split_k(R)
         # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
