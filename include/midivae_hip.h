@@ -41,7 +41,7 @@ enum { MVAE_F32 = 0, MVAE_BF16 = 1 };
 /* where x_t W + b comes from in a recurrent layer */
 enum {
     MVAE_X_DENSE = 0,  /* xp (T,B,G*H) precomputed by mvae_gemm (layers fed by another layer)              */
-    MVAE_X_INDEX = 1,  /* one-hot rows: xp = table[idx[t,b]], table (K,G*H) f32 = W + b  (notes, instruments) */
+    MVAE_X_INDEX = 1,  /* one-hot rows: xp = table[idx[t,b]], table (K,G*H) dtype = W + b (notes, instruments) */
     MVAE_X_SCALAR = 2, /* 1-wide input: xp = xs[t,b]*w + bias                              (velocity roll)  */
     MVAE_X_CONST = 3   /* the same row every step: xp = xp0[b]                  (decoder cells, Appendix A.6) */
 };
@@ -61,11 +61,11 @@ typedef struct {
     const void* u_pack;    /* recurrent kernel packed by mvae_pack_recurrent (direction 0)                    */
     const void* xp;        /* DENSE: (T,B,G*H) dtype                                                          */
     const uint8_t* idx;    /* INDEX: (T,B)                                                                    */
-    const float* table;    /* INDEX: (K,G*H)                                                                  */
+    const void* table;     /* INDEX: (K,G*H) dtype (mvae_make_table)                                          */
     const float* xs;       /* SCALAR: (T,B)                                                                   */
     const float* w_row;    /* SCALAR: (G*H)                                                                   */
     const float* bias;     /* SCALAR: (G*H)                                                                   */
-    const float* xp0;      /* CONST: (B,G*H)                                                                  */
+    const void* xp0;       /* CONST: (B,G*H) dtype                                                            */
     const float* h0;       /* (B,H) or NULL = zeros                                                           */
     const float* c0;       /* LSTM: (B,H) or NULL = zeros                                                     */
     void* hs;              /* (T+1,B,H) dtype or NULL; slot 0 receives h0, slot t+1 receives h_t              */
@@ -196,8 +196,9 @@ int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
 /* elementwise helpers */
 int mvae_tanh_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream);      /* dx = dy*(1-y^2) */
 int mvae_convert(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, size_t n, void* stream);
-/* table (K,N) = W (K,N) + bias (N): the X_INDEX lookup table of a one-hot input layer */
-int mvae_make_table(const float* W, const float* bias, float* table, int32_t K, int32_t N, void* stream);
+/* table (K,N) dst_kind = W (K,N) + bias (N): the X_INDEX lookup table of a one-hot input layer */
+int mvae_make_table(const float* W, const float* bias, void* table, int32_t K, int32_t N, int32_t dst_kind,
+                    void* stream);
 /* out (N_pad,K) dst_kind = transpose of W (K,N) f32, rows N..N_pad-1 zero */
 int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int32_t N_pad, int32_t dst_kind,
                            void* stream);

@@ -108,10 +108,11 @@ __global__ void convert_k(const S* src, D* dst, size_t n) {
         st<D>::store(dst + e, st<S>::load(src + e));
 }
 
-__global__ void make_table_k(const float* W, const float* bias, float* table, int K, int N) {
+template <typename D>
+__global__ void make_table_k(const float* W, const float* bias, D* table, int K, int N) {
     const size_t n = (size_t)K * N;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
-        table[e] = W[e] + bias[e % N];
+        st<D>::store(table + e, W[e] + bias[e % N]);
 }
 
 template <typename D>
@@ -238,10 +239,17 @@ extern "C" int mvae_convert(const void* src, int32_t sk, void* dst, int32_t dk, 
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-extern "C" int mvae_make_table(const float* W, const float* bias, float* table, int32_t K, int32_t N, void* stream) {
+extern "C" int mvae_make_table(const float* W, const float* bias, void* table, int32_t K, int32_t N, int32_t dk,
+                               void* stream) {
     if (!W || !bias || !table || K <= 0 || N <= 0) return MVAE_E_ARG;
-    hipLaunchKernelGGL(make_table_k, dim3(nblocks((size_t)K * N)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W,
-                       bias, table, K, N);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks((size_t)K * N)), b(256);
+    if (dk == MVAE_F32)
+        hipLaunchKernelGGL(make_table_k<float>, g, b, 0, s, W, bias, (float*)table, K, N);
+    else if (dk == MVAE_BF16)
+        hipLaunchKernelGGL(make_table_k<bf16_t>, g, b, 0, s, W, bias, (bf16_t*)table, K, N);
+    else
+        return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

@@ -15,6 +15,8 @@
 //     h_t goes through LDS (double buffered, one barrier per step; GRU needs a second for r*h);
 //   * U is pre-packed in A-fragment order (mvae_pack_recurrent) so each wave-load of U is 1 KiB contiguous;
 //     it is re-read from L2 every step here (the H=256 bf16 resident-U kernel lives in rnn_resident.hip).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -109,11 +111,11 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xv[g][n] = st<WT>::load4(xp + row * GH + g * H + ub[n]);
         } else if (XMODE == MVAE_X_INDEX) {
-            const float* trow = a.table + (size_t)a.idx[row] * GH;
+            const WT* trow = reinterpret_cast<const WT*>(a.table) + (size_t)a.idx[row] * GH;
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) xv[g][n] = *reinterpret_cast<const f32x4*>(trow + g * H + ub[n]);
+                for (int n = 0; n < NT; ++n) xv[g][n] = st<WT>::load4(trow + g * H + ub[n]);
         } else if (XMODE == MVAE_X_SCALAR) {
             const float x = a.xs[row];
 #pragma unroll
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    xv[g][n] = *reinterpret_cast<const f32x4*>(a.xp0 + (size_t)bb * GH + g * H + ub[n]);
+                    xv[g][n] = st<WT>::load4(reinterpret_cast<const WT*>(a.xp0) + (size_t)bb * GH + g * H + ub[n]);
         }
 
         // ---- h_{t-1} U on the matrix cores -----------------------------------------------------------
@@ -511,11 +513,28 @@ int bwd_cell(const mvae_rnn_bwd_args& a, hipStream_t s) {
     return MVAE_E_ARG;
 }
 
+// MVAE_GENERIC_RNN=1 in the environment forces the generic (weights re-read from L2) kernels: A/B measurements
+bool use_resident() {
+    static const bool on = [] {
+        const char* e = getenv("MVAE_GENERIC_RNN");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
 }  // namespace
+
+// rnn_resident.hip: H = 256 / bf16 kernels with the recurrent weights resident in registers + LDS
+int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s);
+int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s);
 
 extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
     if (!a || !a->u_pack || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN && use_resident()) {
+        const int rc = mvae_rnn_fwd_resident(*a, s);
+        if (rc != MVAE_E_UNSUPPORTED) return rc;
+    }
     if (a->dtype == MVAE_F32) return fwd_cell<float>(*a, s);
     if (a->dtype == MVAE_BF16) return fwd_cell<bf16_t>(*a, s);
     return MVAE_E_ARG;
@@ -524,6 +543,10 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
 extern "C" int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream) {
     if (!a || !a->ut_pack || !a->hs || !a->acts || !a->da || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN && use_resident()) {
+        const int rc = mvae_rnn_bwd_resident(*a, s);
+        if (rc != MVAE_E_UNSUPPORTED) return rc;
+    }
     if (a->dtype == MVAE_F32) return bwd_cell<float>(*a, s);
     if (a->dtype == MVAE_BF16) return bwd_cell<bf16_t>(*a, s);
     return MVAE_E_ARG;

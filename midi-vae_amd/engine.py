@@ -155,7 +155,7 @@ class Engine(object):
                 if s.cell == "GRU":
                     buf(p + ".rh", r.T * B * H, **esz)
             if r.xmode == hl.X_INDEX:
-                buf(p + ".table", r.K * GH, **f32)
+                buf(p + ".table", r.K * GH, **esz)
             elif r.xmode == hl.X_DENSE:
                 buf(p + ".xp", r.T * B * GH, **esz)
                 buf(p + ".wt", GH * H, **esz)            # W^T (GH,H): forward projection, k-contiguous
@@ -163,7 +163,7 @@ class Engine(object):
                     buf(p + ".wc", H * GH, **esz)        # W (H,GH) in dtype: backward dx, k-contiguous
                     buf(p + ".dx", r.T * B * H, **esz)   # gradient w.r.t. the lower layer's h sequence
             elif r.xmode == hl.X_CONST:
-                buf(p + ".xp0", B * GH, **f32)
+                buf(p + ".xp0", B * GH, **esz)
                 if self.training:
                     buf(p + ".dxp0", B * GH, **f32)
         # heads

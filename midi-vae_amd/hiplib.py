@@ -82,7 +82,7 @@ SIGNATURES = {
     "mvae_latent_bwd": (_i32, [C.POINTER(LatentBwdArgs), _vp]),
     "mvae_tanh_bwd": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "mvae_convert": (_i32, [_vp, _i32, _vp, _i32, _sz, _vp]),
-    "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_transpose_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_adam_step": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _vp]),

@@ -131,7 +131,7 @@ def convert(src, dst):
 
 def make_table(W, bias, table):
     K, N = W.shape
-    hl.check(hl.load().mvae_make_table(_p(W), _p(bias), _p(table), K, N, _stream()), "mvae_make_table")
+    hl.check(hl.load().mvae_make_table(_p(W), _p(bias), _p(table), K, N, kind_of(table), _stream()), "mvae_make_table")
 
 
 def transpose_convert(W, out, n_pad=None):

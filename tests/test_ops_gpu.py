@@ -50,7 +50,7 @@ def _rnn_problem(cellname, H, T, B, seed, K=7):
 @pytest.mark.parametrize("cellname,cell", CELLS)
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("xmode", ["dense", "index", "scalar", "const"])
-@pytest.mark.parametrize("H,B", [(64, 5), (128, 37)])
+@pytest.mark.parametrize("H,B", [(64, 5), (128, 37), (256, 21)])
 def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
     T = 9
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=H + B)
@@ -64,17 +64,17 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
         kw["xp"] = dev(xp, td)
     elif xmode == "index":
         idx = rng.integers(0, 7, (T, B))
-        table = W + b
+        table = host(dev(W + b, td))
         xp = table[idx]
-        kw["idx"], kw["table"] = dev(idx, torch.uint8), dev(table)
+        kw["idx"], kw["table"] = dev(idx, torch.uint8), dev(table, td)
     elif xmode == "scalar":
         xs = rng.random((T, B))
         xp = xs[..., None] * W[0] + b
         kw["xs"], kw["w_row"], kw["bias"] = dev(xs), dev(W[0]), dev(b)
     else:
-        xp0 = rng.standard_normal((B, GH)) * 0.5
+        xp0 = host(dev(rng.standard_normal((B, GH)) * 0.5, td))
         xp = np.broadcast_to(xp0[None], (T, B, GH)).copy()
-        kw["xp0"] = dev(xp0)
+        kw["xp0"] = dev(xp0, td)
     hs_o, cs_o, acts_o = vo.rnn_forward(cellname, xp, U, h0, c0 if cellname == "LSTM" else None)
 
     up = ops.pack_recurrent(dev(U), cell, dtype, 0)
@@ -105,7 +105,7 @@ def test_rnn_forward_zero_initial_state_and_inference_mode():
 
 @pytest.mark.parametrize("cellname,cell", CELLS)
 @pytest.mark.parametrize("dtype,tol", DTYPES)
-@pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False)])
+@pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False), (256, 19, True), (256, 33, False)])
 def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
     T = 8
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=11 + H)
