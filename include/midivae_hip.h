@@ -46,6 +46,15 @@ enum {
     MVAE_X_CONST = 3   /* the same row every step: xp = xp0[b]                  (decoder cells, Appendix A.6) */
 };
 
+/* Layout of (rows, cols) sequence arrays exchanged with the recurrent kernels.
+ *   MVAE_ROWMAJOR : element (m, n) at m*cols + n.
+ *   MVAE_TILE16   : rows and cols in tiles of 16 (both must be multiples of 16); tile (m/16, n/16) is 256
+ *                   contiguous elements holding the MFMA C-fragment image of the 16x16 block:
+ *                       offset = ((m/16 * cols/16 + n/16) * 64 + ((n%16)/4)*16 + m%16) * 4 + n%4
+ *                   i.e. lane (q = (n%16)/4, r = m%16) owns 4 consecutive n.  One wave reads / writes a whole tile as
+ *                   512 contiguous bytes (bf16) instead of 16 segments at a power-of-two row stride. */
+enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1 };
+
 int mvae_abi_version(void);
 /* human-readable build string (arch, compile date) */
 const char* mvae_build_info(void);
@@ -74,6 +83,8 @@ typedef struct {
     float* h_last;         /* (B,H) or NULL                                                                   */
     int32_t h0_ld;         /* row stride of h0 / c0 in floats (0 = H): states may be column blocks of a wider buffer */
     int32_t h_last_ld;     /* row stride of h_last (0 = H)                                                     */
+    int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR or MVAE_TILE16.
+                              TILE16 needs B % 16 == 0 and is what the resident-weights kernels (H=256, bf16) take */
 } mvae_rnn_fwd_args;
 int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
 
@@ -94,6 +105,7 @@ typedef struct {
     float* dc0;            /* LSTM: (B,H) or NULL                                                             */
     int32_t dh_last_ld;    /* row stride of dh_last (0 = H)                                                   */
     int32_t dh0_ld;        /* row stride of dh0 / dc0 (0 = H)                                                 */
+    int32_t seq_layout;    /* layout of acts, cs and dhs_ext (hs, da, rh are always row-major)                */
 } mvae_rnn_bwd_args;
 int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream);
 
@@ -123,6 +135,7 @@ typedef struct {
     const void* B;
     void* C;
     const float* bias;            /* (N) or NULL                                                              */
+    int32_t c_layout;             /* MVAE_ROWMAJOR (ldc applies) or MVAE_TILE16 (store only, M%16==0, N%16==0)  */
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
 
@@ -192,6 +205,9 @@ typedef struct {
     int32_t lddz;                 /* row stride of dz (0 = Z)                                                */
 } mvae_latent_bwd_args;
 int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
+
+/* (rows, cols) row-major <-> TILE16, same element kind on both sides */
+int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16, void* stream);
 
 /* elementwise helpers */
 int mvae_tanh_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream);      /* dx = dy*(1-y^2) */

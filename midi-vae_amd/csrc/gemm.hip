@@ -178,7 +178,12 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = tanh_f(v[e]);
             }
-            if (a.accumulate) {
+            if (a.c_layout == MVAE_TILE16) {
+                // the lane's four values are exactly its slot of the 16x16 tile image: one contiguous wave store
+                const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
+                if (a.c_kind == MVAE_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + off) = v;
+                else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
+            } else if (a.accumulate) {
                 float* cp = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -237,6 +242,7 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (a->accumulate && a->c_kind != MVAE_F32) return MVAE_E_ARG;
     if (a->split_k > 1 && !a->accumulate) return MVAE_E_ARG;
     if (a->accumulate && a->act != MVAE_ACT_NONE) return MVAE_E_ARG;
+    if (a->c_layout == MVAE_TILE16 && (a->accumulate || (a->M % 16) || (a->N % 16))) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int ak = a->a_kind, bk = a->b_kind;
     // operand type on the matrix cores: bf16 if any stored operand is bf16, else exact f32

@@ -124,6 +124,16 @@ __global__ void transpose_convert_k(const float* W, D* out, int K, int N, int NP
     }
 }
 
+template <typename D>
+__global__ void relayout_k(const D* src, D* dst, int rows, int cols, int to_tile) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / cols), c = (int)(e % cols);
+        const size_t t = ((((size_t)(m >> 4) * (cols >> 4) + (c >> 4)) * 64) + (size_t)(((c & 15) >> 2) * 16 + (m & 15))) * 4 + (c & 3);
+        if (to_tile) dst[t] = src[e]; else dst[e] = src[t];
+    }
+}
+
 // ---- optimizers (Keras 2.0.8 formulas) ------------------------------------------------------
 __global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
                        float gs) {
@@ -234,6 +244,20 @@ extern "C" int mvae_convert(const void* src, int32_t sk, void* dst, int32_t dk, 
         hipLaunchKernelGGL((convert_k<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
     else if (sk == MVAE_BF16 && dk == MVAE_BF16)
         hipLaunchKernelGGL((convert_k<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16,
+                             void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || (rows % 16) || (cols % 16)) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks((size_t)rows * cols)), b(256);
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(relayout_k<float>, g, b, 0, s, (const float*)src, (float*)dst, rows, cols, to_tile16);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(relayout_k<bf16_t>, g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, cols, to_tile16);
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
             wb[GH + i] = a.bias[i];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     int cur = 0;
     for (int t = 0; t < T; ++t) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
                 }
                 st<WT>::store4(rhbuf + r * LDH + ub[n], rr[n] * hreg[n]);
             }
-            __syncthreads();
+            lds_barrier();
             const WT* rhrow = rhbuf + r * LDH + q * FE;
 #pragma unroll 2
             for (int s = 0; s < S; ++s) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
             if (hs && valid) st<WT>::store4(hs + ((size_t)(t + 1) * B + b) * H + ub[n], hnew[n]);
         }
         cur ^= 1;
-        __syncthreads();
+        lds_barrier();
     }
     if (a.h_last && valid) {
 #pragma unroll
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                     st<WT>::store4(gp + 3 * H, dO);
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll 4
             for (int s = 0; s < S2; ++s) {
                 const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                     if (rh) st<WT>::store4(rh + ((size_t)t * B + b) * H + ub[n], rr[n] * hp[n]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             constexpr int SH = H / KG;
 #pragma unroll 4
             for (int s = 2 * SH; s < 3 * SH; ++s) {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                     st<WT>::store4(gp + H, dar);
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll 4
             for (int s = 0; s < 2 * SH; ++s) {
                 const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                 st<WT>::store4(drow + ub[n], dy);
                 if (valid) st<WT>::store4(da + ((size_t)t * B + b) * GH + ub[n], dy);
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll 4
             for (int s = 0; s < S2; ++s) {
                 const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) dh[n] = acc[n];
         }
-        __syncthreads();   // all waves done reading dabuf before the next step overwrites it
+        lds_barrier();   // all waves done reading dabuf before the next step overwrites it
     }
     if (valid) {
 #pragma unroll
@@ -535,6 +535,7 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
         const int rc = mvae_rnn_fwd_resident(*a, s);
         if (rc != MVAE_E_UNSUPPORTED) return rc;
     }
+    if (a->seq_layout != MVAE_ROWMAJOR) return MVAE_E_UNSUPPORTED;   // the generic kernels are row-major only
     if (a->dtype == MVAE_F32) return fwd_cell<float>(*a, s);
     if (a->dtype == MVAE_BF16) return fwd_cell<bf16_t>(*a, s);
     return MVAE_E_ARG;
@@ -547,6 +548,7 @@ extern "C" int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream) {
         const int rc = mvae_rnn_bwd_resident(*a, s);
         if (rc != MVAE_E_UNSUPPORTED) return rc;
     }
+    if (a->seq_layout != MVAE_ROWMAJOR) return MVAE_E_UNSUPPORTED;
     if (a->dtype == MVAE_F32) return bwd_cell<float>(*a, s);
     if (a->dtype == MVAE_BF16) return bwd_cell<bf16_t>(*a, s);
     return MVAE_E_ARG;

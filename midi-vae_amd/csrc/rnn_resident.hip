@@ -1,56 +1,84 @@
 // Resident-weights recurrent kernels for the production shape (H = 256, bf16 MFMA operands) on gfx950.
 //
-// Same contract and numerics as rnn.hip (mvae_rnn_fwd / mvae_rnn_bwd dispatch here when H == 256 and
-// dtype == MVAE_BF16), different data placement:
+// Same contract and numerics as rnn.hip (mvae_rnn_fwd / mvae_rnn_bwd dispatch here when H == 256,
+// dtype == MVAE_BF16, B % 16 == 0 and the cell is GRU or LSTM); different data placement and schedule:
 //
-//   the recurrent kernel U (256 x G*256 bf16 = 384 KiB GRU / 512 KiB LSTM) is loaded ONCE per launch and stays
-//   on chip for all T steps, split between the register file and LDS of the one CU that owns 16 batch rows.
-//   A CU has 4 SIMDs x 512 registers x 64 lanes x 4 B = 512 KiB of registers and 160 KiB of LDS; the workgroup is
-//   4 waves (one per SIMD, launch_bounds(256,1)) so every wave may use the whole 512-register budget.  Wave w owns
-//   hidden units [64w, 64w+64) for all gates: NREG of its MFMA A-fragments live in registers (the matrix pipe
-//   reads A straight from VGPR/AGPR), the remaining ones in a private LDS slab read back with ds_read_b128.
+//  * The recurrent kernel U (256 x G*256 bf16 = 384 KiB GRU / 512 KiB LSTM) is loaded ONCE per launch and stays on
+//    chip for all T steps, split between the register file and LDS of the one CU that owns 16 batch rows.  A CU has
+//    4 SIMDs x 512 registers x 64 lanes x 4 B = 512 KiB of registers and 160 KiB of LDS; the workgroup is 4 waves
+//    (one per SIMD, launch_bounds(256,1)) so each wave owns the full 512-register budget.  Wave w owns hidden units
+//    [64w, 64w+64) for all gates.  Its MFMA A-fragments (1 KiB each) live, by index in order of use, in
+//        [0,NA)        accumulator registers - loaded there by inline asm and read in place by v_mfma (hipcc on its
+//                      own parks such values in AGPRs but copies them back with v_accvgpr_read before every MFMA),
+//        [NA,NA+NV)    vector registers,
+//        [NA+NV, ...)  a private LDS slab read back with ds_read_b128.
+//    Nothing is re-read from L2/HBM inside the time loop except x_t and (backward) the saved activations.
 //
-//   Per step nothing but x_t and the saved activations touch HBM: h_t travels through a 8 KiB LDS tile, the
-//   cell state and the f32 master copy of h never leave registers, and the per-step critical path is
-//   128 (LSTM) / 96 (GRU) MFMAs per wave + one (GRU: two) workgroup barrier.  The generic kernel re-streams U from
-//   L2 every step (17 us/step measured at T=512,B=256); this one is bounded by the CU's MFMA rate (~1 us/step).
+//  * Memory ordering.  hipcc treats vmcnt as out-of-order once loads and stores are both in flight and then waits
+//    for (almost) vmcnt(0) at every use of a loaded value: with per-tile prefetch loads next to per-tile stores
+//    that exposed a store round trip per tile (measured 2 us of a 3.3 us step).  Here every per-step load is issued
+//    ONE STEP ahead and all of a step's loaded registers are pinned at ONE point per step - placed where the
+//    youngest outstanding store is oldest - behind one explicit s_waitcnt vmcnt(0).  Workgroup barriers wait for
+//    LDS only (lds_barrier), never for global memory.
 //
-//   x_t (and in backward the saved gates / cell states / upstream gradient) are prefetched ONE STEP ahead into a
-//   small register queue, re-issued right after they are consumed, so HBM latency is covered by a whole step.
+//  * HBM access shape.  Per-lane 8-byte accesses on row-major (T,B,*) arrays make every wave instruction touch 16
+//    rows at a power-of-two stride (measured: 12 loads + 16 stores = 6000 of a step's 12000 cycles).  Everything
+//    these kernels stream per step therefore uses the TILE16 layout (include/midivae_hip.h): xp, the saved gates,
+//    the saved cell states and the upstream gradient are read / written as 512 contiguous bytes per wave access.
+//    Row-major OUTPUTS consumed by the GEMMs (h sequence, da, r*h) are first assembled in LDS - where the step
+//    needs them anyway - and written back as whole 512-byte row segments.
+//
+//  * Forward LSTM schedule: the gate arithmetic of unit tile n-1 is issued among the MFMA groups of tile n (the
+//    matrix pipe runs a 4-MFMA group for 64 cycles), so only the last tile's arithmetic and the barrier are
+//    exposed.  Backward has a true dependency (all of dh before any gate gradient) and stays phased.
 #include "common.h"
+
+// Phase stamps (build with -DRES_STAMPS): block 0 / wave 0 / lane 0 records s_memtime at marked points of steps
+// [64, 72); read back with mvae_debug_stamps().  Development tooling only.
+#ifdef RES_STAMPS
+__device__ unsigned long long mvae_stamps[8 * 16];
+#define STAMP(k)                                                                                     \
+    do {                                                                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tstep >= 64 && tstep < 72)                        \
+            mvae_stamps[(tstep - 64) * 16 + (k)] = __builtin_readcyclecounter();                     \
+    } while (0)
+extern "C" int mvae_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mvae_stamps), sizeof(mvae_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define STAMP(k)
+#endif
 
 namespace {
 
 constexpr int RH = 256;           // hidden size this file is specialised for
 constexpr int RS = RH / 32;       // k-groups of the forward contraction (8)
 constexpr int RNT = 4;            // unit tiles (16 units) per wave
-constexpr int RLDH = RH + 8;      // padded bf16 row of the h tile in LDS
 
 typedef u16x8 frag;
 
-// Four MFMAs that share one B fragment.  U fragments in the accumulator half of the register file are named
-// with the "a" constraint so the matrix pipe reads them in place (hipcc, left alone, parks such values in AGPRs
-// but copies them back with v_accvgpr_read before every MFMA: 2 VALU per MFMA).  hipcc neither pads hazards
-// inside an asm statement nor models the MFMA: the leading s_nop 1 covers "VALU-written VGPR -> MFMA operand",
-// chain_done() covers "MFMA result -> VALU reader" (4-pass XDL needs 8 states; 10 given).
+// ---- inline-asm building blocks ---------------------------------------------------------------------------
+// Four MFMAs sharing one B fragment.  hipcc neither pads hazards inside an asm statement nor models the MFMA:
+// the leading s_nop 1 covers "VALU-written VGPR -> MFMA operand", chain_done() covers "MFMA result -> VALU reader"
+// (4-pass XDL: 8 wait states required; 10 given).
 template <bool AG>
 __device__ __forceinline__ void mfma4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const frag& u0, const frag& u1,
                                       const frag& u2, const frag& u3, const frag& b) {
     if (AG)
-        asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
-            "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"
-            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-            : "a"(u0), "a"(u1), "a"(u2), "a"(u3), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                     : "a"(u0), "a"(u1), "a"(u2), "a"(u3), "v"(b));
     else
-        asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
-            "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"
-            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-            : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(b));
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %8, %1\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %2, %6, %8, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %7, %8, %3"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+                     : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(b));
 }
 __device__ __forceinline__ void chain_done(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3) {
     asm volatile("s_nop 9" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
 }
-// load 4 fragments straight into AGPRs and wait for them (hipcc does not count asm loads)
+// 4 fragments straight into accumulator registers, waited for in the same statement
 __device__ __forceinline__ void load4_agpr(frag& u0, frag& u1, frag& u2, frag& u3, const frag* p0, const frag* p1,
                                            const frag* p2, const frag* p3) {
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
@@ -59,11 +87,30 @@ __device__ __forceinline__ void load4_agpr(frag& u0, frag& u1, frag& u2, frag& u
                  : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
                  : "memory");
 }
+// Prefetch loads (plain, so hipcc may spill / move them safely).  All values of a step are "consumed" together by
+// the pin*() statements right after ONE vm_drain(): hipcc then has nothing left to wait for at the individual
+// uses, instead of inserting a (store-draining) wait per tile.
+__device__ __forceinline__ void aload8(u16x4& d, const void* p) { d = *reinterpret_cast<const u16x4*>(p); }
+__device__ __forceinline__ void aload4(float& d, const void* p) { d = *reinterpret_cast<const float*>(p); }
+__device__ __forceinline__ void aload1(int& d, const void* p) { d = *reinterpret_cast<const uint8_t*>(p); }
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ties asm-loaded registers to the drain: consumers can only be scheduled after this statement
+__device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pinf(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pini(int& a) { asm volatile("" : "+v"(a)); }
 
-// Where the FPW fragments of a wave live, by their index f in order of use (all bounds multiples of 4):
-//   [0, NA) accumulator registers | [NA, NA+NV) vector registers | [NA+NV, NA+NV+NL) LDS slab | rest: re-read
-//   from L2 every step (only when the 512 KiB of LSTM weights + working set exceed registers + LDS).
+__device__ __forceinline__ f32x4 unpack4(u16x4 p) { return f32x4{bf2f(p[0]), bf2f(p[1]), bf2f(p[2]), bf2f(p[3])}; }
+__device__ __forceinline__ u16x4 pack4(f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    return __builtin_bit_cast(u16x4, __builtin_convertvector(v, bf16x4));     // 2 x v_cvt_pk_bf16_f32
+}
+
+// ---- fragment residency -----------------------------------------------------------------------------------
 #define RES_DECLARE_U(FPW_)                                                                                        \
+    static_assert(NA % 4 == 0 && NV % 4 == 0 && NA + NV <= (FPW_) && NA <= 64, "fragment classes");              \
     frag ua[NA > 0 ? NA : 4];                                                                                     \
     frag uv[NV > 0 ? NV : 4];                                                                                     \
     _Pragma("unroll") for (int f = 0; f < (FPW_); f += 4) {                                                       \
@@ -76,7 +123,7 @@ __device__ __forceinline__ void load4_agpr(frag& u0, frag& u1, frag& u2, frag& u
         else if (f < NA + NV) {                                                                                   \
             uv[f - NA < NV ? f - NA : 0] = *p0; uv[f - NA < NV ? f - NA + 1 : 1] = *p1;                           \
             uv[f - NA < NV ? f - NA + 2 : 2] = *p2; uv[f - NA < NV ? f - NA + 3 : 3] = *p3;                       \
-        } else if (f < NA + NV + NL) {                                                                            \
+        } else {                                                                                                  \
             myl[(size_t)(f - NA - NV) * 64] = *p0; myl[(size_t)(f - NA - NV + 1) * 64] = *p1;                     \
             myl[(size_t)(f - NA - NV + 2) * 64] = *p2; myl[(size_t)(f - NA - NV + 3) * 64] = *p3;                 \
         }                                                                                                         \
@@ -90,49 +137,81 @@ __device__ __forceinline__ void load4_agpr(frag& u0, frag& u1, frag& u2, frag& u
         else if ((f) < NA + NV) mfma4<false>(c0, c1, c2, c3, uv[(f) - NA < NV ? (f) - NA : 0],                     \
                                              uv[(f) - NA < NV ? (f) - NA + 1 : 1], uv[(f) - NA < NV ? (f) - NA + 2 : 2], \
                                              uv[(f) - NA < NV ? (f) - NA + 3 : 3], bf);                           \
-        else if ((f) < NA + NV + NL) {                                                                            \
+        else {                                                                                                    \
             const frag t0 = myl[(size_t)((f) - NA - NV) * 64], t1 = myl[(size_t)((f) - NA - NV + 1) * 64];        \
             const frag t2 = myl[(size_t)((f) - NA - NV + 2) * 64], t3 = myl[(size_t)((f) - NA - NV + 3) * 64];    \
-            mfma4<false>(c0, c1, c2, c3, t0, t1, t2, t3, bf);                                                     \
-        } else {                                                                                                  \
-            const frag t0 = up[(size_t)frag_src(f) * 64 + l], t1 = up[(size_t)frag_src((f) + 1) * 64 + l];        \
-            const frag t2 = up[(size_t)frag_src((f) + 2) * 64 + l], t3 = up[(size_t)frag_src((f) + 3) * 64 + l];  \
             mfma4<false>(c0, c1, c2, c3, t0, t1, t2, t3, bf);                                                     \
         }                                                                                                         \
     } while (0)
 
+// One MFMA phase: NG groups of 4 MFMAs, group gi uses fragments F0 + 4*gi .. +3 and B fragment BFRAG(gi).
+// B fragments come from LDS through a 3-deep register ring: the read for group gi+2 is issued before the MFMAs of
+// group gi, so the ~100-cycle ds_read latency is covered by two 64-cycle groups (hipcc does not hoist loads over
+// volatile asm on its own: measured 164 instead of 64 cycles per group).  HOOK(gi) runs after group gi's MFMAs.
+#define RES_PHASE(c0, c1, c2, c3, F0, NG, BFRAG, HOOK)                                                             \
+    do {                                                                                                          \
+        frag bq_[3];                                                                                              \
+        bq_[0] = BFRAG(0);                                                                                        \
+        bq_[1] = BFRAG((NG) > 1 ? 1 : 0);                                                                         \
+        _Pragma("unroll") for (int gi_ = 0; gi_ < (NG); ++gi_) {                                                  \
+            if (gi_ + 2 < (NG)) bq_[(gi_ + 2) % 3] = BFRAG(gi_ + 2);                                              \
+            RES_MFMA4(c0, c1, c2, c3, (F0) + 4 * gi_, bq_[gi_ % 3]);                                              \
+            HOOK(gi_);                                                                                            \
+        }                                                                                                         \
+        chain_done(c0, c1, c2, c3);                                                                               \
+    } while (0)
+#define RES_NOHOOK(gi)
+
+enum { SAVE_NONE = 0, SAVE_HS = 1, SAVE_ALL = 2 };
+
+// [16 rows][W] bf16 tile in LDS with NO padding; the 16-byte chunk index is XOR-ed with the row so the 16 rows of a
+// ds_read_b128 group hit 16 different bank slots.  col % 4 == 0.
+template <int W>
+__device__ __forceinline__ int sw_off(int row, int col) {
+    return row * W + ((((col >> 3) ^ row) << 3) | (col & 7));
+}
+// Write rows [4w, 4w+4) of a swizzled LDS tile to a row-major global array as whole 16-byte chunks (coalesced).
+template <int W>
+__device__ __forceinline__ void tile_rows_to_global(const bf16_t* tile, bf16_t* gbase /* row 0 of this WG's 16 rows */,
+                                                    int w, int l) {
+    constexpr int CH = W / 8;                    // 16-byte chunks per row
+#pragma unroll 2
+    for (int j = 0; j < (4 * CH) / 64; ++j) {
+        const int c = j * 64 + l, row = 4 * w + c / CH, ch = c % CH;
+        const u16x8 v = *reinterpret_cast<const u16x8*>(tile + row * W + ((ch ^ row) << 3));
+        *reinterpret_cast<u16x8*>(gbase + (size_t)row * W + ch * 8) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-template <int CELL, int XMODE, int NA, int NV, int NL>
+template <int CELL, int XMODE, int SAVE, int NA, int NV>
 __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args a) {
     constexpr int G = mvae_gates(CELL), GH = G * RH;
-    constexpr int FPW = G * RNT * RS;              // fragments per wave
-    constexpr int NLDS = NL;
-    static_assert(NA % 4 == 0 && NV % 4 == 0 && NL % 4 == 0 && NA + NV + NL <= FPW, "fragment classes");
+    constexpr int FPW = G * RNT * RS;              // fragments per wave (LSTM 128, GRU 96)
+    constexpr int NLc = FPW - NA - NV;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* hbuf = reinterpret_cast<bf16_t*>(smem);                         // [2][16][RLDH]
-    bf16_t* rhbuf = hbuf + 2 * 16 * RLDH;                                   // [16][RLDH]      (GRU)
-    frag* ulds = reinterpret_cast<frag*>(rhbuf + (CELL == MVAE_GRU ? 16 * RLDH : 0));   // [4][NLDS][64]
-    float* wb = reinterpret_cast<float*>(ulds + 4 * NLDS * 64);             // [2][GH]         (SCALAR)
-
+    bf16_t* hbuf = reinterpret_cast<bf16_t*>(smem);                         // [2][16][RH] swizzled
+    bf16_t* rhbuf = hbuf + 2 * 16 * RH;                                     // [16][RH] swizzled   (GRU)
+    frag* ulds = reinterpret_cast<frag*>(rhbuf + (CELL == MVAE_GRU ? 16 * RH : 0));     // [4][NL][64]
+    float* wb = reinterpret_cast<float*>(ulds + 4 * NLc * 64);              // [2][GH]         (SCALAR)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
     const int T = a.T, B = a.B;
-    const int b = blockIdx.x * 16 + r;
-    const bool valid = b < B;
-    const int bb = valid ? b : B - 1;
+    const int b = blockIdx.x * 16 + r;               // B % 16 == 0: every row is real
+    const size_t tiles_per_step = (size_t)(B / 16);  // TILE16: row-tile index of (t, this WG) = t*B/16 + blockIdx.x
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
     bf16_t* __restrict__ hs = reinterpret_cast<bf16_t*>(a.hs);
     bf16_t* __restrict__ cs = reinterpret_cast<bf16_t*>(a.cs);
     bf16_t* __restrict__ acts = reinterpret_cast<bf16_t*>(a.acts);
     const bf16_t* __restrict__ xp = reinterpret_cast<const bf16_t*>(a.xp);
     const bf16_t* __restrict__ table = reinterpret_cast<const bf16_t*>(a.table);
-    frag* myl = ulds + (size_t)w * NLDS * 64 + l;
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
 
-    // fragment f of this wave, in order of use.  LSTM: f = (n*8 + ks)*4 + g.
-    // GRU: phase A (z,r) f = ((np*8 + ks)*2 + nn)*2 + g for tile pair np, then phase B (candidate) f = 64 + ks*4 + n.
-    auto frag_src = [&](int f) -> int {        // index of fragment f in the packed U (units of 64-lane fragments)
+    // fragment f of this wave, in order of use.  LSTM: f = (n*8 + ks)*4 + g  (tile n, k-group ks, gate g).
+    // GRU: phase A (z,r) f = ((np*8 + ks)*2 + nn)*2 + g for tile pair np; phase B (candidate) f = 64 + ks*4 + n.
+    auto frag_src = [&](int f) -> int {
         int g, n, ks;
         if (CELL == MVAE_GRU) {
             if (f < 64) { g = f & 1; const int nn = (f >> 1) & 1; ks = (f >> 2) & 7; n = (f >> 5) * 2 + nn; }
@@ -153,13 +232,11 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
 #pragma unroll
     for (int n = 0; n < RNT; ++n) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)bb * ld0 + ub[n]) : z4;
-        creg[n] = (CELL == MVAE_LSTM && a.c0) ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)bb * ld0 + ub[n]) : z4;
-        st<bf16_t>::store4(hbuf + r * RLDH + ub[n], hreg[n]);
-        if (valid) {
-            if (hs) st<bf16_t>::store4(hs + (size_t)b * RH + ub[n], hreg[n]);
-            if (CELL == MVAE_LSTM && cs) st<bf16_t>::store4(cs + (size_t)b * RH + ub[n], creg[n]);
-        }
+        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub[n]) : z4;
+        creg[n] = (CELL == MVAE_LSTM && a.c0) ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)b * ld0 + ub[n]) : z4;
+        *reinterpret_cast<u16x4*>(hbuf + sw_off<RH>(r, ub[n])) = pack4(hreg[n]);
+        if (CELL == MVAE_LSTM && SAVE == SAVE_ALL)     // c_0 -> tile row 0 of the (T+1, B, H) TILE16 array
+            *reinterpret_cast<u16x4*>(cs + (((size_t)blockIdx.x * (RH / 16) + w * RNT + n) * 64 + l) * 4) = pack4(creg[n]);
     }
     if (XMODE == MVAE_X_SCALAR) {
         for (int i = tid; i < GH; i += 256) {
@@ -168,39 +245,45 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
         }
     }
 
-    // ---- x queue: packed bf16x4 per (tile, gate), always holding the NEXT step to be consumed --------------
+    // ---- x queue: packed bf16x4 per (tile, gate) for the step about to be computed ---------------------------
     u16x4 xq[RNT][G];
-    float xs_next = 0.0f;
-    int i_next = 0, i_next2 = 0;
-    auto xload = [&](int t, int n, int g, int irow) -> u16x4 {
-        if (XMODE == MVAE_X_DENSE) return *reinterpret_cast<const u16x4*>(xp + ((size_t)t * B + bb) * GH + g * RH + ub[n]);
-        if (XMODE == MVAE_X_INDEX) return *reinterpret_cast<const u16x4*>(table + (size_t)irow * GH + g * RH + ub[n]);
-        return *reinterpret_cast<const u16x4*>(reinterpret_cast<const bf16_t*>(a.xp0) + (size_t)bb * GH + g * RH + ub[n]);
+    float xs_q = 0.0f;        // SCALAR: x of the step about to be computed
+    int i_q = 0;              // INDEX: table row of the step AFTER the one about to be computed
+    auto xaddr = [&](int t, int n, int g, int irow) -> const bf16_t* {
+        if (XMODE == MVAE_X_DENSE)      // TILE16 (T*B, GH): 512 contiguous bytes per wave
+            return xp + ((((size_t)t * tiles_per_step + blockIdx.x) * (GH / 16) + g * (RH / 16) + w * RNT + n) * 64 + l) * 4;
+        if (XMODE == MVAE_X_INDEX) return table + (size_t)irow * GH + g * RH + ub[n];
+        return reinterpret_cast<const bf16_t*>(a.xp0) + (size_t)b * GH + g * RH + ub[n];
     };
-    if (XMODE == MVAE_X_INDEX) {
-        i_next = a.idx[bb];
-        i_next2 = a.idx[(size_t)(T > 1 ? 1 : 0) * B + bb];
-    }
-    if (XMODE == MVAE_X_SCALAR) xs_next = a.xs[bb];
     if (XMODE != MVAE_X_SCALAR) {
+        const int i0 = XMODE == MVAE_X_INDEX ? (int)a.idx[b] : 0;
 #pragma unroll
         for (int n = 0; n < RNT; ++n)
 #pragma unroll
-            for (int g = 0; g < G; ++g) xq[n][g] = xload(0, n, g, i_next);
+            for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xaddr(0, n, g, i0));
+        if (XMODE == MVAE_X_INDEX) i_q = a.idx[(size_t)(T > 1 ? 1 : 0) * B + b];
+    } else {
+        xs_q = a.xs[b];
     }
-    __syncthreads();
+    vm_drain();
+    lds_barrier();
 
+    float xs_cur = 0.0f;
     int cur = 0;
     for (int t = 0; t < T; ++t) {
-        const int tn = t + 1 < T ? t + 1 : t;             // step whose inputs are (re)loaded during this step
-        const float xs_cur = xs_next;
-        int i_row = i_next2;                              // table row of step t+1
-        if (XMODE == MVAE_X_SCALAR) xs_next = a.xs[(size_t)tn * B + bb];
-        if (XMODE == MVAE_X_INDEX) {
-            i_next = i_next2;
-            i_next2 = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + bb];
-        }
-        // x for (gate g, tile n) of THIS step as f32x4
+        const int tstep = t;
+        STAMP(0);
+        const int tn = t + 1 < T ? t + 1 : t;             // step whose inputs are fetched during this step
+        const bf16_t* htile = hbuf + cur * 16 * RH;       // h_{t-1} (slot t of the saved sequence)
+        bf16_t* hnext = hbuf + (cur ^ 1) * 16 * RH;
+        auto hfrag = [&](const bf16_t* tile, int ks) -> frag {
+            return *reinterpret_cast<const frag*>(tile + sw_off<RH>(r, ks * 32 + q * 8));
+        };
+        // saved-sequence slot t (= h_{t-1}; slot 0 = h0): whole rows straight from the LDS tile
+        if (SAVE >= SAVE_HS) tile_rows_to_global<RH>(htile, hs + ((size_t)t * B + blockIdx.x * 16) * RH, w, l);
+        const size_t otile = ((size_t)t * tiles_per_step + blockIdx.x);          // TILE16 row tile of step t
+
+        // x of THIS step for (tile n, gate g)
         auto xval = [&](int n, int g) -> f32x4 {
             if (XMODE == MVAE_X_SCALAR) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wb + g * RH + ub[n]);
@@ -209,64 +292,79 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
             }
             u16x4 p = xq[n][g];
             if (XMODE == MVAE_X_CONST) asm volatile("" : "+v"(p));   // keep the loop-invariant row PACKED (no LICM of the unpack)
-            return f32x4{bf2f(p[0]), bf2f(p[1]), bf2f(p[2]), bf2f(p[3])};
+            return unpack4(p);
         };
-        auto refill = [&](int n) {
+        // every prefetch load of this step was issued one step ago; the youngest pending store is the previous step's
+        auto step_inputs_ready = [&]() {
+            STAMP(1);
+            vm_drain();
+            STAMP(2);
             if (XMODE == MVAE_X_DENSE || XMODE == MVAE_X_INDEX) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) xq[n][g] = xload(tn, n, g, i_row);
+                for (int n = 0; n < RNT; ++n) {
+                    if (G == 4) pin4(xq[n][0], xq[n][1], xq[n][G > 2 ? 2 : 0], xq[n][G > 3 ? 3 : 0]);
+                    else { pin1(xq[n][0]); pin1(xq[n][G > 1 ? 1 : 0]); pin1(xq[n][G > 2 ? 2 : 0]); }
+                }
+            }
+            if (XMODE == MVAE_X_SCALAR) { pinf(xs_q); xs_cur = xs_q; }
+            if (XMODE == MVAE_X_INDEX) pini(i_q);
+        };
+        auto request_next = [&](int n) {      // right after tile n's x was consumed
+            if (XMODE == MVAE_X_DENSE || XMODE == MVAE_X_INDEX) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) aload8(xq[n][g], xaddr(tn, n, g, i_q));
+            }
+            if (n == RNT - 1) {
+                if (XMODE == MVAE_X_SCALAR) aload4(xs_q, a.xs + (size_t)tn * B + b);
+                if (XMODE == MVAE_X_INDEX) aload1(i_q, a.idx + (size_t)(t + 2 < T ? t + 2 : T - 1) * B + b);
             }
         };
-        const bf16_t* hrow = hbuf + cur * 16 * RLDH + r * RLDH + q * 8;
-        bf16_t* hnext = hbuf + (cur ^ 1) * 16 * RLDH + r * RLDH;
 
-        if (CELL == MVAE_LSTM || CELL == MVAE_RNN) {
+        if (CELL == MVAE_LSTM) {
+            auto lstm_tile = [&](int n, const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3) {
+                const f32x4 xi = xval(n, 0), xf = xval(n, G > 1 ? 1 : 0), xg = xval(n, G > 2 ? 2 : 0), xo = xval(n, G > 3 ? 3 : 0);
+                f32x4 ig, fg, gg, og, hnew;
 #pragma unroll
-            for (int n = 0; n < RNT; ++n) {
-                f32x4 acc[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < RS; ++ks) {
-                    const frag bf = *reinterpret_cast<const frag*>(hrow + ks * 32);
-                    RES_MFMA4(acc[0], acc[1], acc[2], acc[3], (n * RS + ks) * 4, bf);
+                for (int i = 0; i < 4; ++i) {
+                    ig[i] = hard_sigmoid(a0[i] + xi[i]);
+                    fg[i] = hard_sigmoid(a1[i] + xf[i]);
+                    gg[i] = tanh_fast(a2[i] + xg[i]);
+                    og[i] = hard_sigmoid(a3[i] + xo[i]);
+                    creg[n][i] = fg[i] * creg[n][i] + ig[i] * gg[i];
+                    hnew[i] = og[i] * tanh_fast(creg[n][i]);
                 }
-                chain_done(acc[0], acc[1], acc[2], acc[3]);
-                f32x4 hnew;
-                if (CELL == MVAE_LSTM) {
-                    const f32x4 xi = xval(n, 0), xf = xval(n, 1), xg = xval(n, 2), xo = xval(n, 3);
-                    f32x4 ig, fg, gg, og;
+                *reinterpret_cast<u16x4*>(hnext + sw_off<RH>(r, ub[n])) = pack4(hnew);
+                if (SAVE == SAVE_ALL) {
+                    bf16_t* ap = acts + ((otile * (GH / 16) + w * RNT + n) * 64 + l) * 4;     // gate 0 tile; gates 16 tiles apart
+                    *reinterpret_cast<u16x4*>(ap) = pack4(ig);
+                    *reinterpret_cast<u16x4*>(ap + 1 * (RH / 16) * 256) = pack4(fg);
+                    *reinterpret_cast<u16x4*>(ap + 2 * (RH / 16) * 256) = pack4(gg);
+                    *reinterpret_cast<u16x4*>(ap + 3 * (RH / 16) * 256) = pack4(og);
+                    *reinterpret_cast<u16x4*>(cs + (((otile + tiles_per_step) * (RH / 16) + w * RNT + n) * 64 + l) * 4) = pack4(creg[n]);
+                }
+                if (a.h_last && t == T - 1) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hnew;
+            };
+            // software pipeline over unit tiles: MFMAs of tile n with the arithmetic of tile n-1 issued among them
+            f32x4 accA[4], accB[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        ig[i] = hard_sigmoid(acc[0][i] + xi[i]);
-                        fg[i] = hard_sigmoid(acc[1][i] + xf[i]);
-                        gg[i] = tanh_f(acc[2][i] + xg[i]);
-                        og[i] = hard_sigmoid(acc[3][i] + xo[i]);
-                        creg[n][i] = fg[i] * creg[n][i] + ig[i] * gg[i];
-                        hnew[i] = og[i] * tanh_f(creg[n][i]);
-                    }
-                    if (valid) {
-                        if (acts) {
-                            bf16_t* ap = acts + ((size_t)t * B + b) * GH + ub[n];
-                            st<bf16_t>::store4(ap, ig);
-                            st<bf16_t>::store4(ap + RH, fg);
-                            st<bf16_t>::store4(ap + 2 * RH, gg);
-                            st<bf16_t>::store4(ap + 3 * RH, og);
-                        }
-                        if (cs) st<bf16_t>::store4(cs + ((size_t)(t + 1) * B + b) * RH + ub[n], creg[n]);
-                    }
+            for (int n = 0; n <= RNT; ++n) {
+                f32x4* acc = (n & 1) ? accB : accA;
+                f32x4* prev = (n & 1) ? accA : accB;
+                if (n < RNT) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define HF_(ks) hfrag(htile, ks)
+#define LSTM_HOOK_(gi)                                                         \
+    if ((gi) == 1 && n > 0) {                                                 \
+        if (n == 1) step_inputs_ready();                                      \
+        lstm_tile(n - 1, prev[0], prev[1], prev[2], prev[3]);                 \
+        request_next(n - 1);                                                  \
+    }
+                    RES_PHASE(acc[0], acc[1], acc[2], acc[3], n * RS * 4, RS, HF_, LSTM_HOOK_);
+                    STAMP(8 + n);
                 } else {
-                    const f32x4 x0 = xval(n, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hnew[i] = tanh_f(acc[0][i] + x0[i]);
-                    if (acts && valid) st<bf16_t>::store4(acts + ((size_t)t * B + b) * GH + ub[n], hnew);
-                }
-                refill(n);
-                st<bf16_t>::store4(hnext + ub[n], hnew);
-                if (valid) {
-                    if (hs) st<bf16_t>::store4(hs + ((size_t)(t + 1) * B + b) * RH + ub[n], hnew);
-                    // the f32 master copy of h is not needed by LSTM / SimpleRNN steps: emit the final state here
-                    if (a.h_last && t == T - 1) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hnew;
+                    lstm_tile(n - 1, prev[0], prev[1], prev[2], prev[3]);
+                    request_next(n - 1);
                 }
             }
         } else {
@@ -279,87 +377,88 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                 for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) acc[nn][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < RS; ++ks) {
-                    const frag bf = *reinterpret_cast<const frag*>(hrow + ks * 32);
-                    RES_MFMA4(acc[0][0], acc[0][1], acc[1][0], acc[1][1], (np * RS + ks) * 4, bf);
-                }
-                chain_done(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+#ifndef HF_
+#define HF_(ks) hfrag(htile, ks)
+#endif
+                RES_PHASE(acc[0][0], acc[0][1], acc[1][0], acc[1][1], np * RS * 4, RS, HF_, RES_NOHOOK);
+                if (np == 0) step_inputs_ready();
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) {
                     const int n = np * 2 + nn;
-                    const f32x4 xz = xval(n, 0), xr = xval(n, 1);
+                    const f32x4 xz = xval(n, 0), xr = xval(n, G > 1 ? 1 : 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         zg[n][i] = hard_sigmoid(acc[nn][0][i] + xz[i]);
                         rg[n][i] = hard_sigmoid(acc[nn][1][i] + xr[i]);
                     }
-                    st<bf16_t>::store4(rhbuf + r * RLDH + ub[n], rg[n] * hreg[n]);
+                    *reinterpret_cast<u16x4*>(rhbuf + sw_off<RH>(r, ub[n])) = pack4(rg[n] * hreg[n]);
                 }
             }
-            __syncthreads();
+            STAMP(3);
+            lds_barrier();
+            STAMP(4);
             // ---- GRU phase B: candidate ---------------------------------------------------------------------
             f32x4 acc[RNT];
 #pragma unroll
             for (int n = 0; n < RNT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bf16_t* rhrow = rhbuf + r * RLDH + q * 8;
-#pragma unroll
-            for (int ks = 0; ks < RS; ++ks) {
-                const frag bf = *reinterpret_cast<const frag*>(rhrow + ks * 32);
-                RES_MFMA4(acc[0], acc[1], acc[2], acc[3], 64 + ks * 4, bf);
-            }
-            chain_done(acc[0], acc[1], acc[2], acc[3]);
+#define RHF_(ks) hfrag(rhbuf, ks)
+            RES_PHASE(acc[0], acc[1], acc[2], acc[3], 64, RS, RHF_, RES_NOHOOK);
+            STAMP(5);
 #pragma unroll
             for (int n = 0; n < RNT; ++n) {
-                const f32x4 xh = xval(n, 2);
+                const f32x4 xh = xval(n, G > 2 ? 2 : 0);
                 f32x4 hh, hnew;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    hh[i] = tanh_f(acc[n][i] + xh[i]);
+                    hh[i] = tanh_fast(acc[n][i] + xh[i]);
                     hnew[i] = zg[n][i] * hreg[n][i] + (1.0f - zg[n][i]) * hh[i];
                 }
-                if (acts && valid) {
-                    bf16_t* ap = acts + ((size_t)t * B + b) * GH + ub[n];
-                    st<bf16_t>::store4(ap, zg[n]);
-                    st<bf16_t>::store4(ap + RH, rg[n]);
-                    st<bf16_t>::store4(ap + 2 * RH, hh);
-                }
-                refill(n);
                 hreg[n] = hnew;
-                st<bf16_t>::store4(hnext + ub[n], hnew);
-                if (hs && valid) st<bf16_t>::store4(hs + ((size_t)(t + 1) * B + b) * RH + ub[n], hnew);
+                *reinterpret_cast<u16x4*>(hnext + sw_off<RH>(r, ub[n])) = pack4(hnew);
+                if (SAVE == SAVE_ALL) {
+                    bf16_t* ap = acts + ((otile * (GH / 16) + w * RNT + n) * 64 + l) * 4;
+                    *reinterpret_cast<u16x4*>(ap) = pack4(zg[n]);
+                    *reinterpret_cast<u16x4*>(ap + 1 * (RH / 16) * 256) = pack4(rg[n]);
+                    *reinterpret_cast<u16x4*>(ap + 2 * (RH / 16) * 256) = pack4(hh);
+                }
+                request_next(n);
             }
         }
         cur ^= 1;
-        __syncthreads();
+        STAMP(6);
+        lds_barrier();
+        STAMP(7);
     }
-    if (CELL == MVAE_GRU && a.h_last && valid) {
+    if (SAVE >= SAVE_HS) tile_rows_to_global<RH>(hbuf + cur * 16 * RH, hs + ((size_t)T * B + blockIdx.x * 16) * RH, w, l);
+    if (CELL == MVAE_GRU && a.h_last) {
 #pragma unroll
         for (int n = 0; n < RNT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hreg[n];
     }
+    vm_drain();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward through time
 // ---------------------------------------------------------------------------------------------------------
-template <int CELL, bool HAS_EXT, int NA, int NV, int NL>
+// The da tile in LDS is [16 rows][GH] bf16, swizzled, unpadded: LSTM needs every byte (32 KiB tile + 128 KiB of
+// weights = all 160 KiB).
+
+template <int CELL, bool HAS_EXT, int NA, int NV>
 __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args a) {
     constexpr int G = mvae_gates(CELL), GH = G * RH;
     constexpr int S2 = GH / 32;                    // k-groups of the backward contraction (over gate columns)
     constexpr int FPW = RNT * S2;
-    constexpr int NLDS = NL;
-    constexpr int LDA = GH + 8;
-    static_assert(NA % 4 == 0 && NV % 4 == 0 && NL % 4 == 0 && NA + NV + NL <= FPW, "fragment classes");
+    constexpr int NLc = FPW - NA - NV;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* dabuf = reinterpret_cast<bf16_t*>(smem);                        // [16][LDA]
-    frag* ulds = reinterpret_cast<frag*>(dabuf + 16 * LDA);                 // [4][NLDS][64]
+    bf16_t* dabuf = reinterpret_cast<bf16_t*>(smem);                        // [16][GH] swizzled
+    frag* ulds = reinterpret_cast<frag*>(dabuf + 16 * GH);                  // [4][NL][64]
+    bf16_t* rhtile = reinterpret_cast<bf16_t*>(ulds + 4 * NLc * 64);        // [16][RH] swizzled   (GRU)
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
     const int T = a.T, B = a.B;
     const int b = blockIdx.x * 16 + r;
-    const bool valid = b < B;
-    const int bb = valid ? b : B - 1;
+    const size_t tiles_per_step = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
     const bf16_t* __restrict__ hs = reinterpret_cast<const bf16_t*>(a.hs);
     const bf16_t* __restrict__ cs = reinterpret_cast<const bf16_t*>(a.cs);
@@ -367,7 +466,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
     const bf16_t* __restrict__ dext = reinterpret_cast<const bf16_t*>(a.dhs_ext);
     bf16_t* __restrict__ da = reinterpret_cast<bf16_t*>(a.da);
     bf16_t* __restrict__ rh = reinterpret_cast<bf16_t*>(a.rh);
-    frag* myl = ulds + (size_t)w * NLDS * 64 + l;
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
 
     // fragment f = ks*4 + n  (A rows = hidden units of tile w*4+n, k-group ks over gate columns)
     auto frag_src = [&](int f) -> int { return (w * RNT + (f & 3)) * S2 + (f >> 2); };
@@ -381,37 +480,54 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
 #pragma unroll
     for (int n = 0; n < RNT; ++n) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bb * (a.dh_last_ld ? a.dh_last_ld : RH) + ub[n]) : z4;
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * (a.dh_last_ld ? a.dh_last_ld : RH) + ub[n]) : z4;
         dc[n] = z4;
     }
-    auto ld4 = [&](const bf16_t* base, size_t row, int width, int col) -> u16x4 {
-        return *reinterpret_cast<const u16x4*>(base + row * width + col);
+    // queue of saved forward values for the step about to be processed (requested one step earlier)
+    u16x4 qa[RNT][G], qs[RNT], qd[RNT], carry[RNT];   // gates; c_{t-1} (LSTM) / h_{t-1} (GRU); upstream grad; c_t
+    // TILE16 addresses of this lane's 4-unit slot: saved gates (cols GH), cell states / upstream gradient (cols H)
+    auto a_ptr = [&](int t, int n, int g) -> const bf16_t* {
+        return acts + ((((size_t)t * tiles_per_step + blockIdx.x) * (GH / 16) + g * (RH / 16) + w * RNT + n) * 64 + l) * 4;
     };
-    auto unpack = [](u16x4 p) -> f32x4 { return f32x4{bf2f(p[0]), bf2f(p[1]), bf2f(p[2]), bf2f(p[3])}; };
-
-    // queue of saved forward values for the NEXT step to be processed (one step of prefetch distance)
-    u16x4 qa[RNT][G], qs[RNT], qd[RNT], carry[RNT];   // gates; c_{t-1} (LSTM) or h_{t-1} (GRU); upstream grad; c_t
+    auto h_ptr = [&](const bf16_t* base, int t, int n) -> const bf16_t* {
+        return base + ((((size_t)t * tiles_per_step + blockIdx.x) * (RH / 16) + w * RNT + n) * 64 + l) * 4;
+    };
     {
         const int t = T - 1;
-        const size_t row = (size_t)t * B + bb;
 #pragma unroll
         for (int n = 0; n < RNT; ++n) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) qa[n][g] = ld4(acts, row, GH, g * RH + ub[n]);
+            for (int g = 0; g < G; ++g) qa[n][g] = *reinterpret_cast<const u16x4*>(a_ptr(t, n, g));
             if (CELL == MVAE_LSTM) {
-                qs[n] = ld4(cs, row, RH, ub[n]);
-                carry[n] = ld4(cs, (size_t)(t + 1) * B + bb, RH, ub[n]);
+                qs[n] = *reinterpret_cast<const u16x4*>(h_ptr(cs, t, n));
+                carry[n] = *reinterpret_cast<const u16x4*>(h_ptr(cs, t + 1, n));
             }
-            if (CELL == MVAE_GRU) qs[n] = ld4(hs, row, RH, ub[n]);
-            if (HAS_EXT) qd[n] = ld4(dext, row, RH, ub[n]);
+            if (CELL == MVAE_GRU) qs[n] = *reinterpret_cast<const u16x4*>(hs + ((size_t)t * B + b) * RH + ub[n]);
+            if (HAS_EXT) qd[n] = *reinterpret_cast<const u16x4*>(h_ptr(dext, t, n));
         }
     }
-    bf16_t* drow = dabuf + r * LDA;
-    const bf16_t* brow = dabuf + r * LDA + q * 8;
+    vm_drain();
+    lds_barrier();
+
+    // B fragment (k-group ks of the da tile) for this lane: row r, 8 columns from ks*32 + q*8
+    auto bfrag = [&](int ks) -> frag { return *reinterpret_cast<const frag*>(dabuf + sw_off<GH>(r, ks * 32 + q * 8)); };
+    auto put_da = [&](int col, f32x4 v) { *reinterpret_cast<u16x4*>(dabuf + sw_off<GH>(r, col)) = pack4(v); };
 
     for (int t = T - 1; t >= 0; --t) {
-        const int tp = t > 0 ? t - 1 : 0;                    // the step prefetched during this one
-        const size_t prow = (size_t)tp * B + bb;
+        const int tp = t > 0 ? t - 1 : 0;                           // the step requested during this one
+        bf16_t* da_rows = da + ((size_t)t * B + blockIdx.x * 16) * GH;   // this WG's 16 rows of da[t], row-major
+        const int tstep = T - 1 - t;
+        STAMP(0);
+        // this step's loads were issued a full step ago; the youngest store precedes the previous MFMA phase
+        vm_drain();
+        STAMP(1);
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) {
+            if (G == 4) pin4(qa[n][0], qa[n][G > 1 ? 1 : 0], qa[n][G > 2 ? 2 : 0], qa[n][G > 3 ? 3 : 0]);
+            else { pin1(qa[n][0]); pin1(qa[n][G > 1 ? 1 : 0]); pin1(qa[n][G > 2 ? 2 : 0]); }
+            pin1(qs[n]);
+            if (HAS_EXT) pin1(qd[n]);
+        }
         f32x4 acc[RNT];
 #pragma unroll
         for (int n = 0; n < RNT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -419,14 +535,15 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
         if (CELL == MVAE_LSTM) {
 #pragma unroll
             for (int n = 0; n < RNT; ++n) {
-                const f32x4 ig = unpack(qa[n][0]), fg = unpack(qa[n][1]), gg = unpack(qa[n][2]), og = unpack(qa[n][G > 3 ? 3 : 0]);
-                const f32x4 c = unpack(carry[n]), cp = unpack(qs[n]);
+                const f32x4 ig = unpack4(qa[n][0]), fg = unpack4(qa[n][G > 1 ? 1 : 0]), gg = unpack4(qa[n][G > 2 ? 2 : 0]),
+                            og = unpack4(qa[n][G > 3 ? 3 : 0]);
+                const f32x4 c = unpack4(carry[n]), cp = unpack4(qs[n]);
                 f32x4 d = dh[n];
-                if (HAS_EXT) d += unpack(qd[n]);
+                if (HAS_EXT) d += unpack4(qd[n]);
                 f32x4 di, df, dg, dO;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float tc = tanh_f(c[i]);
+                    const float tc = tanh_fast(c[i]);
                     const float dct = dc[n][i] + d[i] * og[i] * (1.0f - tc * tc);
                     di[i] = dct * gg[i] * dhard_sigmoid(ig[i]);
                     df[i] = dct * cp[i] * dhard_sigmoid(fg[i]);
@@ -434,63 +551,50 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                     dO[i] = d[i] * tc * dhard_sigmoid(og[i]);
                     dc[n][i] = dct * fg[i];
                 }
-                st<bf16_t>::store4(drow + ub[n], di);
-                st<bf16_t>::store4(drow + RH + ub[n], df);
-                st<bf16_t>::store4(drow + 2 * RH + ub[n], dg);
-                st<bf16_t>::store4(drow + 3 * RH + ub[n], dO);
-                if (valid) {
-                    bf16_t* gp = da + ((size_t)t * B + b) * GH + ub[n];
-                    st<bf16_t>::store4(gp, di);
-                    st<bf16_t>::store4(gp + RH, df);
-                    st<bf16_t>::store4(gp + 2 * RH, dg);
-                    st<bf16_t>::store4(gp + 3 * RH, dO);
-                }
+                put_da(ub[n], di);
+                put_da(RH + ub[n], df);
+                put_da(2 * RH + ub[n], dg);
+                put_da(3 * RH + ub[n], dO);
                 carry[n] = qs[n];                         // c_{t-1} is the next step's c_t
 #pragma unroll
-                for (int g = 0; g < G; ++g) qa[n][g] = ld4(acts, prow, GH, g * RH + ub[n]);
-                qs[n] = ld4(cs, prow, RH, ub[n]);
-                if (HAS_EXT) qd[n] = ld4(dext, prow, RH, ub[n]);
+                for (int g = 0; g < G; ++g) aload8(qa[n][g], a_ptr(tp, n, g));
+                aload8(qs[n], h_ptr(cs, tp, n));
+                if (HAS_EXT) aload8(qd[n], h_ptr(dext, tp, n));
             }
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < S2; ++ks) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + ks * 32);
-                RES_MFMA4(acc[0], acc[1], acc[2], acc[3], ks * 4, bf);
-            }
-            chain_done(acc[0], acc[1], acc[2], acc[3]);
+            lds_barrier();
+            tile_rows_to_global<GH>(dabuf, da_rows, w, l);      // da[t]: whole rows, issued ahead of the MFMA phase
+#define BF_(ks) bfrag(ks)
+            RES_PHASE(acc[0], acc[1], acc[2], acc[3], 0, S2, BF_, RES_NOHOOK);
 #pragma unroll
             for (int n = 0; n < RNT; ++n) dh[n] = acc[n];
         } else if (CELL == MVAE_GRU) {
             f32x4 z[RNT], rr[RNT], hp[RNT], hh[RNT], d[RNT];
 #pragma unroll
             for (int n = 0; n < RNT; ++n) {
-                z[n] = unpack(qa[n][0]);
-                rr[n] = unpack(qa[n][1]);
-                hh[n] = unpack(qa[n][G > 2 ? 2 : 0]);
-                hp[n] = unpack(qs[n]);
+                z[n] = unpack4(qa[n][0]);
+                rr[n] = unpack4(qa[n][G > 1 ? 1 : 0]);
+                hh[n] = unpack4(qa[n][G > 2 ? 2 : 0]);
+                hp[n] = unpack4(qs[n]);
                 d[n] = dh[n];
-                if (HAS_EXT) d[n] += unpack(qd[n]);
+                if (HAS_EXT) d[n] += unpack4(qd[n]);
                 f32x4 dah;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dah[i] = d[n][i] * (1.0f - z[n][i]) * (1.0f - hh[n][i] * hh[n][i]);
-                st<bf16_t>::store4(drow + 2 * RH + ub[n], dah);
-                if (valid) {
-                    st<bf16_t>::store4(da + ((size_t)t * B + b) * GH + 2 * RH + ub[n], dah);
-                    if (rh) st<bf16_t>::store4(rh + ((size_t)t * B + b) * RH + ub[n], rr[n] * hp[n]);
-                }
+                put_da(2 * RH + ub[n], dah);
+                if (rh) *reinterpret_cast<u16x4*>(rhtile + sw_off<RH>(r, ub[n])) = pack4(rr[n] * hp[n]);
 #pragma unroll
-                for (int g = 0; g < G; ++g) qa[n][g] = ld4(acts, prow, GH, g * RH + ub[n]);
-                qs[n] = ld4(hs, prow, RH, ub[n]);
-                if (HAS_EXT) qd[n] = ld4(dext, prow, RH, ub[n]);
+                for (int g = 0; g < G; ++g) aload8(qa[n][g], a_ptr(tp, n, g));
+                aload8(qs[n], hs + ((size_t)tp * B + b) * RH + ub[n]);
+                if (HAS_EXT) aload8(qd[n], h_ptr(dext, tp, n));
             }
-            __syncthreads();
+            STAMP(2);
+            lds_barrier();
+            STAMP(3);
+            if (rh) tile_rows_to_global<RH>(rhtile, rh + ((size_t)t * B + blockIdx.x * 16) * RH, w, l);
             constexpr int SH = RH / 32;
-#pragma unroll
-            for (int ks = 2 * SH; ks < 3 * SH; ++ks) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + ks * 32);
-                RES_MFMA4(acc[0], acc[1], acc[2], acc[3], ks * 4, bf);
-            }
-            chain_done(acc[0], acc[1], acc[2], acc[3]);
+#define BFH_(gi) bfrag(2 * SH + (gi))
+            RES_PHASE(acc[0], acc[1], acc[2], acc[3], 2 * SH * 4, SH, BFH_, RES_NOHOOK);
+            STAMP(4);
             f32x4 drh[RNT];
 #pragma unroll
             for (int n = 0; n < RNT; ++n) {
@@ -502,76 +606,85 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                     daz[i] = d[n][i] * (hp[n][i] - hh[n][i]) * dhard_sigmoid(z[n][i]);
                     dar[i] = drh[n][i] * hp[n][i] * dhard_sigmoid(rr[n][i]);
                 }
-                st<bf16_t>::store4(drow + ub[n], daz);
-                st<bf16_t>::store4(drow + RH + ub[n], dar);
-                if (valid) {
-                    bf16_t* gp = da + ((size_t)t * B + b) * GH + ub[n];
-                    st<bf16_t>::store4(gp, daz);
-                    st<bf16_t>::store4(gp + RH, dar);
-                }
+                put_da(ub[n], daz);
+                put_da(RH + ub[n], dar);
             }
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < 2 * SH; ++ks) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + ks * 32);
-                RES_MFMA4(acc[0], acc[1], acc[2], acc[3], ks * 4, bf);
-            }
-            chain_done(acc[0], acc[1], acc[2], acc[3]);
+            STAMP(5);
+            lds_barrier();
+            STAMP(6);
+            tile_rows_to_global<GH>(dabuf, da_rows, w, l);
+#ifndef BF_
+#define BF_(ks) bfrag(ks)
+#endif
+            RES_PHASE(acc[0], acc[1], acc[2], acc[3], 0, 2 * SH, BF_, RES_NOHOOK);
 #pragma unroll
             for (int n = 0; n < RNT; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dh[n][i] = d[n][i] * z[n][i] + drh[n][i] * rr[n][i] + acc[n][i];
         }
-        __syncthreads();
+        STAMP(7);
+        lds_barrier();
+        STAMP(8);
     }
-    if (valid) {
-        const int ldd = a.dh0_ld ? a.dh0_ld : RH;
+    const int ldd = a.dh0_ld ? a.dh0_ld : RH;
 #pragma unroll
-        for (int n = 0; n < RNT; ++n) {
-            if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub[n]) = dh[n];
-            if (CELL == MVAE_LSTM && a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * ldd + ub[n]) = dc[n];
-        }
+    for (int n = 0; n < RNT; ++n) {
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub[n]) = dh[n];
+        if (CELL == MVAE_LSTM && a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * ldd + ub[n]) = dc[n];
     }
+    vm_drain();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------------
-// fragment placement per kernel: NA in accumulator registers, NV in vector registers, NL in LDS (per wave)
+// fragment placement per kernel: A in accumulator registers, V in vector registers, the rest in LDS (per wave)
 template <int CELL> struct res_cfg;
 template <> struct res_cfg<MVAE_LSTM> {   // 128 fragments per wave
-    static constexpr int FA = 60, FV = 32, FL = 32;     // + 4 streamed;  LDS 17 + 128 KiB
-    static constexpr int BA = 60, BV = 28, BL = 28;     // + 12 streamed; LDS 33 + 112 KiB
+    static constexpr int FA = 64, FV = 28;     // 36 in LDS: 16 + 144 KiB = all of it
+    static constexpr int FV_SCALAR = 32;       // 32 in LDS: 16 + 128 + 8 KiB (scalar-input weights)
+    static constexpr int BA = 64, BV = 32;     // 32 in LDS: 32 + 128 KiB = all of it
 };
 template <> struct res_cfg<MVAE_GRU> {    // 96 fragments per wave
-    static constexpr int FA = 60, FV = 8, FL = 28;      // LDS 25 + 112 KiB
-    static constexpr int BA = 60, BV = 8, BL = 28;      // LDS 25 + 112 KiB
+    static constexpr int FA = 64, FV = 8;      // 24 in LDS: 24 + 96 KiB
+    static constexpr int FV_SCALAR = 8;
+    static constexpr int BA = 64, BV = 8;      // 24 in LDS: 24 + 8 + 96 KiB
 };
 
-template <int CELL, int XMODE>
+template <int CELL, int XMODE, int SAVE>
 int launch_fwd_res(const mvae_rnn_fwd_args& a, hipStream_t s) {
     typedef res_cfg<CELL> C;
-    const size_t lds = (size_t)(2 + (CELL == MVAE_GRU ? 1 : 0)) * 16 * RLDH * sizeof(bf16_t) +
-                       (size_t)4 * C::FL * 64 * sizeof(frag) +
-                       (XMODE == MVAE_X_SCALAR ? (size_t)2 * mvae_gates(CELL) * RH * sizeof(float) : 0);
+    constexpr int FVx = XMODE == MVAE_X_SCALAR ? C::FV_SCALAR : C::FV;
+    constexpr int G = mvae_gates(CELL), NL = G * RNT * RS - C::FA - FVx;
+    const size_t lds = (size_t)(2 + (CELL == MVAE_GRU ? 1 : 0)) * 16 * RH * sizeof(bf16_t) +
+                       (size_t)4 * NL * 64 * sizeof(frag) + (XMODE == MVAE_X_SCALAR ? (size_t)2 * G * RH * sizeof(float) : 0);
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_res_k<CELL, XMODE, C::FA, C::FV, C::FL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_res_k<CELL, XMODE, SAVE, C::FA, FVx>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MVAE_E_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((rnn_fwd_res_k<CELL, XMODE, C::FA, C::FV, C::FL>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rnn_fwd_res_k<CELL, XMODE, SAVE, C::FA, FVx>), dim3(a.B / 16), dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
+}
+template <int CELL, int XMODE>
+int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    if (a.acts) {
+        if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
+        return launch_fwd_res<CELL, XMODE, SAVE_ALL>(a, s);
+    }
+    if (a.cs) return MVAE_E_UNSUPPORTED;
+    return a.hs ? launch_fwd_res<CELL, XMODE, SAVE_HS>(a, s) : launch_fwd_res<CELL, XMODE, SAVE_NONE>(a, s);
 }
 template <int CELL>
 int fwd_res_xmode(const mvae_rnn_fwd_args& a, hipStream_t s) {
     switch (a.xmode) {
-        case MVAE_X_DENSE: return a.xp ? launch_fwd_res<CELL, MVAE_X_DENSE>(a, s) : MVAE_E_ARG;
-        case MVAE_X_INDEX: return (a.idx && a.table) ? launch_fwd_res<CELL, MVAE_X_INDEX>(a, s) : MVAE_E_ARG;
-        case MVAE_X_SCALAR: return (a.xs && a.w_row && a.bias) ? launch_fwd_res<CELL, MVAE_X_SCALAR>(a, s) : MVAE_E_ARG;
-        case MVAE_X_CONST: return a.xp0 ? launch_fwd_res<CELL, MVAE_X_CONST>(a, s) : MVAE_E_ARG;
+        case MVAE_X_DENSE: return a.xp ? fwd_res_save<CELL, MVAE_X_DENSE>(a, s) : MVAE_E_ARG;
+        case MVAE_X_INDEX: return (a.idx && a.table) ? fwd_res_save<CELL, MVAE_X_INDEX>(a, s) : MVAE_E_ARG;
+        case MVAE_X_SCALAR: return (a.xs && a.w_row && a.bias) ? fwd_res_save<CELL, MVAE_X_SCALAR>(a, s) : MVAE_E_ARG;
+        case MVAE_X_CONST: return a.xp0 ? fwd_res_save<CELL, MVAE_X_CONST>(a, s) : MVAE_E_ARG;
     }
     return MVAE_E_ARG;
 }
@@ -579,16 +692,17 @@ int fwd_res_xmode(const mvae_rnn_fwd_args& a, hipStream_t s) {
 template <int CELL, bool HAS_EXT>
 int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
     typedef res_cfg<CELL> C;
-    constexpr int G = mvae_gates(CELL);
-    const size_t lds = (size_t)16 * (G * RH + 8) * sizeof(bf16_t) + (size_t)4 * C::BL * 64 * sizeof(frag);
+    constexpr int G = mvae_gates(CELL), NL = RNT * (G * RH / 32) - C::BA - C::BV;
+    const size_t lds = (size_t)16 * G * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag) +
+                       (CELL == MVAE_GRU ? (size_t)16 * RH * sizeof(bf16_t) : 0);
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_res_k<CELL, HAS_EXT, C::BA, C::BV, C::BL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_res_k<CELL, HAS_EXT, C::BA, C::BV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MVAE_E_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL((rnn_bwd_res_k<CELL, HAS_EXT, C::BA, C::BV, C::BL>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rnn_bwd_res_k<CELL, HAS_EXT, C::BA, C::BV>), dim3(a.B / 16), dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
@@ -597,13 +711,13 @@ int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
 
 // Entry points used by rnn.hip's dispatch.  Return MVAE_E_UNSUPPORTED when the shape is not this file's.
 int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16) return MVAE_E_UNSUPPORTED;
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16) return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) return fwd_res_xmode<MVAE_LSTM>(a, s);
     if (a.cell == MVAE_GRU) return fwd_res_xmode<MVAE_GRU>(a, s);
     return MVAE_E_UNSUPPORTED;
 }
 int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16) return MVAE_E_UNSUPPORTED;
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16) return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) {
         if (!a.cs) return MVAE_E_ARG;
         return a.dhs_ext ? launch_bwd_res<MVAE_LSTM, true>(a, s) : launch_bwd_res<MVAE_LSTM, false>(a, s);

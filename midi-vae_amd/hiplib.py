@@ -12,12 +12,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmidivae_hip.so")
+LIB_PATH = os.environ.get("MVAE_LIB", os.path.join(_HERE, "libmidivae_hip.so"))   # MVAE_LIB: experiment builds
 
 GRU, LSTM, RNN = 0, 1, 2
 F32, BF16, ONEHOT = 0, 1, 2
 X_DENSE, X_INDEX, X_SCALAR, X_CONST = 0, 1, 2, 3
 ACT_NONE, ACT_TANH = 0, 1
+ROWMAJOR, TILE16 = 0, 1
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
@@ -30,20 +31,20 @@ class RnnFwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("xmode", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("u_pack", _vp), ("xp", _vp), ("idx", _vp), ("table", _vp), ("xs", _vp), ("w_row", _vp),
                 ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
-                ("h_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32)]
+                ("h_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32), ("seq_layout", _i32)]
 
 
 class RnnBwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("ut_pack", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp), ("dhs_ext", _vp), ("dh_last", _vp),
-                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32)]
+                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32), ("seq_layout", _i32)]
 
 
 class GemmArgs(C.Structure):
     _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("trans_a", _i32), ("trans_b", _i32),
                 ("a_kind", _i32), ("b_kind", _i32), ("c_kind", _i32), ("lda", _i32), ("ldb", _i32), ("ldc", _i32),
                 ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
-                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp)]
+                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32)]
 
 
 class HeadArgs(C.Structure):
@@ -80,6 +81,7 @@ SIGNATURES = {
     "mvae_head_np": (_i32, [_i32]),
     "mvae_latent_fwd": (_i32, [C.POINTER(LatentFwdArgs), _vp]),
     "mvae_latent_bwd": (_i32, [C.POINTER(LatentBwdArgs), _vp]),
+    "mvae_relayout": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_tanh_bwd": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "mvae_convert": (_i32, [_vp, _i32, _vp, _i32, _sz, _vp]),
     "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),

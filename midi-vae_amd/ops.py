@@ -50,7 +50,7 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
-            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, h0_ld=0, h_last_ld=0):
+            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, h0_ld=0, h_last_ld=0, seq_layout=0):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -60,19 +60,19 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
     else:
         xmode = hl.X_CONST
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _p(xp), _p(idx), _p(table), _p(xs), _p(w_row),
-                      _p(bias), _p(xp0), _pv(h0), _pv(c0), _p(hs), _p(cs), _p(acts), _pv(h_last), h0_ld, h_last_ld)
+                      _p(bias), _p(xp0), _pv(h0), _pv(c0), _p(hs), _p(cs), _p(acts), _pv(h_last), h0_ld, h_last_ld, seq_layout)
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, rh=None, dh0=None,
-            dc0=None, dh_last_ld=0, dh0_ld=0):
+            dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0):
     a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _p(hs), _p(cs), _p(acts), _p(dhs_ext), _pv(dh_last), _p(da),
-                      _p(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld)
+                      _p(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, seq_layout)
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
-         accumulate=False, split_k=1, alpha=1.0, a_kind=None):
+         accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0):
     """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths."""
     a_kind = kind_of(A) if a_kind is None else a_kind
     if lda is None:
@@ -82,7 +82,7 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
     if ldc is None:
         ldc = N
     g = hl.GemmArgs(M, N, K, int(trans_a), int(trans_b), a_kind, kind_of(B), kind_of(C), lda, ldb, ldc,
-                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias))
+                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout)
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
 
 
@@ -118,6 +118,10 @@ def latent_bwd(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, mu
     a = hl.LatentBwdArgs(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, _p(mu), _p(logvar), _p(eps),
                          _pv(dz), _p(style_probs), _p(style_target), _p(style_row_weight), _p(dmu), _p(dlogvar), lddz)
     hl.check(hl.load().mvae_latent_bwd(a, _stream()), "mvae_latent_bwd")
+
+
+def relayout(src, dst, rows, cols, to_tile16):
+    hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols, int(to_tile16), _stream()), "mvae_relayout")
 
 
 def tanh_bwd(y, dy, dx):

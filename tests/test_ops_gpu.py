@@ -27,6 +27,18 @@ def host(t):
     return t.detach().float().cpu().numpy().astype(np.float64)
 
 
+def tile16(t, rows, cols, to_tile):
+    """device relayout of a (rows, cols) view between row-major and TILE16 (returns a new tensor, same shape)"""
+    out = torch.empty_like(t)
+    ops.relayout(t.contiguous(), out, rows, cols, to_tile)
+    return out
+
+
+def resident(H, B, dtype, cell):
+    """the shapes the resident-weights kernels take (TILE16 sequence layout)"""
+    return H == 256 and B % 16 == 0 and dtype == hl.BF16 and cell != hl.RNN
+
+
 def close(got, want, tol, what=""):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -50,7 +62,7 @@ def _rnn_problem(cellname, H, T, B, seed, K=7):
 @pytest.mark.parametrize("cellname,cell", CELLS)
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("xmode", ["dense", "index", "scalar", "const"])
-@pytest.mark.parametrize("H,B", [(64, 5), (128, 37), (256, 21)])
+@pytest.mark.parametrize("H,B", [(64, 5), (128, 37), (256, 21), (256, 32)])
 def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
     T = 9
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=H + B)
@@ -82,9 +94,16 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
     cs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if cellname == "LSTM" else None
     acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
     h_last = torch.zeros((B, H), device=DEV)
+    res = resident(H, B, dtype, cell)
+    if res and "xp" in kw:
+        kw["xp"] = tile16(kw["xp"], T * B, GH, True)
     ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
-                acts=acts, h_last=h_last, **kw)
+                acts=acts, h_last=h_last, seq_layout=hl.TILE16 if res else hl.ROWMAJOR, **kw)
     torch.cuda.synchronize()
+    if res:
+        acts = tile16(acts, T * B, GH, False)
+        if cs is not None:
+            cs = tile16(cs, (T + 1) * B, H, False)
     close(host(hs), hs_o, tol, "hs")
     close(host(acts), acts_o, tol, "acts")
     close(host(h_last), hs_o[-1], tol, "h_last")
@@ -105,7 +124,8 @@ def test_rnn_forward_zero_initial_state_and_inference_mode():
 
 @pytest.mark.parametrize("cellname,cell", CELLS)
 @pytest.mark.parametrize("dtype,tol", DTYPES)
-@pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False), (256, 19, True), (256, 33, False)])
+@pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False), (256, 19, True), (256, 33, False), (256, 32, True),
+                                     (256, 16, False)])
 def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
     T = 8
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=11 + H)
@@ -126,8 +146,15 @@ def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
     rh = torch.zeros((T, B, H), dtype=td, device=DEV)
     dh0 = torch.zeros((B, H), device=DEV)
     dc0 = torch.zeros((B, H), device=DEV)
-    ops.rnn_bwd(cell, dtype, T, B, H, ut, dev(hs_o, td), dev(cs_o, td) if cs_o is not None else None, dev(acts_o, td), da,
-                dhs_ext=dev(dext, td) if ext else None, dh_last=dev(dlast), rh=rh, dh0=dh0, dc0=dc0)
+    res = resident(H, B, dtype, cell)
+    acts_d, cs_d = dev(acts_o, td), dev(cs_o, td) if cs_o is not None else None
+    dext_d = dev(dext, td) if ext else None
+    if res:
+        acts_d = tile16(acts_d, T * B, GH, True)
+        cs_d = tile16(cs_d, (T + 1) * B, H, True) if cs_d is not None else None
+        dext_d = tile16(dext_d, T * B, H, True) if ext else None
+    ops.rnn_bwd(cell, dtype, T, B, H, ut, dev(hs_o, td), cs_d, acts_d, da, dhs_ext=dext_d, dh_last=dev(dlast), rh=rh,
+                dh0=dh0, dc0=dc0, seq_layout=hl.TILE16 if res else hl.ROWMAJOR)
     torch.cuda.synchronize()
     close(host(da), da_o, tol, "da")
     close(host(dh0), dh0_o, tol, "dh0")
@@ -163,6 +190,29 @@ def test_gemm(ta, tb, dtype, tol, M, N, K):
         ops.gemm(Ad, Bd, C3, M, N, K, trans_a=ta, trans_b=tb)
         torch.cuda.synchronize()
         close(host(C3), want, 2e-2 * np.sqrt(K), "bf16 out")
+
+
+@pytest.mark.parametrize("dtype", [hl.F32, hl.BF16])
+def test_gemm_tile16_output_and_relayout_roundtrip(dtype):
+    rng = np.random.default_rng(1)
+    M, N, K = 320, 192, 64
+    td = ops.torch_dtype(dtype)
+    A, B = dev(rng.standard_normal((M, K)), td), dev(rng.standard_normal((N, K)), td)
+    bias = dev(rng.standard_normal((N,)))
+    C_rm = torch.zeros((M, N), dtype=td, device=DEV)
+    C_t = torch.zeros((M, N), dtype=td, device=DEV)
+    ops.gemm(A, B, C_rm, M, N, K, trans_b=True, bias=bias)
+    ops.gemm(A, B, C_t, M, N, K, trans_b=True, bias=bias, c_layout=hl.TILE16)
+    back = tile16(C_t, M, N, False)
+    torch.cuda.synchronize()
+    assert torch.equal(back, C_rm)
+    # the layout formula of include/midivae_hip.h, restated on the host
+    m, n = np.meshgrid(np.arange(M), np.arange(N), indexing="ij")
+    off = (((m // 16) * (N // 16) + n // 16) * 64 + ((n % 16) // 4) * 16 + m % 16) * 4 + n % 4
+    want = np.empty(M * N)
+    want[off.ravel()] = host(C_rm).ravel()
+    assert np.array_equal(host(C_t).ravel(), want)
+    assert torch.equal(tile16(back, M, N, True), C_t)
 
 
 def test_gemm_leading_dimensions_and_column_blocks():

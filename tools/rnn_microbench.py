@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Time the recurrent kernels alone (T steps, B rows, H=256 bf16) - us per step for every input mode.
+   python tools/rnn_microbench.py [--cell LSTM] [--T 512] [--B 256]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import midi_vae_amd  # noqa: F401,E402
+from midi_vae_amd import hiplib as hl, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cell", default="LSTM")
+ap.add_argument("--T", type=int, default=512)
+ap.add_argument("--B", type=int, default=256)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-major sequences)")
+a = ap.parse_args()
+cell = hl.CELL_CODE[a.cell]
+LAY = hl.ROWMAJOR if a.rowmajor else hl.TILE16
+G, H, T, B = hl.GATES[cell], 256, a.T, a.B
+GH = G * H
+dev = "cuda:0"
+bf = torch.bfloat16
+rng = np.random.default_rng(0)
+U = torch.tensor(rng.standard_normal((H, GH)) * 0.03, dtype=torch.float32, device=dev)
+up, ut = ops.pack_recurrent(U, cell, hl.BF16, 0), ops.pack_recurrent(U, cell, hl.BF16, 1)
+xp = torch.tensor(rng.standard_normal((T, B, GH)) * 0.5, device=dev).to(bf)
+idx = torch.tensor(rng.integers(0, 61, (T, B)), dtype=torch.uint8, device=dev)
+table = torch.tensor(rng.standard_normal((61, GH)) * 0.5, device=dev).to(bf)
+xs = torch.rand((T, B), device=dev)
+w_row, bias = torch.randn(GH, device=dev) * 0.1, torch.randn(GH, device=dev) * 0.1
+xp0 = torch.tensor(rng.standard_normal((B, GH)) * 0.5, device=dev).to(bf)
+hs = torch.zeros((T + 1, B, H), dtype=bf, device=dev)
+cs = torch.zeros((T + 1, B, H), dtype=bf, device=dev) if a.cell == "LSTM" else None
+acts = torch.zeros((T, B, GH), dtype=bf, device=dev)
+da = torch.zeros((T, B, GH), dtype=bf, device=dev)
+rh = torch.zeros((T, B, H), dtype=bf, device=dev)
+dext = torch.tensor(rng.standard_normal((T, B, H)) * 0.01, device=dev).to(bf)
+hl_ = torch.zeros((B, H), device=dev)
+
+
+def timeit(fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.reps
+
+
+modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": dict(xs=xs, w_row=w_row, bias=bias),
+         "const": dict(xp0=xp0)}
+flop = 2.0 * B * H * GH * T
+for name, kw in modes.items():
+    ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=LAY, **kw))
+    print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
+ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY))
+print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
+for ext in (True, False):
+    ms = timeit(lambda: ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, da, dhs_ext=dext if ext else None, rh=rh,
+                                    dh0=hl_, seq_layout=LAY))
+    print("bwd ext=%d  %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (ext, ms, ms * 1e3 / T, flop / ms / 1e9))
