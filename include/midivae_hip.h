@@ -168,6 +168,8 @@ typedef struct {
     uint8_t* argmax;              /* (R) or NULL: first-max index (kind 0), round(p) (kind 1)                */
     void* dlogits;                /* (R,NP) dtype, NP = N rounded up to 16; required if want_grad            */
     float* scalars;               /* (2) accumulated atomically                                              */
+    int32_t b_stride, b_valid;    /* rows are (t, b) with b = row % b_stride; rows with b >= b_valid are padding and
+                                     are excluded from the metric count (0,0 = every row counts)             */
 } mvae_head_args;
 int mvae_head(const mvae_head_args* a, void* stream);
 /* padded column count NP used for `wt` rows and `dlogits` columns of an N-wide head (16/32/64/128; <0 = too wide) */

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + q * 4 + i;
         const bool rv = row < R;
+        const bool counted = rv && (a.b_stride <= 0 || (row % a.b_stride) < a.b_valid);
         const int rc = rv ? row : R - 1;
         const float rw = a.row_weight ? a.row_weight[rc] : 1.0f;
         if (KIND == 0) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
             const float ce = has_t ? -logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
             if (rv && r == 0) {
                 loss_acc += rw * ce;
-                hit_acc += (am == (has_t ? tg : 0)) ? 1.0f : 0.0f;
+                hit_acc += (counted && am == (has_t ? tg : 0)) ? 1.0f : 0.0f;
                 if (a.argmax) a.argmax[row] = (uint8_t)am;
             }
             if (rv) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
             if (rv && r == 0) {
                 loss_acc += rw * (pr - y) * (pr - y);
                 const float rounded = rintf(pr);                          // Keras binary_accuracy: round half to even
-                hit_acc += (rounded == y) ? 1.0f : 0.0f;
+                hit_acc += (counted && rounded == y) ? 1.0f : 0.0f;
                 if (a.probs) a.probs[row] = pr;
                 if (a.argmax) a.argmax[row] = (uint8_t)rounded;
                 if (a.want_grad) st<WT>::store(dl + (size_t)row * NP, a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr));

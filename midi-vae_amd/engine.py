@@ -28,6 +28,14 @@ S_NOTES_LOSS, S_NOTES_HITS, S_INSTR_LOSS, S_INSTR_HITS, S_VEL_LOSS, S_VEL_HITS, 
 N_SCALARS = 16
 
 
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class _Rec(object):
     """One recurrent layer: its parameter prefix, geometry, input mode and (per batch size) its buffers."""
 
@@ -47,7 +55,11 @@ class Engine(object):
         self.kind = {"bf16": hl.BF16, "f32": hl.F32}[dtype]
         self.dt = ops.torch_dtype(self.kind)
         self.cell = hl.CELL_CODE[spec.cell]
-        self.maxB = int(max_batch)
+        # the resident-weights recurrent kernels (H=256, bf16, GRU/LSTM) stream TILE16 sequences; everything else is
+        # row-major.  Batches are padded to a multiple of 16 rows (one workgroup = 16 rows) with zero-weight rows.
+        self.tile16 = (spec.H == 256 and self.kind == hl.BF16 and spec.cell in ("GRU", "LSTM"))
+        self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR
+        self.maxB = (int(max_batch) + 15) // 16 * 16
         self.layout = ParamLayout.build(spec)
         self.use_graphs = use_graphs
         self._graphs = {}
@@ -62,10 +74,31 @@ class Engine(object):
         self.P = {n: L.view(self.params, n) for n in L.entries}
         self.G = {n: L.view(self.grads, n) for n in L.entries}
         self.scal = torch.zeros(N_SCALARS, **f32)
+        # Each recurrent kernel occupies B/16 CUs of 256, so the independent branches of the graph (notes stack /
+        # velocity / instrument, forward and backward) run on their own HIP streams, and parameter-gradient GEMMs
+        # (needed only by the optimizer) go to a fourth stream off the critical path.  Fork / join is event based.
+        with torch.cuda.device(self.device):
+            self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+        self.multi_stream = True
         self.set_params(init_params(spec, seed))
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
+
+    # ---- stream helpers -------------------------------------------------------------------------------------
+    def _fork(self, *streams):
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+
+    def _join(self, *streams):
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            cur.wait_stream(st)
+
+    def _on(self, stream):
+        """context: run on ``stream`` (or stay on the current one when multi-stream execution is off)"""
+        return torch.cuda.stream(stream) if self.multi_stream else _NullCtx()
 
     def _timed(self, key, fn):
         """Run ``fn`` (one kernel launch); when profiling, bracket it with HIP events on the launch stream."""
@@ -224,63 +257,81 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     # input staging (host NumPy -> device).  Layout conversion to time-major happens here, once, on the host.
     # ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def pad16(B):
+        return (int(B) + 15) // 16 * 16
+
     def _up(self, name, arr, tdtype):
         a = np.ascontiguousarray(arr)
         t = torch.from_numpy(a).to(self.device, non_blocking=False).to(tdtype)
         self.store[name][:t.numel()].copy_(t.reshape(-1))
 
+    def _up_tm(self, name, arr_bt, tdtype, fill=0):
+        """(B, L) batch-major host array -> (L, Bp) time-major device buffer, pad rows = ``fill``."""
+        arr_bt = np.asarray(arr_bt)
+        B, L = arr_bt.shape
+        out = np.full((L, self.pad16(B)), fill, dtype=arr_bt.dtype)
+        out[:, :B] = arr_bt.T
+        self._up(name, out, tdtype)
+
+    def _up_rows(self, name, arr, width, tdtype=torch.float32):
+        """(B, width) host array -> first B rows of the (Bp, width) device buffer; pad rows zeroed."""
+        arr = np.asarray(arr).reshape(-1, width)
+        B = arr.shape[0]
+        out = np.zeros((self.pad16(B), width), dtype=arr.dtype)
+        out[:B] = arr
+        self._up(name, out, tdtype)
+
     def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None):
         """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; eps (B,Z) f32 ALREADY scaled by
         epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
         B = x_idx.shape[0]
-        self._up("in.x_idx", np.asarray(x_idx, np.uint8).T, torch.uint8)
+        self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
         if self.spec.meta_instrument:
-            self._up("in.i_idx", np.asarray(i_idx, np.uint8).T, torch.uint8)
+            self._up_tm("in.i_idx", np.asarray(i_idx, np.uint8), torch.uint8)
         if self.spec.meta_velocity:
-            self._up("in.vel", np.asarray(vel, np.float32).T, torch.float32)
-        if eps is None:
-            self._v("in.eps", B, self.spec.Z).zero_()
-        else:
-            self._up("in.eps", np.asarray(eps, np.float32), torch.float32)
+            self._up_tm("in.vel", np.asarray(vel, np.float32), torch.float32)
+        self._up_rows("in.eps", np.zeros((B, self.spec.Z), np.float32) if eps is None else np.asarray(eps, np.float32),
+                      self.spec.Z)
         return B
 
     def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None):
         s = self.spec
-        zh = self._v("zh", B, s.zin)
+        Bp = self.pad16(B)
+        zh = self._v("zh", Bp, s.zin)
+        zh[B:].zero_()
         if s.history:
             if hist is None:
                 zh[:, s.Z:].zero_()
             else:
-                zh[:, s.Z:].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
+                zh[:B, s.Z:].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
         if z is not None:
-            zh[:, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
-        for name, val, shape in (("in.start_notes", start_notes, (B, s.Dout)), ("in.start_instr", start_instr, (B, s.ID)),
-                                 ("in.start_vel", start_vel, (B,))):
-            if val is None:
-                self._v(name, *shape).zero_()
-            else:
-                self._up(name, np.asarray(val, np.float32).reshape(shape), torch.float32)
+            zh[:B, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
+        for name, val, width in (("in.start_notes", start_notes, s.Dout), ("in.start_instr", start_instr, s.ID),
+                                 ("in.start_vel", start_vel, 1)):
+            self._up_rows(name, np.zeros((B, width), np.float32) if val is None else np.asarray(val, np.float32), width)
 
     def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None):
         """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
-        (score*w / mean(w != 0), then the mean over the axes) into one factor per row."""
+        (score*w / mean(w != 0), then the mean over the axes) into one factor per row; padding
+        rows get target 255 ("no target") and weight 0."""
         s = self.spec
         T, V = s.T, s.V
-        self._up("in.y_idx", np.asarray(y_idx, np.uint8).T, torch.uint8)
+        self._up_tm("in.y_idx", np.asarray(y_idx, np.uint8), torch.uint8, fill=255)
 
         def norm(w, n_other):
             w = np.asarray(w, np.float64)
             nz = np.mean(w != 0)
-            return w / (nz * w.size * n_other)
+            return (w / (nz * w.size * n_other)).astype(np.float32)
 
         wn = np.ones((B, T)) if w_notes is None else w_notes
-        self._up("in.rw_notes", norm(wn, 1).T, torch.float32)
+        self._up_tm("in.rw_notes", norm(wn, 1), torch.float32)
         if s.meta_instrument:
             wi = np.ones((B,)) if w_instr is None else w_instr
-            self._up("in.rw_instr", np.broadcast_to(norm(wi, V)[None, :], (V, B)), torch.float32)
+            self._up_tm("in.rw_instr", np.repeat(norm(wi, V)[:, None], V, axis=1), torch.float32)
         if s.meta_velocity:
             wv = np.ones((B,)) if w_vel is None else w_vel
-            self._up("in.rw_vel", np.broadcast_to(norm(wv, T)[None, :], (T, B)), torch.float32)
+            self._up_tm("in.rw_vel", np.repeat(norm(wv, T)[:, None], T, axis=1), torch.float32)
         if s.style:
             ws = np.ones((B,)) if w_style is None else w_style
             self._up("in.rw_style", norm(ws, 1), torch.float32)
@@ -315,7 +366,7 @@ class Engine(object):
     def _rec_forward(self, r, B, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None, start=None):
         s, P, p = self.spec, self.P, r.prefix
         H, GH, T = s.H, s.GH, r.T
-        kw = {}
+        kw = {}          # NB: B is the PADDED batch here
         if r.xmode == hl.X_INDEX:
             kw.update(idx=idx, table=self._v(p + ".table", r.K, GH))
         elif r.xmode == hl.X_SCALAR:
@@ -327,30 +378,37 @@ class Engine(object):
         else:
             lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:]
             xp = self._v(p + ".xp", T, B, GH)
-            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, T * B, GH, H, trans_b=True, bias=P[p + ".b"])
+            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, T * B, GH, H, trans_b=True, bias=P[p + ".b"],
+                     c_layout=self.lay)
             kw.update(xp=xp)
         self._timed(("rnn_fwd", p), lambda: ops.rnn_fwd(
             self.cell, self.kind, T, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
             hs=self._v(p + ".hs", T + 1, B, H), cs=self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None,
-            acts=self._v(p + ".acts", T, B, GH) if self.training else None, h_last=h_last, h_last_ld=h_last_ld, **kw))
+            acts=self._v(p + ".acts", T, B, GH) if self.training else None, h_last=h_last, h_last_ld=h_last_ld, seq_layout=self.lay, **kw))
 
     def encoder_forward(self, B):
         """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502."""
         s, P = self.spec, self.P
         H, Z = s.H, s.Z
+        Breal, B = B, self.pad16(B)
         cat = self._v("cat", B, self.ncat * H)
         ldc = self.ncat * H
+        self._fork(self.s_vel, self.s_instr)
+        k = 1
+        if s.meta_instrument:
+            with self._on(self.s_instr):
+                self._rec_forward(self.enc_instr, B, idx=self._v("in.i_idx", s.V, B), h_last=cat[:, k * H:(k + 1) * H],
+                                  h_last_ld=ldc)
+            k += 1
+        if s.meta_velocity:
+            with self._on(self.s_vel):
+                self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H],
+                                  h_last_ld=ldc)
         for i, r in enumerate(self.enc_notes):
             last = i == len(self.enc_notes) - 1
             self._rec_forward(r, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H] if last else None,
                               h_last_ld=ldc if last else 0)
-        k = 1
-        if s.meta_instrument:
-            self._rec_forward(self.enc_instr, B, idx=self._v("in.i_idx", s.V, B), h_last=cat[:, k * H:(k + 1) * H],
-                              h_last_ld=ldc)
-            k += 1
-        if s.meta_velocity:
-            self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc)
+        self._join(self.s_vel, self.s_instr)
         h = cat
         if self.has_pack:
             pk = self._v("pack", B, H)
@@ -367,16 +425,17 @@ class Engine(object):
         ops.gemm(h, P["enc.zmean.W"], mu, B, Z, h1w, lda=H, bias=P["enc.zmean.b"])
         ops.gemm(h2, P["enc.zlogvar.W"], lv, B, Z, H - h1w if s.split else H, lda=H, bias=P["enc.zlogvar.b"])
         zh = self._v("zh", B, s.zin)
-        ops.latent_fwd(B, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / B, mu, lv,
+        ops.latent_fwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / Breal, mu, lv,
                        self._v("in.eps", B, Z), zh, self.scal[S_KL:S_KL + 3],
-                       style_target=self._v("in.c_idx", B) if (s.style and self._have_targets) else None,
-                       style_row_weight=self._v("in.rw_style", B) if (s.style and self._have_targets) else None,
+                       style_target=self._v("in.c_idx", Breal) if (s.style and self._have_targets) else None,
+                       style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
                        style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
 
     def decoder_forward(self, B, want_probs=False):
         """reference vae_definition.py:519-645 (decoder heads) + losses :332-441 when targets are staged."""
         s, P = self.spec, self.P
         H, T, V = s.H, s.T, s.V
+        Breal, B = B, self.pad16(B)
         zh = self._v("zh", B, s.zin)
         S = self._v("S", B, self.n_init * H)
         ops.gemm(zh, P["dec.init.W"], S, B, self.n_init * H, s.zin, bias=P["dec.init.b"], act=hl.ACT_TANH)
@@ -389,6 +448,30 @@ class Engine(object):
             return dict(h0=h0, c0=c0, h0_ld=ldS)
 
         tg = self._have_targets
+        self._fork(self.s_vel, self.s_instr)
+        if s.meta_instrument:
+            with self._on(self.s_instr):
+                r = self.dec_instr
+                self._rec_forward(r, B, start=self._v("in.start_instr", B, s.ID), **states(r))
+                top = self._v(r.prefix + ".hs", V + 1, B, H)[1:]
+                ops.head(0, self.kind, V * B, H, s.ID, top, self._v("instr.wt", self.np_instr, H), P["dec.instr.out.b"],
+                         target_idx=self._v("in.i_idx", V * B) if tg else None,
+                         row_weight=self._v("in.rw_instr", V * B) if tg else None, grad_scale=s.w_instr,
+                         probs=self._v("out.instr_p", V * B, s.ID) if want_probs else None,
+                         argmax=self._v("instr.argmax", V * B),
+                         dlogits=self._v("instr.dl", V * B, self.np_instr) if (self.training and tg) else None,
+                         scalars=self.scal[S_INSTR_LOSS:S_INSTR_LOSS + 2], b_stride=B, b_valid=Breal)
+        if s.meta_velocity:
+            with self._on(self.s_vel):
+                r = self.dec_vel
+                self._rec_forward(r, B, start=self._v("in.start_vel", B, 1), **states(r))
+                top = self._v(r.prefix + ".hs", T + 1, B, H)[1:]
+                ops.head(1, self.kind, T * B, H, 1, top, self._v("vel.wt", 16, H), P["dec.vel.out.b"],
+                         target_val=self._v("in.vel", T * B) if tg else None,
+                         row_weight=self._v("in.rw_vel", T * B) if tg else None, grad_scale=s.w_vel,
+                         probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
+                         dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
+                         scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
         for r in self.dec_notes:
             self._rec_forward(r, B, start=self._v("in.start_notes", B, s.Dout), **states(r))
         top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
@@ -398,28 +481,8 @@ class Engine(object):
                  probs=self._v("out.notes_p", T * B, s.Dout) if want_probs else None,
                  argmax=self._v("notes.argmax", T * B),
                  dlogits=self._v("notes.dl", T * B, self.np_notes) if (self.training and tg) else None,
-                 scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2])
-        if s.meta_instrument:
-            r = self.dec_instr
-            self._rec_forward(r, B, start=self._v("in.start_instr", B, s.ID), **states(r))
-            top = self._v(r.prefix + ".hs", V + 1, B, H)[1:]
-            ops.head(0, self.kind, V * B, H, s.ID, top, self._v("instr.wt", self.np_instr, H), P["dec.instr.out.b"],
-                     target_idx=self._v("in.i_idx", V * B) if tg else None,
-                     row_weight=self._v("in.rw_instr", V * B) if tg else None, grad_scale=s.w_instr,
-                     probs=self._v("out.instr_p", V * B, s.ID) if want_probs else None,
-                     argmax=self._v("instr.argmax", V * B),
-                     dlogits=self._v("instr.dl", V * B, self.np_instr) if (self.training and tg) else None,
-                     scalars=self.scal[S_INSTR_LOSS:S_INSTR_LOSS + 2])
-        if s.meta_velocity:
-            r = self.dec_vel
-            self._rec_forward(r, B, start=self._v("in.start_vel", B, 1), **states(r))
-            top = self._v(r.prefix + ".hs", T + 1, B, H)[1:]
-            ops.head(1, self.kind, T * B, H, 1, top, self._v("vel.wt", 16, H), P["dec.vel.out.b"],
-                     target_val=self._v("in.vel", T * B) if tg else None,
-                     row_weight=self._v("in.rw_vel", T * B) if tg else None, grad_scale=s.w_vel,
-                     probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
-                     dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
-                     scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2])
+                 scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2], b_stride=B, b_valid=Breal)
+        self._join(self.s_vel, self.s_instr)
 
     # ------------------------------------------------------------------------------------------------------
     # backward
@@ -440,34 +503,40 @@ class Engine(object):
         self._timed(("rnn_bwd", p), lambda: ops.rnn_bwd(
             self.cell, self.kind, T, B, H, self.store[p + ".ut_pack"], hs,
             self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None, self._v(p + ".acts", T, B, GH), da,
-            dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld))
+            dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld,
+            seq_layout=self.lay))
         da2, hprev = da.view(R, GH), hs[:T].reshape(R, H)
         sk = self._split_k(R)
-        # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
-        if s.cell == "GRU":
-            ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk)
-            ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                     accumulate=True, split_k=sk)
-        else:
-            ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+        # critical path first: the gradient the lower layer's BPTT waits for
         dx = None
-        if r.xmode == hl.X_CONST:
-            dxp0 = self._v(p + ".dxp0", B, GH)
-            ops.sum_over_time(da, T, B * GH, dxp0)
-            ops.colsum(dxp0, B, GH, G[p + ".b"])
-            ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
-        else:
-            ops.colsum(da2, R, GH, G[p + ".b"])
-            if r.xmode == hl.X_INDEX:
-                ops.gemm(idx.view(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True,
-                         split_k=sk)
-            elif r.xmode == hl.X_SCALAR:
-                ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk)
+        if r.xmode == hl.X_DENSE:
+            dx = self._v(p + ".dx", T, B, H)
+            ops.gemm(da2, self._v(p + ".wc", H, GH), dx, R, H, GH, trans_b=True, c_layout=self.lay)
+        # parameter gradients: off the critical path (only the optimizer needs them)
+        self._fork(self.s_grad)
+        with self._on(self.s_grad):
+            # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
+            if s.cell == "GRU":
+                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk)
+                ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
+                         accumulate=True, split_k=sk)
             else:
-                lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
-                ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
-                dx = self._v(p + ".dx", T, B, H)
-                ops.gemm(da2, self._v(p + ".wc", H, GH), dx, R, H, GH, trans_b=True)
+                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+            if r.xmode == hl.X_CONST:
+                dxp0 = self._v(p + ".dxp0", B, GH)
+                ops.sum_over_time(da, T, B * GH, dxp0)
+                ops.colsum(dxp0, B, GH, G[p + ".b"])
+                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+            else:
+                ops.colsum(da2, R, GH, G[p + ".b"])
+                if r.xmode == hl.X_INDEX:
+                    ops.gemm(idx.view(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True,
+                             split_k=sk)
+                elif r.xmode == hl.X_SCALAR:
+                    ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                else:
+                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
+                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
         return dx
 
     def _head_backward(self, B, name, r, N, NP, outW, outb):
@@ -477,16 +546,19 @@ class Engine(object):
         R = T * B
         dl = self._v(name + ".dl", R, NP)
         top = self._v(r.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
-        ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
-        ops.colsum(dl, R, N, G[outb], ldx=NP)
         dhs = self._v(name + ".dhs", T, B, H)
-        ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP)        # dl (R,NP) * W^T (NP,H); pad rows are zero
+        ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
+        self._fork(self.s_grad)
+        with self._on(self.s_grad):
+            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
+            ops.colsum(dl, R, N, G[outb], ldx=NP)
         return dhs
 
     def backward(self, B):
         """Reverse of encoder_forward/decoder_forward; accumulates into self.grads (zeroed by the caller)."""
         s, P, G = self.spec, self.P, self.G
         H, Z, T, V = s.H, s.Z, s.T, s.V
+        Breal, B = B, self.pad16(B)
         dS = self._v("dS", B, self.n_init * H)
         ldS = self.n_init * H
 
@@ -495,19 +567,24 @@ class Engine(object):
             return dict(dh0=dS[:, k * H:(k + 1) * H], dc0=dS[:, (k + 1) * H:(k + 2) * H] if s.cell == "LSTM" else None,
                         dh0_ld=ldS)
 
-        # ---- decoder -----------------------------------------------------------------------------------
+        # ---- decoder: three independent branches ---------------------------------------------------------
+        self._fork(self.s_vel, self.s_instr)
+        if s.meta_instrument:
+            with self._on(self.s_instr):
+                dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
+                                           "dec.instr.out.b")
+                self._rec_backward(self.dec_instr, B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
+                                   **dstates(self.dec_instr))
+        if s.meta_velocity:
+            with self._on(self.s_vel):
+                dext = self._head_backward(B, "vel", self.dec_vel, 1, 16, "dec.vel.out.W", "dec.vel.out.b")
+                self._rec_backward(self.dec_vel, B, dhs_ext=dext, start=self._v("in.start_vel", B, 1),
+                                   **dstates(self.dec_vel))
         dext = self._head_backward(B, "notes", self.dec_notes[-1], s.Dout, self.np_notes, "dec.notes.out.W",
                                    "dec.notes.out.b")
         for r in reversed(self.dec_notes):
             dext = self._rec_backward(r, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), **dstates(r))
-        if s.meta_instrument:
-            dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
-                                       "dec.instr.out.b")
-            self._rec_backward(self.dec_instr, B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
-                               **dstates(self.dec_instr))
-        if s.meta_velocity:
-            dext = self._head_backward(B, "vel", self.dec_vel, 1, 16, "dec.vel.out.W", "dec.vel.out.b")
-            self._rec_backward(self.dec_vel, B, dhs_ext=dext, start=self._v("in.start_vel", B, 1), **dstates(self.dec_vel))
+        self._join(self.s_vel, self.s_instr)
         # initial-state Denses: S = tanh([z|hist] Winit + b)
         S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
         ops.tanh_bwd(S, dS, dS)
@@ -518,10 +595,13 @@ class Engine(object):
         # ---- latent ------------------------------------------------------------------------------------
         mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
         dmu, dlv = self._v("dmu", B, Z), self._v("dlv", B, Z)
-        ops.latent_bwd(B, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / B, mu, lv,
+        if B > Breal:            # padding rows carry no gradient
+            dmu[Breal:].zero_()
+            dlv[Breal:].zero_()
+        ops.latent_bwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / Breal, mu, lv,
                        self._v("in.eps", B, Z), dzh, dmu, dlv, style_probs=self._v("style_p", B, s.C) if s.style else None,
-                       style_target=self._v("in.c_idx", B) if s.style else None,
-                       style_row_weight=self._v("in.rw_style", B) if s.style else None, lddz=s.zin)
+                       style_target=self._v("in.c_idx", Breal) if s.style else None,
+                       style_row_weight=self._v("in.rw_style", Breal) if s.style else None, lddz=s.zin)
         h = self._tail
         h1w = H // 2 if s.split else H
         h2w = H - h1w if s.split else H
@@ -558,19 +638,23 @@ class Engine(object):
             ops.gemm(dt, P["enc.pack.W"], dcat, B, ldc, H, trans_b=True)
         else:
             dcat = dt
-        # ---- encoder recurrences -------------------------------------------------------------------------
+        # ---- encoder recurrences: three independent branches -------------------------------------------------
+        self._fork(self.s_vel, self.s_instr)
         k = 1
         if s.meta_instrument:
-            self._rec_backward(self.enc_instr, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                               idx=self._v("in.i_idx", V, B))
+            with self._on(self.s_instr):
+                self._rec_backward(self.enc_instr, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                   idx=self._v("in.i_idx", V, B))
             k += 1
         if s.meta_velocity:
-            self._rec_backward(self.enc_vel, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                               xs=self._v("in.vel", T, B))
+            with self._on(self.s_vel):
+                self._rec_backward(self.enc_vel, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                   xs=self._v("in.vel", T, B))
         dext, dlast, dld = None, dcat[:, 0:H], ldc
         for r in reversed(self.enc_notes):
             dext = self._rec_backward(r, B, dhs_ext=dext, dh_last=dlast, dh_last_ld=dld, idx=self._v("in.x_idx", T, B))
             dlast, dld = None, 0
+        self._join(self.s_vel, self.s_instr, self.s_grad)
 
     # ------------------------------------------------------------------------------------------------------
     # steps
@@ -619,7 +703,7 @@ class Engine(object):
         if self._weights_dirty:
             self.prepare_weights()
         self.encoder_forward(B)
-        return self._v("zh", B, self.spec.zin)[:, :self.spec.Z]
+        return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
 
     def decode(self, B, want_probs=True):
         """``decoder.predict`` on the staged [z|history]; argmax note indices are always produced on device."""
@@ -655,19 +739,20 @@ class Engine(object):
     def outputs(self, B):
         """Batch-major NumPy copies of the decoder outputs of the last forward run with want_probs=True."""
         s = self.spec
+        Bp = self.pad16(B)
         out = OrderedDict()
-        out["notes"] = self._v("out.notes_p", s.T, B, s.Dout).permute(1, 0, 2).cpu().numpy()
+        out["notes"] = self._v("out.notes_p", s.T, Bp, s.Dout)[:, :B].permute(1, 0, 2).cpu().numpy()
         if s.meta_instrument:
-            out["instr"] = self._v("out.instr_p", s.V, B, s.ID).permute(1, 0, 2).cpu().numpy()
+            out["instr"] = self._v("out.instr_p", s.V, Bp, s.ID)[:, :B].permute(1, 0, 2).cpu().numpy()
         if s.meta_velocity:
-            out["vel"] = self._v("out.vel_p", s.T, B, 1).permute(1, 0, 2).cpu().numpy()
+            out["vel"] = self._v("out.vel_p", s.T, Bp, 1)[:, :B].permute(1, 0, 2).cpu().numpy()
         if s.style:
-            out["style"] = self._v("style_p", B, s.C).cpu().numpy()
+            out["style"] = self._v("style_p", Bp, s.C)[:B].cpu().numpy()
         return out
 
     def note_indices(self, B):
         """(B,T) uint8 argmax note index per row - the fused form of sample_vector(...,'argmax')."""
-        return self._v("notes.argmax", self.spec.T, B).t().contiguous().cpu().numpy()
+        return self._v("notes.argmax", self.spec.T, self.pad16(B))[:, :B].t().contiguous().cpu().numpy()
 
     def latent(self, B):
-        return self._v("zh", B, self.spec.zin)[:, :self.spec.Z].cpu().numpy()
+        return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z].cpu().numpy()

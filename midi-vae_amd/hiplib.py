@@ -51,7 +51,7 @@ class HeadArgs(C.Structure):
     _fields_ = [("kind", _i32), ("dtype", _i32), ("R", _i32), ("H", _i32), ("N", _i32), ("want_grad", _i32),
                 ("hs", _vp), ("wt", _vp), ("bias", _vp), ("target_idx", _vp), ("target_val", _vp),
                 ("row_weight", _vp), ("grad_scale", _f32), ("probs", _vp), ("argmax", _vp), ("dlogits", _vp),
-                ("scalars", _vp)]
+                ("scalars", _vp), ("b_stride", _i32), ("b_valid", _i32)]
 
 
 class LatentFwdArgs(C.Structure):

@@ -100,9 +100,10 @@ def head_np(N):
 
 
 def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None, row_weight=None, grad_scale=1.0,
-         probs=None, argmax=None, dlogits=None, scalars=None):
+         probs=None, argmax=None, dlogits=None, scalars=None, b_stride=0, b_valid=0):
     a = hl.HeadArgs(kind, dtype, R, H, N, int(dlogits is not None), hs.data_ptr(), _p(wt), _p(bias), _p(target_idx),
-                    _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars))
+                    _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars),
+                    b_stride, b_valid)
     hl.check(hl.load().mvae_head(a, _stream()), "mvae_head")
 
 
