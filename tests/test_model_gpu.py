@@ -1,0 +1,94 @@
+"""The reference-shaped calls (fit / evaluate / predict on the packers' lists) end to end on the GPU vs the oracle."""
+import numpy as np
+import pytest
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd import packers as pk
+from midi_vae_amd.config import build_settings, create_kwargs
+from midi_vae_amd.model import VAE
+from midi_vae_amd.synth import make_windows, to_reference_format
+from oracle.vae_oracle import OracleVAE, history_from_z, make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cell, n=20, seed=0):
+    s = build_settings(cell_type=cell, lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=8,
+                       learning_rate=1e-3)
+    m = VAE().create(compute_dtype="f32", seed=seed, **create_kwargs(s))
+    w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=5)
+    X, Y, C, I, V, D = to_reference_format(w)
+    return s, m, (X, Y, C, I, V, D)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_fit_history_matches_oracle_trajectory(cell):
+    s, m, (X, Y, C, I, V, D) = _setup(cell)
+    n, bs = X.shape[0], s["batch_size"]
+    H = np.zeros((n, s["latent_dim"]))
+    S = np.zeros((n, s["signature_vector_length"]))
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+    hist = m.autoencoder.fit(x, y, epochs=1, batch_size=bs, shuffle=False, sample_weight=sw, verbose=False)
+    for k in ("loss", "decoder_loss_1", "decoder_acc_1", "decoder_loss_2", "decoder_loss_3", "composer_decoder_loss",
+              "composer_decoder_acc"):
+        assert k in hist.history and len(hist.history[k]) == 1
+    # oracle: same init, same minibatches (ragged last one: 20 = 8 + 8 + 4), same epsilon stream
+    spec = m.spec
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    from midi_vae_amd.layout import init_params
+    p = {k: v.astype(np.float64) for k, v in init_params(spec, 0).items()}
+    st = orc.new_opt_state(p)
+    rng = np.random.default_rng(1)
+    tot = 0.0
+    Coh = np.eye(s["num_classes"])[np.full(n, C)]
+    It = np.tile(I[None], (n, 1, 1))
+    for lo in range(0, n, bs):
+        hi = min(n, lo + bs)
+        eps = (rng.standard_normal((hi - lo, spec.Z)) * spec.epsilon_std).astype(np.float32).astype(np.float64)
+        b = dict(X=X[lo:hi], I=It[lo:hi], Vel=V[lo:hi, :, None], Hist=H[lo:hi], Y=Y[lo:hi], C=Coh[lo:hi])
+        tot += orc.train_step(p, st, b, eps)["loss"] * (hi - lo)
+    assert abs(hist.history["loss"][0] - tot / n) < 1e-3
+    got = m.autoencoder.get_weights()
+    names = m.autoencoder._names()
+    for nme, a in zip(names, got):
+        assert np.allclose(a, p[nme], rtol=2e-3, atol=3e-5), nme
+
+
+def test_evaluate_predict_and_history_prepass():
+    s, m, (X, Y, C, I, V, D) = _setup("GRU")
+    n = X.shape[0]
+    enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+    z = m.encoder.predict(enc_in, batch_size=s["batch_size"], verbose=False)
+    assert z.shape == (n, s["latent_dim"]) and np.all(np.isfinite(z))
+    H = history_from_z(z)                                  # reference vae_training.py:795-798
+    S = np.zeros((n, s["signature_vector_length"]))
+    x, y = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H)
+    res = m.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)
+    names = m.autoencoder.metrics_names
+    assert len(res) == len(names) == 9
+    total = res[0]
+    parts = res[1] + s["meta_instrument_weight"] * res[2] + s["meta_velocity_weight"] * res[3] + s["composer_weight"] * res[4]
+    kl = total - parts                                     # the reference derives KL this way (vae_training.py:525-538)
+    assert 0 <= kl < 1.0
+    outs = m.autoencoder.predict(x, batch_size=s["batch_size"])
+    assert [o.shape for o in outs] == [(n, 16, 61), (n, 4, 16), (n, 16, 1), (n, 2)]
+    assert np.allclose(outs[0].sum(-1), 1, atol=1e-5)
+    # decoder alone with a latent swap (reference vae_evaluation.py:2471-2483), then the host argmax decode
+    z2 = z.copy()
+    z2[:, [0, 1]] = z2[:, [1, 0]]
+    dec_in = pk.prepare_decoder_input(s, z2, C, S, None)
+    d_out = m.decoder.predict(dec_in, batch_size=s["batch_size"])
+    Yd, Id, Vd, Dd, Nd = pk.process_decoder_outputs(s, d_out, "argmax")
+    assert Yd.shape == (n * 16, 60)
+    idx = m.decoder.predict_note_indices(dec_in, batch_size=s["batch_size"])
+    assert np.array_equal(pk.notes_from_indices(s, idx, 61), Yd)      # fused device argmax == host argmax decode
+
+
+def test_weights_survive_engine_regrowth(tmp_path):
+    s, m, (X, Y, C, I, V, D) = _setup("GRU")
+    enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+    m._shared.rng = np.random.default_rng(0)
+    z1 = m.encoder.predict(enc_in, batch_size=4)
+    m._shared.rng = np.random.default_rng(0)
+    z2 = m.encoder.predict(enc_in, batch_size=20)          # bigger batch -> engine is rebuilt, weights carried over
+    assert np.allclose(z1[:4], z2[:4], atol=1e-5)

@@ -1,0 +1,133 @@
+"""The drop-in Python surface (VAE.create / model views / root modules) - everything that needs no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd.config import build_settings, create_kwargs
+from midi_vae_amd.layout import ModelSpec, ParamLayout, dec_init_blocks, init_params, spec_from_create_kwargs
+from midi_vae_amd.model import VAE
+from oracle.vae_oracle import make_cfg, param_shapes
+
+
+def _kw(**over):
+    return create_kwargs(build_settings(**over))
+
+
+def test_create_accepts_the_reference_call_and_exposes_three_models():
+    m = VAE().create(**_kw())
+    assert m.encoder is not None and m.decoder is not None and m.autoencoder is not None
+    assert m.lstm_size == 256 and m.cell_type == "GRU"          # attributes mirrored like vae_definition.py:109-172
+    assert m.autoencoder.metrics_names == ["loss", "decoder_loss", "decoder_loss", "decoder_loss",
+                                           "composer_decoder_loss", "decoder_acc", "decoder_acc", "decoder_acc",
+                                           "composer_decoder_acc"]
+    assert m.autoencoder.count_params() == 2966094             # matches SURVEY section 8 "reference default 2.97 M"
+    assert "Total params" in m.encoder.summary()
+    m.autoencoder.reset_states()
+
+
+def test_history_keys_are_the_ones_the_training_script_reads():
+    m = VAE().create(**_kw())
+    keys = [k for k, _ in m.autoencoder._history_keys()]
+    for k in ("loss", "decoder_loss_1", "decoder_acc_1", "decoder_loss_2", "decoder_acc_2", "decoder_loss_3",
+              "decoder_acc_3", "composer_decoder_loss", "composer_decoder_acc"):     # vae_training.py:817-864
+        assert k in keys
+    m2 = VAE().create(**_kw(meta_instrument=False, meta_velocity=False, include_composer_decoder=False))
+    assert [k for k, _ in m2.autoencoder._history_keys()] == ["loss", "acc"]
+    assert m2.autoencoder.metrics_names == ["loss", "acc"]
+
+
+@pytest.mark.parametrize("switch", ["bidirectional", "teacher_force", "meta_held_notes", "meta_next_notes",
+                                    "signature_decoder", "composer_decoder_at_notes_output", "use_embedding"])
+def test_unimplemented_switches_fail_loudly(switch):
+    kw = _kw()
+    kw[switch] = True
+    with pytest.raises((NotImplementedError, AssertionError)):
+        VAE().create(**kw)
+
+
+def test_asserts_of_the_reference_are_kept():
+    kw = _kw()
+    kw["beta"] = 0
+    with pytest.raises(AssertionError):
+        VAE().create(**kw)
+    kw = _kw()
+    kw["lstm_size"] = 100
+    with pytest.raises(NotImplementedError):
+        VAE().create(**kw)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "SimpleRNN"])
+def test_layout_agrees_with_oracle_naming_and_roundtrips(cell):
+    spec = spec_from_create_kwargs(_kw(cell_type=cell, latent_dim=64))
+    L = ParamLayout.build(spec)
+    o = param_shapes(make_cfg(**spec.oracle_cfg()))
+    assert set(o) == set(L.oracle_names())
+    for k, shp in o.items():
+        assert tuple(shp) == L.entries[k].shape, k
+    p = init_params(spec, 3)
+    back = L.unpack(L.pack(p))
+    assert all(np.array_equal(p[k], back[k]) for k in p)
+    # decoder-side tensors form one contiguous bucket at the end (first gradient all-reduce bucket)
+    assert all((L.entries[n].offset >= L.dec_begin) == n.startswith("dec.") for n in L.entries)
+    # initial-state Denses are column blocks of one matrix
+    nb = len(dec_init_blocks(spec))
+    assert L.entries["dec.init.W"].shape == (spec.zin, nb * spec.H)
+    assert L.entries["dec.notes.init.0.0.W"].row_stride == nb * spec.H
+
+
+def test_initialisers():
+    spec = ModelSpec(cell="LSTM", H=64, Z=32)
+    p = init_params(spec, 0)
+    U = p["enc.notes.0.U"].astype(np.float64)
+    assert np.allclose(U @ U.T, np.eye(64), atol=1e-5)                 # orthogonal recurrent kernels
+    lim = np.sqrt(6.0 / (61 + 4 * 64))
+    assert np.abs(p["enc.notes.0.W"]).max() <= lim + 1e-7              # glorot_uniform over the concatenated width
+    assert np.all(p["enc.notes.0.b"][64:128] == 1) and p["enc.notes.0.b"][:64].sum() == 0    # Keras unit_forget_bias
+    assert np.all(p["dec.notes.0.b"] == 0)                             # recurrentshop cells: plain zero bias
+
+
+def test_save_and_load_weights_roundtrip(tmp_path):
+    m = VAE().create(**_kw(latent_dim=64))
+    for view, name in ((m.autoencoder, "autoencoderEpoch10.pickle"), (m.encoder, "encoderEpoch10.pickle"),
+                       (m.decoder, "decoderEpoch10.pickle")):          # file names of vae_training.py:966-978
+        view.save_weights(str(tmp_path / name))
+    m2 = VAE().create(seed=123, **_kw(latent_dim=64))
+    before = m2.autoencoder.get_weights()
+    m2.encoder.load_weights(str(tmp_path / "encoderEpoch10.pickle"))
+    m2.decoder.load_weights(str(tmp_path / "decoderEpoch10.pickle"), by_name=False)
+    after, ref = m2.autoencoder.get_weights(), m.autoencoder.get_weights()
+    assert any(not np.array_equal(a, b) for a, b in zip(before, after))
+    assert all(np.array_equal(a, b) for a, b in zip(after, ref))
+    m3 = VAE().create(**_kw(latent_dim=32))
+    with pytest.raises(ValueError):
+        m3.autoencoder.load_weights(str(tmp_path / "autoencoderEpoch10.pickle"))
+
+
+def test_root_modules_are_drop_in(golden):
+    import settings
+    import vae_definition as vd
+    out = vd.prepare_encoder_input_list(golden["X"], golden["I"], golden["V"], golden["D"])
+    assert [a.shape for a in out] == [(5, 64, 61), (5, 4, 16), (5, 64, 1)]
+    x, y, w = vd.prepare_autoencoder_input_and_output_list(golden["X"], golden["Y"], 1, golden["I"], golden["V"],
+                                                           golden["D"], golden["S"], golden["H"], return_sample_weight=True)
+    assert len(x) == 7 and len(y) == 4 and len(w) == 4
+    assert vd.sample_notes_prediction(golden["probs_notes"], "argmax").shape == (5 * 64, 60)
+    assert hasattr(vd, "VAE") and settings.output_length == 64
+
+
+def test_non_onehot_input_is_rejected_not_silently_accepted():
+    from midi_vae_amd.model import _to_index
+    with pytest.raises(NotImplementedError):
+        _to_index(np.full((2, 3, 4), 0.25), "notes input")
+    assert _to_index(np.eye(4)[None], "x").tolist() == [[0, 1, 2, 3]]
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from midi_vae_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(ModelSpec(H=64, Z=32), max_batch=16)
