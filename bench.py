@@ -96,7 +96,7 @@ def main():
     T = args.seq_len * args.voices
     spec = ModelSpec(cell=args.cell, H=256, Z=args.latent, Din=61, Dout=61, T=T, V=args.voices, ID=16, C=2, Le=2, Ld=2)
     B = args.batch
-    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234)
+    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234, use_graphs=args.graphs)
     w = make_windows(B, T, 61, args.voices, 16, 2, args.latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
     eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
     eng.stage_decoder_inputs(B, hist=w["hist"])
@@ -115,7 +115,8 @@ def main():
     torch.cuda.synchronize()
     first_loss = eng.metrics(B)["loss"] if args.warmup else float("nan")
 
-    eng.prof = {}
+    if not args.graphs:
+        eng.prof = {}           # per-kernel HIP events; with graph replay the dominant kernel is timed in a second pass
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,6 +132,11 @@ def main():
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if args.graphs:
+        # same process, same inputs, same K steps, launched eagerly so individual launches can be bracketed with events
+        eng.prof = {}
+        for _ in range(args.steps):
+            step()
     prof = eng.prof_summary()
     eng.prof = None
     m = eng.metrics(B)

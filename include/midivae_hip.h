@@ -81,6 +81,8 @@ typedef struct {
     void* cs;              /* LSTM: (T+1,B,H) dtype or NULL                                                   */
     void* acts;            /* (T,B,G*H) dtype post-activation gates, or NULL (inference)                      */
     float* h_last;         /* (B,H) or NULL                                                                   */
+    float* c_last;         /* LSTM: final cell state (B,H) f32 or NULL (row stride h_last_ld): lets a sequence be
+                              run as consecutive launches (time chunks) without rounding the carried state     */
     int32_t h0_ld;         /* row stride of h0 / c0 in floats (0 = H): states may be column blocks of a wider buffer */
     int32_t h_last_ld;     /* row stride of h_last (0 = H)                                                     */
     int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR or MVAE_TILE16.
@@ -99,6 +101,7 @@ typedef struct {
     const void* acts;      /* (T,B,G*H) dtype                                                                 */
     const void* dhs_ext;   /* (T,B,H) dtype gradient arriving at h_t from the layer above, or NULL            */
     const float* dh_last;  /* (B,H) gradient arriving at the final state, or NULL                             */
+    const float* dc_last;  /* LSTM: gradient arriving at the final CELL state (time-chunked BPTT), or NULL     */
     void* da;              /* (T,B,G*H) dtype: gradient w.r.t. xp                                             */
     void* rh;              /* GRU: (T,B,H) dtype r_t*h_{t-1} (left operand of the candidate-kernel gradient)  */
     float* dh0;            /* (B,H) or NULL                                                                   */

@@ -236,9 +236,12 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
         cur ^= 1;
         lds_barrier();
     }
-    if (a.h_last && valid) {
+    if (valid) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hreg[n];
+        for (int n = 0; n < NT; ++n) {
+            if (a.h_last) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hreg[n];
+            if (CELL == MVAE_LSTM && a.c_last) *reinterpret_cast<f32x4*>(a.c_last + (size_t)b * ldl + ub[n]) = creg[n];
+        }
     }
 }
 
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
     for (int n = 0; n < NT; ++n) {
         f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)bb * (a.dh_last_ld ? a.dh_last_ld : H) + ub[n]) : z4;
-        dc[n] = z4;
+        dc[n] = (CELL == MVAE_LSTM && a.dc_last)
+                    ? *reinterpret_cast<const f32x4*>(a.dc_last + (size_t)bb * (a.dh_last_ld ? a.dh_last_ld : H) + ub[n]) : z4;
     }
     WT* drow = dabuf + r * LDA;
     const WT* brow = dabuf + r * LDA + q * FE;

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
     bf16_t* rhbuf = hbuf + 2 * 16 * RH;                                     // [16][RH] swizzled   (GRU)
     frag* ulds = reinterpret_cast<frag*>(rhbuf + (CELL == MVAE_GRU ? 16 * RH : 0));     // [4][NL][64]
     float* wb = reinterpret_cast<float*>(ulds + 4 * NLc * 64);              // [2][GH]         (SCALAR)
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: addresses become SGPR base + lane offset
     const int T = a.T, B = a.B;
     const int b = blockIdx.x * 16 + r;               // B % 16 == 0: every row is real
     const size_t tiles_per_step = (size_t)(B / 16);  // TILE16: row-tile index of (t, this WG) = t*B/16 + blockIdx.x
@@ -342,7 +343,10 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                     *reinterpret_cast<u16x4*>(ap + 3 * (RH / 16) * 256) = pack4(og);
                     *reinterpret_cast<u16x4*>(cs + (((otile + tiles_per_step) * (RH / 16) + w * RNT + n) * 64 + l) * 4) = pack4(creg[n]);
                 }
-                if (a.h_last && t == T - 1) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hnew;
+                if (t == T - 1) {
+                    if (a.h_last) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hnew;
+                    if (a.c_last) *reinterpret_cast<f32x4*>(a.c_last + (size_t)b * ldl + ub[n]) = creg[n];
+                }
             };
             // software pipeline over unit tiles: MFMAs of tile n with the arithmetic of tile n-1 issued among them
             f32x4 accA[4], accB[4];
@@ -455,7 +459,8 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
     frag* ulds = reinterpret_cast<frag*>(dabuf + 16 * GH);                  // [4][NL][64]
     bf16_t* rhtile = reinterpret_cast<bf16_t*>(ulds + 4 * NLc * 64);        // [16][RH] swizzled   (GRU)
 
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: addresses become SGPR base + lane offset
     const int T = a.T, B = a.B;
     const int b = blockIdx.x * 16 + r;
     const size_t tiles_per_step = (size_t)(B / 16);
@@ -481,7 +486,8 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
     for (int n = 0; n < RNT; ++n) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * (a.dh_last_ld ? a.dh_last_ld : RH) + ub[n]) : z4;
-        dc[n] = z4;
+        dc[n] = (CELL == MVAE_LSTM && a.dc_last)
+                    ? *reinterpret_cast<const f32x4*>(a.dc_last + (size_t)b * (a.dh_last_ld ? a.dh_last_ld : RH) + ub[n]) : z4;
     }
     // queue of saved forward values for the step about to be processed (requested one step earlier)
     u16x4 qa[RNT][G], qs[RNT], qd[RNT], carry[RNT];   // gates; c_{t-1} (LSTM) / h_{t-1} (GRU); upstream grad; c_t

@@ -79,7 +79,11 @@ class Engine(object):
         # (needed only by the optimizer) go to a fourth stream off the critical path.  Fork / join is event based.
         with torch.cuda.device(self.device):
             self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+            self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
         self.multi_stream = True
+        # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
+        # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
+        self.time_chunks = 4
         self.set_params(init_params(spec, seed))
         self._build_graph_description()
         self._alloc(self.maxB)
@@ -179,6 +183,8 @@ class Engine(object):
             p = r.prefix
             buf(p + ".u_pack", GH * H, **esz)
             buf(p + ".ut_pack", GH * H, **esz)
+            buf(p + ".sh", B * H, **f32)                 # carried f32 state between time chunks (h, c, dh, dc)
+            buf(p + ".sc", B * H, **f32)
             buf(p + ".hs", (r.T + 1) * B * H, **esz)
             if s.cell == "LSTM":
                 buf(p + ".cs", (r.T + 1) * B * H, **esz)
@@ -363,28 +369,75 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------------
-    def _rec_forward(self, r, B, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None, start=None):
+    def _nchunks(self, layers):
+        T = layers[0].T
+        n = self.time_chunks if (len(layers) > 1 and self.multi_stream) else 1
+        while n > 1 and (T % n or (T // n) < 16):
+            n -= 1
+        return n
+
+    def _rec_forward(self, r, B, k=0, nch=1, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None,
+                     start=None):
+        """Time chunk k of nch of one recurrent layer (B = padded batch).  Chunk 0 starts from (h0, c0); later chunks
+        from the f32 state the previous launch left in <layer>.sh/.sc; the last chunk also writes ``h_last``."""
         s, P, p = self.spec, self.P, r.prefix
         H, GH, T = s.H, s.GH, r.T
-        kw = {}          # NB: B is the PADDED batch here
+        Tc = T // nch
+        t0 = k * Tc
+        sh, sc = self._v(p + ".sh", B, H), self._v(p + ".sc", B, H)
+        kw = {}
         if r.xmode == hl.X_INDEX:
-            kw.update(idx=idx, table=self._v(p + ".table", r.K, GH))
+            kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
         elif r.xmode == hl.X_SCALAR:
-            kw.update(xs=xs, w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
+            kw.update(xs=xs[t0:t0 + Tc], w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
         elif r.xmode == hl.X_CONST:
             xp0 = self._v(p + ".xp0", B, GH)
-            ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])      # start W + b (Appendix A.6)
+            if k == 0:
+                ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])      # start W + b (Appendix A.6)
             kw.update(xp0=xp0)
         else:
-            lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:]
-            xp = self._v(p + ".xp", T, B, GH)
-            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, T * B, GH, H, trans_b=True, bias=P[p + ".b"],
+            lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc]
+            xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
+            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, Tc * B, GH, H, trans_b=True, bias=P[p + ".b"],
                      c_layout=self.lay)
             kw.update(xp=xp)
+        lstm = s.cell == "LSTM"
+        last = k == nch - 1
+        if k > 0:
+            h0, c0, h0_ld = sh, (sc if lstm else None), 0
         self._timed(("rnn_fwd", p), lambda: ops.rnn_fwd(
-            self.cell, self.kind, T, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
-            hs=self._v(p + ".hs", T + 1, B, H), cs=self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None,
-            acts=self._v(p + ".acts", T, B, GH) if self.training else None, h_last=h_last, h_last_ld=h_last_ld, seq_layout=self.lay, **kw))
+            self.cell, self.kind, Tc, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
+            hs=self._v(p + ".hs", T + 1, B, H)[t0:t0 + Tc + 1],
+            cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None,
+            acts=self._v(p + ".acts", T, B, GH)[t0:t0 + Tc] if self.training else None,
+            h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
+            c_last=(sc if (lstm and not last) else None), seq_layout=self.lay, **kw))
+
+    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
+        """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
+        nch = self._nchunks(layers)
+        streams = [None] + self.s_layer[:len(layers) - 1]
+        done = [[torch.cuda.Event() for _ in range(nch)] for _ in layers]
+        if nch > 1:
+            self._fork(*streams[1:])
+        for k in range(nch):
+            for li, r in enumerate(layers):
+                top = li == len(layers) - 1
+                st = states(r) if states else {}
+                def run():
+                    if li > 0 and nch > 1:
+                        torch.cuda.current_stream().wait_event(done[li - 1][k])
+                    self._rec_forward(r, B, k, nch, idx=idx, start=start, h_last=h_last if top else None,
+                                      h_last_ld=h_last_ld if top else 0, **st)
+                    if nch > 1:
+                        done[li][k].record()
+                if li > 0 and nch > 1:
+                    with torch.cuda.stream(streams[li]):
+                        run()
+                else:
+                    run()
+        if nch > 1:
+            self._join(*streams[1:])
 
     def encoder_forward(self, B):
         """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502."""
@@ -404,10 +457,7 @@ class Engine(object):
             with self._on(self.s_vel):
                 self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H],
                                   h_last_ld=ldc)
-        for i, r in enumerate(self.enc_notes):
-            last = i == len(self.enc_notes) - 1
-            self._rec_forward(r, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H] if last else None,
-                              h_last_ld=ldc if last else 0)
+        self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc)
         self._join(self.s_vel, self.s_instr)
         h = cat
         if self.has_pack:
@@ -472,8 +522,7 @@ class Engine(object):
                          probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
                          dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
                          scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
-        for r in self.dec_notes:
-            self._rec_forward(r, B, start=self._v("in.start_notes", B, s.Dout), **states(r))
+        self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout))
         top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
         ops.head(0, self.kind, T * B, H, s.Dout, top, self._v("notes.wt", self.np_notes, H), P["dec.notes.out.b"],
                  target_idx=self._v("in.y_idx", T * B) if tg else None,
@@ -490,33 +539,43 @@ class Engine(object):
     def _split_k(self, K):
         return int(min(64, max(1, K // 2048)))
 
-    def _rec_backward(self, r, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0, idx=None,
-                      xs=None, start=None):
-        """BPTT of one layer + its parameter gradients.  Returns the gradient w.r.t. the lower layer's h sequence
-        for X_DENSE layers (None otherwise)."""
-        s, P, G, p = self.spec, self.P, self.G, r.prefix
+    def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0):
+        """BPTT over time chunk k (chunks run from the LAST to the first) + the gradient for the layer below."""
+        s, p = self.spec, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        Tc = T // nch
+        t0 = k * Tc
+        lstm = s.cell == "LSTM"
+        sh, sc = self._v(p + ".sh", B, H), self._v(p + ".sc", B, H)
+        first, final = k == nch - 1, k == 0
+        da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
+        self._timed(("rnn_bwd", p), lambda: ops.rnn_bwd(
+            self.cell, self.kind, Tc, B, H, self.store[p + ".ut_pack"], self._v(p + ".hs", T + 1, B, H)[t0:t0 + Tc + 1],
+            self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None, self._v(p + ".acts", T, B, GH)[t0:t0 + Tc],
+            da, dhs_ext=None if dhs_ext is None else dhs_ext[t0:t0 + Tc],
+            dh_last=(dh_last if first else sh), dh_last_ld=(dh_last_ld if first else 0),
+            dc_last=(None if (first or not lstm) else sc),
+            rh=self._v(p + ".rh", T, B, H)[t0:t0 + Tc] if s.cell == "GRU" else None,
+            dh0=(dh0 if final else sh), dc0=((dc0 if final else sc) if lstm else None), dh0_ld=(dh0_ld if final else 0),
+            seq_layout=self.lay))
+        if r.xmode == hl.X_DENSE:       # critical path: what the lower layer's BPTT waits for
+            dx = self._v(p + ".dx", T, B, H)[t0:t0 + Tc]
+            ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay)
+
+    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None):
+        """Parameter gradients of one layer from its complete da: off the critical path, on the gradient stream."""
+        s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
         R = T * B
         hs = self._v(p + ".hs", T + 1, B, H)
         da = self._v(p + ".da", T, B, GH)
-        rh = self._v(p + ".rh", T, B, H) if s.cell == "GRU" else None
-        self._timed(("rnn_bwd", p), lambda: ops.rnn_bwd(
-            self.cell, self.kind, T, B, H, self.store[p + ".ut_pack"], hs,
-            self._v(p + ".cs", T + 1, B, H) if s.cell == "LSTM" else None, self._v(p + ".acts", T, B, GH), da,
-            dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, rh=rh, dh0=dh0, dc0=dc0, dh0_ld=dh0_ld,
-            seq_layout=self.lay))
         da2, hprev = da.view(R, GH), hs[:T].reshape(R, H)
         sk = self._split_k(R)
-        # critical path first: the gradient the lower layer's BPTT waits for
-        dx = None
-        if r.xmode == hl.X_DENSE:
-            dx = self._v(p + ".dx", T, B, H)
-            ops.gemm(da2, self._v(p + ".wc", H, GH), dx, R, H, GH, trans_b=True, c_layout=self.lay)
-        # parameter gradients: off the critical path (only the optimizer needs them)
         self._fork(self.s_grad)
         with self._on(self.s_grad):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
+                rh = self._v(p + ".rh", T, B, H)
                 ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
                          accumulate=True, split_k=sk)
@@ -537,7 +596,37 @@ class Engine(object):
                 else:
                     lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
                     ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
-        return dx
+
+    def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
+                        start=None):
+        """BPTT through a stack (top layer first), pipelined over time chunks in reverse order."""
+        nch = self._nchunks(layers)
+        order = list(reversed(layers))               # order[0] = top layer
+        streams = [None] + self.s_layer[:len(layers) - 1]
+        done = [[torch.cuda.Event() for _ in range(nch)] for _ in order]
+        if nch > 1:
+            self._fork(*streams[1:])
+        for k in range(nch - 1, -1, -1):
+            for li, r in enumerate(order):
+                top = li == 0
+                ds = dstates(r) if dstates else {}
+                def run():
+                    if li > 0 and nch > 1:
+                        torch.cuda.current_stream().wait_event(done[li - 1][k])
+                    ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
+                    self._rec_bptt(r, B, k, nch, dhs_ext=ext, dh_last=dh_last if top else None,
+                                   dh_last_ld=dh_last_ld if top else 0, **ds)
+                    if nch > 1:
+                        done[li][k].record()
+                    if k == 0:
+                        self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
+                if li > 0 and nch > 1:
+                    with torch.cuda.stream(streams[li]):
+                        run()
+                else:
+                    run()
+        if nch > 1:
+            self._join(*streams[1:])
 
     def _head_backward(self, B, name, r, N, NP, outW, outb):
         """d(logits) -> gradient of the output Dense and of the top cell's h sequence."""
@@ -573,17 +662,15 @@ class Engine(object):
             with self._on(self.s_instr):
                 dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
                                            "dec.instr.out.b")
-                self._rec_backward(self.dec_instr, B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
-                                   **dstates(self.dec_instr))
+                self._stack_backward([self.dec_instr], B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
+                                     dstates=dstates)
         if s.meta_velocity:
             with self._on(self.s_vel):
                 dext = self._head_backward(B, "vel", self.dec_vel, 1, 16, "dec.vel.out.W", "dec.vel.out.b")
-                self._rec_backward(self.dec_vel, B, dhs_ext=dext, start=self._v("in.start_vel", B, 1),
-                                   **dstates(self.dec_vel))
+                self._stack_backward([self.dec_vel], B, dhs_ext=dext, start=self._v("in.start_vel", B, 1), dstates=dstates)
         dext = self._head_backward(B, "notes", self.dec_notes[-1], s.Dout, self.np_notes, "dec.notes.out.W",
                                    "dec.notes.out.b")
-        for r in reversed(self.dec_notes):
-            dext = self._rec_backward(r, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), **dstates(r))
+        self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates)
         self._join(self.s_vel, self.s_instr)
         # initial-state Denses: S = tanh([z|hist] Winit + b)
         S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
@@ -643,17 +730,14 @@ class Engine(object):
         k = 1
         if s.meta_instrument:
             with self._on(self.s_instr):
-                self._rec_backward(self.enc_instr, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                   idx=self._v("in.i_idx", V, B))
+                self._stack_backward([self.enc_instr], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                     idx=self._v("in.i_idx", V, B))
             k += 1
         if s.meta_velocity:
             with self._on(self.s_vel):
-                self._rec_backward(self.enc_vel, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                   xs=self._v("in.vel", T, B))
-        dext, dlast, dld = None, dcat[:, 0:H], ldc
-        for r in reversed(self.enc_notes):
-            dext = self._rec_backward(r, B, dhs_ext=dext, dh_last=dlast, dh_last_ld=dld, idx=self._v("in.x_idx", T, B))
-            dlast, dld = None, 0
+                self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                     xs=self._v("in.vel", T, B))
+        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B))
         self._join(self.s_vel, self.s_instr, self.s_grad)
 
     # ------------------------------------------------------------------------------------------------------
@@ -673,19 +757,68 @@ class Engine(object):
         self._have_targets = True
         self.scal.zero_()
         self.grads.zero_()
-        if self._weights_dirty:
+        if self._weights_dirty or self.use_graphs:
             self.prepare_weights()
         self.encoder_forward(B)
         self.decoder_forward(B)
         self.backward(B)
 
     def train_step(self, B, allreduce=None):
-        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch."""
+        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.
+        With ``use_graphs`` the launch sequence (all streams, events and the ~200 kernels of a step) is captured once
+        per batch size into a hipGraph and replayed: the step is otherwise bound by host-side launch issue."""
+        if self.use_graphs and self.prof is None:
+            return self._graph_step(B, allreduce)
         self.forward_backward(B)
         gs = 1.0
         if allreduce is not None:
             gs = allreduce(self.grads)
         self.optimizer_step(gs if gs is not None else 1.0)
+
+    def _graph_step(self, B, allreduce):
+        key = (B, allreduce is not None)
+        if key not in self._graphs:
+            world_scale = [1.0]
+            self._weights_dirty = True
+
+            def body_fb():
+                self.forward_backward(B)
+
+            def body_opt():
+                self.optimizer_step(world_scale[0])
+
+            # warm-up on a side stream (lazy module loads, hipFuncSetAttribute, allocator) - required before capture
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                snap = (self.params.clone(), self.opt_m.clone(), self.opt_v.clone(), self.t_done.clone())
+                body_fb()
+                if allreduce is not None:
+                    world_scale[0] = allreduce(self.grads) or 1.0
+                body_opt()
+                self.params.copy_(snap[0]); self.opt_m.copy_(snap[1]); self.opt_v.copy_(snap[2]); self.t_done.copy_(snap[3])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._weights_dirty = True
+            if allreduce is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body_fb()
+                    body_opt()
+                self._graphs[key] = (g, None)
+            else:           # the collective stays outside the graphs: capture the two halves separately
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    body_fb()
+                with torch.cuda.graph(g2):
+                    body_opt()
+                self._graphs[key] = (g1, g2)
+        g1, g2 = self._graphs[key]
+        self._weights_dirty = True      # replay always re-prepares the packed weights (first kernels of the graph)
+        g1.replay()
+        if g2 is not None:
+            allreduce(self.grads)
+            g2.replay()
 
     def eval_step(self, B, want_probs=False):
         """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""

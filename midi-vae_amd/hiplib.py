@@ -31,13 +31,13 @@ class RnnFwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("xmode", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("u_pack", _vp), ("xp", _vp), ("idx", _vp), ("table", _vp), ("xs", _vp), ("w_row", _vp),
                 ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
-                ("h_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32), ("seq_layout", _i32)]
+                ("h_last", _vp), ("c_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32), ("seq_layout", _i32)]
 
 
 class RnnBwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("ut_pack", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp), ("dhs_ext", _vp), ("dh_last", _vp),
-                ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32), ("seq_layout", _i32)]
+                ("dc_last", _vp), ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32), ("seq_layout", _i32)]
 
 
 class GemmArgs(C.Structure):

@@ -50,7 +50,7 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
-            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, h0_ld=0, h_last_ld=0, seq_layout=0):
+            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, c_last=None, h0_ld=0, h_last_ld=0, seq_layout=0):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -59,15 +59,16 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
         xmode = hl.X_SCALAR
     else:
         xmode = hl.X_CONST
-    a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _p(xp), _p(idx), _p(table), _p(xs), _p(w_row),
-                      _p(bias), _p(xp0), _pv(h0), _pv(c0), _p(hs), _p(cs), _p(acts), _pv(h_last), h0_ld, h_last_ld, seq_layout)
+    a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _pv(xp), _pv(idx), _p(table), _pv(xs), _p(w_row),
+                      _p(bias), _p(xp0), _pv(h0), _pv(c0), _pv(hs), _pv(cs), _pv(acts), _pv(h_last), _pv(c_last), h0_ld, h_last_ld,
+                      seq_layout)
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
-def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, rh=None, dh0=None,
-            dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0):
-    a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _p(hs), _p(cs), _p(acts), _p(dhs_ext), _pv(dh_last), _p(da),
-                      _p(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, seq_layout)
+def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, dc_last=None, rh=None,
+            dh0=None, dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0):
+    a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _pv(hs), _pv(cs), _pv(acts), _pv(dhs_ext), _pv(dh_last),
+                      _pv(dc_last), _pv(da), _pv(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, seq_layout)
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 

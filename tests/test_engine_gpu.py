@@ -139,6 +139,36 @@ def test_encode_decode_and_argmax(dtype):
         assert np.array_equal(eng.note_indices(B), np.argmax(out_o["notes"], -1).astype(np.uint8))
 
 
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_time_chunk_pipelining_is_exact(cell, dtype):
+    """T=64 -> stacked layers run as 4 chunks of 16 steps on separate streams with f32 state carried between
+    launches: gradients must match the oracle, and match the un-chunked run of the same engine closely."""
+    B = 16
+    spec, params, batch, raw = _problem(cell, B, seed=21, T=64)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    res = {}
+    for chunks in (4, 1):
+        eng = Engine(spec, max_batch=B, dtype=dtype)
+        eng.time_chunks = chunks
+        assert eng._nchunks(eng.enc_notes) == chunks
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        res[chunks] = (eng.metrics(B), eng.get_grads())
+    m, g = res[4]
+    tol = 3e-4 if dtype == "f32" else 3e-2
+    assert abs(m["loss"] - m_o["loss"]) <= tol * (1 + abs(m_o["loss"]))
+    for k in g_o:
+        if np.linalg.norm(g_o[k]) > 1e-9:
+            assert _rel_l2(g[k], g_o[k]) < (2e-3 if dtype == "f32" else 8e-2), (k, _rel_l2(g[k], g_o[k]))
+        if dtype == "f32" and np.linalg.norm(res[1][1][k]) > 1e-9:
+            assert _rel_l2(g[k], res[1][1][k]) < 1e-4, k       # chunked == un-chunked up to atomic-add ordering
+
+
 def test_ragged_batch_reuses_buffers():
     """A smaller last minibatch (songs are not multiples of batch_size) runs in the same engine."""
     spec, params, batch, raw = _problem("GRU", 5, seed=2)
