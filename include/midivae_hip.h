@@ -139,6 +139,9 @@ typedef struct {
     void* C;
     const float* bias;            /* (N) or NULL                                                              */
     int32_t c_layout;             /* MVAE_ROWMAJOR (ldc applies) or MVAE_TILE16 (store only, M%16==0, N%16==0)  */
+    int32_t max_blocks;           /* 0 = one workgroup per output tile; >0 = at most this many workgroups, each looping
+                                     over tiles: keeps a throughput GEMM from occupying every CU while latency-critical
+                                     recurrent launches (which need whole idle CUs) run beside it                 */
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
 

@@ -13,4 +13,12 @@ through the repo-root shim ``midi_vae_amd.py`` which registers this directory as
   synth     synthetic piano-roll windows
   dp        data-parallel sharding over torch.distributed (RCCL)
 """
+import os as _os
+
+# The engine runs the independent branches of the step on separate HIP streams (notes stack / velocity / instrument /
+# pipelined layers / gradient GEMMs).  ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
+# with more streams than queues, unrelated streams share a queue and serialise (seen in profiles/r01_b: the
+# gradient GEMMs delayed the lower layer's BPTT by milliseconds).  Must be set before the HIP runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"

@@ -116,14 +116,20 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int M = a.M, N = a.N, K = a.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int splits = a.split_k > 1 ? a.split_k : 1;
+    const int total_tiles = tiles_n * tiles_m * splits;
+    // persistent tile loop (one iteration when the grid covers every tile)
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int bx = tile % tiles_n, by = (tile / tiles_n) % tiles_m, bz = tile / (tiles_n * tiles_m);
+    const int m0 = by * BM, n0 = bx * BN;
     int kbeg = 0, kend = K;
-    if (a.split_k > 1) {
-        const int per = ((K + a.split_k - 1) / a.split_k + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * per;
+    if (splits > 1) {
+        const int per = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+        kbeg = bz * per;
         kend = min(K, kbeg + per);
-        if (kbeg >= kend) return;
+        if (kbeg >= kend) continue;
     }
 
     f32x4 acc[MI][NI];
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
             const int n = n0 + wn * (BN / 2) + j * 16 + q * 4;
             if (n >= N) continue;
             f32x4 v = acc[i][j] * a.alpha;
-            if (a.bias && (blockIdx.z == 0 || !a.accumulate)) {
+            if (a.bias && (bz == 0 || !a.accumulate)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (n + e < N) v[e] += a.bias[n + e];
@@ -209,17 +215,228 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
             }
         }
     }
+    }   // tile loop
+}
+
+
+// ===========================================================================================================
+// Fast path: bf16 operands stored in bf16 (or one-hot A), 128x128 tiles, M%128 == N%128 == K%64 == 0, 16-byte
+// aligned rows.  Differences from the generic kernel above:
+//   * global -> LDS staging is a straight 16-byte copy (no float round trip), issued for tile k+1 BEFORE the MFMAs
+//     of tile k (register prefetch) into the other half of a double-buffered LDS image: one barrier per K tile;
+//   * BK = 64: 32 MFMAs per wave per barrier;
+//   * an operand that is row-contiguous in memory ([k][row]: both operands of every weight-gradient GEMM) is
+//     staged AS IS and read with ds_read_b64_tr_b16, the LDS transpose read of gfx950 - the generic kernel
+//     transposes with eight 2-byte LDS stores per 16 bytes loaded.
+// ===========================================================================================================
+constexpr int FBM = 128, FBN = 128, FBK = 64;
+constexpr int F_LDK = FBK + 8;        // k-contiguous image: [row][FBK + 8]  (144 B rows: conflict-free b128 reads)
+constexpr int F_LDR = 128 + 16;       // row-contiguous image: [k][128 + 16] (288 B rows = 32 mod 256: tr reads spread)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <bool RC>   // element count of one operand image
+constexpr int f_img() { return RC ? FBK * F_LDR : 128 * F_LDK; }
+
+// fragment (8 consecutive k for row base+r, k-slot q) of k-group kg (32 k) from an operand image
+template <bool RC>
+__device__ __forceinline__ u16x8 f_frag(const bf16_t* img, int rbase, int kg, int q, int r) {
+    if (!RC) return *reinterpret_cast<const u16x8*>(img + (rbase + r) * F_LDK + kg * 32 + q * 8);
+    // lane r of a 16-lane group hands in the 8-byte chunk (k = k0 + r/4, rows rbase + 4*(r%4) ..+3); the transpose
+    // read returns k0..k0+3 of row rbase + r
+    const int k0 = kg * 32 + q * 8;
+    const bf16_t* p0 = img + (k0 + (r >> 2)) * F_LDR + rbase + (r & 3) * 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * F_LDR));
+    return u16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2],
+                 (bf16_t)hi[3]};
+}
+
+// One thread's share of an operand tile: 128 rows x 64 k bf16 = 16 KiB = 1024 chunks of 16 B -> 4 per thread.
+template <bool RC, bool ONEHOT>
+struct f_stage {
+    u16x8 v[4];
+    // chunk c (0..1023):  KC: row = c / 8, k8 = c % 8 ;  RC: k = c / 16, row8 = c % 16
+    __device__ __forceinline__ void load(const void* base, int ld, int row0, int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            if (ONEHOT) {
+                const int k = c >> 4, r8 = (c & 15) * 8;
+                const int hot = (int)reinterpret_cast<const uint8_t*>(base)[k0 + k] - (row0 + r8);
+                u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (hot == e) ? (bf16_t)0x3f80 : (bf16_t)0;
+                v[i] = z;
+            } else if (RC) {
+                const int k = c >> 4, r8 = (c & 15) * 8;
+                v[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_t*>(base) + (size_t)(k0 + k) * ld + row0 + r8);
+            } else {
+                const int row = c >> 3, k8 = (c & 7) * 8;
+                v[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_t*>(base) + (size_t)(row0 + row) * ld + k0 + k8);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256;
+            if (RC) *reinterpret_cast<u16x8*>(img + (c >> 4) * F_LDR + (c & 15) * 8) = v[i];
+            else *reinterpret_cast<u16x8*>(img + (c >> 3) * F_LDK + (c & 7) * 8) = v[i];
+        }
+    }
+};
+
+template <bool A_RC, bool B_RC, bool ONEHOT>
+__global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IA = f_img<A_RC>(), IB = f_img<B_RC>();
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                  // [2][IA]
+    bf16_t* Bs = As + 2 * IA;                                      // [2][IB]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int wm = w >> 1, wn = w & 1;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tiles_n = N / FBN, tiles_m = (M + FBM - 1) / FBM;      // M < 128 only for the one-hot table gradient
+    const int splits = a.split_k > 1 ? a.split_k : 1;
+    const int total_tiles = tiles_n * tiles_m * splits;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int bx = tile % tiles_n, by = (tile / tiles_n) % tiles_m, bz = tile / (tiles_n * tiles_m);
+        const int m0 = by * FBM, n0 = bx * FBN;
+        int kbeg = 0, kend = K;
+        if (splits > 1) {
+            const int per = ((K + splits - 1) / splits + FBK - 1) / FBK * FBK;
+            kbeg = bz * per;
+            kend = min(K, kbeg + per);
+            if (kbeg >= kend) continue;
+        }
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        f_stage<A_RC, ONEHOT> sa;
+        f_stage<B_RC, false> sb;
+        sa.load(a.A, a.lda, m0, kbeg, tid);
+        sb.load(a.B, a.ldb, n0, kbeg, tid);
+        __syncthreads();                       // previous output tile's readers are done with both images
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+            const bool more = k0 + FBK < kend;
+            if (more) {                        // global loads for the next K tile fly under this tile's MFMAs
+                sa.load(a.A, a.lda, m0, k0 + FBK, tid);
+                sb.load(a.B, a.ldb, n0, k0 + FBK, tid);
+            }
+            const bf16_t* Ai = As + cur * IA;
+            const bf16_t* Bi = Bs + cur * IB;
+#pragma unroll
+            for (int kg = 0; kg < FBK / 32; ++kg) {
+                u16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = f_frag<A_RC>(Ai, wm * 64 + i * 16, kg, q, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = f_frag<B_RC>(Bi, wn * 64 + j * 16, kg, q, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);   // rows: n, cols: m
+            }
+            if (more) {
+                sa.store(As + (cur ^ 1) * IA, tid);
+                sb.store(Bs + (cur ^ 1) * IB, tid);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + r;
+            if (ONEHOT && m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + q * 4;
+                f32x4 v = acc[i][j] * a.alpha;
+                if (a.bias && (bz == 0 || !a.accumulate)) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+                if (a.act == MVAE_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanh_f(v[e]);
+                }
+                if (a.c_layout == MVAE_TILE16) {
+                    const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
+                    if (a.c_kind == MVAE_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + off) = v;
+                    else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
+                } else if (a.accumulate) {
+                    float* cp = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
+                } else if (a.c_kind == MVAE_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n) = v;
+                } else {
+                    st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, v);
+                }
+            }
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC, bool ONEHOT>
+int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * (f_img<A_RC>() + f_img<B_RC>()) * sizeof(bf16_t);
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_k<A_RC, B_RC, ONEHOT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    const int sk = a.split_k > 1 ? a.split_k : 1;
+    long long tiles = (long long)(a.N / FBN) * ((a.M + FBM - 1) / FBM) * sk;
+    if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
+    hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
+// true when the fast kernel can take this problem
+bool fast_ok(const mvae_gemm_args& a) {
+    const bool onehot = a.a_kind == MVAE_A_ONEHOT;
+    if (!(a.b_kind == MVAE_BF16 && (a.a_kind == MVAE_BF16 || onehot))) return false;
+    if ((a.N % FBN) || (a.K % FBK)) return false;
+    if (onehot) { if (a.M > FBM || !a.trans_a) return false; }          // one M tile; rows >= M are never hot
+    else if (a.M % FBM) return false;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!onehot && (!al16(a.A) || (a.lda % 8))) return false;
+    if (!al16(a.B) || (a.ldb % 8)) return false;
+    if (a.bias && !al16(a.bias)) return false;
+    if (a.c_layout == MVAE_ROWMAJOR) {
+        if (a.c_kind == MVAE_F32 && (!al16(a.C) || (a.ldc % 4))) return false;
+        if (a.c_kind == MVAE_BF16 && ((reinterpret_cast<uintptr_t>(a.C) & 7) || (a.ldc % 4))) return false;
+    }
+    return true;
+}
+
+int dispatch_fast(const mvae_gemm_args& a, hipStream_t s) {
+    const bool a_rc = a.trans_a != 0, b_rc = a.trans_b == 0;     // row-contiguous = [k][row] in memory
+    if (a.a_kind == MVAE_A_ONEHOT)      // a full 128-row tile is computed; only rows < M are stored
+        return b_rc ? launch_fast<true, true, true>(a, s) : launch_fast<true, false, true>(a, s);
+    if (a_rc) return b_rc ? launch_fast<true, true, false>(a, s) : launch_fast<true, false, false>(a, s);
+    return b_rc ? launch_fast<false, true, false>(a, s) : launch_fast<false, false, false>(a, s);
 }
 
 template <typename OT, int AKIND, int BKIND, bool TA, bool TB>
 int launch(const mvae_gemm_args& a, hipStream_t s) {
     const int sk = a.split_k > 1 ? a.split_k : 1;
     if ((long long)a.M * a.N >= 256 * 1024 && a.M >= 128 && a.N >= 128) {
-        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, sk);
-        hipLaunchKernelGGL((gemm_k<OT, AKIND, BKIND, TA, TB, 128, 128>), grid, dim3(256), 0, s, a);
+        long long tiles = (long long)((a.N + 127) / 128) * ((a.M + 127) / 128) * sk;
+        if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
+        hipLaunchKernelGGL((gemm_k<OT, AKIND, BKIND, TA, TB, 128, 128>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else {
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64, sk);
-        hipLaunchKernelGGL((gemm_k<OT, AKIND, BKIND, TA, TB, 64, 64>), grid, dim3(256), 0, s, a);
+        long long tiles = (long long)((a.N + 63) / 64) * ((a.M + 63) / 64) * sk;
+        if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
+        hipLaunchKernelGGL((gemm_k<OT, AKIND, BKIND, TA, TB, 64, 64>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     }
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
@@ -244,6 +461,7 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (a->accumulate && a->act != MVAE_ACT_NONE) return MVAE_E_ARG;
     if (a->c_layout == MVAE_TILE16 && (a->accumulate || (a->M % 16) || (a->N % 16))) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (fast_ok(*a)) return dispatch_fast(*a, s);
     const int ak = a->a_kind, bk = a->b_kind;
     // operand type on the matrix cores: bf16 if any stored operand is bf16, else exact f32
     if (ak == MVAE_F32 && bk == MVAE_F32) return by_trans<float, MVAE_F32, MVAE_F32>(*a, s);

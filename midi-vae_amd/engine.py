@@ -84,6 +84,9 @@ class Engine(object):
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
         # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
         self.time_chunks = 4
+        # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
+        # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
+        self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(init_params(spec, seed))
         self._build_graph_description()
         self._alloc(self.maxB)
@@ -537,7 +540,9 @@ class Engine(object):
     # backward
     # ------------------------------------------------------------------------------------------------------
     def _split_k(self, K):
-        return int(min(64, max(1, K // 2048)))
+        # weight-gradient GEMMs have a tiny output (H x G*H = 16 tiles of 128x128) and K = T*B: split K so that
+        # tiles x splits ~ the CU count; more splits only add atomic traffic (212 vs 367 TFLOP/s at 64 vs 16)
+        return int(min(16, max(1, K // 8192)))
 
     def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0):
         """BPTT over time chunk k (chunks run from the LAST to the first) + the gradient for the layer below."""
@@ -576,26 +581,26 @@ class Engine(object):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)
-                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk)
+                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                         accumulate=True, split_k=sk)
+                         accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
             else:
-                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
                 ops.sum_over_time(da, T, B * GH, dxp0)
                 ops.colsum(dxp0, B, GH, G[p + ".b"])
-                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=self.grad_gemm_blocks)
             else:
                 ops.colsum(da2, R, GH, G[p + ".b"])
                 if r.xmode == hl.X_INDEX:
                     ops.gemm(idx.view(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True,
                              split_k=sk)
                 elif r.xmode == hl.X_SCALAR:
-                    ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                    ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
                 else:
                     lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
-                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
                         start=None):
@@ -639,7 +644,8 @@ class Engine(object):
         ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
         self._fork(self.s_grad)
         with self._on(self.s_grad):
-            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
+            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R),
+                     max_blocks=self.grad_gemm_blocks)
             ops.colsum(dl, R, N, G[outb], ldx=NP)
         return dhs
 

@@ -44,7 +44,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("trans_a", _i32), ("trans_b", _i32),
                 ("a_kind", _i32), ("b_kind", _i32), ("c_kind", _i32), ("lda", _i32), ("ldb", _i32), ("ldc", _i32),
                 ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
-                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32)]
+                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32)]
 
 
 class HeadArgs(C.Structure):

@@ -73,7 +73,7 @@ def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh
 
 
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
-         accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0):
+         accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0):
     """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths."""
     a_kind = kind_of(A) if a_kind is None else a_kind
     if lda is None:
@@ -83,7 +83,7 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
     if ldc is None:
         ldc = N
     g = hl.GemmArgs(M, N, K, int(trans_a), int(trans_b), a_kind, kind_of(B), kind_of(C), lda, ldb, ldc,
-                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout)
+                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks)
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
 
 

@@ -166,7 +166,7 @@ def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
-@pytest.mark.parametrize("M,N,K", [(50, 61, 33), (300, 192, 256), (128, 128, 1000)])
+@pytest.mark.parametrize("M,N,K", [(50, 61, 33), (300, 192, 256), (128, 128, 1000), (256, 384, 1024), (512, 128, 192)])
 def test_gemm(ta, tb, dtype, tol, M, N, K):
     rng = np.random.default_rng(M + N + K)
     td = ops.torch_dtype(dtype)
@@ -232,7 +232,7 @@ def test_gemm_leading_dimensions_and_column_blocks():
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 1e-5), (hl.BF16, 1e-2)])
 def test_gemm_onehot_table_gradient(dtype, tol):
     rng = np.random.default_rng(9)
-    R, D, N = 700, 61, 192
+    R, D, N = 1024, 61, 256
     idx = rng.integers(0, D, (R,))
     da = rng.standard_normal((R, N))
     dad = dev(da, ops.torch_dtype(dtype))

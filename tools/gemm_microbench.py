@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""GEMM shapes of the train step (BASELINE configs[1]) - TFLOP/s per variant."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import midi_vae_amd  # noqa
+from midi_vae_amd import hiplib as hl, ops
+dev, bf = "cuda:0", torch.bfloat16
+R, H, GH = 512 * 256, 256, 1024
+hs = torch.randn((R, H), device=dev).to(bf); da = (torch.randn((R, GH), device=dev) * 0.1).to(bf)
+wt = torch.randn((GH, H), device=dev).to(bf); wc = torch.randn((H, GH), device=dev).to(bf)
+xp = torch.zeros((R, GH), dtype=bf, device=dev); dx = torch.zeros((R, H), dtype=bf, device=dev)
+dU = torch.zeros((H, GH), device=dev); idx = torch.randint(0, 61, (R,), dtype=torch.uint8, device=dev)
+dW = torch.zeros((61, GH), device=dev); bias = torch.zeros(GH, device=dev)
+def t(fn, flop, name, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("%-44s %8.3f ms  %7.1f TFLOP/s" % (name, ms, flop / ms / 1e9))
+f = 2.0 * R * H * GH
+t(lambda: ops.gemm(hs, wt, xp, R, GH, H, trans_b=True, bias=bias, c_layout=hl.TILE16), f, "xp = hs W^T (NT, tile16 out)")
+t(lambda: ops.gemm(da, wc, dx, R, H, GH, trans_b=True, c_layout=hl.TILE16), f, "dx = da W (NT, K=1024)")
+t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=64), f, "dU = hs^T da (TN split-K 64)")
+t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=16), f, "dU = hs^T da (TN split-K 16)")
+t(lambda: ops.gemm(idx, da, dW, 61, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=64), 2.0 * R * 61 * GH, "dWtab = onehot^T da (split-K 64)")
