@@ -32,6 +32,8 @@
 //    matrix pipe runs a 4-MFMA group for 64 cycles), so only the last tile's arithmetic and the barrier are
 //    exposed.  Backward has a true dependency (all of dh before any gate gradient) and stays phased.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 // Phase stamps (build with -DRES_STAMPS): block 0 / wave 0 / lane 0 records s_memtime at marked points of steps
 // [64, 72); read back with mvae_debug_stamps().  Development tooling only.
@@ -47,6 +49,34 @@ extern "C" int mvae_debug_stamps(unsigned long long* out) {
 }
 #else
 #define STAMP(k)
+#endif
+
+// Timing ablations (development only; results are wrong when any is set): -DABL_NOL=1 skips the LDS reads of
+// LDS-resident fragments, ABL_NOTRG the row-major write-back, ABL_NOSAVE the saved-activation stores, ABL_NOX the
+// input prefetch, ABL_NOMATH the gate arithmetic, ABL_NOBAR the barriers.
+#ifndef ABL_NOL
+#define ABL_NOL 0
+#endif
+#ifndef ABL_NOTRG
+#define ABL_NOTRG 0
+#endif
+#ifndef ABL_NOSAVE
+#define ABL_NOSAVE 0
+#endif
+#ifndef ABL_NOX
+#define ABL_NOX 0
+#endif
+#ifndef ABL_NOMATH
+#define ABL_NOMATH 0
+#endif
+#ifndef ABL_NOBAR
+#define ABL_NOBAR 0
+#endif
+#ifndef ABL_NOB
+#define ABL_NOB 0      // B fragments: no LDS reads after the first two of a step
+#endif
+#ifndef ABL_NOTRANS
+#define ABL_NOTRANS 0  // exp / rcp replaced by multiplies
 #endif
 
 namespace {
@@ -83,6 +113,18 @@ __device__ __forceinline__ void load4_agpr(frag& u0, frag& u1, frag& u2, frag& u
                                            const frag* p2, const frag* p3) {
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
                  "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&a"(u0), "=&a"(u1), "=&a"(u2), "=&a"(u3)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+// Same without the wait: the caller issues every group, then ONE vm_drain() before the first MFMA (a wait per group
+// serialises 16 HBM/L2 round trips = tens of microseconds per launch).  ONLY for kernels without scratch: hipcc may
+// spill an asm output right after the statement, i.e. before the data has landed.  The Makefile fails the build if a
+// kernel named *_il_k has a non-zero scratch size.
+__device__ __forceinline__ void load4_agpr_nowait(frag& u0, frag& u1, frag& u2, frag& u3, const frag* p0, const frag* p1,
+                                                  const frag* p2, const frag* p3) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                 "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
                  : "=&a"(u0), "=&a"(u1), "=&a"(u2), "=&a"(u3)
                  : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
                  : "memory");
@@ -137,6 +179,7 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
         else if ((f) < NA + NV) mfma4<false>(c0, c1, c2, c3, uv[(f) - NA < NV ? (f) - NA : 0],                     \
                                              uv[(f) - NA < NV ? (f) - NA + 1 : 1], uv[(f) - NA < NV ? (f) - NA + 2 : 2], \
                                              uv[(f) - NA < NV ? (f) - NA + 3 : 3], bf);                           \
+        else if (ABL_NOL) mfma4<true>(c0, c1, c2, c3, ua[0], ua[1], ua[2], ua[3], bf);                            \
         else {                                                                                                    \
             const frag t0 = myl[(size_t)((f) - NA - NV) * 64], t1 = myl[(size_t)((f) - NA - NV + 1) * 64];        \
             const frag t2 = myl[(size_t)((f) - NA - NV + 2) * 64], t3 = myl[(size_t)((f) - NA - NV + 3) * 64];    \
@@ -163,6 +206,10 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
 #define RES_NOHOOK(gi)
 
 enum { SAVE_NONE = 0, SAVE_HS = 1, SAVE_ALL = 2 };
+__device__ __forceinline__ void res_barrier() {
+    if (ABL_NOBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else lds_barrier();
+}
 
 // [16 rows][W] bf16 tile in LDS with NO padding; the 16-byte chunk index is XOR-ed with the row so the 16 rows of a
 // ds_read_b128 group hit 16 different bank slots.  col % 4 == 0.
@@ -175,6 +222,7 @@ template <int W>
 __device__ __forceinline__ void tile_rows_to_global(const bf16_t* tile, bf16_t* gbase /* row 0 of this WG's 16 rows */,
                                                     int w, int l) {
     constexpr int CH = W / 8;                    // 16-byte chunks per row
+    if (ABL_NOTRG) return;
 #pragma unroll 2
     for (int j = 0; j < (4 * CH) / 64; ++j) {
         const int c = j * 64 + l, row = 4 * w + c / CH, ch = c % CH;
@@ -311,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
             if (XMODE == MVAE_X_INDEX) pini(i_q);
         };
         auto request_next = [&](int n) {      // right after tile n's x was consumed
+            if (ABL_NOX) return;
             if (XMODE == MVAE_X_DENSE || XMODE == MVAE_X_INDEX) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) aload8(xq[n][g], xaddr(tn, n, g, i_q));
@@ -327,6 +376,8 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                 f32x4 ig, fg, gg, og, hnew;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if (ABL_NOMATH) { ig[i] = a0[i] + xi[i]; fg[i] = a1[i] + xf[i]; gg[i] = a2[i] + xg[i]; og[i] = a3[i] + xo[i];
+                                      creg[n][i] += ig[i]; hnew[i] = og[i] + fg[i] + gg[i]; continue; }
                     ig[i] = hard_sigmoid(a0[i] + xi[i]);
                     fg[i] = hard_sigmoid(a1[i] + xf[i]);
                     gg[i] = tanh_fast(a2[i] + xg[i]);
@@ -335,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                     hnew[i] = og[i] * tanh_fast(creg[n][i]);
                 }
                 *reinterpret_cast<u16x4*>(hnext + sw_off<RH>(r, ub[n])) = pack4(hnew);
-                if (SAVE == SAVE_ALL) {
+                if (SAVE == SAVE_ALL && !ABL_NOSAVE) {
                     bf16_t* ap = acts + ((otile * (GH / 16) + w * RNT + n) * 64 + l) * 4;     // gate 0 tile; gates 16 tiles apart
                     *reinterpret_cast<u16x4*>(ap) = pack4(ig);
                     *reinterpret_cast<u16x4*>(ap + 1 * (RH / 16) * 256) = pack4(fg);
@@ -348,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                     if (a.c_last) *reinterpret_cast<f32x4*>(a.c_last + (size_t)b * ldl + ub[n]) = creg[n];
                 }
             };
+#if RES_LSTM_PIPELINE
             // software pipeline over unit tiles: MFMAs of tile n with the arithmetic of tile n-1 issued among them
             f32x4 accA[4], accB[4];
 #pragma unroll
@@ -371,6 +423,22 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                     request_next(n - 1);
                 }
             }
+#else
+            // register-lean schedule: one accumulator set; the gate arithmetic of a tile follows its own MFMAs
+#pragma unroll
+            for (int n = 0; n < RNT; ++n) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef HF_
+#define HF_(ks) hfrag(htile, ks)
+#endif
+                RES_PHASE(acc[0], acc[1], acc[2], acc[3], n * RS * 4, RS, HF_, RES_NOHOOK);
+                if (n == 0) step_inputs_ready();
+                lstm_tile(n, acc[0], acc[1], acc[2], acc[3]);
+                request_next(n);
+            }
+#endif
         } else {
             // ---- GRU phase A: z, r for tile pairs -------------------------------------------------------------
             f32x4 zg[RNT], rg[RNT];
@@ -399,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                 }
             }
             STAMP(3);
-            lds_barrier();
+            res_barrier();
             STAMP(4);
             // ---- GRU phase B: candidate ---------------------------------------------------------------------
             f32x4 acc[RNT];
@@ -419,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
                 }
                 hreg[n] = hnew;
                 *reinterpret_cast<u16x4*>(hnext + sw_off<RH>(r, ub[n])) = pack4(hnew);
-                if (SAVE == SAVE_ALL) {
+                if (SAVE == SAVE_ALL && !ABL_NOSAVE) {
                     bf16_t* ap = acts + ((otile * (GH / 16) + w * RNT + n) * 64 + l) * 4;
                     *reinterpret_cast<u16x4*>(ap) = pack4(zg[n]);
                     *reinterpret_cast<u16x4*>(ap + 1 * (RH / 16) * 256) = pack4(rg[n]);
@@ -430,13 +498,344 @@ __global__ __launch_bounds__(256, 1) void rnn_fwd_res_k(const mvae_rnn_fwd_args 
         }
         cur ^= 1;
         STAMP(6);
-        lds_barrier();
+        res_barrier();
         STAMP(7);
     }
     if (SAVE >= SAVE_HS) tile_rows_to_global<RH>(hbuf + cur * 16 * RH, hs + ((size_t)T * B + blockIdx.x * 16) * RH, w, l);
     if (CELL == MVAE_GRU && a.h_last) {
 #pragma unroll
         for (int n = 0; n < RNT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub[n]) = hreg[n];
+    }
+    vm_drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTM forward, slot-interleaved
+// ---------------------------------------------------------------------------------------------------------
+// One wave per SIMD issues in order: a 16x16x32 MFMA occupies the matrix pipe for ~16 cycles and only 2-3 other
+// instructions can be issued underneath it (tools/probes/mfma_probe.hip: 65.6 cycles per 4 MFMAs bare, +0 for 2
+// VALU per MFMA, ~+5 cycles per further VALU).  So every MFMA is its own asm statement, and the gate arithmetic
+// of the PREVIOUS unit tile is cut into 32 pieces of ~3 instructions, one per MFMA slot.  Empty volatile asm
+// statements ("pins") on the piece's operands keep hipcc from moving a piece out of its slot: volatile statements
+// keep their order, and a piece sits between the pin that defines its inputs and the pin that uses its outputs.
+// Global addresses are a wave-uniform base (SGPR pair) + one per-lane 32-bit offset + immediates.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+#define SF_LAMBDA(ic) [&](auto ic) __attribute__((always_inline))
+template <bool AG>
+__device__ __forceinline__ void mfma1(f32x4& c, const frag& u, const frag& b) {
+    if (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(u), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(u), "v"(b));
+}
+__device__ __forceinline__ void pinv(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pinq(frag& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pinu(unsigned& v) { asm volatile("" : "+v"(v)); }
+// explicitly global (address space 1) views: a pointer that went through an asm pin is no longer provably global,
+// and hipcc would fall back to flat_ instructions
+typedef __attribute__((address_space(1))) unsigned char gbyte;
+typedef __attribute__((address_space(1))) u16x4 g_u16x4;
+typedef __attribute__((address_space(1))) u16x8 g_u16x8;
+__device__ __forceinline__ gbyte* to_global(const void* p) { return (gbyte*)(const_cast<void*>(p)); }
+__device__ __forceinline__ void pins(gbyte*& p) { asm volatile("" : "+s"(p)); }
+
+template <int XMODE, int SAVE, int NA, int NV>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args a) {
+    constexpr int G = 4, GH = G * RH;
+    constexpr int FPW = G * RNT * RS, NGRP = FPW / 4;
+    // Residency class of fragment f (f = order of use: (tile*8 + kgroup)*4 + gate):
+    //   T  the 4 fragments of tile 0's last k-group: streamed from L2 every step into the accumulator set that is
+    //      idle while tile 0 runs (nothing else is free: 512 registers + 160 KiB hold U, the h tiles and the state)
+    //   A  the first NA others in accumulator registers, V the next NV in vector registers, L the rest in LDS
+    constexpr int TB = 28, NT = 4, NLc = FPW - NT - NA - NV;
+    static_assert(XMODE != MVAE_X_SCALAR, "scalar inputs run on the phased kernel");
+    static_assert(NA % 4 == 0 && NV % 4 == 0 && NLc >= 0 && NA <= 64, "fragment classes");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* hbuf = smem;                                             // [2][16][RH] bf16, swizzled
+    frag* ulds = reinterpret_cast<frag*>(smem + 2 * 16 * RH * 2);           // [4][NL][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
+
+    auto frag_ptr = [&](int f) -> const frag* {
+        const int g = f % G, ks = (f / G) % RS, n = f / (G * RS);
+        return up + (size_t)((g * (RH / 16) + w * RNT + n) * RS + ks) * 64 + l;
+    };
+    frag ua[NA > 0 ? NA : 4], uv[NV > 0 ? NV : 4];
+    static_for<0, (FPW - NT) / 4>(SF_LAMBDA(ic) {
+        constexpr int i = decltype(ic)::value * 4;                 // class index of 4 consecutive fragments
+        constexpr int f = i < TB ? i : i + NT;
+        if constexpr (i < NA) load4_agpr_nowait(ua[i], ua[i + 1], ua[i + 2], ua[i + 3], frag_ptr(f), frag_ptr(f + 1), frag_ptr(f + 2), frag_ptr(f + 3));
+        else if constexpr (i < NA + NV) {
+            uv[i - NA] = *frag_ptr(f); uv[i - NA + 1] = *frag_ptr(f + 1); uv[i - NA + 2] = *frag_ptr(f + 2); uv[i - NA + 3] = *frag_ptr(f + 3);
+        } else {
+            myl[(size_t)(i - NA - NV) * 64] = *frag_ptr(f); myl[(size_t)(i - NA - NV + 1) * 64] = *frag_ptr(f + 1);
+            myl[(size_t)(i - NA - NV + 2) * 64] = *frag_ptr(f + 2); myl[(size_t)(i - NA - NV + 3) * 64] = *frag_ptr(f + 3);
+        }
+    });
+    const frag* tsrc = frag_ptr(TB);            // T fragments: gates 0..3 are (RH/16)*RS*64 fragments apart
+
+    const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
+    unsigned lane8 = (unsigned)l * 8u;          // this lane's 8 bytes inside a TILE16 tile
+    const int ub0 = w * 64 + q * 4;             // first of this lane's 4 units in tile 0 (tile n: + 16 n)
+
+    // Swizzled LDS byte offsets, all derived by XOR from three per-lane values (chunk index ^ row is XOR-linear):
+    //   h write of tile n      : hw0 ^ (n << 5)              B fragment of k-group ks : bf4[ks & 3] + 256 * (ks >> 2)
+    //   row-major copy chunk j : tl0 ^ (j * 1056)  (rows 4w + 2j + l/32, chunk l % 32)
+    unsigned hw0 = (unsigned)r * 512u + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned bf4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf4[j] = (unsigned)r * 512u + ((((unsigned)j * 4u + (unsigned)q) ^ (unsigned)r) << 4);
+    const unsigned row0 = 4u * w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    unsigned tl0 = row0 * 512u + ((ch0 ^ row0) << 4);
+    unsigned tg0 = row0 * 512u + ch0 * 16u;
+
+    f32x4 creg[RNT];
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 h0v = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
+        creg[n] = a.c0 ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
+        *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(h0v);
+        if (SAVE == SAVE_ALL)
+            *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned char*>(a.cs) +
+                                      ((size_t)blockIdx.x * (RH / 16) + w * RNT + n) * 512 + lane8) = pack4(creg[n]);
+    }
+
+    // ---- x queue (packed bf16x4 per tile and gate) for the step about to be computed --------------------------
+    u16x4 xq[RNT][G];
+    unsigned xoff = 0;                          // per-lane byte offset of the x source
+    int i_q = 0;
+    const unsigned char* xbase0;                // wave-uniform base (step 0 for DENSE)
+    if (XMODE == MVAE_X_DENSE) {
+        xoff = lane8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)blockIdx.x * (GH / 16) + w * RNT) * 512;
+    } else if (XMODE == MVAE_X_INDEX) {
+        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
+        i_q = a.idx[(size_t)(T > 1 ? 1 : 0) * B + b];
+    } else {
+        xoff = (unsigned)b * (GH * 2) + q * 8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 128;
+    }
+    constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;     // bytes between gates / tiles
+    constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n)
+#pragma unroll
+        for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+
+    constexpr float K2 = 2.8853900817779268f;   // 2 / ln 2
+    f32x4 accA[4], accB[4], hn = {0.f, 0.f, 0.f, 0.f};
+    frag bq[3], lt[4];
+    auto request_t = [&]() __attribute__((always_inline)) {      // T fragments into the idle accumulator set
+#pragma unroll
+        for (int g = 0; g < 4; ++g) accB[g] = __builtin_bit_cast(f32x4, tsrc[(size_t)g * (RH / 16) * RS * 64]);
+    };
+    request_t();
+    vm_drain();
+    lds_barrier();
+
+    gbyte *acts_p[G], *cs_p, *hs_p;              // step t:   saved gates (per gate), c_t (slot t+1), h_{t-1} (slot t)
+    gbyte* x_p[G];                               // step t+1: inputs (per gate)
+    const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
+        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
+    }
+    cs_p = to_global(a.cs) + ((tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
+    hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
+
+    for (int t = 0; t < T; ++t) {
+        const int tstep = t;
+        (void)tstep;
+        // the three per-lane offset seeds are "redefined" every step so that hipcc derives the others where they are
+        // used instead of keeping a dozen loop-invariant registers
+        pinu(hw0); pinu(tl0);
+        unsigned char* hcur = hbuf;                                        // bf4 / tl0 / hw0 carry the buffer bit
+        // Wave-uniform running pointers (SGPR pairs, one per gate: the 8 KiB between gates exceeds the instruction's
+        // immediate range).  The pins stop hipcc from folding them back into per-lane 64-bit address arithmetic.
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(acts_p[3]); pins(cs_p); pins(hs_p);
+        pins(x_p[0]); pins(x_p[1]); pins(x_p[2]); pins(x_p[3]);
+        STAMP(0);
+        bq[0] = *reinterpret_cast<const frag*>(hcur + bf4[0]);
+        bq[1] = *reinterpret_cast<const frag*>(hcur + bf4[1]);
+        if (SAVE >= SAVE_HS && !ABL_NOTRG) {     // row-major copy of h_{t-1}: staged in the (idle) LDS-fragment registers
+            lt[0] = *reinterpret_cast<const frag*>(hcur + tl0);
+            lt[1] = *reinterpret_cast<const frag*>(hcur + (tl0 ^ 1056u));
+        }
+
+        // next step's x of (tile m, gate g), into the registers whose values were just consumed
+        auto request_x = [&](auto mc, auto gc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value, g = decltype(gc)::value;
+            if (XMODE != MVAE_X_CONST && !ABL_NOX) {
+                if (XMODE == MVAE_X_INDEX && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 8;   // (tile 3 overwrites i_q last)
+                pinu(xoff);
+                xq[m][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + m * XN + xoff);
+                if (XMODE == MVAE_X_INDEX && m == RNT - 1 && g == G - 1)
+                    i_q = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + b];
+            }
+        };
+        // saved activations of tile m (gates i,f,g,o from its accumulator set Q, then c): one store per call
+        auto save = [&](auto mc, auto kc, f32x4* Q) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value, k = decltype(kc)::value;
+            if (SAVE == SAVE_ALL && !ABL_NOSAVE) {
+                // (the 32-bit lane offset is re-defined in this basic block so that instruction selection sees
+                //  "uniform base + zext(lane offset)" and uses the SGPR-base addressing mode)
+                pinu(lane8);
+                if constexpr (k < G) *reinterpret_cast<g_u16x4*>(acts_p[k < G ? k : 0] + m * 512 + lane8) = pack4(Q[k < G ? k : 0]);
+                else *reinterpret_cast<g_u16x4*>(cs_p + m * 512 + lane8) = pack4(creg[m]);
+            }
+        };
+
+        // One piece of tile m's gate arithmetic.  P = that tile's accumulators (gate pre-activations).  Two elements
+        // move in lockstep through 16 single-instruction stages, one stage per MFMA slot: 2 VALU per slot is what a
+        // 16-cycle MFMA hides (tools/probes/slot_probe.hip), and the partner's instruction separates every exp / rcp
+        // from its consumer (no hazard nops).
+        float tf[4];
+        auto piece = [&](auto mc, auto slc, f32x4* P) __attribute__((always_inline)) {
+            // (the tail - no MFMAs to hide under - runs each stage for all 4 elements: 4 independent chains)
+            constexpr int m = decltype(mc)::value, sl = decltype(slc)::value;
+            constexpr bool tail = m == RNT - 1;
+            constexpr int pr = tail ? 0 : sl >> 4, sub = tail ? sl >> 1 : sl & 15, ne = tail ? ((sl & 1) ? 0 : 4) : 2;
+#pragma unroll
+            for (int k = 0; k < ne; ++k) {
+                const int e = 2 * pr + k;
+                // tiles 1..3 start their accumulators at x (see below); tile 0 adds it here
+                auto pre = [&](int g) -> float { return m == 0 ? P[g][e] + bf2f(xq[m][g][e]) : P[g][e]; };
+                if constexpr (sub == 0) P[0][e] = hard_sigmoid(pre(0));
+                if constexpr (sub == 1) P[1][e] = hard_sigmoid(pre(1));
+                if constexpr (sub == 2) P[3][e] = hard_sigmoid(pre(3));
+                if constexpr (sub == 3) P[2][e] = pre(2) * K2;
+                if constexpr (sub == 4) P[2][e] = ABL_NOTRANS ? P[2][e] * 0.5f : __builtin_amdgcn_exp2f(P[2][e]);
+                if constexpr (sub == 5) P[2][e] = P[2][e] + 1.0f;
+                if constexpr (sub == 6) P[2][e] = ABL_NOTRANS ? P[2][e] * 0.5f : __builtin_amdgcn_rcpf(P[2][e]);
+                if constexpr (sub == 7) P[2][e] = 1.0f - 2.0f * P[2][e];
+                if constexpr (sub == 8) tf[k] = P[1][e] * creg[m][e];
+                if constexpr (sub == 9) creg[m][e] = P[0][e] * P[2][e] + tf[k];
+                if constexpr (sub == 10) hn[e] = creg[m][e] * K2;
+                if constexpr (sub == 11) hn[e] = ABL_NOTRANS ? hn[e] * 0.5f : __builtin_amdgcn_exp2f(hn[e]);
+                if constexpr (sub == 12) hn[e] = hn[e] + 1.0f;
+                if constexpr (sub == 13) hn[e] = ABL_NOTRANS ? hn[e] * 0.5f : __builtin_amdgcn_rcpf(hn[e]);
+                if constexpr (sub == 14) hn[e] = 1.0f - 2.0f * hn[e];
+                if constexpr (sub == 15) hn[e] = P[3][e] * hn[e];
+            }
+            // tile 0's x is consumed by slot 19: its next-step loads go out one per 4 slots (a VMEM instruction costs
+            // ~16 cycles of the CU's address unit; four waves bursting 9 of them stall each other)
+            if constexpr (m == 0 && sl >= 19 && (sl - 19) % 4 == 0 && (sl - 19) / 4 < G)
+                request_x(mc, std::integral_constant<int, (sl - 19) / 4 < G ? (sl - 19) / 4 : 0>{});
+            // saves as soon as a quantity is final for all 4 elements (i: slot 16, f: 17, o: 18, g: 23, c: 25), apart
+            if constexpr (!tail) {
+                if constexpr (sl == 20) save(mc, std::integral_constant<int, 0>{}, P);
+                if constexpr (sl == 22) save(mc, std::integral_constant<int, 1>{}, P);
+                if constexpr (sl == 24) save(mc, std::integral_constant<int, 3>{}, P);
+                if constexpr (sl == 26) save(mc, std::integral_constant<int, 2>{}, P);
+                if constexpr (sl == 29) save(mc, std::integral_constant<int, 4>{}, P);
+            } else {        // stage s runs at tail slot 2s: i final after stage 0, f 1, o 2, g 7, c 9
+                if constexpr (sl == 7) save(mc, std::integral_constant<int, 0>{}, P);
+                if constexpr (sl == 11) save(mc, std::integral_constant<int, 1>{}, P);
+                if constexpr (sl == 15) save(mc, std::integral_constant<int, 3>{}, P);
+                if constexpr (sl == 19) save(mc, std::integral_constant<int, 2>{}, P);
+                if constexpr (sl == 23) save(mc, std::integral_constant<int, 4>{}, P);
+            }
+            if constexpr (sl == 31) {
+                // tile m complete: h -> the other LDS tile
+                *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ ((m << 5) | 8192))) = pack4(hn);
+                if (t == T - 1) {
+                    if (a.h_last) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub0 + 16 * m) = hn;
+                    if (a.c_last) *reinterpret_cast<f32x4*>(a.c_last + (size_t)b * ldl + ub0 + 16 * m) = creg[m];
+                }
+            }
+        };
+        static_for<0, RNT + 1>(SF_LAMBDA(nc) {
+            constexpr int n = decltype(nc)::value;
+            f32x4* acc = (n & 1) ? accB : accA;
+            f32x4* P = (n & 1) ? accA : accB;
+            if constexpr (n == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if constexpr (n < RNT) {
+                // Accumulators start at this step's x (one unpack per value instead of zero + unpack + add), and the
+                // next step's x of this tile is requested a whole step ahead (spread over slots 1, 5, 9, 13).  Tile 0
+                // cannot: its x would have to be waited for at the very top of the step, behind the previous tail's stores.
+                if constexpr (n == 1) asm volatile("s_nop 3");     // the T fragments were MFMA operands a moment ago
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = unpack4(xq[n][g]);
+            }
+            static_for<0, 32>(SF_LAMBDA(slc) {
+                constexpr int sl = decltype(slc)::value;
+                if constexpr (n < RNT) {
+                    constexpr int ks = sl >> 2, g = sl & 3, gi = n * RS + ks, f = gi * 4 + g;
+                    constexpr int ci = f < TB ? f : f - NT;                       // class index (T excluded)
+                    if constexpr (n == 0 && sl == TB) {
+                        // One wait per step: this step's x and T fragments (requested during the previous step) and
+                        // every older store.  The saved-sequence row-major copy of h_{t-1} follows it.
+                        STAMP(1);
+                        vm_drain();
+                        STAMP(2);
+#pragma unroll
+                        for (int m = 0; m < RNT; ++m) pin4(xq[m][0], xq[m][1], xq[m][2], xq[m][3]);   // (CONST: keeps the rows packed)
+                        if (XMODE == MVAE_X_INDEX) pini(i_q);
+                        pinv(accB[0]); pinv(accB[1]); pinv(accB[2]); pinv(accB[3]);
+                        if (SAVE >= SAVE_HS && !ABL_NOTRG) {
+                            pinu(tg0);
+                            *reinterpret_cast<g_u16x8*>(hs_p + tg0) = lt[0];
+                            *reinterpret_cast<g_u16x8*>(hs_p + 1024 + tg0) = lt[1];
+                        }
+                    }
+                    if constexpr (g == 0 && gi + 2 < NGRP && !ABL_NOB)
+                        bq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(hcur + bf4[(ks + 2) & 3] + 256 * (((ks + 2) & 7) >> 2));
+                    if constexpr (sl == 0)    // VALU-initialised accumulators -> first MFMA of the tile
+                        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                    constexpr int bi = ABL_NOB ? (gi & 1) : gi % 3;
+                    if constexpr (f >= TB && f < TB + NT) mfma1<false>(acc[g], __builtin_bit_cast(frag, accB[g]), bq[bi]);
+                    else if constexpr (ci < NA) mfma1<true>(acc[g], ua[ci], bq[bi]);
+                    else if constexpr (ci < NA + NV) mfma1<false>(acc[g], uv[ci - NA], bq[bi]);
+                    else mfma1<false>(acc[g], lt[g], bq[bi]);
+                    // fragments of the next group that live in LDS: into the register this MFMA just read
+                    constexpr int fn = f + 4, cn = fn - NT;
+                    if constexpr (fn < FPW && fn >= TB + NT && cn >= NA + NV && !ABL_NOL)
+                        lt[g] = myl[(size_t)(cn - NA - NV) * 64];
+                    if constexpr (n >= 1 && (sl & 3) == 1 && sl < 16) request_x(nc, std::integral_constant<int, (sl >> 2) & 3>{});
+                    __builtin_amdgcn_sched_barrier(0);   // MFMA first, then the slot's fillers: strict alternation
+                }
+                if constexpr (n > 0 && !ABL_NOMATH) piece(std::integral_constant<int, (n > 0 ? n - 1 : 0)>{}, slc, P);
+                __builtin_amdgcn_sched_barrier(0);       // nothing moves across a slot boundary
+            });
+            // the tail reads the last tile's accumulators right away (4-pass MFMA: 8 wait states required)
+            if constexpr (n == RNT - 1) asm volatile("s_nop 9" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            STAMP(8 + n);
+        });
+        request_t();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acts_p[g] += acts_step;
+            if (XMODE == MVAE_X_DENSE && t + 2 < T) x_p[g] += acts_step;
+        }
+        cs_p += cs_step;
+        hs_p += hs_step;
+        // flip the h tiles: every swizzled offset carries the buffer bit
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf4[j] ^= 8192u;
+        hw0 ^= 8192u;
+        tl0 ^= 8192u;
+        STAMP(6);
+        res_barrier();
+        STAMP(7);
+    }
+    if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
+        *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
+        *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
     }
     vm_drain();
 }
@@ -567,7 +966,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                 aload8(qs[n], h_ptr(cs, tp, n));
                 if (HAS_EXT) aload8(qd[n], h_ptr(dext, tp, n));
             }
-            lds_barrier();
+            res_barrier();
             tile_rows_to_global<GH>(dabuf, da_rows, w, l);      // da[t]: whole rows, issued ahead of the MFMA phase
 #define BF_(ks) bfrag(ks)
             RES_PHASE(acc[0], acc[1], acc[2], acc[3], 0, S2, BF_, RES_NOHOOK);
@@ -594,7 +993,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                 if (HAS_EXT) aload8(qd[n], h_ptr(dext, tp, n));
             }
             STAMP(2);
-            lds_barrier();
+            res_barrier();
             STAMP(3);
             if (rh) tile_rows_to_global<RH>(rhtile, rh + ((size_t)t * B + blockIdx.x * 16) * RH, w, l);
             constexpr int SH = RH / 32;
@@ -616,7 +1015,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                 put_da(RH + ub[n], dar);
             }
             STAMP(5);
-            lds_barrier();
+            res_barrier();
             STAMP(6);
             tile_rows_to_global<GH>(dabuf, da_rows, w, l);
 #ifndef BF_
@@ -629,7 +1028,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
                 for (int i = 0; i < 4; ++i) dh[n][i] = d[n][i] * z[n][i] + drh[n][i] * rr[n][i] + acc[n][i];
         }
         STAMP(7);
-        lds_barrier();
+        res_barrier();
         STAMP(8);
     }
     const int ldd = a.dh0_ld ? a.dh0_ld : RH;
@@ -645,16 +1044,33 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
 // dispatch
 // ---------------------------------------------------------------------------------------------------------
 // fragment placement per kernel: A in accumulator registers, V in vector registers, the rest in LDS (per wave)
+#ifndef RES_LSTM_FA
+#define RES_LSTM_IA 64
+#define RES_LSTM_IV 24
+#define RES_LSTM_FA 64
+#define RES_LSTM_FV 28
+#define RES_LSTM_FVS 32
+#define RES_LSTM_BA 64
+#define RES_LSTM_BV 32
+#define RES_GRU_FA 64
+#define RES_GRU_FV 8
+#define RES_GRU_BA 64
+#define RES_GRU_BV 8
+#endif
+#ifndef RES_LSTM_PIPELINE
+#define RES_LSTM_PIPELINE 1
+#endif
 template <int CELL> struct res_cfg;
 template <> struct res_cfg<MVAE_LSTM> {   // 128 fragments per wave
-    static constexpr int FA = 64, FV = 28;     // 36 in LDS: 16 + 144 KiB = all of it
-    static constexpr int FV_SCALAR = 32;       // 32 in LDS: 16 + 128 + 8 KiB (scalar-input weights)
-    static constexpr int BA = 64, BV = 32;     // 32 in LDS: 32 + 128 KiB = all of it
+    static constexpr int IA = RES_LSTM_IA, IV = RES_LSTM_IV;     // slot-interleaved forward
+    static constexpr int FA = RES_LSTM_FA, FV = RES_LSTM_FV;     // rest in LDS (16 KiB h tiles + <= 144 KiB)
+    static constexpr int FV_SCALAR = RES_LSTM_FVS;               // 8 KiB of LDS go to the scalar-input weights
+    static constexpr int BA = RES_LSTM_BA, BV = RES_LSTM_BV;     // rest in LDS (32 KiB da tile + <= 128 KiB)
 };
 template <> struct res_cfg<MVAE_GRU> {    // 96 fragments per wave
-    static constexpr int FA = 64, FV = 8;      // 24 in LDS: 24 + 96 KiB
-    static constexpr int FV_SCALAR = 8;
-    static constexpr int BA = 64, BV = 8;      // 24 in LDS: 24 + 8 + 96 KiB
+    static constexpr int FA = RES_GRU_FA, FV = RES_GRU_FV;
+    static constexpr int FV_SCALAR = RES_GRU_FV;
+    static constexpr int BA = RES_GRU_BA, BV = RES_GRU_BV;
 };
 
 template <int CELL, int XMODE, int SAVE>
@@ -675,13 +1091,38 @@ int launch_fwd_res(const mvae_rnn_fwd_args& a, hipStream_t s) {
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
+// LSTM with dense / indexed / constant inputs: the slot-interleaved kernel (MVAE_LSTM_PHASED=1 keeps the phased one)
+template <int XMODE, int SAVE>
+int launch_lstm_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    typedef res_cfg<MVAE_LSTM> C;
+    constexpr int NL = 4 * RNT * RS - 4 - C::IA - C::IV;
+    const size_t lds = (size_t)2 * 16 * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_il_k<XMODE, SAVE, C::IA, C::IV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((lstm_fwd_il_k<XMODE, SAVE, C::IA, C::IV>), dim3(a.B / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+inline bool lstm_phased() {
+    static const bool v = [] { const char* e = getenv("MVAE_LSTM_PHASED"); return e && e[0] == '1'; }();
+    return v;
+}
 template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.acts) {
         if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
+        if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
+            if (!lstm_phased()) return launch_lstm_il<XMODE, SAVE_ALL>(a, s);
         return launch_fwd_res<CELL, XMODE, SAVE_ALL>(a, s);
     }
     if (a.cs) return MVAE_E_UNSUPPORTED;
+    if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
+        if (!lstm_phased()) return a.hs ? launch_lstm_il<XMODE, SAVE_HS>(a, s) : launch_lstm_il<XMODE, SAVE_NONE>(a, s);
     return a.hs ? launch_fwd_res<CELL, XMODE, SAVE_HS>(a, s) : launch_fwd_res<CELL, XMODE, SAVE_NONE>(a, s);
 }
 template <int CELL>
