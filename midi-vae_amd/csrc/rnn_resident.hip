@@ -1041,12 +1041,213 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LSTM backward, slot-interleaved
+// ---------------------------------------------------------------------------------------------------------
+// Step t:  E  gate gradients of the wave's 64 units from dh_t, dc_t and the saved forward values -> da tile (LDS)
+//          M  dh_{t-1} = U^T-fragments x da tile: 128 single-MFMA slots; their gaps carry the row-major copy of the
+//             da tile to HBM and the loads of step t-1's saved values (the registers those land in were consumed in
+//             E, and a whole M phase - more than an HBM round trip - passes before the next E needs them)
+// Fragment classes in order of use: T (first k-group; streamed from L2 during E into the registers that stage
+// LDS-resident fragments during M), A accumulator registers, V vector registers, L LDS.
+template <bool HAS_EXT, int NA, int NV>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args a) {
+    constexpr int G = 4, GH = G * RH, S2 = GH / 32, FPW = RNT * S2;
+    constexpr int NT = 4, NLc = FPW - NT - NA - NV;
+    static_assert(NA % 4 == 0 && NV % 4 == 0 && NLc >= 0 && NA <= 64 && NLc <= 32, "fragment classes");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dabuf = smem;                                              // [16][GH] bf16, swizzled (32 KiB)
+    frag* ulds = reinterpret_cast<frag*>(smem + 16 * GH * 2);                 // [4][NL][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
+
+    // fragment f = ks*4 + n  (A rows = hidden units of tile w*4+n, k-group ks over the gate columns)
+    auto frag_ptr = [&](int f) -> const frag* { return up + (size_t)((w * RNT + (f & 3)) * S2 + (f >> 2)) * 64 + l; };
+    frag ua[NA > 0 ? NA : 4], uv[NV > 0 ? NV : 4];
+    static_for<0, (FPW - NT) / 4>(SF_LAMBDA(ic) {
+        constexpr int i = decltype(ic)::value * 4, f = i + NT;
+        if constexpr (i < NA) load4_agpr_nowait(ua[i], ua[i + 1], ua[i + 2], ua[i + 3], frag_ptr(f), frag_ptr(f + 1), frag_ptr(f + 2), frag_ptr(f + 3));
+        else if constexpr (i < NA + NV) {
+            uv[i - NA] = *frag_ptr(f); uv[i - NA + 1] = *frag_ptr(f + 1); uv[i - NA + 2] = *frag_ptr(f + 2); uv[i - NA + 3] = *frag_ptr(f + 3);
+        } else {
+            myl[(size_t)(i - NA - NV) * 64] = *frag_ptr(f); myl[(size_t)(i - NA - NV + 1) * 64] = *frag_ptr(f + 1);
+            myl[(size_t)(i - NA - NV + 2) * 64] = *frag_ptr(f + 2); myl[(size_t)(i - NA - NV + 3) * 64] = *frag_ptr(f + 3);
+        }
+    });
+    const frag* tsrc = frag_ptr(0);             // T fragments: tiles 0..3 of k-group 0 are S2*64 fragments apart
+
+    const int ub0 = w * 64 + q * 4;
+    unsigned lane8 = (unsigned)l * 8u;
+    // swizzled da-tile offsets (bytes), XOR-linear in (gate, tile) / k-group / copy chunk:
+    //   this lane's 4 values of (gate g, tile n): da0 ^ (g*512 + n*32)      B fragment ks: bb4[ks & 3] + 256*(ks >> 2)
+    //   copy chunk j (row 4w + j/2, 16-byte chunk (j&1)*64 + l): (tc0 ^ ((j>>1) << 4)) + (j>>1)*2048 + (j&1)*1024
+    unsigned da0 = (unsigned)r * (GH * 2) + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned bb4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bb4[j] = (unsigned)r * (GH * 2) + ((((unsigned)j * 4u + (unsigned)q) ^ (unsigned)r) << 4);
+    unsigned tc0 = 4u * w * (GH * 2) + ((((unsigned)l) ^ (4u * w)) << 4);
+    unsigned tg0 = (unsigned)l * 16u;
+
+    f32x4 dh[RNT], dc[RNT];
+    const int ldl = a.dh_last_ld ? a.dh_last_ld : RH;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * ldl + ub0 + 16 * n) : z4;
+        dc[n] = a.dc_last ? *reinterpret_cast<const f32x4*>(a.dc_last + (size_t)b * ldl + ub0 + 16 * n) : z4;
+    }
+    // wave-uniform running pointers for step t-1 (the step whose values are fetched during step t)
+    gbyte *acts_p[G], *cs_p, *dx_p, *da_p;
+    const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, da_step = (size_t)B * GH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
+    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;     // c_{t-1} of step T-1
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
+
+    // saved forward values of the step about to be processed
+    u16x4 qa[RNT][G], qs[RNT], qd[RNT], carry[RNT];   // gates; c_{t-1}; upstream gradient; c_t
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) qa[n][g] = *reinterpret_cast<const g_u16x4*>(acts_p[g] + n * 512 + lane8);
+        qs[n] = *reinterpret_cast<const g_u16x4*>(cs_p + n * 512 + lane8);
+        carry[n] = *reinterpret_cast<const g_u16x4*>(cs_p + cs_step + n * 512 + lane8);
+        if (HAS_EXT) qd[n] = *reinterpret_cast<const g_u16x4*>(dx_p + n * 512 + lane8);
+    }
+    // from here on the pointers address step t-1 while step t runs
+#pragma unroll
+    for (int g = 0; g < G; ++g) acts_p[g] -= (T > 1 ? acts_step : 0);
+    cs_p -= (T > 1 ? cs_step : 0);
+    dx_p -= (T > 1 ? cs_step : 0);
+
+    frag bq[3], lt[4];
+    vm_drain();
+    lds_barrier();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int tstep = T - 1 - t;
+        (void)tstep;
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(acts_p[3]); pins(cs_p); pins(da_p);
+        if (HAS_EXT) pins(dx_p);
+        pinu(da0); pinu(tc0);
+        STAMP(0);
+        // ---- E: everything requested during the previous M phase has had that whole phase to arrive ------------
+        vm_drain();
+        STAMP(1);
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) {
+            pin4(qa[n][0], qa[n][1], qa[n][2], qa[n][3]);
+            pin1(qs[n]);
+            if (HAS_EXT) pin1(qd[n]);
+        }
+        // T fragments for this step's first k-group, into the registers that are idle until the M phase
+#pragma unroll
+        for (int n = 0; n < 4; ++n) lt[n] = tsrc[(size_t)n * S2 * 64];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) {
+            const f32x4 ig = unpack4(qa[n][0]), fg = unpack4(qa[n][1]), gg = unpack4(qa[n][2]), og = unpack4(qa[n][3]);
+            const f32x4 c = unpack4(carry[n]), cp = unpack4(qs[n]);
+            f32x4 d = dh[n];
+            if (HAS_EXT) d += unpack4(qd[n]);
+            f32x4 di, df, dg, dO;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float tc = tanh_fast(c[i]);
+                const float dct = dc[n][i] + d[i] * og[i] * (1.0f - tc * tc);
+                di[i] = dct * gg[i] * dhard_sigmoid(ig[i]);
+                df[i] = dct * cp[i] * dhard_sigmoid(fg[i]);
+                dg[i] = dct * ig[i] * (1.0f - gg[i] * gg[i]);
+                dO[i] = d[i] * tc * dhard_sigmoid(og[i]);
+                dc[n][i] = dct * fg[i];
+            }
+            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);
+            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (1 * 512 + n * 32))) = pack4(df);
+            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
+            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (3 * 512 + n * 32))) = pack4(dO);
+            carry[n] = qs[n];                         // c_{t-1} is the next step's c_t
+        }
+        STAMP(2);
+        vm_drain();                                   // the T fragments (L2 hits issued a whole E phase ago)
+        pinq(lt[0]); pinq(lt[1]); pinq(lt[2]); pinq(lt[3]);
+        res_barrier();
+        STAMP(3);
+
+        // ---- M -------------------------------------------------------------------------------------------------
+        f32x4 acc[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + bb4[0]);
+        bq[1] = *reinterpret_cast<const frag*>(dabuf + bb4[1]);
+        static_for<0, FPW>(SF_LAMBDA(sc) {
+            constexpr int sl = decltype(sc)::value, gi = sl >> 2, n = sl & 3, ci = sl - NT;
+            if constexpr (n == 0 && gi + 2 < S2)
+                bq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + bb4[(gi + 2) & 3] + 256 * ((gi + 2) >> 2));
+            if constexpr (sl == 0) asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            if constexpr (sl < NT) mfma1<false>(acc[n], lt[n], bq[gi % 3]);
+            else if constexpr (ci < NA) mfma1<true>(acc[n], ua[ci < NA ? ci : 0], bq[gi % 3]);
+            else if constexpr (ci < NA + NV) mfma1<false>(acc[n], uv[(ci >= NA && ci < NA + NV) ? ci - NA : 0], bq[gi % 3]);
+            else mfma1<false>(acc[n], lt[n], bq[gi % 3]);
+            constexpr int cn = ci + 4;      // the next group's fragment for this tile
+            if constexpr (sl + 4 < FPW && cn >= NA + NV && !ABL_NOL) lt[n] = myl[(size_t)(cn - NA - NV) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            // fillers.  Slots 1..: step t-1's saved values, one load per 2 slots; then the row-major copy of the da
+            // tile, 8 chunks per lane staged through the (until the last groups idle) lt registers.
+            if constexpr (!ABL_NOX && sl >= 1 && sl < 1 + 2 * 24 && (sl - 1) % 2 == 0) {
+                constexpr int k = (sl - 1) / 2;                // 0..15 gates, 16..19 c_{t-1}, 20..23 upstream gradient
+                pinu(lane8);
+                if constexpr (k < 16) qa[k >> 2][k & 3] = *reinterpret_cast<const g_u16x4*>(acts_p[k & 3] + (k >> 2) * 512 + lane8);
+                else if constexpr (k < 20) qs[k - 16] = *reinterpret_cast<const g_u16x4*>(cs_p + (k - 16) * 512 + lane8);
+                else if constexpr (HAS_EXT) qd[k - 20] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 20) * 512 + lane8);
+            }
+            if constexpr (!ABL_NOTRG && sl >= 50 && sl < 50 + 4 * 8 + 8 && (sl - 50) % 4 == 0) {
+                constexpr int j = (sl - 50) / 4;               // read chunk j (j < 8), store chunk j - 2
+                if constexpr (j >= 2) {
+                    constexpr int js = j - 2;
+                    pinu(tg0);
+                    *reinterpret_cast<g_u16x8*>(da_p + (js >> 1) * 2048 + (js & 1) * 1024 + tg0) = lt[js & 3];
+                }
+                if constexpr (j < 8)
+                    lt[j & 3] = *reinterpret_cast<const frag*>(dabuf + (tc0 ^ ((j >> 1) << 4)) + (j >> 1) * 2048 + (j & 1) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) dh[n] = acc[n];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acts_p[g] -= (t > 1 ? acts_step : 0);
+        cs_p -= (t > 1 ? cs_step : 0);
+        if (HAS_EXT) dx_p -= (t > 1 ? cs_step : 0);
+        da_p -= da_step;
+        STAMP(7);
+        res_barrier();
+        STAMP(8);
+    }
+    const int ldd = a.dh0_ld ? a.dh0_ld : RH;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 16 * n) = dh[n];
+        if (a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * ldd + ub0 + 16 * n) = dc[n];
+    }
+    vm_drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------------
 // fragment placement per kernel: A in accumulator registers, V in vector registers, the rest in LDS (per wave)
 #ifndef RES_LSTM_FA
 #define RES_LSTM_IA 64
 #define RES_LSTM_IV 24
+#define RES_LSTM_JA 64
+#define RES_LSTM_JV 28
 #define RES_LSTM_FA 64
 #define RES_LSTM_FV 28
 #define RES_LSTM_FVS 32
@@ -1060,9 +1261,14 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
 #ifndef RES_LSTM_PIPELINE
 #define RES_LSTM_PIPELINE 1
 #endif
+inline bool lstm_phased() {
+    static const bool v = [] { const char* e = getenv("MVAE_LSTM_PHASED"); return e && e[0] == '1'; }();
+    return v;
+}
 template <int CELL> struct res_cfg;
 template <> struct res_cfg<MVAE_LSTM> {   // 128 fragments per wave
-    static constexpr int IA = RES_LSTM_IA, IV = RES_LSTM_IV;     // slot-interleaved forward
+    static constexpr int IA = RES_LSTM_IA, IV = RES_LSTM_IV;     // slot-interleaved forward (+4 streamed, rest LDS)
+    static constexpr int JA = RES_LSTM_JA, JV = RES_LSTM_JV;     // slot-interleaved backward (+4 streamed, 32 LDS)
     static constexpr int FA = RES_LSTM_FA, FV = RES_LSTM_FV;     // rest in LDS (16 KiB h tiles + <= 144 KiB)
     static constexpr int FV_SCALAR = RES_LSTM_FVS;               // 8 KiB of LDS go to the scalar-input weights
     static constexpr int BA = RES_LSTM_BA, BV = RES_LSTM_BV;     // rest in LDS (32 KiB da tile + <= 128 KiB)
@@ -1108,10 +1314,7 @@ int launch_lstm_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-inline bool lstm_phased() {
-    static const bool v = [] { const char* e = getenv("MVAE_LSTM_PHASED"); return e && e[0] == '1'; }();
-    return v;
-}
+
 template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.acts) {
@@ -1136,9 +1339,27 @@ int fwd_res_xmode(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return MVAE_E_ARG;
 }
 
+template <bool HAS_EXT>
+int launch_lstm_bwd_il(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    typedef res_cfg<MVAE_LSTM> C;
+    constexpr int NL = RNT * (4 * RH / 32) - 4 - C::JA - C::JV;
+    const size_t lds = (size_t)16 * 4 * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_il_k<HAS_EXT, C::JA, C::JV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_il_k<HAS_EXT, C::JA, C::JV>), dim3(a.B / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 template <int CELL, bool HAS_EXT>
 int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
     typedef res_cfg<CELL> C;
+    if constexpr (CELL == MVAE_LSTM)
+        if (!lstm_phased()) return launch_lstm_bwd_il<HAS_EXT>(a, s);
     constexpr int G = mvae_gates(CELL), NL = RNT * (G * RH / 32) - C::BA - C::BV;
     const size_t lds = (size_t)16 * G * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag) +
                        (CELL == MVAE_GRU ? (size_t)16 * RH * sizeof(bf16_t) : 0);
