@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +98,8 @@ def main():
     spec = ModelSpec(cell=args.cell, H=256, Z=args.latent, Din=61, Dout=61, T=T, V=args.voices, ID=16, C=2, Le=2, Ld=2)
     B = args.batch
     eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234, use_graphs=args.graphs)
+    if args.chunks:
+        eng.time_chunks = args.chunks
     w = make_windows(B, T, 61, args.voices, 16, 2, args.latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
     eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
     eng.stage_decoder_inputs(B, hist=w["hist"])
@@ -115,8 +118,9 @@ def main():
     torch.cuda.synchronize()
     first_loss = eng.metrics(B)["loss"] if args.warmup else float("nan")
 
+    eng.prof_kinds = {"rnn_bwd"}     # bracket only the dominant kernel's launches (each event pair costs launch slots)
     if not args.graphs:
-        eng.prof = {}           # per-kernel HIP events; with graph replay the dominant kernel is timed in a second pass
+        eng.prof = {}           # HIP events on the launch streams; with graph replay: timed in a second pass
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -143,19 +147,20 @@ def main():
 
     if rank == 0:
         G, H = spec.G, spec.H
-        # dominant kernel: the long (T-step) recurrences.  Algorithmic work per launch = the recurrent GEMM only:
-        # 2*B*H*(G*H) flop per step (forward h U; backward da U^T), T steps per launch.
-        longk = {k: v for k, v in prof.items() if not k[1].endswith("instr") and "instr" not in k[1]}
-        by_kind = {}
-        for (kind, _), (n, ms) in longk.items():
-            by_kind.setdefault(kind, []).append((n, ms))
-        tot = {k: sum(n * ms for n, ms in v) for k, v in by_kind.items()}
-        dom = max(tot, key=tot.get)
-        launches = sum(n for n, _ in by_kind[dom])
-        avg_ms = tot[dom] / launches
-        flop = 2.0 * B * H * G * H * T
-        achieved = flop / (avg_ms * 1e-3) / 1e12
+        # Dominant kernel: backpropagation through time of the T-step recurrent layers (every launch of it in the timed
+        # region was bracketed with HIP events on its stream).  Algorithmic work = the recurrent GEMM only:
+        # 2 * B * H * (G*H) flop per time step (da U^T), summed over the steps each launch covers (the stacked layers
+        # run as time chunks) - SURVEY section 8d.
+        longk = {k: v for k, v in prof.items() if "instr" not in k[1]}
+        launches = sum(n for n, _, _ in longk.values())
+        tot_ms = sum(n * ms for n, ms, _ in longk.values())
+        tot_steps = sum(n * st for n, _, st in longk.values())
+        Bp = (B + 15) // 16 * 16
+        flop_step = 2.0 * Bp * H * G * H
+        avg_ms = tot_ms / launches
+        achieved = flop_step * tot_steps / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        cus = Bp // 16                      # one workgroup (= one CU) per 16 batch rows
         out = {
             "metric": "MIDI roll windows/sec (train step)", "value": B * world * args.steps / elapsed,
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,11 +172,14 @@ def main():
                        "global_batch": B * world, "T": T, "cell": args.cell, "parallelism": "dp%d" % world},
             "elbo": {"loss_after_warmup": first_loss, "loss_final": m["loss"], "kl": m["kl"],
                      "notes_loss": m["notes_loss"]},
-            "roofline": {"bound": "mfma", "kernel": "%s_k<%s,%s,T=%d>" % (dom, args.cell, args.dtype, T),
+            "roofline": {"bound": "mfma", "kernel": "rnn_bwd (BPTT, %s %s, resident recurrent weights)" % (args.cell, args.dtype),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
-                         "flop_per_launch": flop,
-                         "all_kernels_ms_per_step": {"%s:%s" % k: n * ms / args.steps for k, (n, ms) in prof.items()}},
+                         "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": tot_ms * 1e3 / tot_steps,
+                         "flop_per_time_step": flop_step,
+                         # the recurrence is latency-bound by design: B/16 workgroups, one per CU, step after step
+                         "cus_occupied": cus, "frac_of_occupied_cus": achieved / (peak * cus / 256.0),
+                         "launch_ms_per_step_by_layer": {k[1]: n * ms / args.steps for k, (n, ms, _) in prof.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec)

@@ -147,8 +147,11 @@ int mvae_gemm(const mvae_gemm_args* a, void* stream);
 
 /* out[n] (+)= sum_r X[r, n]  for X (R, N) of `kind`; ldx elements between rows; atomic f32 accumulate */
 int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream);
-/* out[b, n] = sum_t X[t, b, n]   (gradient of an X_CONST row) */
-int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, void* stream);
+/* out[n] += sum_r wgt[r] * X[r, n]: the kernel gradient of a 1-feature (scalar) input layer, dW = xs^T da */
+int mvae_colsum_weighted(const void* X, int32_t kind, const float* wgt, int32_t R, int32_t N, int32_t ldx, float* out,
+                         void* stream);
+/* out[b, n] (+)= sum_t X[t, b, n]   (gradient of an X_CONST row; accumulate != 0 adds to out, e.g. per time chunk) */
+int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, int32_t accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Output heads: Dense(H -> N) + activation + Keras weighted loss + metric + d(logits), fused, over all

@@ -256,7 +256,9 @@ template <bool RC, bool ONEHOT>
 struct f_stage {
     u16x8 v[4];
     // chunk c (0..1023):  KC: row = c / 8, k8 = c % 8 ;  RC: k = c / 16, row8 = c % 16
-    __device__ __forceinline__ void load(const void* base, int ld, int row0, int k0, int tid) {
+    // rlim: first row index that may not be read (row-contiguous operands narrower than the tile re-read their last
+    // 8 columns instead of running into the next k row; those output columns are never stored)
+    __device__ __forceinline__ void load(const void* base, int ld, int row0, int k0, int tid, int rlim = 1 << 30) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * 256;
@@ -268,8 +270,8 @@ struct f_stage {
                 for (int e = 0; e < 8; ++e) z[e] = (hot == e) ? (bf16_t)0x3f80 : (bf16_t)0;
                 v[i] = z;
             } else if (RC) {
-                const int k = c >> 4, r8 = (c & 15) * 8;
-                v[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_t*>(base) + (size_t)(k0 + k) * ld + row0 + r8);
+                const int k = c >> 4, r8 = min(row0 + (c & 15) * 8, rlim - 8);
+                v[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_t*>(base) + (size_t)(k0 + k) * ld + r8);
             } else {
                 const int row = c >> 3, k8 = (c & 7) * 8;
                 v[i] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const bf16_t*>(base) + (size_t)(row0 + row) * ld + k0 + k8);
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
     const int wm = w >> 1, wn = w & 1;
     const int M = a.M, N = a.N, K = a.K;
-    const int tiles_n = N / FBN, tiles_m = (M + FBM - 1) / FBM;      // M < 128 only for the one-hot table gradient
+    const int tiles_n = (N + FBN - 1) / FBN, tiles_m = (M + FBM - 1) / FBM;   // M < 128: one-hot table gradient
+    const int nlim = B_RC ? (a.ldb < tiles_n * FBN ? a.ldb : 1 << 30) : 1 << 30;   // N < 128: head kernels (accumulate)
     const int splits = a.split_k > 1 ? a.split_k : 1;
     const int total_tiles = tiles_n * tiles_m * splits;
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
         f_stage<A_RC, ONEHOT> sa;
         f_stage<B_RC, false> sb;
         sa.load(a.A, a.lda, m0, kbeg, tid);
-        sb.load(a.B, a.ldb, n0, kbeg, tid);
+        sb.load(a.B, a.ldb, n0, kbeg, tid, nlim);
         __syncthreads();                       // previous output tile's readers are done with both images
         sa.store(As, tid);
         sb.store(Bs, tid);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             const bool more = k0 + FBK < kend;
             if (more) {                        // global loads for the next K tile fly under this tile's MFMAs
                 sa.load(a.A, a.lda, m0, k0 + FBK, tid);
-                sb.load(a.B, a.ldb, n0, k0 + FBK, tid);
+                sb.load(a.B, a.ldb, n0, k0 + FBK, tid, nlim);
             }
             const bf16_t* Ai = As + cur * IA;
             const bf16_t* Bi = Bs + cur * IB;
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + q * 4;
+                if (n >= N) continue;
                 f32x4 v = acc[i][j] * a.alpha;
                 if (a.bias && (bz == 0 || !a.accumulate)) v += *reinterpret_cast<const f32x4*>(a.bias + n);
                 if (a.act == MVAE_ACT_TANH) {
@@ -371,7 +375,8 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                 } else if (a.accumulate) {
                     float* cp = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, v[e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) atomicAdd(cp + e, v[e]);
                 } else if (a.c_kind == MVAE_F32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n) = v;
                 } else {
@@ -393,7 +398,7 @@ int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
         raised = true;
     }
     const int sk = a.split_k > 1 ? a.split_k : 1;
-    long long tiles = (long long)(a.N / FBN) * ((a.M + FBM - 1) / FBM) * sk;
+    long long tiles = (long long)((a.N + FBN - 1) / FBN) * ((a.M + FBM - 1) / FBM) * sk;
     if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
     hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT>), dim3((unsigned)tiles), dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
@@ -404,14 +409,18 @@ int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
 bool fast_ok(const mvae_gemm_args& a) {
     const bool onehot = a.a_kind == MVAE_A_ONEHOT;
     if (!(a.b_kind == MVAE_BF16 && (a.a_kind == MVAE_BF16 || onehot))) return false;
-    if ((a.N % FBN) || (a.K % FBK)) return false;
+    if (a.K % FBK) return false;
+    if (a.N % FBN) {    // one narrow N tile: row-contiguous B whose rows hold >= 8 columns, accumulate mode, no bias
+        if (!(a.N < FBN && !a.trans_b && a.accumulate && !a.bias && a.c_layout == MVAE_ROWMAJOR && a.ldb >= 8 &&
+              a.ldb >= ((a.N + 7) / 8) * 8)) return false;
+    }
     if (onehot) { if (a.M > FBM || !a.trans_a) return false; }          // one M tile; rows >= M are never hot
     else if (a.M % FBM) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!onehot && (!al16(a.A) || (a.lda % 8))) return false;
     if (!al16(a.B) || (a.ldb % 8)) return false;
     if (a.bias && !al16(a.bias)) return false;
-    if (a.c_layout == MVAE_ROWMAJOR) {
+    if (a.c_layout == MVAE_ROWMAJOR && !a.accumulate) {     // (accumulate = scalar atomics: any ldc)
         if (a.c_kind == MVAE_F32 && (!al16(a.C) || (a.ldc % 4))) return false;
         if (a.c_kind == MVAE_BF16 && ((reinterpret_cast<uintptr_t>(a.C) & 7) || (a.ldc % 4))) return false;
     }

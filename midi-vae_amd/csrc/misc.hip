@@ -78,22 +78,87 @@ __global__ void latent_bwd_k(const mvae_latent_bwd_args a) {
 
 // ---- reductions -----------------------------------------------------------------------------------------------
 template <typename WT>
-__global__ void colsum_k(const WT* __restrict__ X, int R, int N, int ldx, int rows_per_block, float* __restrict__ out) {
+__global__ void colsum_k(const WT* __restrict__ X, const float* __restrict__ wgt, int R, int N, int ldx, int rows_per_block,
+                         float* __restrict__ out) {
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.0f;
-        for (int rr = r0; rr < r1; ++rr) s += st<WT>::load(X + (size_t)rr * ldx + n);
+        for (int rr = r0; rr < r1; ++rr) s += st<WT>::load(X + (size_t)rr * ldx + n) * (wgt ? wgt[rr] : 1.0f);
         atomicAdd(out + n, s);
+    }
+}
+// bf16, N % 8 == 0, 16-byte aligned rows: each thread owns 8 columns (one 16-byte load per row), the block's 256
+// threads cover 256 / (N/8) rows at a time; partial sums meet in LDS, one atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_bf16x8_k(const bf16_t* __restrict__ X, const float* __restrict__ wgt, int R, int N,
+                                                       int ldx, int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[256 * 8];
+    const int c8 = N / 8, lanes_r = 256 / c8;           // c8 in {1,2,4,...,256}: callers check N/8 divides 256
+    const int col = (threadIdx.x % c8) * 8, rsub = threadIdx.x / c8;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rr = r0 + rsub;
+    for (; rr + 3 * lanes_r < r1; rr += 4 * lanes_r) {        // 4 independent 16-byte loads in flight
+        u16x8 v[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = *reinterpret_cast<const u16x8*>(X + (size_t)(rr + u * lanes_r) * ldx + col);
+            w[u] = wgt ? wgt[rr + u * lanes_r] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf2f(v[u][e]) * w[u];
+    }
+    for (; rr < r1; rr += lanes_r) {
+        const u16x8 v = *reinterpret_cast<const u16x8*>(X + (size_t)rr * ldx + col);
+        const float w = wgt ? wgt[rr] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]) * w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(rsub * c8 + threadIdx.x % c8) * 8 + e] = s[e];
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float t = 0.0f;
+        for (int k = 0; k < lanes_r; ++k) t += red[(k * c8 + n / 8) * 8 + n % 8];
+        atomicAdd(out + n, t);
     }
 }
 
 template <typename WT>
-__global__ void sum_time_k(const WT* __restrict__ X, int T, int BN, float* __restrict__ out) {
+__global__ void sum_time_k(const WT* __restrict__ X, int T, int BN, int t_per_block, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= BN) return;
+    const int t0 = blockIdx.y * t_per_block, t1 = min(T, t0 + t_per_block);
     float s = 0.0f;
-    for (int t = 0; t < T; ++t) s += st<WT>::load(X + (size_t)t * BN + e);
-    out[e] = s;
+    for (int t = t0; t < t1; ++t) s += st<WT>::load(X + (size_t)t * BN + e);
+    atomicAdd(out + e, s);
+}
+// bf16, BN % 8 == 0: 8 elements (16 bytes) per thread, the time range split over gridDim.y
+__global__ __launch_bounds__(256) void sum_time_bf16x8_k(const bf16_t* __restrict__ X, int T, int BN, int t_per_block,
+                                                         float* __restrict__ out) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= BN) return;
+    const int t0 = blockIdx.y * t_per_block, t1 = min(T, t0 + t_per_block);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int t = t0;
+    for (; t + 3 < t1; t += 4) {
+        u16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u16x8*>(X + (size_t)(t + u) * BN + e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += bf2f(v[u][k]);
+    }
+    for (; t < t1; ++t) {
+        const u16x8 v = *reinterpret_cast<const u16x8*>(X + (size_t)t * BN + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += bf2f(v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(out + e + k, s[k]);
 }
 
 // ---- elementwise ----------------------------------------------------------------------------------------------
@@ -196,28 +261,59 @@ extern "C" int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream) {
     return MVAE_OK;
 }
 
-extern "C" int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream) {
+static int colsum_impl(const void* X, int32_t kind, const float* wgt, int32_t R, int32_t N, int32_t ldx, float* out, hipStream_t s) {
     if (!X || !out || R <= 0 || N <= 0 || ldx < N) return MVAE_E_ARG;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int c8 = N / 8;
+    const bool vec = kind == MVAE_BF16 && (N % 8) == 0 && c8 <= 256 && (256 % c8) == 0 && (ldx % 8) == 0 &&
+                     (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (vec) {
+        // enough blocks to fill the chip, enough rows per block to amortise the LDS reduction and the atomics
+        int rpb = (R + 2047) / 2048;
+        const int lanes_r = 256 / c8;
+        if (rpb < 16 * lanes_r) rpb = 16 * lanes_r;
+        const int blocks = (R + rpb - 1) / rpb;
+        hipLaunchKernelGGL(colsum_bf16x8_k, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, wgt, R, N, ldx, rpb, out);
+        MVAE_CHECK_LAUNCH();
+        return MVAE_OK;
+    }
     int rpb = (R + 1023) / 1024;
     if (rpb < 8) rpb = 8;
     const int blocks = (R + rpb - 1) / rpb;
     if (kind == MVAE_F32)
-        hipLaunchKernelGGL(colsum_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)X, R, N, ldx, rpb, out);
+        hipLaunchKernelGGL(colsum_k<float>, dim3(blocks), dim3(256), 0, s, (const float*)X, wgt, R, N, ldx, rpb, out);
     else if (kind == MVAE_BF16)
-        hipLaunchKernelGGL(colsum_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, R, N, ldx, rpb, out);
+        hipLaunchKernelGGL(colsum_k<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, wgt, R, N, ldx, rpb, out);
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-extern "C" int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, void* stream) {
+extern "C" int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream) {
+    return colsum_impl(X, kind, nullptr, R, N, ldx, out, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int mvae_colsum_weighted(const void* X, int32_t kind, const float* wgt, int32_t R, int32_t N, int32_t ldx, float* out,
+                                    void* stream) {
+    if (!wgt) return MVAE_E_ARG;
+    return colsum_impl(X, kind, wgt, R, N, ldx, out, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, int32_t accumulate, void* stream) {
     if (!X || !out || T <= 0 || BN <= 0) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (kind == MVAE_F32)
-        hipLaunchKernelGGL(sum_time_k<float>, dim3((BN + 255) / 256), dim3(256), 0, s, (const float*)X, T, BN, out);
+    if (!accumulate && hipMemsetAsync(out, 0, (size_t)BN * sizeof(float), s) != hipSuccess) return MVAE_E_LAUNCH;
+    // split the time range so that >= ~1024 blocks exist; every block adds its partial sums atomically
+    const bool vec = kind == MVAE_BF16 && (BN % 8) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    const int bx = vec ? (BN / 8 + 255) / 256 : (BN + 255) / 256;
+    int by = (1024 + bx - 1) / bx;
+    if (by > T) by = T;
+    if (by < 1) by = 1;
+    const int tpb = (T + by - 1) / by;
+    by = (T + tpb - 1) / tpb;
+    if (vec)
+        hipLaunchKernelGGL(sum_time_bf16x8_k, dim3(bx, by), dim3(256), 0, s, (const bf16_t*)X, T, BN, tpb, out);
+    else if (kind == MVAE_F32)
+        hipLaunchKernelGGL(sum_time_k<float>, dim3(bx, by), dim3(256), 0, s, (const float*)X, T, BN, tpb, out);
     else if (kind == MVAE_BF16)
-        hipLaunchKernelGGL(sum_time_k<bf16_t>, dim3((BN + 255) / 256), dim3(256), 0, s, (const bf16_t*)X, T, BN, out);
+        hipLaunchKernelGGL(sum_time_k<bf16_t>, dim3(bx, by), dim3(256), 0, s, (const bf16_t*)X, T, BN, tpb, out);
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();

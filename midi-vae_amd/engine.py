@@ -64,6 +64,7 @@ class Engine(object):
         self.use_graphs = use_graphs
         self._graphs = {}
         self.prof = None       # dict -> per-kernel HIP-event pairs are recorded on the launch stream (bench.py)
+        self.prof_kinds = None # None = every timed launch, else a set of kinds ("rnn_fwd", "rnn_bwd")
         L, dev = self.layout, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         self.params = torch.zeros(L.total, **f32)
@@ -79,6 +80,7 @@ class Engine(object):
         # (needed only by the optimizer) go to a fourth stream off the critical path.  Fork / join is event based.
         with torch.cuda.device(self.device):
             self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+            self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
         self.multi_stream = True
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
@@ -86,6 +88,10 @@ class Engine(object):
         self.time_chunks = 4
         # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
         # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
+        # Parameter-gradient GEMMs once per layer (after its last BPTT chunk), NOT per time chunk: throughput GEMMs running
+        # beside the latency-bound recurrences slow those down by more than the ~1 ms tail they would save (measured:
+        # 14.1 ms per step with per-chunk gradients, 13.0 ms without; bounding their grids is worse still).
+        self.grad_per_chunk = False
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(init_params(spec, seed))
         self._build_graph_description()
@@ -107,21 +113,25 @@ class Engine(object):
         """context: run on ``stream`` (or stay on the current one when multi-stream execution is off)"""
         return torch.cuda.stream(stream) if self.multi_stream else _NullCtx()
 
-    def _timed(self, key, fn):
-        """Run ``fn`` (one kernel launch); when profiling, bracket it with HIP events on the launch stream."""
-        if self.prof is None:
+    def _timed(self, key, fn, steps=0):
+        """Run ``fn`` (one kernel launch); when profiling, bracket it with HIP events on the launch stream.
+        ``prof_kinds`` (a set of key[0] values) limits which launches are bracketed: every event pair costs launch
+        slots, and bench.py times its step with the dominant kernel's launches bracketed only."""
+        if self.prof is None or (self.prof_kinds is not None and key[0] not in self.prof_kinds):
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.prof.setdefault(key, []).append((e0, e1))
+        self.prof.setdefault(key, []).append((e0, e1, steps))
 
     def prof_summary(self):
-        """key -> (launches, mean ms) for the event pairs collected since ``self.prof = {}`` (sync first)."""
+        """key -> (launches, mean ms, mean time steps per launch) for the event pairs collected since
+        ``self.prof = {}`` (synchronises first)."""
         torch.cuda.synchronize()
-        return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b in v]))) for k, v in (self.prof or {}).items()}
+        return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b, _ in v])), float(np.mean([n for _, _, n in v])))
+                for k, v in (self.prof or {}).items()}
 
     # ------------------------------------------------------------------------------------------------------
     # parameters
@@ -414,7 +424,7 @@ class Engine(object):
             cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None,
             acts=self._v(p + ".acts", T, B, GH)[t0:t0 + Tc] if self.training else None,
             h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
-            c_last=(sc if (lstm and not last) else None), seq_layout=self.lay, **kw))
+            c_last=(sc if (lstm and not last) else None), seq_layout=self.lay, **kw), steps=Tc)
 
     def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
@@ -562,45 +572,61 @@ class Engine(object):
             dc_last=(None if (first or not lstm) else sc),
             rh=self._v(p + ".rh", T, B, H)[t0:t0 + Tc] if s.cell == "GRU" else None,
             dh0=(dh0 if final else sh), dc0=((dc0 if final else sc) if lstm else None), dh0_ld=(dh0_ld if final else 0),
-            seq_layout=self.lay))
-        if r.xmode == hl.X_DENSE:       # critical path: what the lower layer's BPTT waits for
-            dx = self._v(p + ".dx", T, B, H)[t0:t0 + Tc]
-            ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay)
+            seq_layout=self.lay), steps=Tc)
 
-    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None):
-        """Parameter gradients of one layer from its complete da: off the critical path, on the gradient stream."""
+    def _rec_dx(self, r, B, k=0, nch=1):
+        """Gradient w.r.t. the input sequence of layer ``r`` (= what the layer below receives at its h_t), time chunk k.
+        Runs on the LOWER layer's stream, right before that layer's BPTT of the chunk: the upper layer's next chunk
+        launches without waiting for it."""
+        s, p = self.spec, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        Tc = T // nch
+        t0 = k * Tc
+        da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
+        dx = self._v(p + ".dx", T, B, H)[t0:t0 + Tc]
+        ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay)
+
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None):
+        """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
+        into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
+        is done - only the last chunk's share is left when the recurrence finishes."""
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
-        R = T * B
+        Tc = T // nch
+        t0 = k * Tc
+        R = Tc * B
         hs = self._v(p + ".hs", T + 1, B, H)
-        da = self._v(p + ".da", T, B, GH)
-        da2, hprev = da.view(R, GH), hs[:T].reshape(R, H)
+        da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
+        da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
         sk = self._split_k(R)
-        self._fork(self.s_grad)
+        mb = self.grad_gemm_blocks
+        self._fork(self.s_grad, self.s_grad2)
         with self._on(self.s_grad):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
-                rh = self._v(p + ".rh", T, B, H)
-                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
+                rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
+                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=mb)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                         accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
+                         accumulate=True, split_k=sk, max_blocks=mb)
             else:
-                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
+                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
+        with self._on(self.s_grad2):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
-                ops.sum_over_time(da, T, B * GH, dxp0)
-                ops.colsum(dxp0, B, GH, G[p + ".b"])
-                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=self.grad_gemm_blocks)
+                ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1))
+                if k == 0:
+                    ops.colsum(dxp0, B, GH, G[p + ".b"])
+                    ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=mb)
             else:
                 ops.colsum(da2, R, GH, G[p + ".b"])
                 if r.xmode == hl.X_INDEX:
-                    ops.gemm(idx.view(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True,
-                             split_k=sk)
-                elif r.xmode == hl.X_SCALAR:
-                    ops.gemm(xs.view(R, 1), da2, G[p + ".W"], 1, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
+                    ops.gemm(idx[t0:t0 + Tc].reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
+                             accumulate=True, split_k=sk)
+                elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
+                    ops.colsum_weighted(da2, xs[t0:t0 + Tc].reshape(-1), R, GH, G[p + ".W"])
                 else:
-                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
-                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=self.grad_gemm_blocks)
+                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc].reshape(R, H)
+                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
                         start=None):
@@ -616,15 +642,19 @@ class Engine(object):
                 top = li == 0
                 ds = dstates(r) if dstates else {}
                 def run():
-                    if li > 0 and nch > 1:
-                        torch.cuda.current_stream().wait_event(done[li - 1][k])
+                    if li > 0:
+                        if nch > 1:
+                            torch.cuda.current_stream().wait_event(done[li - 1][k])
+                        self._rec_dx(order[li - 1], B, k, nch)
                     ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
                     self._rec_bptt(r, B, k, nch, dhs_ext=ext, dh_last=dh_last if top else None,
                                    dh_last_ld=dh_last_ld if top else 0, **ds)
                     if nch > 1:
                         done[li][k].record()
-                    if k == 0:
-                        self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
+                    if self.grad_per_chunk:
+                        self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start)
+                    elif k == 0:
+                        self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
                 if li > 0 and nch > 1:
                     with torch.cuda.stream(streams[li]):
                         run()
@@ -744,7 +774,7 @@ class Engine(object):
                 self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                      xs=self._v("in.vel", T, B))
         self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B))
-        self._join(self.s_vel, self.s_instr, self.s_grad)
+        self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
 
     # ------------------------------------------------------------------------------------------------------
     # steps

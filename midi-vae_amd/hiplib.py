@@ -76,7 +76,8 @@ SIGNATURES = {
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mvae_head": (_i32, [C.POINTER(HeadArgs), _vp]),
     "mvae_head_np": (_i32, [_i32]),
     "mvae_latent_fwd": (_i32, [C.POINTER(LatentFwdArgs), _vp]),

@@ -92,8 +92,15 @@ def colsum(X, R, N, out, ldx=None):
              "mvae_colsum")
 
 
-def sum_over_time(X, T, BN, out):
-    hl.check(hl.load().mvae_sum_over_time(_p(X), kind_of(X), T, BN, _p(out), _stream()), "mvae_sum_over_time")
+def colsum_weighted(X, wgt, R, N, out, ldx=None):
+    """out[n] += sum_r wgt[r] * X[r, n]  (wgt f32)"""
+    hl.check(hl.load().mvae_colsum_weighted(X.data_ptr(), kind_of(X), _p(wgt), R, N, N if ldx is None else ldx, _p(out),
+                                            _stream()), "mvae_colsum_weighted")
+
+
+def sum_over_time(X, T, BN, out, accumulate=False):
+    hl.check(hl.load().mvae_sum_over_time(_p(X), kind_of(X), T, BN, _p(out), int(accumulate), _stream()),
+             "mvae_sum_over_time")
 
 
 def head_np(N):

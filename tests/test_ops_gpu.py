@@ -346,6 +346,53 @@ def test_latent_block():
     close(host(dlv), dlv_o, 1e-5)
 
 
+@pytest.mark.parametrize("N,ldx", [(1024, 1024), (256, 256), (64, 64), (8, 16)])
+def test_colsum_bf16_vector_path_plain_and_weighted(N, ldx):
+    """16-byte loads, 8 columns per thread, LDS reduction + atomics; also with per-row weights (scalar-input dW)."""
+    rng = np.random.default_rng(N)
+    R = 4099
+    X = dev(rng.standard_normal((R, ldx)), torch.bfloat16)
+    wgt = rng.random(R)
+    out = torch.full((N,), 0.5, device=DEV)              # accumulates on top of what is there
+    ops.colsum(X, R, N, out, ldx=ldx)
+    outw = torch.zeros((N,), device=DEV)
+    ops.colsum_weighted(X, dev(wgt), R, N, outw, ldx=ldx)
+    torch.cuda.synchronize()
+    Xh = host(X)[:, :N]
+    close(host(out), 0.5 + Xh.sum(0), 2e-4 * np.sqrt(R))
+    close(host(outw), (Xh * wgt[:, None].astype(np.float32)).sum(0), 2e-4 * np.sqrt(R))
+
+
+def test_sum_over_time_split_and_accumulate():
+    rng = np.random.default_rng(8)
+    T, BN = 96, 16 * 1024
+    X = dev(rng.standard_normal((T, BN)), torch.bfloat16)
+    out = torch.full((BN,), 7.0, device=DEV)             # overwritten without accumulate
+    ops.sum_over_time(X, T, BN, out)
+    acc = torch.zeros((BN,), device=DEV)
+    ops.sum_over_time(X[:40], 40, BN, acc)
+    ops.sum_over_time(X[40:], T - 40, BN, acc, accumulate=True)
+    torch.cuda.synchronize()
+    want = host(X).sum(0)
+    close(host(out), want, 1e-4)
+    close(host(acc), want, 1e-4)
+
+
+def test_gemm_fast_narrow_n_accumulate():
+    """Head kernel gradient: dW (H, 61) += hs^T (H, R) dl (R, 64 padded): one narrow N tile on the fast path."""
+    rng = np.random.default_rng(9)
+    R, H, N, NP = 4096, 256, 61, 64
+    A = dev(rng.standard_normal((R, H)), torch.bfloat16)
+    Bm = rng.standard_normal((R, NP))
+    Bm[:, N:] = 0
+    Bd = dev(Bm, torch.bfloat16)
+    C = torch.ones((H, N), device=DEV)
+    ops.gemm(A, Bd, C, H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=4)
+    torch.cuda.synchronize()
+    want = 1.0 + host(A).T.astype(np.float64) @ host(Bd)[:, :N].astype(np.float64)
+    close(host(C), want, 2e-3 * np.sqrt(R) / 8)
+
+
 def test_reductions_and_elementwise():
     rng = np.random.default_rng(6)
     X = rng.standard_normal((1000, 192))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Host-side enqueue time of one training step vs its device time (is the step launch-bound?).
+   python tools/host_overhead.py [--cell LSTM] [--chunks 4]"""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import midi_vae_amd  # noqa
+from midi_vae_amd.engine import Engine
+from midi_vae_amd.layout import ModelSpec
+from midi_vae_amd.synth import make_windows
+ap = argparse.ArgumentParser()
+ap.add_argument("--cell", default="LSTM"); ap.add_argument("--chunks", type=int, default=0)
+ap.add_argument("--grad-blocks", type=int, default=0); ap.add_argument("--no-chunk-grads", action="store_true"); ap.add_argument("--one-grad-stream", action="store_true")
+a = ap.parse_args()
+T, B = 512, 256
+spec = ModelSpec(cell=a.cell, H=256, Z=64, Din=61, Dout=61, T=T, V=4, ID=16, C=2, Le=2, Ld=2)
+eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
+if a.chunks:
+    eng.time_chunks = a.chunks
+eng.grad_gemm_blocks = a.grad_blocks
+if a.no_chunk_grads:
+    eng.grad_per_chunk = False
+if a.one_grad_stream:
+    eng.s_grad2 = eng.s_grad
+w = make_windows(B, T, 61, 4, 16, 2, 64, seed=1, epsilon_std=spec.epsilon_std)
+eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
+eng.stage_decoder_inputs(B, hist=w["hist"])
+eng.stage_targets(B, w["x_idx"], w["c_idx"])
+for _ in range(3):
+    eng.train_step(B)
+torch.cuda.synchronize()
+host, dev = [], []
+for _ in range(6):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.train_step(B)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.append((t1 - t0) * 1e3); dev.append((t2 - t0) * 1e3)
+print("host enqueue ms/step:", ["%.2f" % h for h in host])
+print("enqueue + drain ms/step:", ["%.2f" % d for d in dev])

@@ -16,6 +16,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define DSW asm volatile("ds_write_b64 %0, %1" :: "v"(loff), "v"(st2));
 #define GST asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(goff), "v"(st2), "s"(gout) : "memory");
 #define GLD asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(ld2) : "v"(goff), "s"(gout) : "memory");
+#define GST4 asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(goff4), "v"(lb), "s"(gout) : "memory");
+#define GLD4 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(lb) : "v"(goff4), "s"(gout) : "memory");
+#define GST1 asm volatile("global_store_dword %0, %1, %2" :: "v"(goff1), "v"(pk), "s"(gout) : "memory");
 
 template <int PAT>
 __global__ __launch_bounds__(256, 1) void probe(const frag* src, float* out, unsigned long long* cyc, int iters) {
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(256, 1) void probe(const frag* src, float* out, uns
     frag b = src[l + 64], lb = b;
     f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     float x0 = 0.1f * l, x1 = 0.2f, x2 = 0.3f, x3 = 0.4f, k1 = 0.999f, k2 = 0.001f;
-    unsigned pk = 0, loff = (threadIdx.x * 16) & 16383, goff = threadIdx.x * 8;
+    unsigned pk = 0, loff = (threadIdx.x * 16) & 16383, goff = threadIdx.x * 8, goff4 = threadIdx.x * 16, goff1 = threadIdx.x * 4;
     u32x2 st2 = {1u, 2u}, ld2 = {0u, 0u};
     char* gout = reinterpret_cast<char*>(out) + 65536;
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -53,10 +56,16 @@ __global__ __launch_bounds__(256, 1) void probe(const frag* src, float* out, uns
     if (PAT == 14) { GLD }                                                                              \
     if (PAT == 15) { EXP(X) FMA(Y) FMA(Y) FMA(Y) }                                                      \
     if (PAT == 16) { FMA(X) NOP0 NOP0 FMA(Y) }                                                          \
-    if (PAT == 17) { DSR FMA(X) FMA(Y) }
+    if (PAT == 17) { DSR FMA(X) FMA(Y) }                                                                \
+    if (PAT == 18) { GST4 }                                                                             \
+    if (PAT == 19) { GLD4 }                                                                             \
+    if (PAT == 20) { GST1 }                                                                             \
+    if (PAT == 21) { if ((g & 1) == 0) { GLD4 } }                                                       \
+    if (PAT == 22) { if ((g & 3) == 0) { GLD4 } }                                                       \
+    if (PAT == 23) { if ((g & 3) == 0) { GLD } }
             SLOT(c0, x0, x1) SLOT(c1, x2, x3) SLOT(c2, x1, x0) SLOT(c3, x3, x2)
         }
-        if (PAT == 7 || PAT == 17 || PAT == 14 || PAT == 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (PAT == 7 || PAT == 17 || PAT == 14 || PAT == 8 || PAT >= 18) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_nop 9" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -94,5 +103,11 @@ int main() {
     run("+ ds_write_b64", probe<13>, src, out, cyc);
     run("+ global_store_dwordx2 (saddr)", probe<8>, src, out, cyc);
     run("+ global_load_dwordx2 (saddr)", probe<14>, src, out, cyc);
+    run("+ global_store_dwordx4", probe<18>, src, out, cyc);
+    run("+ global_load_dwordx4", probe<19>, src, out, cyc);
+    run("+ global_store_dword", probe<20>, src, out, cyc);
+    run("+ global_load_dwordx4 every 8th slot", probe<21>, src, out, cyc);
+    run("+ global_load_dwordx4 every 16th slot", probe<22>, src, out, cyc);
+    run("+ global_load_dwordx2 every 16th slot", probe<23>, src, out, cyc);
     return 0;
 }
