@@ -10,6 +10,7 @@
 // accumulator values are four consecutive n of one m: the epilogue is one 8/16-byte store per fragment.
 // f32 operands use v_mfma_f32_16x16x4_f32 (exact f32, parity mode), bf16 operands v_mfma_f32_16x16x32_bf16.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -471,6 +472,18 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (a->c_layout == MVAE_TILE16 && (a->accumulate || (a->M % 16) || (a->N % 16))) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (fast_ok(*a)) return dispatch_fast(*a, s);
+    // A handful of output tiles with a long K (the Dense layers around the latent: M = batch, K up to nInit*H = 2304) is
+    // a few workgroups marching through K for 100+ us on an otherwise idle chip: zero C and split K over atomics.
+    mvae_gemm_args split;
+    static const bool autosplit = !getenv("MVAE_NO_AUTOSPLIT");
+    if (autosplit && !a->accumulate && a->split_k <= 1 && a->c_kind == MVAE_F32 && a->c_layout == MVAE_ROWMAJOR &&
+        a->act == MVAE_ACT_NONE && a->K >= 512 && (long long)((a->M + 63) / 64) * ((a->N + 63) / 64) <= 32 && a->ldc == a->N) {
+        if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), s) != hipSuccess) return MVAE_E_LAUNCH;
+        split = *a;
+        split.accumulate = 1;
+        split.split_k = a->K / 128 < 16 ? a->K / 128 : 16;
+        a = &split;
+    }
     const int ak = a->a_kind, bk = a->b_kind;
     // operand type on the matrix cores: bf16 if any stored operand is bf16, else exact f32
     if (ak == MVAE_F32 && bk == MVAE_F32) return by_trans<float, MVAE_F32, MVAE_F32>(*a, s);

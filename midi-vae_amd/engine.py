@@ -98,6 +98,13 @@ class Engine(object):
         self._alloc(self.maxB)
         self._views_cache = {}
 
+    def _mark(self, name):
+        """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect)"""
+        if getattr(self, "marks", None) is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
     # ---- stream helpers -------------------------------------------------------------------------------------
     def _fork(self, *streams):
         cur = torch.cuda.current_stream()
@@ -109,15 +116,26 @@ class Engine(object):
         for st in streams:
             cur.wait_stream(st)
 
+    def _side(self, fn):
+        """Run ``fn`` (parameter-gradient work nobody waits for before the optimizer) on the second gradient stream,
+        ordered after everything enqueued so far on the current stream."""
+        if not self.multi_stream or not getattr(self, "side_grads", True):
+            fn()
+            return
+        self.s_grad2.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.s_grad2):
+            fn()
+
     def _on(self, stream):
         """context: run on ``stream`` (or stay on the current one when multi-stream execution is off)"""
         return torch.cuda.stream(stream) if self.multi_stream else _NullCtx()
 
     def _timed(self, key, fn, steps=0):
         """Run ``fn`` (one kernel launch); when profiling, bracket it with HIP events on the launch stream.
-        ``prof_kinds`` (a set of key[0] values) limits which launches are bracketed: every event pair costs launch
+        ``prof_kinds`` (a set of kinds like "rnn_bwd" and / or full keys like ("rnn_bwd", "dec.notes.1")) limits which
+        launches are bracketed: every event pair costs launch
         slots, and bench.py times its step with the dominant kernel's launches bracketed only."""
-        if self.prof is None or (self.prof_kinds is not None and key[0] not in self.prof_kinds):
+        if self.prof is None or (self.prof_kinds is not None and key[0] not in self.prof_kinds and key not in self.prof_kinds):
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -360,23 +378,33 @@ class Engine(object):
     # weight preparation: packed / transposed / converted copies the kernels consume (once per optimizer step)
     # ------------------------------------------------------------------------------------------------------
     def prepare_weights(self):
+        """Derived copies of the parameters the kernels consume (MFMA-fragment packed recurrent kernels, bf16 / transposed
+        input kernels, one-hot lookup tables).  ~25 tiny kernels, 0.3 ms per step."""
         s, P = self.spec, self.P
-        for r in self.all_rec:
+
+        def rec_job(r):
             p = r.prefix
             ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 0, out=self.store[p + ".u_pack"])
-            if self.training:
-                ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 1, out=self.store[p + ".ut_pack"])
             if r.xmode == hl.X_INDEX:
                 ops.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
             elif r.xmode == hl.X_DENSE:
                 ops.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
-                if self.training:
+            if self.training:
+                ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 1, out=self.store[p + ".ut_pack"])
+                if r.xmode == hl.X_DENSE:
                     ops.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
-        ops.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
-        if s.meta_instrument:
-            ops.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
-        if s.meta_velocity:
-            ops.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+
+        def heads_job():
+            ops.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
+            if s.meta_instrument:
+                ops.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
+            if s.meta_velocity:
+                ops.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+
+        # (sequential on the main stream: spreading these jobs over the side streams was measured 1 ms SLOWER per step)
+        for r in self.all_rec:
+            rec_job(r)
+        heads_job()
         self._weights_dirty = False
 
     # ------------------------------------------------------------------------------------------------------
@@ -708,11 +736,12 @@ class Engine(object):
                                    "dec.notes.out.b")
         self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates)
         self._join(self.s_vel, self.s_instr)
+        self._mark("  decoder BPTT")
         # initial-state Denses: S = tanh([z|hist] Winit + b)
         S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
         ops.tanh_bwd(S, dS, dS)
-        ops.gemm(zh, dS, G["dec.init.W"], s.zin, ldS, B, trans_a=True, accumulate=True)
-        ops.colsum(dS, B, ldS, G["dec.init.b"])
+        self._side(lambda: (ops.gemm(zh, dS, G["dec.init.W"], s.zin, ldS, B, trans_a=True, accumulate=True),
+                            ops.colsum(dS, B, ldS, G["dec.init.b"])))
         dzh = self._v("dzh", B, s.zin)
         ops.gemm(dS, P["dec.init.W"], dzh, B, s.zin, ldS, trans_b=True)
         # ---- latent ------------------------------------------------------------------------------------
@@ -729,10 +758,11 @@ class Engine(object):
         h1w = H // 2 if s.split else H
         h2w = H - h1w if s.split else H
         dt = self._v("dtail", B, H)
-        ops.gemm(h, dmu, G["enc.zmean.W"], h1w, Z, B, trans_a=True, lda=H, accumulate=True)
-        ops.colsum(dmu, B, Z, G["enc.zmean.b"])
-        ops.gemm(h[:, h1w:] if s.split else h, dlv, G["enc.zlogvar.W"], h2w, Z, B, trans_a=True, lda=H, accumulate=True)
-        ops.colsum(dlv, B, Z, G["enc.zlogvar.b"])
+        self._side(lambda: (ops.gemm(h, dmu, G["enc.zmean.W"], h1w, Z, B, trans_a=True, lda=H, accumulate=True),
+                            ops.colsum(dmu, B, Z, G["enc.zmean.b"]),
+                            ops.gemm(h[:, h1w:] if s.split else h, dlv, G["enc.zlogvar.W"], h2w, Z, B, trans_a=True, lda=H,
+                                     accumulate=True),
+                            ops.colsum(dlv, B, Z, G["enc.zlogvar.b"])))
         if s.split:
             ops.gemm(dmu, P["enc.zmean.W"], dt, B, h1w, Z, trans_b=True, ldc=H)
             ops.gemm(dlv, P["enc.zlogvar.W"], dt[:, h1w:], B, h2w, Z, trans_b=True, ldc=H)
@@ -746,8 +776,8 @@ class Engine(object):
             ex = self._v("extra", B, H)
             src = self._v("pack", B, H) if self.has_pack else self._v("cat", B, H)
             ops.tanh_bwd(ex, dt, dt)
-            ops.gemm(src, dt, G["enc.extra.W"], H, H, B, trans_a=True, accumulate=True)
-            ops.colsum(dt, B, H, G["enc.extra.b"])
+            self._side(lambda dt=dt: (ops.gemm(src, dt, G["enc.extra.W"], H, H, B, trans_a=True, accumulate=True),
+                                      ops.colsum(dt, B, H, G["enc.extra.b"])))
             dt2 = self._v("dtail2", B, H)
             ops.gemm(dt, P["enc.extra.W"], dt2, B, H, H, trans_b=True)
             dt = dt2
@@ -755,12 +785,13 @@ class Engine(object):
         if self.has_pack:
             pk, cat = self._v("pack", B, H), self._v("cat", B, ldc)
             ops.tanh_bwd(pk, dt, dt)
-            ops.gemm(cat, dt, G["enc.pack.W"], ldc, H, B, trans_a=True, accumulate=True)
-            ops.colsum(dt, B, H, G["enc.pack.b"])
+            self._side(lambda dt=dt: (ops.gemm(cat, dt, G["enc.pack.W"], ldc, H, B, trans_a=True, accumulate=True),
+                                      ops.colsum(dt, B, H, G["enc.pack.b"])))
             dcat = self._v("dcat", B, ldc)
             ops.gemm(dt, P["enc.pack.W"], dcat, B, ldc, H, trans_b=True)
         else:
             dcat = dt
+        self._mark("  latent block backward")
         # ---- encoder recurrences: three independent branches -------------------------------------------------
         self._fork(self.s_vel, self.s_instr)
         k = 1
@@ -793,11 +824,16 @@ class Engine(object):
         self._have_targets = True
         self.scal.zero_()
         self.grads.zero_()
+        self._mark("step start")
         if self._weights_dirty or self.use_graphs:
             self.prepare_weights()
+        self._mark("weights prepared")
         self.encoder_forward(B)
+        self._mark("encoder forward (incl. latent)")
         self.decoder_forward(B)
+        self._mark("decoder forward + heads")
         self.backward(B)
+        self._mark("backward")
 
     def train_step(self, B, allreduce=None):
         """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.

@@ -10,6 +10,7 @@ from midi_vae_amd.layout import ModelSpec
 from midi_vae_amd.synth import make_windows
 ap = argparse.ArgumentParser()
 ap.add_argument("--cell", default="LSTM"); ap.add_argument("--chunks", type=int, default=0)
+ap.add_argument("--no-side-grads", action="store_true");
 ap.add_argument("--grad-blocks", type=int, default=0); ap.add_argument("--no-chunk-grads", action="store_true"); ap.add_argument("--one-grad-stream", action="store_true")
 a = ap.parse_args()
 T, B = 512, 256
@@ -18,6 +19,7 @@ eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
 if a.chunks:
     eng.time_chunks = a.chunks
 eng.grad_gemm_blocks = a.grad_blocks
+eng.side_grads = not a.no_side_grads
 if a.no_chunk_grads:
     eng.grad_per_chunk = False
 if a.one_grad_stream:
@@ -40,3 +42,29 @@ for _ in range(6):
     host.append((t1 - t0) * 1e3); dev.append((t2 - t0) * 1e3)
 print("host enqueue ms/step:", ["%.2f" % h for h in host])
 print("enqueue + drain ms/step:", ["%.2f" % d for d in dev])
+
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    eng.train_step(B)
+torch.cuda.synchronize()
+print("10 steps back to back: %.2f ms/step" % ((time.perf_counter() - t0) * 100))
+eng.prof, eng.prof_kinds = {}, {"rnn_bwd"}
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    eng.train_step(B)
+torch.cuda.synchronize()
+print("10 steps back to back, BPTT launches bracketed with events: %.2f ms/step" % ((time.perf_counter() - t0) * 100))
+eng.prof = None
+# section times of one step (events on the main stream at section boundaries)
+eng.marks = []
+eng.train_step(B)
+e_end = torch.cuda.Event(enable_timing=True); e_end.record()
+torch.cuda.synchronize()
+prev = eng.marks[0][1]
+for name, e in eng.marks[1:] + [("optimizer", e_end)]:
+    print("%-36s %7.3f ms" % (name, prev.elapsed_time(e)) if not name.startswith("  ") else "%-36s   (at +%.3f ms)" % (name, eng.marks[0][1].elapsed_time(e)))
+    if not name.startswith("  "):
+        prev = e
+eng.marks = None
