@@ -52,8 +52,14 @@ enum {
  *                   contiguous elements holding the MFMA C-fragment image of the 16x16 block:
  *                       offset = ((m/16 * cols/16 + n/16) * 64 + ((n%16)/4)*16 + m%16) * 4 + n%4
  *                   i.e. lane (q = (n%16)/4, r = m%16) owns 4 consecutive n.  One wave reads / writes a whole tile as
- *                   512 contiguous bytes (bf16) instead of 16 segments at a power-of-two row stride. */
-enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1 };
+ *                   512 contiguous bytes (bf16) instead of 16 segments at a power-of-two row stride.
+ *   MVAE_TILE16P  : TILE16 with the tiles (m/16, 2j) and (m/16, 2j+1) interleaved per lane (cols % 32 == 0):
+ *                       offset = ((m/16 * cols/32 + n/32) * 64 + ((n%16)/4)*16 + m%16) * 8 + ((n%32)/16)*4 + n%4
+ *                   one lane's 8 values of a tile pair are 16 contiguous bytes: one memory instruction instead of two
+ *                   (a VMEM instruction costs the CU's address unit the same 16 cycles whatever its width).
+ *                   As a seq_layout it means: xp and dhs_ext TILE16, the saved activations (acts, cs) TILE16P - the
+ *                   layout the slot-interleaved LSTM kernels use; forward and backward of a layer must agree. */
+enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1, MVAE_TILE16P = 2 };
 
 int mvae_abi_version(void);
 /* human-readable build string (arch, compile date) */
@@ -85,8 +91,10 @@ typedef struct {
                               run as consecutive launches (time chunks) without rounding the carried state     */
     int32_t h0_ld;         /* row stride of h0 / c0 in floats (0 = H): states may be column blocks of a wider buffer */
     int32_t h_last_ld;     /* row stride of h_last (0 = H)                                                     */
-    int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR or MVAE_TILE16.
-                              TILE16 needs B % 16 == 0 and is what the resident-weights kernels (H=256, bf16) take */
+    int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR, MVAE_TILE16 or
+                              MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
+                              (H=256, bf16): TILE16 the phased ones (GRU, LSTM), TILE16P the slot-interleaved LSTM
+                              ones (not for MVAE_X_SCALAR inputs)                                                  */
 } mvae_rnn_fwd_args;
 int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
 
@@ -217,7 +225,13 @@ typedef struct {
 } mvae_latent_bwd_args;
 int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
 
-/* (rows, cols) row-major <-> TILE16, same element kind on both sides */
+/* out (R, N) TILE16 of out_kind = xs[r] * w[n] + bias[n]: the input projection x*W + b of a 1-feature input (velocity
+ * roll, reference vae_definition.py:456-470) written out, so that the layer can run on the MVAE_X_DENSE kernels
+ * (R % 16 == 0, N % 16 == 0, w and bias 16-byte aligned) */
+int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, void* out, int32_t out_kind, int32_t R, int32_t N,
+                           void* stream);
+/* (rows, cols) row-major <-> tiled, same element kind on both sides.
+ * to_tile16: 0 TILE16 -> row-major, 1 row-major -> TILE16, 2 TILE16P -> row-major, 3 row-major -> TILE16P */
 int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16, void* stream);
 
 /* elementwise helpers */

@@ -189,13 +189,31 @@ __global__ void transpose_convert_k(const float* W, D* out, int K, int N, int NP
     }
 }
 
+// out (R, N) in TILE16 = xs[r] * w[n] + bias[n]: the input projection of a 1-feature layer, expanded so that the layer
+// runs on the dense-input recurrent kernels.  One thread = 4 consecutive n of one row = its 8 / 16 bytes of a tile.
+template <typename D>
+__global__ void outer_bias_tile16_k(const float* __restrict__ xs, const float* __restrict__ w, const float* __restrict__ bias,
+                                    D* __restrict__ out, int R, int N) {
+    const size_t total = (size_t)R * N / 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = e >> 6;
+        const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
+        const float x = xs[m];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + n), bv = *reinterpret_cast<const f32x4*>(bias + n);
+        st<D>::store4(out + e * 4, x * wv + bv);
+    }
+}
+
 template <typename D>
 __global__ void relayout_k(const D* src, D* dst, int rows, int cols, int to_tile) {
     const size_t n = (size_t)rows * cols;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(e / cols), c = (int)(e % cols);
-        const size_t t = ((((size_t)(m >> 4) * (cols >> 4) + (c >> 4)) * 64) + (size_t)(((c & 15) >> 2) * 16 + (m & 15))) * 4 + (c & 3);
-        if (to_tile) dst[t] = src[e]; else dst[e] = src[t];
+        const size_t lane = (size_t)(((c & 15) >> 2) * 16 + (m & 15));
+        const size_t t = (to_tile & 2)
+            ? ((((size_t)(m >> 4) * (cols >> 5) + (c >> 5)) * 64) + lane) * 8 + ((c & 31) >> 4) * 4 + (c & 3)
+            : ((((size_t)(m >> 4) * (cols >> 4) + (c >> 4)) * 64) + lane) * 4 + (c & 3);
+        if (to_tile & 1) dst[t] = src[e]; else dst[e] = src[t];
     }
 }
 
@@ -347,13 +365,29 @@ extern "C" int mvae_convert(const void* src, int32_t sk, void* dst, int32_t dk, 
 }
 extern "C" int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16,
                              void* stream) {
-    if (!src || !dst || rows <= 0 || cols <= 0 || (rows % 16) || (cols % 16)) return MVAE_E_ARG;
+    if (!src || !dst || rows <= 0 || cols <= 0 || (rows % 16) || (cols % ((to_tile16 & 2) ? 32 : 16)) || to_tile16 < 0 || to_tile16 > 3)
+        return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 g(nblocks((size_t)rows * cols)), b(256);
     if (kind == MVAE_F32)
         hipLaunchKernelGGL(relayout_k<float>, g, b, 0, s, (const float*)src, (float*)dst, rows, cols, to_tile16);
     else if (kind == MVAE_BF16)
         hipLaunchKernelGGL(relayout_k<bf16_t>, g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, cols, to_tile16);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, void* out, int32_t out_kind, int32_t R,
+                                      int32_t N, void* stream) {
+    if (!xs || !w || !bias || !out || R <= 0 || N <= 0 || (R % 16) || (N % 16)) return MVAE_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15)) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks((size_t)R * N / 4)), b(256);
+    if (out_kind == MVAE_F32)
+        hipLaunchKernelGGL(outer_bias_tile16_k<float>, g, b, 0, s, xs, w, bias, (float*)out, R, N);
+    else if (out_kind == MVAE_BF16)
+        hipLaunchKernelGGL(outer_bias_tile16_k<bf16_t>, g, b, 0, s, xs, w, bias, (bf16_t*)out, R, N);
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();

@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
 
     const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
     unsigned lane8 = (unsigned)l * 8u;          // this lane's 8 bytes inside a TILE16 tile
+    unsigned lane16 = (unsigned)l * 16u;        // ... 16 bytes inside a TILE16P tile pair
     const int ub0 = w * 64 + q * 4;             // first of this lane's 4 units in tile 0 (tile n: + 16 n)
 
     // Swizzled LDS byte offsets, all derived by XOR from three per-lane values (chunk index ^ row is XOR-linear):
@@ -606,9 +607,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         const f32x4 h0v = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
         creg[n] = a.c0 ? *reinterpret_cast<const f32x4*>(a.c0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
         *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(h0v);
-        if (SAVE == SAVE_ALL)
+        if (SAVE == SAVE_ALL)      // c_0 -> slot 0 of the (T+1, B, H) TILE16P array: 8 bytes of the lane's 16 per tile pair
             *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned char*>(a.cs) +
-                                      ((size_t)blockIdx.x * (RH / 16) + w * RNT + n) * 512 + lane8) = pack4(creg[n]);
+                                      ((size_t)blockIdx.x * (RH / 32) + w * 2 + (n >> 1)) * 1024 + (unsigned)l * 16u + (n & 1) * 8) = pack4(creg[n]);
     }
 
     // ---- x queue (packed bf16x4 per tile and gate) for the step about to be computed --------------------------
@@ -650,10 +651,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
+        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
         x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
     }
-    cs_p = to_global(a.cs) + ((tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
+    cs_p = to_global(a.cs) + ((tps + blockIdx.x) * (RH / 32) + w * 2) * 1024;
     hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
 
     for (int t = 0; t < T; ++t) {
@@ -686,18 +687,24 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
                     i_q = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + b];
             }
         };
-        // saved activations of tile m (gates i,f,g,o from its accumulator set Q, then c): one store per call
+        u16x4 held[G + 1];
+        // Saved activations of tile m, quantity k (gates i,f,g,o from the tile's accumulator set Q, then c).  TILE16P:
+        // an even tile parks its packed values, the odd tile stores the pair as ONE 16-byte access per lane.
         auto save = [&](auto mc, auto kc, f32x4* Q) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value, k = decltype(kc)::value;
             if (SAVE == SAVE_ALL && !ABL_NOSAVE) {
-                // (the 32-bit lane offset is re-defined in this basic block so that instruction selection sees
-                //  "uniform base + zext(lane offset)" and uses the SGPR-base addressing mode)
-                pinu(lane8);
-                if constexpr (k < G) *reinterpret_cast<g_u16x4*>(acts_p[k < G ? k : 0] + m * 512 + lane8) = pack4(Q[k < G ? k : 0]);
-                else *reinterpret_cast<g_u16x4*>(cs_p + m * 512 + lane8) = pack4(creg[m]);
+                const u16x4 mine = pack4(k < G ? Q[k < G ? k : 0] : creg[m]);
+                if constexpr ((m & 1) == 0) held[k] = mine;
+                else {
+                    // (the 32-bit lane offset is re-defined in this basic block so that instruction selection sees
+                    //  "uniform base + zext(lane offset)" and uses the SGPR-base addressing mode)
+                    pinu(lane16);
+                    const u16x8 pair = {held[k][0], held[k][1], held[k][2], held[k][3], mine[0], mine[1], mine[2], mine[3]};
+                    if constexpr (k < G) *reinterpret_cast<g_u16x8*>(acts_p[k < G ? k : 0] + (m >> 1) * 1024 + lane16) = pair;
+                    else *reinterpret_cast<g_u16x8*>(cs_p + (m >> 1) * 1024 + lane16) = pair;
+                }
             }
         };
-
         // One piece of tile m's gate arithmetic.  P = that tile's accumulators (gate pre-activations).  Two elements
         // move in lockstep through 16 single-instruction stages, one stage per MFMA slot: 2 VALU per slot is what a
         // 16-cycle MFMA hides (tools/probes/slot_probe.hip), and the partner's instruction separates every exp / rcp
@@ -1082,7 +1089,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const frag* tsrc = frag_ptr(0);             // T fragments: tiles 0..3 of k-group 0 are S2*64 fragments apart
 
     const int ub0 = w * 64 + q * 4;
-    unsigned lane8 = (unsigned)l * 8u;
+    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
     // swizzled da-tile offsets (bytes), XOR-linear in (gate, tile) / k-group / copy chunk:
     //   this lane's 4 values of (gate g, tile n): da0 ^ (g*512 + n*32)      B fragment ks: bb4[ks & 3] + 256*(ks >> 2)
     //   copy chunk j (row 4w + j/2, 16-byte chunk (j&1)*64 + l): (tc0 ^ ((j>>1) << 4)) + (j>>1)*2048 + (j&1)*1024
@@ -1106,20 +1113,25 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, da_step = (size_t)B * GH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g)
-        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
-    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;     // c_{t-1} of step T-1
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 32) + w * 2) * 1024;      // c_{t-1} of step T-1
     dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
     da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
 
-    // saved forward values of the step about to be processed
-    u16x4 qa[RNT][G], qs[RNT], qd[RNT], carry[RNT];   // gates; c_{t-1}; upstream gradient; c_t
+    // saved forward values of the step about to be processed; acts / cs are TILE16P: element 0..3 of a 16-byte lane
+    // chunk belong to tile 2j, 4..7 to tile 2j+1
+    u16x8 qa[2][G], qs[2], carry[2];       // gates; c_{t-1}; c_t
+    u16x4 qd[RNT];                         // upstream gradient (TILE16)
 #pragma unroll
-    for (int n = 0; n < RNT; ++n) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) qa[n][g] = *reinterpret_cast<const g_u16x4*>(acts_p[g] + n * 512 + lane8);
-        qs[n] = *reinterpret_cast<const g_u16x4*>(cs_p + n * 512 + lane8);
-        carry[n] = *reinterpret_cast<const g_u16x4*>(cs_p + cs_step + n * 512 + lane8);
-        if (HAS_EXT) qd[n] = *reinterpret_cast<const g_u16x4*>(dx_p + n * 512 + lane8);
+        for (int g = 0; g < G; ++g) qa[j][g] = *reinterpret_cast<const g_u16x8*>(acts_p[g] + j * 1024 + lane16);
+        qs[j] = *reinterpret_cast<const g_u16x8*>(cs_p + j * 1024 + lane16);
+        carry[j] = *reinterpret_cast<const g_u16x8*>(cs_p + cs_step + j * 1024 + lane16);
+    }
+    if (HAS_EXT) {
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) qd[n] = *reinterpret_cast<const g_u16x4*>(dx_p + n * 512 + lane8);
     }
     // from here on the pointers address step t-1 while step t runs
 #pragma unroll
@@ -1142,18 +1154,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         vm_drain();
         STAMP(1);
 #pragma unroll
-        for (int n = 0; n < RNT; ++n) {
-            pin4(qa[n][0], qa[n][1], qa[n][2], qa[n][3]);
-            pin1(qs[n]);
-            if (HAS_EXT) pin1(qd[n]);
+        for (int j = 0; j < 2; ++j) {
+            pinq(qa[j][0]); pinq(qa[j][1]); pinq(qa[j][2]); pinq(qa[j][3]); pinq(qs[j]);
+        }
+        if (HAS_EXT) {
+#pragma unroll
+            for (int n = 0; n < RNT; ++n) pin1(qd[n]);
         }
         // T fragments for this step's first k-group, into the registers that are idle until the M phase
 #pragma unroll
         for (int n = 0; n < 4; ++n) lt[n] = tsrc[(size_t)n * S2 * 64];
 #pragma unroll
         for (int n = 0; n < RNT; ++n) {
-            const f32x4 ig = unpack4(qa[n][0]), fg = unpack4(qa[n][1]), gg = unpack4(qa[n][2]), og = unpack4(qa[n][3]);
-            const f32x4 c = unpack4(carry[n]), cp = unpack4(qs[n]);
+            auto half = [&](const u16x8& v) -> f32x4 {
+                const int o = (n & 1) * 4;
+                return f32x4{bf2f(v[o]), bf2f(v[o + 1]), bf2f(v[o + 2]), bf2f(v[o + 3])};
+            };
+            const f32x4 ig = half(qa[n >> 1][0]), fg = half(qa[n >> 1][1]), gg = half(qa[n >> 1][2]), og = half(qa[n >> 1][3]);
+            const f32x4 c = half(carry[n >> 1]), cp = half(qs[n >> 1]);
             f32x4 d = dh[n];
             if (HAS_EXT) d += unpack4(qd[n]);
             f32x4 di, df, dg, dO;
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (1 * 512 + n * 32))) = pack4(df);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (3 * 512 + n * 32))) = pack4(dO);
-            carry[n] = qs[n];                         // c_{t-1} is the next step's c_t
+            if (n & 1) carry[n >> 1] = qs[n >> 1];      // c_{t-1} is the next step's c_t
         }
         STAMP(2);
         vm_drain();                                   // the T fragments (L2 hits issued a whole E phase ago)
@@ -1197,14 +1215,20 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
             constexpr int cn = ci + 4;      // the next group's fragment for this tile
             if constexpr (sl + 4 < FPW && cn >= NA + NV && !ABL_NOL) lt[n] = myl[(size_t)(cn - NA - NV) * 64];
             __builtin_amdgcn_sched_barrier(0);
-            // fillers.  Slots 1..: step t-1's saved values, one load per 2 slots; then the row-major copy of the da
+            // fillers.  Slots 1..40: step t-1's saved values, one load per 3 slots; then the row-major copy of the da
             // tile, 8 chunks per lane staged through the (until the last groups idle) lt registers.
-            if constexpr (!ABL_NOX && sl >= 1 && sl < 1 + 2 * 24 && (sl - 1) % 2 == 0) {
-                constexpr int k = (sl - 1) / 2;                // 0..15 gates, 16..19 c_{t-1}, 20..23 upstream gradient
-                pinu(lane8);
-                if constexpr (k < 16) qa[k >> 2][k & 3] = *reinterpret_cast<const g_u16x4*>(acts_p[k & 3] + (k >> 2) * 512 + lane8);
-                else if constexpr (k < 20) qs[k - 16] = *reinterpret_cast<const g_u16x4*>(cs_p + (k - 16) * 512 + lane8);
-                else if constexpr (HAS_EXT) qd[k - 20] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 20) * 512 + lane8);
+            if constexpr (!ABL_NOX && sl >= 1 && sl < 1 + 3 * 14 && (sl - 1) % 3 == 0) {
+                constexpr int k = (sl - 1) / 3;                // 0..7 gates (pair j = k/4), 8..9 c_{t-1}, 10..13 upstream gradient
+                if constexpr (k < 8) {
+                    pinu(lane16);
+                    qa[k >> 2][k & 3] = *reinterpret_cast<const g_u16x8*>(acts_p[k & 3] + (k >> 2) * 1024 + lane16);
+                } else if constexpr (k < 10) {
+                    pinu(lane16);
+                    qs[k - 8] = *reinterpret_cast<const g_u16x8*>(cs_p + (k - 8) * 1024 + lane16);
+                } else if constexpr (HAS_EXT) {
+                    pinu(lane8);
+                    qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + lane8);
+                }
             }
             if constexpr (!ABL_NOTRG && sl >= 50 && sl < 50 + 4 * 8 + 8 && (sl - 50) % 4 == 0) {
                 constexpr int j = (sl - 50) / 4;               // read chunk j (j < 8), store chunk j - 2
@@ -1261,10 +1285,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
 #ifndef RES_LSTM_PIPELINE
 #define RES_LSTM_PIPELINE 1
 #endif
-inline bool lstm_phased() {
-    static const bool v = [] { const char* e = getenv("MVAE_LSTM_PHASED"); return e && e[0] == '1'; }();
-    return v;
-}
+
 template <int CELL> struct res_cfg;
 template <> struct res_cfg<MVAE_LSTM> {   // 128 fragments per wave
     static constexpr int IA = RES_LSTM_IA, IV = RES_LSTM_IV;     // slot-interleaved forward (+4 streamed, rest LDS)
@@ -1297,7 +1318,7 @@ int launch_fwd_res(const mvae_rnn_fwd_args& a, hipStream_t s) {
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-// LSTM with dense / indexed / constant inputs: the slot-interleaved kernel (MVAE_LSTM_PHASED=1 keeps the phased one)
+// LSTM with dense / indexed / constant inputs and seq_layout TILE16P: the slot-interleaved kernel
 template <int XMODE, int SAVE>
 int launch_lstm_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     typedef res_cfg<MVAE_LSTM> C;
@@ -1320,12 +1341,14 @@ int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.acts) {
         if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
         if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
-            if (!lstm_phased()) return launch_lstm_il<XMODE, SAVE_ALL>(a, s);
+            if (a.seq_layout == MVAE_TILE16P) return launch_lstm_il<XMODE, SAVE_ALL>(a, s);
+        if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
         return launch_fwd_res<CELL, XMODE, SAVE_ALL>(a, s);
     }
     if (a.cs) return MVAE_E_UNSUPPORTED;
     if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
-        if (!lstm_phased()) return a.hs ? launch_lstm_il<XMODE, SAVE_HS>(a, s) : launch_lstm_il<XMODE, SAVE_NONE>(a, s);
+        if (a.seq_layout == MVAE_TILE16P) return a.hs ? launch_lstm_il<XMODE, SAVE_HS>(a, s) : launch_lstm_il<XMODE, SAVE_NONE>(a, s);
+    if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     return a.hs ? launch_fwd_res<CELL, XMODE, SAVE_HS>(a, s) : launch_fwd_res<CELL, XMODE, SAVE_NONE>(a, s);
 }
 template <int CELL>
@@ -1359,7 +1382,8 @@ template <int CELL, bool HAS_EXT>
 int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
     typedef res_cfg<CELL> C;
     if constexpr (CELL == MVAE_LSTM)
-        if (!lstm_phased()) return launch_lstm_bwd_il<HAS_EXT>(a, s);
+        if (a.seq_layout == MVAE_TILE16P) return launch_lstm_bwd_il<HAS_EXT>(a, s);
+    if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     constexpr int G = mvae_gates(CELL), NL = RNT * (G * RH / 32) - C::BA - C::BV;
     const size_t lds = (size_t)16 * G * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag) +
                        (CELL == MVAE_GRU ? (size_t)16 * RH * sizeof(bf16_t) : 0);
@@ -1379,13 +1403,15 @@ int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
 
 // Entry points used by rnn.hip's dispatch.  Return MVAE_E_UNSUPPORTED when the shape is not this file's.
 int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16) return MVAE_E_UNSUPPORTED;
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || (a.seq_layout != MVAE_TILE16 && a.seq_layout != MVAE_TILE16P))
+        return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) return fwd_res_xmode<MVAE_LSTM>(a, s);
     if (a.cell == MVAE_GRU) return fwd_res_xmode<MVAE_GRU>(a, s);
     return MVAE_E_UNSUPPORTED;
 }
 int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16) return MVAE_E_UNSUPPORTED;
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || (a.seq_layout != MVAE_TILE16 && a.seq_layout != MVAE_TILE16P))
+        return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) {
         if (!a.cs) return MVAE_E_ARG;
         return a.dhs_ext ? launch_bwd_res<MVAE_LSTM, true>(a, s) : launch_bwd_res<MVAE_LSTM, false>(a, s);

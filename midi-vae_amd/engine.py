@@ -58,7 +58,7 @@ class Engine(object):
         # the resident-weights recurrent kernels (H=256, bf16, GRU/LSTM) stream TILE16 sequences; everything else is
         # row-major.  Batches are padded to a multiple of 16 rows (one workgroup = 16 rows) with zero-weight rows.
         self.tile16 = (spec.H == 256 and self.kind == hl.BF16 and spec.cell in ("GRU", "LSTM"))
-        self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR
+        self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR          # what the GEMM epilogues write (xp, dX)
         self.maxB = (int(max_batch) + 15) // 16 * 16
         self.layout = ParamLayout.build(spec)
         self.use_graphs = use_graphs
@@ -97,6 +97,20 @@ class Engine(object):
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
+
+    def _seq_layout(self, r):
+        """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM kernels (TILE16P saved
+        activations) wherever they apply, else the phased resident kernels (TILE16), else the generic row-major ones."""
+        if not self.tile16:
+            return hl.ROWMAJOR
+        if self.spec.cell == "LSTM":       # (a 1-feature input is expanded to x*W + b first: _scalar_as_dense)
+            return hl.TILE16P
+        return hl.TILE16
+
+    def _scalar_as_dense(self, r):
+        """1-feature input layers (velocity roll) of an LSTM model: x*W + b is written out (T*B*G*H bf16, one streaming
+        kernel, ~0.1 ms) so that the layer runs on the slot-interleaved dense-input kernels (2.1 instead of 3.9 us/step)."""
+        return r.xmode == hl.X_SCALAR and self._seq_layout(r) == hl.TILE16P
 
     def _mark(self, name):
         """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect)"""
@@ -226,6 +240,8 @@ class Engine(object):
                     buf(p + ".rh", r.T * B * H, **esz)
             if r.xmode == hl.X_INDEX:
                 buf(p + ".table", r.K * GH, **esz)
+            elif self._scalar_as_dense(r):
+                buf(p + ".xp", r.T * B * GH, **esz)
             elif r.xmode == hl.X_DENSE:
                 buf(p + ".xp", r.T * B * GH, **esz)
                 buf(p + ".wt", GH * H, **esz)            # W^T (GH,H): forward projection, k-contiguous
@@ -429,6 +445,10 @@ class Engine(object):
         kw = {}
         if r.xmode == hl.X_INDEX:
             kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
+        elif self._scalar_as_dense(r):
+            xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
+            ops.outer_bias_tile16(xs[t0:t0 + Tc], P[p + ".W"].view(-1), P[p + ".b"], xp, Tc * B, GH)
+            kw.update(xp=xp)
         elif r.xmode == hl.X_SCALAR:
             kw.update(xs=xs[t0:t0 + Tc], w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
         elif r.xmode == hl.X_CONST:
@@ -452,7 +472,7 @@ class Engine(object):
             cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None,
             acts=self._v(p + ".acts", T, B, GH)[t0:t0 + Tc] if self.training else None,
             h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
-            c_last=(sc if (lstm and not last) else None), seq_layout=self.lay, **kw), steps=Tc)
+            c_last=(sc if (lstm and not last) else None), seq_layout=self._seq_layout(r), **kw), steps=Tc)
 
     def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
@@ -600,7 +620,7 @@ class Engine(object):
             dc_last=(None if (first or not lstm) else sc),
             rh=self._v(p + ".rh", T, B, H)[t0:t0 + Tc] if s.cell == "GRU" else None,
             dh0=(dh0 if final else sh), dc0=((dc0 if final else sc) if lstm else None), dh0_ld=(dh0_ld if final else 0),
-            seq_layout=self.lay), steps=Tc)
+            seq_layout=self._seq_layout(r)), steps=Tc)
 
     def _rec_dx(self, r, B, k=0, nch=1):
         """Gradient w.r.t. the input sequence of layer ``r`` (= what the layer below receives at its h_t), time chunk k.

@@ -18,7 +18,7 @@ GRU, LSTM, RNN = 0, 1, 2
 F32, BF16, ONEHOT = 0, 1, 2
 X_DENSE, X_INDEX, X_SCALAR, X_CONST = 0, 1, 2, 3
 ACT_NONE, ACT_TANH = 0, 1
-ROWMAJOR, TILE16 = 0, 1
+ROWMAJOR, TILE16, TILE16P = 0, 1, 2
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
@@ -76,6 +76,7 @@ SIGNATURES = {
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mvae_head": (_i32, [C.POINTER(HeadArgs), _vp]),

@@ -92,6 +92,12 @@ def colsum(X, R, N, out, ldx=None):
              "mvae_colsum")
 
 
+def outer_bias_tile16(xs, w, bias, out, R, N):
+    """out (R, N) TILE16 = xs[r] * w[n] + bias[n]"""
+    hl.check(hl.load().mvae_outer_bias_tile16(_p(xs), _p(w), _p(bias), _p(out), kind_of(out), R, N, _stream()),
+             "mvae_outer_bias_tile16")
+
+
 def colsum_weighted(X, wgt, R, N, out, ldx=None):
     """out[n] += sum_r wgt[r] * X[r, n]  (wgt f32)"""
     hl.check(hl.load().mvae_colsum_weighted(X.data_ptr(), kind_of(X), _p(wgt), R, N, N if ldx is None else ldx, _p(out),
@@ -129,8 +135,10 @@ def latent_bwd(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, mu
     hl.check(hl.load().mvae_latent_bwd(a, _stream()), "mvae_latent_bwd")
 
 
-def relayout(src, dst, rows, cols, to_tile16):
-    hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols, int(to_tile16), _stream()), "mvae_relayout")
+def relayout(src, dst, rows, cols, to_tile16, paired=False):
+    """row-major <-> TILE16 (or TILE16P with ``paired``); ``to_tile16`` True = row-major -> tiled"""
+    hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols, int(bool(to_tile16)) + (2 if paired else 0),
+                                     _stream()), "mvae_relayout")
 
 
 def tanh_bwd(y, dy, dx):

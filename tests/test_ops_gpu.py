@@ -27,11 +27,19 @@ def host(t):
     return t.detach().float().cpu().numpy().astype(np.float64)
 
 
-def tile16(t, rows, cols, to_tile):
-    """device relayout of a (rows, cols) view between row-major and TILE16 (returns a new tensor, same shape)"""
+def tile16(t, rows, cols, to_tile, paired=False):
+    """device relayout of a (rows, cols) view between row-major and TILE16 / TILE16P (returns a new tensor, same shape)"""
     out = torch.empty_like(t)
-    ops.relayout(t.contiguous(), out, rows, cols, to_tile)
+    ops.relayout(t.contiguous(), out, rows, cols, to_tile, paired=paired)
     return out
+
+
+def seq_layouts(res, cellname, xmode="dense"):
+    """sequence layouts (= kernel families) to exercise: generic row-major; resident phased (TILE16); and for LSTM
+    without a scalar input also the slot-interleaved kernels (TILE16P: saved activations in tile pairs)"""
+    if not res:
+        return [hl.ROWMAJOR]
+    return [hl.TILE16, hl.TILE16P] if (cellname == "LSTM" and xmode != "scalar") else [hl.TILE16]
 
 
 def resident(H, B, dtype, cell):
@@ -90,25 +98,27 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
     hs_o, cs_o, acts_o = vo.rnn_forward(cellname, xp, U, h0, c0 if cellname == "LSTM" else None)
 
     up = ops.pack_recurrent(dev(U), cell, dtype, 0)
-    hs = torch.zeros((T + 1, B, H), dtype=td, device=DEV)
-    cs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if cellname == "LSTM" else None
-    acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
-    h_last = torch.zeros((B, H), device=DEV)
     res = resident(H, B, dtype, cell)
     if res and "xp" in kw:
         kw["xp"] = tile16(kw["xp"], T * B, GH, True)
-    ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
-                acts=acts, h_last=h_last, seq_layout=hl.TILE16 if res else hl.ROWMAJOR, **kw)
-    torch.cuda.synchronize()
-    if res:
-        acts = tile16(acts, T * B, GH, False)
+    for lay in seq_layouts(res, cellname, xmode):
+        hs = torch.zeros((T + 1, B, H), dtype=td, device=DEV)
+        cs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if cellname == "LSTM" else None
+        acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
+        h_last = torch.zeros((B, H), device=DEV)
+        ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
+                    acts=acts, h_last=h_last, seq_layout=lay, **kw)
+        torch.cuda.synchronize()
+        if res:
+            acts = tile16(acts, T * B, GH, False, paired=lay == hl.TILE16P)
+            if cs is not None:
+                cs = tile16(cs, (T + 1) * B, H, False, paired=lay == hl.TILE16P)
+        what = " (layout %d)" % lay
+        close(host(hs), hs_o, tol, "hs" + what)
+        close(host(acts), acts_o, tol, "acts" + what)
+        close(host(h_last), hs_o[-1], tol, "h_last" + what)
         if cs is not None:
-            cs = tile16(cs, (T + 1) * B, H, False)
-    close(host(hs), hs_o, tol, "hs")
-    close(host(acts), acts_o, tol, "acts")
-    close(host(h_last), hs_o[-1], tol, "h_last")
-    if cs is not None:
-        close(host(cs), cs_o, tol, "cs")
+            close(host(cs), cs_o, tol, "cs" + what)
 
 
 def test_rnn_forward_zero_initial_state_and_inference_mode():
@@ -142,26 +152,29 @@ def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
     da_o, dU_o, dh0_o, dc0_o = vo.rnn_backward(cellname, hs_o, cs_o, acts_o, U, dext, dlast)
 
     ut = ops.pack_recurrent(dev(U), cell, dtype, 1)
-    da = torch.zeros((T, B, GH), dtype=td, device=DEV)
-    rh = torch.zeros((T, B, H), dtype=td, device=DEV)
-    dh0 = torch.zeros((B, H), device=DEV)
-    dc0 = torch.zeros((B, H), device=DEV)
     res = resident(H, B, dtype, cell)
-    acts_d, cs_d = dev(acts_o, td), dev(cs_o, td) if cs_o is not None else None
-    dext_d = dev(dext, td) if ext else None
-    if res:
-        acts_d = tile16(acts_d, T * B, GH, True)
-        cs_d = tile16(cs_d, (T + 1) * B, H, True) if cs_d is not None else None
-        dext_d = tile16(dext_d, T * B, H, True) if ext else None
-    ops.rnn_bwd(cell, dtype, T, B, H, ut, dev(hs_o, td), cs_d, acts_d, da, dhs_ext=dext_d, dh_last=dev(dlast), rh=rh,
-                dh0=dh0, dc0=dc0, seq_layout=hl.TILE16 if res else hl.ROWMAJOR)
-    torch.cuda.synchronize()
-    close(host(da), da_o, tol, "da")
-    close(host(dh0), dh0_o, tol, "dh0")
-    if cellname == "LSTM":
-        close(host(dc0), dc0_o, tol, "dc0")
-    if cellname == "GRU":
-        close(host(rh), acts_o[:, :, H:2 * H] * hs_o[:-1], tol, "rh")
+    for lay in seq_layouts(res, cellname):
+        da = torch.zeros((T, B, GH), dtype=td, device=DEV)
+        rh = torch.zeros((T, B, H), dtype=td, device=DEV)
+        dh0 = torch.zeros((B, H), device=DEV)
+        dc0 = torch.zeros((B, H), device=DEV)
+        acts_d, cs_d = dev(acts_o, td), dev(cs_o, td) if cs_o is not None else None
+        dext_d = dev(dext, td) if ext else None
+        if res:
+            pr = lay == hl.TILE16P
+            acts_d = tile16(acts_d, T * B, GH, True, paired=pr)
+            cs_d = tile16(cs_d, (T + 1) * B, H, True, paired=pr) if cs_d is not None else None
+            dext_d = tile16(dext_d, T * B, H, True) if ext else None
+        ops.rnn_bwd(cell, dtype, T, B, H, ut, dev(hs_o, td), cs_d, acts_d, da, dhs_ext=dext_d, dh_last=dev(dlast), rh=rh,
+                    dh0=dh0, dc0=dc0, seq_layout=lay)
+        torch.cuda.synchronize()
+        what = " (layout %d)" % lay
+        close(host(da), da_o, tol, "da" + what)
+        close(host(dh0), dh0_o, tol, "dh0" + what)
+        if cellname == "LSTM":
+            close(host(dc0), dc0_o, tol, "dc0" + what)
+        if cellname == "GRU":
+            close(host(rh), acts_o[:, :, H:2 * H] * hs_o[:-1], tol, "rh" + what)
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
@@ -213,6 +226,10 @@ def test_gemm_tile16_output_and_relayout_roundtrip(dtype):
     want[off.ravel()] = host(C_rm).ravel()
     assert np.array_equal(host(C_t).ravel(), want)
     assert torch.equal(tile16(back, M, N, True), C_t)
+    if N % 32 == 0:      # TILE16P round trip (same values, tile pairs interleaved per lane)
+        pr = tile16(back, M, N, True, paired=True)
+        assert torch.equal(tile16(pr, M, N, False, paired=True), back)
+        assert not torch.equal(pr, C_t)
 
 
 def test_gemm_leading_dimensions_and_column_blocks():
@@ -361,6 +378,17 @@ def test_colsum_bf16_vector_path_plain_and_weighted(N, ldx):
     Xh = host(X)[:, :N]
     close(host(out), 0.5 + Xh.sum(0), 2e-4 * np.sqrt(R))
     close(host(outw), (Xh * wgt[:, None].astype(np.float32)).sum(0), 2e-4 * np.sqrt(R))
+
+
+def test_outer_bias_tile16():
+    rng = np.random.default_rng(12)
+    R, N = 48, 1024
+    xs, w, b = rng.random(R), rng.standard_normal(N), rng.standard_normal(N)
+    out = torch.zeros((R, N), dtype=torch.bfloat16, device=DEV)
+    ops.outer_bias_tile16(dev(xs), dev(w), dev(b), out, R, N)
+    back = tile16(out, R, N, False)
+    torch.cuda.synchronize()
+    close(host(back), xs[:, None] * w[None] + b[None], 1e-2)
 
 
 def test_sum_over_time_split_and_accumulate():

@@ -18,9 +18,10 @@ ap.add_argument("--T", type=int, default=512)
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-major sequences)")
+ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
-LAY = hl.ROWMAJOR if a.rowmajor else hl.TILE16
+LAY = hl.ROWMAJOR if a.rowmajor else (hl.TILE16 if (a.phased or a.cell != "LSTM") else hl.TILE16P)
 G, H, T, B = hl.GATES[cell], 256, a.T, a.B
 GH = G * H
 dev = "cuda:0"
@@ -59,7 +60,8 @@ modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": di
          "const": dict(xp0=xp0)}
 flop = 2.0 * B * H * GH * T
 for name, kw in modes.items():
-    ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=LAY, **kw))
+    lay = hl.TILE16 if (name == "scalar" and LAY == hl.TILE16P) else LAY
+    ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=lay, **kw))
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
 ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
