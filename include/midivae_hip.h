@@ -225,6 +225,22 @@ typedef struct {
 } mvae_latent_bwd_args;
 int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
 
+/* Every derived copy of the parameters a step needs, in ONE launch (25 tiny dependent kernels cost 0.3 - 0.8 ms of queue
+ * latency per training step otherwise).  Each job is one of the single calls above:
+ *   MVAE_PREP_PACK_RECURRENT   src = U (a=H, b=G*H) f32, c = direction        -> dst as mvae_pack_recurrent(kind)
+ *   MVAE_PREP_MAKE_TABLE       src = W (a=K, b=N), src2 = bias (N)            -> dst (K, N) kind     (mvae_make_table)
+ *   MVAE_PREP_TRANSPOSE_CONVERT src = W (a=K, b=N), c = N_pad                 -> dst (N_pad, K) kind (mvae_transpose_convert)
+ *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)     */
+enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3 };
+typedef struct {
+    int32_t op, kind;          /* MVAE_PREP_*, element kind of dst (MVAE_F32 / MVAE_BF16) */
+    int32_t a, b, c, reserved;
+    const void* src;
+    const void* src2;
+    void* dst;
+} mvae_prep_job;
+int mvae_prepare_batch(const mvae_prep_job* jobs /* host array */, int32_t n_jobs, void* stream);
+
 /* out (R, N) TILE16 of out_kind = xs[r] * w[n] + bias[n]: the input projection x*W + b of a 1-feature input (velocity
  * roll, reference vae_definition.py:456-470) written out, so that the layer can run on the MVAE_X_DENSE kernels
  * (R % 16 == 0, N % 16 == 0, w and bias 16-byte aligned) */

@@ -130,3 +130,45 @@ __device__ __forceinline__ void lds_barrier() {
         hipError_t e__ = hipGetLastError();                   \
         if (e__ != hipSuccess) return MVAE_E_LAUNCH;          \
     } while (0)
+
+// ---- weight preparation bodies (shared by the single kernels and the batched mvae_prepare_batch launch) -----------
+// block `bid` of `nb` blocks (256 threads) of a grid-stride loop
+template <typename WT>
+__device__ __forceinline__ void pack_recurrent_body(const float* __restrict__ U, WT* __restrict__ out, int H, int GH, int direction,
+                                                    int bid, int nb) {
+    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
+    const int rowsA = direction == 0 ? GH : H;   // A rows
+    const int K = direction == 0 ? H : GH;       // contraction length
+    const int S = K / KG;
+    const size_t total = (size_t)rowsA * K;
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < total; e += (size_t)nb * blockDim.x) {
+        const int j = (int)(e % FE);
+        const int l = (int)((e / FE) % 64);
+        const size_t f = e / (FE * 64);
+        const int s = (int)(f % S);
+        const int mt = (int)(f / S);
+        const int arow = mt * 16 + (l & 15);
+        const int k = s * KG + (l >> 4) * FE + j;
+        const float v = direction == 0 ? U[(size_t)k * GH + arow]      // A[gate col][h]   = U[h][gate col]
+                                       : U[(size_t)arow * GH + k];     // A[unit][gate col] = U[unit][gate col]
+        st<WT>::store(out + e, v);
+    }
+}
+template <typename D>
+__device__ __forceinline__ void make_table_body(const float* W, const float* bias, D* table, int K, int N, int bid, int nb) {
+    const size_t n = (size_t)K * N;
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x)
+        st<D>::store(table + e, W[e] + bias[e % N]);
+}
+template <typename D>
+__device__ __forceinline__ void transpose_convert_body(const float* W, D* out, int K, int N, int NPAD, int bid, int nb) {
+    const size_t n = (size_t)NPAD * K;
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
+        const int nn = (int)(e / K), k = (int)(e % K);
+        st<D>::store(out + e, nn < N ? W[(size_t)k * N + nn] : 0.0f);
+    }
+}
+template <typename D>
+__device__ __forceinline__ void convert_f32_body(const float* src, D* dst, size_t n, int bid, int nb) {
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) st<D>::store(dst + e, src[e]);
+}

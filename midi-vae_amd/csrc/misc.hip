@@ -175,18 +175,12 @@ __global__ void convert_k(const S* src, D* dst, size_t n) {
 
 template <typename D>
 __global__ void make_table_k(const float* W, const float* bias, D* table, int K, int N) {
-    const size_t n = (size_t)K * N;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
-        st<D>::store(table + e, W[e] + bias[e % N]);
+    make_table_body<D>(W, bias, table, K, N, blockIdx.x, gridDim.x);
 }
 
 template <typename D>
 __global__ void transpose_convert_k(const float* W, D* out, int K, int N, int NPAD) {
-    const size_t n = (size_t)NPAD * K;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const int nn = (int)(e / K), k = (int)(e % K);
-        st<D>::store(out + e, nn < N ? W[(size_t)k * N + nn] : 0.0f);
-    }
+    transpose_convert_body<D>(W, out, K, N, NPAD, blockIdx.x, gridDim.x);
 }
 
 // out (R, N) in TILE16 = xs[r] * w[n] + bias[n]: the input projection of a 1-feature layer, expanded so that the layer
@@ -376,6 +370,58 @@ extern "C" int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t r
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+// ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
+constexpr int PREP_MAX_JOBS = 32, PREP_BLOCKS_PER_JOB = 64;
+struct prep_batch {
+    int32_t n;
+    mvae_prep_job jobs[PREP_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
+    const int j = blockIdx.x / PREP_BLOCKS_PER_JOB, bid = blockIdx.x % PREP_BLOCKS_PER_JOB, nb = PREP_BLOCKS_PER_JOB;
+    const mvae_prep_job& job = pb.jobs[j];
+    const float* src = reinterpret_cast<const float*>(job.src);
+    const bool bf = job.kind == MVAE_BF16;
+    switch (job.op) {
+        case MVAE_PREP_PACK_RECURRENT:
+            if (bf) pack_recurrent_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, job.c, bid, nb);
+            else pack_recurrent_body<float>(src, reinterpret_cast<float*>(job.dst), job.a, job.b, job.c, bid, nb);
+            break;
+        case MVAE_PREP_MAKE_TABLE:
+            if (bf) make_table_body<bf16_t>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, bid, nb);
+            else make_table_body<float>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<float*>(job.dst), job.a, job.b, bid, nb);
+            break;
+        case MVAE_PREP_TRANSPOSE_CONVERT:
+            if (bf) transpose_convert_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, job.c, bid, nb);
+            else transpose_convert_body<float>(src, reinterpret_cast<float*>(job.dst), job.a, job.b, job.c, bid, nb);
+            break;
+        case MVAE_PREP_CONVERT:
+            if (bf) convert_f32_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), (size_t)job.a * job.b, bid, nb);
+            else convert_f32_body<float>(src, reinterpret_cast<float*>(job.dst), (size_t)job.a * job.b, bid, nb);
+            break;
+    }
+}
+extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, void* stream) {
+    if (!jobs || n_jobs < 0) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int j0 = 0; j0 < n_jobs; j0 += PREP_MAX_JOBS) {
+        prep_batch pb;
+        pb.n = n_jobs - j0 < PREP_MAX_JOBS ? n_jobs - j0 : PREP_MAX_JOBS;
+        for (int j = 0; j < pb.n; ++j) {
+            const mvae_prep_job& job = jobs[j0 + j];
+            if (!job.src || !job.dst || job.op < 0 || job.op > MVAE_PREP_CONVERT || (job.kind != MVAE_F32 && job.kind != MVAE_BF16) ||
+                (job.op == MVAE_PREP_MAKE_TABLE && !job.src2))
+                return MVAE_E_ARG;
+            if (job.op == MVAE_PREP_PACK_RECURRENT) {
+                const int K = job.c == 0 ? job.a : job.b, KG = job.kind == MVAE_BF16 ? 32 : 4;     // as mvae_pack_recurrent
+                if (job.a <= 0 || (job.a % 16) || (job.b % 16) || (K % KG)) return MVAE_E_ARG;
+            }
+            pb.jobs[j] = job;
+        }
+        hipLaunchKernelGGL(prepare_batch_k, dim3(pb.n * PREP_BLOCKS_PER_JOB), dim3(256), 0, s, pb);
+        MVAE_CHECK_LAUNCH();
+    }
     return MVAE_OK;
 }
 extern "C" int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, void* out, int32_t out_kind, int32_t R,

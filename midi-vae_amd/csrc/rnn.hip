@@ -26,23 +26,7 @@ namespace {
 // ----------------------------------------------------------------------------------------------------------
 template <typename WT>
 __global__ void pack_recurrent_k(const float* __restrict__ U, WT* __restrict__ out, int H, int GH, int direction) {
-    constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
-    const int rowsA = direction == 0 ? GH : H;   // A rows
-    const int K = direction == 0 ? H : GH;       // contraction length
-    const int S = K / KG;
-    const size_t total = (size_t)rowsA * K;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(e % FE);
-        const int l = (int)((e / FE) % 64);
-        const size_t f = e / (FE * 64);
-        const int s = (int)(f % S);
-        const int mt = (int)(f / S);
-        const int arow = mt * 16 + (l & 15);
-        const int k = s * KG + (l >> 4) * FE + j;
-        const float v = direction == 0 ? U[(size_t)k * GH + arow]      // A[gate col][h]   = U[h][gate col]
-                                       : U[(size_t)arow * GH + k];     // A[unit][gate col] = U[unit][gate col]
-        st<WT>::store(out + e, v);
-    }
+    pack_recurrent_body<WT>(U, out, H, GH, direction, blockIdx.x, gridDim.x);
 }
 
 // ----------------------------------------------------------------------------------------------------------

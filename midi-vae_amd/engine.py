@@ -97,6 +97,7 @@ class Engine(object):
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
+        self._prep = None
 
     def _seq_layout(self, r):
         """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM kernels (TILE16P saved
@@ -395,32 +396,29 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     def prepare_weights(self):
         """Derived copies of the parameters the kernels consume (MFMA-fragment packed recurrent kernels, bf16 / transposed
-        input kernels, one-hot lookup tables).  ~25 tiny kernels, 0.3 ms per step."""
+        input kernels, one-hot lookup tables): ~25 jobs in ONE launch (mvae_prepare_batch) - as separate kernels they cost
+        0.3 ms per step, 0.8 ms with several steps queued."""
         s, P = self.spec, self.P
 
-        def rec_job(r):
-            p = r.prefix
-            ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 0, out=self.store[p + ".u_pack"])
-            if r.xmode == hl.X_INDEX:
-                ops.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
-            elif r.xmode == hl.X_DENSE:
-                ops.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
-            if self.training:
-                ops.pack_recurrent(P[p + ".U"], self.cell, self.kind, 1, out=self.store[p + ".ut_pack"])
-                if r.xmode == hl.X_DENSE:
-                    ops.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
-
-        def heads_job():
-            ops.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
+        if self._prep is None:          # built once: every source / destination is a fixed view
+            pb = self._prep = ops.PrepBatch()
+            for r in self.all_rec:
+                p = r.prefix
+                pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
+                if r.xmode == hl.X_INDEX:
+                    pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+                elif r.xmode == hl.X_DENSE:
+                    pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
+                if self.training:
+                    pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
+                    if r.xmode == hl.X_DENSE:
+                        pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
+            pb.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
             if s.meta_instrument:
-                ops.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
+                pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
             if s.meta_velocity:
-                ops.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
-
-        # (sequential on the main stream: spreading these jobs over the side streams was measured 1 ms SLOWER per step)
-        for r in self.all_rec:
-            rec_job(r)
-        heads_job()
+                pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+        self._prep.run()
         self._weights_dirty = False
 
     # ------------------------------------------------------------------------------------------------------

@@ -47,6 +47,14 @@ class GemmArgs(C.Structure):
                 ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32)]
 
 
+class PrepJob(C.Structure):
+    _fields_ = [("op", _i32), ("kind", _i32), ("a", _i32), ("b", _i32), ("c", _i32), ("reserved", _i32),
+                ("src", _vp), ("src2", _vp), ("dst", _vp)]
+
+
+PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT = 0, 1, 2, 3
+
+
 class HeadArgs(C.Structure):
     _fields_ = [("kind", _i32), ("dtype", _i32), ("R", _i32), ("H", _i32), ("N", _i32), ("want_grad", _i32),
                 ("hs", _vp), ("wt", _vp), ("bias", _vp), ("target_idx", _vp), ("target_val", _vp),
@@ -76,6 +84,7 @@ SIGNATURES = {
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -161,6 +161,40 @@ def transpose_convert(W, out, n_pad=None):
                                               _stream()), "mvae_transpose_convert")
 
 
+class PrepBatch:
+    """Job list for mvae_prepare_batch (every derived weight copy of a step in one launch).  The tensors are referenced by
+    address: they must stay allocated and in place for as long as the batch is used."""
+
+    def __init__(self):
+        self.jobs = []
+        self._keep = []
+        self._arr = None
+
+    def _add(self, op, dst, a, b, c, src, src2=None):
+        self.jobs.append(hl.PrepJob(op, kind_of(dst), int(a), int(b), int(c), 0, _p(src), _p(src2), _p(dst)))
+        self._keep += [src, src2, dst]
+        self._arr = None
+
+    def pack_recurrent(self, U, out, direction):
+        H, GH = U.shape
+        self._add(hl.PREP_PACK_RECURRENT, out, H, GH, direction, U)
+
+    def make_table(self, W, bias, table):
+        self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], 0, W, bias)
+
+    def transpose_convert(self, W, out, n_pad=None):
+        K, N = W.shape
+        self._add(hl.PREP_TRANSPOSE_CONVERT, out, K, N, N if n_pad is None else n_pad, W)
+
+    def convert(self, src, dst):
+        self._add(hl.PREP_CONVERT, dst, src.numel(), 1, 0, src)
+
+    def run(self):
+        if self._arr is None:
+            self._arr = (hl.PrepJob * len(self.jobs))(*self.jobs)
+        hl.check(hl.load().mvae_prepare_batch(self._arr, len(self.jobs), _stream()), "mvae_prepare_batch")
+
+
 def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     hl.check(hl.load().mvae_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, t, grad_scale,
                                       _stream()), "mvae_adam_step")

@@ -380,6 +380,28 @@ def test_colsum_bf16_vector_path_plain_and_weighted(N, ldx):
     close(host(outw), (Xh * wgt[:, None].astype(np.float32)).sum(0), 2e-4 * np.sqrt(R))
 
 
+def test_prepare_batch_matches_single_calls():
+    """mvae_prepare_batch = the single weight-preparation calls, bit for bit, in one launch."""
+    rng = np.random.default_rng(13)
+    H, GH, K = 256, 1024, 61
+    U, W, b, Wd = (dev(rng.standard_normal(sh)) for sh in ((H, GH), (K, GH), (GH,), (H, GH)))
+    bf = torch.bfloat16
+    want = [ops.pack_recurrent(U, hl.LSTM, hl.BF16, 0), ops.pack_recurrent(U, hl.LSTM, hl.BF16, 1),
+            torch.zeros((K, GH), dtype=bf, device=DEV), torch.zeros((GH, H), dtype=bf, device=DEV),
+            torch.zeros((H, GH), dtype=bf, device=DEV), torch.zeros((64, H), dtype=bf, device=DEV)]
+    Wh = dev(rng.standard_normal((H, 61)))
+    ops.make_table(W, b, want[2]); ops.transpose_convert(Wd, want[3]); ops.convert(Wd, want[4])
+    ops.transpose_convert(Wh, want[5], n_pad=64)
+    got = [torch.zeros_like(w) for w in want]
+    pb = ops.PrepBatch()
+    pb.pack_recurrent(U, got[0], 0); pb.pack_recurrent(U, got[1], 1); pb.make_table(W, b, got[2])
+    pb.transpose_convert(Wd, got[3]); pb.convert(Wd, got[4]); pb.transpose_convert(Wh, got[5], n_pad=64)
+    pb.run()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
 def test_outer_bias_tile16():
     rng = np.random.default_rng(12)
     R, N = 48, 1024

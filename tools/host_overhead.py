@@ -68,3 +68,21 @@ for name, e in eng.marks[1:] + [("optimizer", e_end)]:
     if not name.startswith("  "):
         prev = e
 eng.marks = None
+
+# the same with 4 steps queued back to back (no host synchronisation in between): sections of the last one
+eng.marks = []
+for _ in range(4):
+    eng.train_step(B)
+e_end = torch.cuda.Event(enable_timing=True); e_end.record()
+torch.cuda.synchronize()
+n = len(eng.marks) // 4
+last = eng.marks[-n:]
+prev = last[0][1]
+print("back to back, last of 4 steps:")
+for name, e in last[1:] + [("optimizer", e_end)]:
+    if not name.startswith("  "):
+        print("%-36s %7.3f ms" % (name, prev.elapsed_time(e)))
+        prev = e
+    else:
+        print("%-36s   (at +%.3f ms)" % (name, last[0][1].elapsed_time(e)))
+eng.marks = None
