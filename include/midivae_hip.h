@@ -91,6 +91,17 @@ typedef struct {
                               run as consecutive launches (time chunks) without rounding the carried state     */
     int32_t h0_ld;         /* row stride of h0 / c0 in floats (0 = H): states may be column blocks of a wider buffer */
     int32_t h_last_ld;     /* row stride of h_last (0 = H)                                                     */
+    /* ---- time-pipelined stacks (slot-interleaved LSTM kernels only; all NULL / 0 otherwise) ----------------------
+     * A stack of layers runs as ONE launch per layer, plus ONE persistent mvae_gemm launch per layer interface (its
+     * chunk_* fields): layer l publishes chunk k (chunk_steps time steps) of hs in a counter, the GEMM waits for it,
+     * projects the chunk and publishes xp, layer l+1 waits for that.  All device-side (system-scope loads / atomics,
+     * ~microseconds per hand-over; stream-level wait/write values cost 50-100 us each).  Counters are plain 32-bit
+     * words in device memory, zeroed by the caller before the launches. */
+    int32_t chunk_steps;         /* time steps per pipeline chunk; chunk k = steps [k*chunk_steps, (k+1)*chunk_steps)    */
+    const uint32_t* wait_ready;  /* [chunks] chunk k of xp may be read once wait_ready[k] >= wait_value (kernel polls)    */
+    uint32_t wait_value;         /* 0 = 1                                                                                 */
+    uint32_t* signal_done;       /* [chunks] += 1 per WAVE (4 * B/16 of them) once chunk k of hs is complete and visible  */
+    uint32_t* status;            /* [1] set non-zero if a wait timed out (~2 s): results are invalid                      */
     int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR, MVAE_TILE16 or
                               MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
                               (H=256, bf16): TILE16 the phased ones (GRU, LSTM), TILE16P the slot-interleaved LSTM
@@ -116,6 +127,13 @@ typedef struct {
     float* dc0;            /* LSTM: (B,H) or NULL                                                             */
     int32_t dh_last_ld;    /* row stride of dh_last (0 = H)                                                   */
     int32_t dh0_ld;        /* row stride of dh0 / dc0 (0 = H)                                                 */
+    /* time-pipelined stacks, as in mvae_rnn_fwd_args: wait_ready gates dhs_ext (chunk k = steps [k*cs, (k+1)*cs), consumed
+     * from the last chunk to the first), signal_done publishes da */
+    int32_t chunk_steps;
+    const uint32_t* wait_ready;
+    uint32_t wait_value;
+    uint32_t* signal_done;
+    uint32_t* status;
     int32_t seq_layout;    /* layout of acts, cs and dhs_ext (hs, da, rh are always row-major)                */
 } mvae_rnn_bwd_args;
 int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream);
@@ -150,8 +168,23 @@ typedef struct {
     int32_t max_blocks;           /* 0 = one workgroup per output tile; >0 = at most this many workgroups, each looping
                                      over tiles: keeps a throughput GEMM from occupying every CU while latency-critical
                                      recurrent launches (which need whole idle CUs) run beside it                 */
+    int32_t sys_release;          /* != 0: every workgroup ends with a system-scope release (L2 write-back), so that a
+                                     kernel ALREADY RUNNING on another XCD sees C after a stream-ordered flag write  */
+    /* persistent chunked mode (fast bf16 path only, split_k <= 1, max_blocks > 0 = the persistent grid): the M rows are
+     * processed in chunks of chunk_rows (multiple of 128); chunk c starts once chunk_wait[c] >= chunk_wait_value and is
+     * published by chunk_done[c] += 1 per wave (4 * max_blocks in total).  chunk_reverse: last chunk first. */
+    int32_t chunk_rows, chunk_reverse;
+    const uint32_t* chunk_wait;
+    uint32_t chunk_wait_value;
+    uint32_t* chunk_done;
+    uint32_t* chunk_status;       /* [1] set non-zero if a wait timed out                                          */
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
+
+/* Stream-ordered synchronisation with RUNNING kernels (hipStreamWaitValue32 / hipStreamWriteValue32 on plain device
+ * memory): `stream` proceeds once *addr >= value / writes value to *addr after everything enqueued before it on `stream`. */
+int mvae_stream_wait_value32(void* stream, const uint32_t* addr, uint32_t value);
+int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value);
 
 /* out[n] (+)= sum_r X[r, n]  for X (R, N) of `kind`; ldx elements between rows; atomic f32 accumulate */
 int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream);

@@ -131,6 +131,103 @@ __device__ __forceinline__ void lds_barrier() {
         if (e__ != hipSuccess) return MVAE_E_LAUNCH;          \
     } while (0)
 
+// ---- device-side hand-over between RUNNING kernels (time-pipelined stacks, include/midivae_hip.h) -------------------
+// Single asm blocks with scalar control flow and one or two temporary VGPRs: as C++ (a thread-0 loop, barriers, an
+// atomic) they cost the 256-VGPR LSTM backward kernel registers it does not have, and an extra basic block in its step
+// loop breaks hipcc's allocation.  Every WAVE waits / publishes by itself: no barrier; a counter's consumer expects one
+// increment per producer wave.
+//
+// wave_wait_ge: until *flag >= value (system-scope loads), then drop this XCD's possibly stale cache lines of the data the
+// flag guards.  Bounded (~2 s): then *status = 1 and the kernel carries on - it never hangs.
+__device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status) {
+    unsigned tmp, spins, val;
+    asm volatile(
+        "s_mov_b32 %1, 0\n"
+        "L_wait_%=:\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "global_load_dword %0, %0, %3 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %2, %0\n\t"
+        "s_cmp_ge_u32 %2, %4\n\t"
+        "s_cbranch_scc1 L_ready_%=\n\t"
+        "s_sleep 8\n\t"
+        "s_add_u32 %1, %1, 1\n\t"
+        "s_cmp_lt_u32 %1, 0x1000000\n\t"
+        "s_cbranch_scc1 L_wait_%=\n"
+        "L_ready_%=:\n\t"
+        "buffer_inv sc0 sc1"
+        : "=&v"(tmp), "=&s"(spins), "=&s"(val)
+        : "s"(flag), "s"(value)
+        : "memory", "scc");
+    if (spins >= 0x1000000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the same under a scalar condition evaluated inside the block: if (t == bound) wait
+__device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status) {
+    unsigned tmp, spins, val;
+    asm volatile(
+        "s_mov_b32 %1, 0\n\t"
+        "s_cmp_lg_u32 %3, %4\n\t"
+        "s_cbranch_scc1 L_skip_%=\n"
+        "L_wait_%=:\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "global_load_dword %0, %0, %5 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %2, %0\n\t"
+        "s_cmp_ge_u32 %2, %6\n\t"
+        "s_cbranch_scc1 L_ready_%=\n\t"
+        "s_sleep 8\n\t"
+        "s_add_u32 %1, %1, 1\n\t"
+        "s_cmp_lt_u32 %1, 0x1000000\n\t"
+        "s_cbranch_scc1 L_wait_%=\n"
+        "L_ready_%=:\n\t"
+        "buffer_inv sc0 sc1\n"
+        "L_skip_%=:"
+        : "=&v"(tmp), "=&s"(spins), "=&s"(val)
+        : "s"(t), "s"(bound), "s"(flag), "s"(value)
+        : "memory", "scc");
+    if (spins >= 0x1000000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// This wave's global stores so far are written back to memory, then ONE increment (by its first lane) of the counter.
+__device__ __forceinline__ void wave_signal_done(uint32_t* counter) {
+    unsigned t0, t1;
+    unsigned long long save;
+    asm volatile(
+        "s_waitcnt vmcnt(0)\n\t"
+        "buffer_wbl2 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 %2, exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "v_mov_b32 %1, 1\n\t"
+        "global_atomic_add %0, %1, %3 sc1\n\t"
+        "s_mov_b64 exec, %2\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(t0), "=&v"(t1), "=&s"(save)
+        : "s"(counter)
+        : "memory");
+}
+__device__ __forceinline__ void wave_signal_done_if(int t, int bound, uint32_t* counter) {
+    unsigned t0, t1;
+    unsigned long long save;
+    asm volatile(
+        "s_cmp_lg_u32 %3, %4\n\t"
+        "s_cbranch_scc1 L_skip_%=\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "buffer_wbl2 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 %2, exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %0, 0\n\t"
+        "v_mov_b32 %1, 1\n\t"
+        "global_atomic_add %0, %1, %5 sc1\n\t"
+        "s_mov_b64 exec, %2\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        "L_skip_%=:"
+        : "=&v"(t0), "=&v"(t1), "=&s"(save)
+        : "s"(t), "s"(bound), "s"(counter)
+        : "memory", "scc");
+}
+
 // ---- weight preparation bodies (shared by the single kernels and the batched mvae_prepare_batch launch) -----------
 // block `bid` of `nb` blocks (256 threads) of a grid-stride loop
 template <typename WT>

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
         }
     }
     }   // tile loop
+    if (a.sys_release) __threadfence_system();
 }
 
 
@@ -301,9 +302,15 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     const int tiles_n = (N + FBN - 1) / FBN, tiles_m = (M + FBM - 1) / FBM;   // M < 128: one-hot table gradient
     const int nlim = B_RC ? (a.ldb < tiles_n * FBN ? a.ldb : 1 << 30) : 1 << 30;   // N < 128: head kernels (accumulate)
     const int splits = a.split_k > 1 ? a.split_k : 1;
-    const int total_tiles = tiles_n * tiles_m * splits;
+    // persistent chunked mode: a fixed grid walks the M tiles chunk by chunk, handing over with device-side counters
+    const int tiles_mc = a.chunk_rows ? a.chunk_rows / FBM : tiles_m;          // M tiles per chunk
+    const int nchunks = tiles_m / tiles_mc;
+    const int total_tiles = tiles_n * tiles_mc * splits;
+    for (int ci = 0; ci < nchunks; ++ci) {
+    const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
+    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int bx = tile % tiles_n, by = (tile / tiles_n) % tiles_m, bz = tile / (tiles_n * tiles_m);
+        const int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
         const int m0 = by * FBM, n0 = bx * FBN;
         int kbeg = 0, kend = K;
         if (splits > 1) {
@@ -386,6 +393,9 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             }
         }
     }
+    if (a.chunk_done) wave_signal_done(a.chunk_done + chunk);
+    }   // chunk loop
+    if (a.sys_release) __threadfence_system();
 }
 
 template <bool A_RC, bool B_RC, bool ONEHOT>
@@ -401,6 +411,7 @@ int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
     const int sk = a.split_k > 1 ? a.split_k : 1;
     long long tiles = (long long)((a.N + FBN - 1) / FBN) * ((a.M + FBM - 1) / FBM) * sk;
     if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
+    if (a.chunk_rows) tiles = a.max_blocks;          // persistent grid: every workgroup passes through every chunk
     hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT>), dim3((unsigned)tiles), dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
@@ -471,6 +482,12 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (a->accumulate && a->act != MVAE_ACT_NONE) return MVAE_E_ARG;
     if (a->c_layout == MVAE_TILE16 && (a->accumulate || (a->M % 16) || (a->N % 16))) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a->chunk_rows || a->chunk_wait || a->chunk_done) {      // persistent chunked mode: fast path only
+        if (a->chunk_rows <= 0 || (a->chunk_rows % FBM) || (a->M % a->chunk_rows) || a->split_k > 1 || a->max_blocks <= 0 ||
+            a->max_blocks > 256 || a->accumulate)
+            return MVAE_E_ARG;
+        if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
+    }
     if (fast_ok(*a)) return dispatch_fast(*a, s);
     // A handful of output tiles with a long K (the Dense layers around the latent: M = batch, K up to nInit*H = 2304) is
     // a few workgroups marching through K for 100+ us on an otherwise idle chip: zero C and split K over atomics.

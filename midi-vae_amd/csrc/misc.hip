@@ -372,6 +372,17 @@ extern "C" int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t r
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
+// ---- stream-ordered synchronisation with running kernels ------------------------------------------------------------
+extern "C" int mvae_stream_wait_value32(void* stream, const uint32_t* addr, uint32_t value) {
+    if (!addr) return MVAE_E_ARG;
+    return hipStreamWaitValue32(reinterpret_cast<hipStream_t>(stream), const_cast<uint32_t*>(addr), value, hipStreamWaitValueGte,
+                                0xFFFFFFFFu) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
+}
+extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value) {
+    if (!addr) return MVAE_E_ARG;
+    return hipStreamWriteValue32(reinterpret_cast<hipStream_t>(stream), addr, value, 0) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
+}
+
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
 constexpr int PREP_MAX_JOBS = 32, PREP_BLOCKS_PER_JOB = 64;
 struct prep_batch {

@@ -628,6 +628,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         xoff = (unsigned)b * (GH * 2) + q * 8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 128;
     }
+    // pipelined stack bookkeeping without divisions: chunk pk (ending before step phi) is the one being computed
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = 0, phi = cs_steps;
+    if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready, wait_value, a.status);      // chunk 0 of xp
     constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;     // bytes between gates / tiles
     constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
 #pragma unroll
@@ -663,6 +668,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         // the three per-lane offset seeds are "redefined" every step so that hipcc derives the others where they are
         // used instead of keeping a dozen loop-invariant registers
         pinu(hw0); pinu(tl0);
+        // pipelined stack: x of step t+1 is requested during this step - its chunk must have been published
+        if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready && t + 1 < T && t + 1 == phi)
+            wave_wait_ge(a.wait_ready + pk + 1, wait_value, a.status);
         unsigned char* hcur = hbuf;                                        // bf4 / tl0 / hw0 carry the buffer bit
         // Wave-uniform running pointers (SGPR pairs, one per gate: the 8 KiB between gates exceeds the instruction's
         // immediate range).  The pins stop hipcc from folding them back into per-lane 64-bit address arithmetic.
@@ -839,10 +847,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         STAMP(6);
         res_barrier();
         STAMP(7);
+        // pipelined stack: hs slot t (= h_{t-1}) left this step, so the chunk ending at step t-1 is complete
+        if (cs_steps && t == phi) {
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(a.signal_done + pk);
+            ++pk;
+            phi += cs_steps;
+        }
     }
     if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
         *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
         *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
+        if (cs_steps && a.signal_done) wave_signal_done(a.signal_done + pk);
     }
     vm_drain();
 }
@@ -1089,16 +1104,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const frag* tsrc = frag_ptr(0);             // T fragments: tiles 0..3 of k-group 0 are S2*64 fragments apart
 
     const int ub0 = w * 64 + q * 4;
-    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
+    unsigned lane16 = (unsigned)l * 16u;     // this lane's 16 bytes of a TILE16P pair / of a row-major copy chunk; half of it: TILE16
     // swizzled da-tile offsets (bytes), XOR-linear in (gate, tile) / k-group / copy chunk:
-    //   this lane's 4 values of (gate g, tile n): da0 ^ (g*512 + n*32)      B fragment ks: bb4[ks & 3] + 256*(ks >> 2)
+    //   this lane's 4 values of (gate g, tile n): da0 ^ (g*512 + n*32)      B fragment ks: (bb0 ^ ((ks&3) << 6)) + 256*(ks >> 2)
     //   copy chunk j (row 4w + j/2, 16-byte chunk (j&1)*64 + l): (tc0 ^ ((j>>1) << 4)) + (j>>1)*2048 + (j&1)*1024
     unsigned da0 = (unsigned)r * (GH * 2) + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
-    unsigned bb4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bb4[j] = (unsigned)r * (GH * 2) + ((((unsigned)j * 4u + (unsigned)q) ^ (unsigned)r) << 4);
+    unsigned bb0 = (unsigned)r * (GH * 2) + (((unsigned)q ^ (unsigned)r) << 4);     // B fragment ks: (bb0 ^ ((ks & 3) << 6)) + 256 * (ks >> 2)
     unsigned tc0 = 4u * w * (GH * 2) + ((((unsigned)l) ^ (4u * w)) << 4);
-    unsigned tg0 = (unsigned)l * 16u;
 
     f32x4 dh[RNT], dc[RNT];
     const int ldl = a.dh_last_ld ? a.dh_last_ld : RH;
@@ -1118,6 +1130,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
     da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
 
+    // pipelined stack bookkeeping: chunk pk (first step plo) is the one being processed; one division, before the loop
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;   // (the division runs on the VALU)
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status);
+    int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;      // step at whose start chunk pk-1 must be ready (-1: never)
+    int psig = (cs_steps && a.signal_done) ? plo : -1;                 // step after which chunk pk is published
     // saved forward values of the step about to be processed; acts / cs are TILE16P: element 0..3 of a 16-byte lane
     // chunk belong to tile 2j, 4..7 to tile 2j+1
     u16x8 qa[2][G], qs[2], carry[2];       // gates; c_{t-1}; c_t
@@ -1131,7 +1150,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     }
     if (HAS_EXT) {
 #pragma unroll
-        for (int n = 0; n < RNT; ++n) qd[n] = *reinterpret_cast<const g_u16x4*>(dx_p + n * 512 + lane8);
+        for (int n = 0; n < RNT; ++n) qd[n] = *reinterpret_cast<const g_u16x4*>(dx_p + n * 512 + (lane16 >> 1));
     }
     // from here on the pointers address step t-1 while step t runs
 #pragma unroll
@@ -1139,7 +1158,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     cs_p -= (T > 1 ? cs_step : 0);
     dx_p -= (T > 1 ? cs_step : 0);
 
-    frag bq[3], lt[4];
+    frag bq[2], lt[4];      // B fragments: one k-group ahead (a third ring slot costs 4 registers this kernel lacks)
     vm_drain();
     lds_barrier();
 
@@ -1148,8 +1167,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         (void)tstep;
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(acts_p[3]); pins(cs_p); pins(da_p);
         if (HAS_EXT) pins(dx_p);
-        pinu(da0); pinu(tc0);
+        pinu(da0); pinu(tc0); pinu(bb0);
         STAMP(0);
+        // pipelined stack: the upstream gradient of step t-1 is requested during this step's M phase
+        if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
         // ---- E: everything requested during the previous M phase has had that whole phase to arrive ------------
         vm_drain();
         STAMP(1);
@@ -1201,17 +1222,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         f32x4 acc[RNT];
 #pragma unroll
         for (int n = 0; n < RNT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bq[0] = *reinterpret_cast<const frag*>(dabuf + bb4[0]);
-        bq[1] = *reinterpret_cast<const frag*>(dabuf + bb4[1]);
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + bb0);
         static_for<0, FPW>(SF_LAMBDA(sc) {
             constexpr int sl = decltype(sc)::value, gi = sl >> 2, n = sl & 3, ci = sl - NT;
-            if constexpr (n == 0 && gi + 2 < S2)
-                bq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + bb4[(gi + 2) & 3] + 256 * ((gi + 2) >> 2));
+            if constexpr (n == 0 && gi + 1 < S2)
+                bq[(gi + 1) & 1] = *reinterpret_cast<const frag*>(dabuf + (bb0 ^ (((gi + 1) & 3) << 6)) + 256 * ((gi + 1) >> 2));
             if constexpr (sl == 0) asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-            if constexpr (sl < NT) mfma1<false>(acc[n], lt[n], bq[gi % 3]);
-            else if constexpr (ci < NA) mfma1<true>(acc[n], ua[ci < NA ? ci : 0], bq[gi % 3]);
-            else if constexpr (ci < NA + NV) mfma1<false>(acc[n], uv[(ci >= NA && ci < NA + NV) ? ci - NA : 0], bq[gi % 3]);
-            else mfma1<false>(acc[n], lt[n], bq[gi % 3]);
+            if constexpr (sl < NT) mfma1<false>(acc[n], lt[n], bq[gi & 1]);
+            else if constexpr (ci < NA) mfma1<true>(acc[n], ua[ci < NA ? ci : 0], bq[gi & 1]);
+            else if constexpr (ci < NA + NV) mfma1<false>(acc[n], uv[(ci >= NA && ci < NA + NV) ? ci - NA : 0], bq[gi & 1]);
+            else mfma1<false>(acc[n], lt[n], bq[gi & 1]);
             constexpr int cn = ci + 4;      // the next group's fragment for this tile
             if constexpr (sl + 4 < FPW && cn >= NA + NV && !ABL_NOL) lt[n] = myl[(size_t)(cn - NA - NV) * 64];
             __builtin_amdgcn_sched_barrier(0);
@@ -1226,16 +1246,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
                     pinu(lane16);
                     qs[k - 8] = *reinterpret_cast<const g_u16x8*>(cs_p + (k - 8) * 1024 + lane16);
                 } else if constexpr (HAS_EXT) {
-                    pinu(lane8);
-                    qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + lane8);
+                    unsigned l8 = lane16 >> 1;
+                    pinu(l8);
+                    qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + l8);
                 }
             }
             if constexpr (!ABL_NOTRG && sl >= 50 && sl < 50 + 4 * 8 + 8 && (sl - 50) % 4 == 0) {
                 constexpr int j = (sl - 50) / 4;               // read chunk j (j < 8), store chunk j - 2
                 if constexpr (j >= 2) {
                     constexpr int js = j - 2;
-                    pinu(tg0);
-                    *reinterpret_cast<g_u16x8*>(da_p + (js >> 1) * 2048 + (js & 1) * 1024 + tg0) = lt[js & 3];
+                    pinu(lane16);
+                    *reinterpret_cast<g_u16x8*>(da_p + (js >> 1) * 2048 + (js & 1) * 1024 + lane16) = lt[js & 3];
                 }
                 if constexpr (j < 8)
                     lt[j & 3] = *reinterpret_cast<const frag*>(dabuf + (tc0 ^ ((j >> 1) << 4)) + (j >> 1) * 2048 + (j & 1) * 1024);
@@ -1253,6 +1274,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         STAMP(7);
         res_barrier();
         STAMP(8);
+        // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
+        wave_signal_done_if(t, psig, a.signal_done + pk);
+        {   // scalar bookkeeping (s_cselect, no branch): next chunk once its first step has been processed
+            const bool adv = cs_steps && t == plo;
+            pk -= adv ? 1 : 0;
+            plo -= adv ? cs_steps : 0;
+            pwait = (a.wait_ready && plo > 0) ? plo : -1;
+            psig = a.signal_done ? plo : -1;
+        }
     }
     const int ldd = a.dh0_ld ? a.dh0_ld : RH;
 #pragma unroll

@@ -82,10 +82,16 @@ class Engine(object):
             self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
             self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
+            self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
         # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
         self.time_chunks = 4
+        # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
+        # every pipe_chunk time steps (no relaunch, no weight reload, layers 32 steps apart instead of T/4)
+        self.pipeline = True
+        self.pipe_chunk = 32
+        self.pipe_gemm_blocks = 64       # persistent grid of the projection / dX GEMM between two pipelined layers
         # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
         # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
         # Parameter-gradient GEMMs once per layer (after its last BPTT chunk), NOT per time chunk: throughput GEMMs running
@@ -225,6 +231,9 @@ class Engine(object):
             st[name] = torch.zeros(int(n), **kw)
 
         esz = dict(dtype=dt, device=dev)
+        # time-pipelined stacks: progress counters / ready flags (4 stack slots x 1024 words) and the time-out status word
+        st["sync"] = torch.zeros(4 * 1024, dtype=torch.int32, device=dev)
+        st["pipe_status"] = torch.zeros(1, dtype=torch.int32, device=dev)
         for r in self.all_rec:
             p = r.prefix
             buf(p + ".u_pack", GH * H, **esz)
@@ -432,7 +441,7 @@ class Engine(object):
         return n
 
     def _rec_forward(self, r, B, k=0, nch=1, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None,
-                     start=None):
+                     start=None, pipe=None, xp_external=False):
         """Time chunk k of nch of one recurrent layer (B = padded batch).  Chunk 0 starts from (h0, c0); later chunks
         from the f32 state the previous launch left in <layer>.sh/.sc; the last chunk also writes ``h_last``."""
         s, P, p = self.spec, self.P, r.prefix
@@ -455,11 +464,12 @@ class Engine(object):
                 ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])      # start W + b (Appendix A.6)
             kw.update(xp0=xp0)
         else:
-            lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc]
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
-            ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, Tc * B, GH, H, trans_b=True, bias=P[p + ".b"],
-                     c_layout=self.lay)
+            if not xp_external:      # (pipelined stacks produce xp chunk by chunk on the projection stream: _rec_xp)
+                self._rec_xp(r, B, k, nch)
             kw.update(xp=xp)
+        if pipe:
+            kw.update(pipe)
         lstm = s.cell == "LSTM"
         last = k == nch - 1
         if k > 0:
@@ -472,8 +482,70 @@ class Engine(object):
             h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
             c_last=(sc if (lstm and not last) else None), seq_layout=self._seq_layout(r), **kw), steps=Tc)
 
-    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
+    def _rec_xp(self, r, B, k=0, nch=1, **chunked):
+        """Input projection x*W + b of a stacked layer (x = the lower layer's h sequence), time chunk k of nch; or, with
+        the chunk_* arguments of ops.gemm, the whole sequence as ONE persistent launch (time-pipelined stacks)."""
+        s, P, p = self.spec, self.P, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        Tc = T // nch
+        t0 = k * Tc
+        lower_hs = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc]
+        xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
+        ops.gemm(lower_hs, self._v(p + ".wt", GH, H), xp, Tc * B, GH, H, trans_b=True, bias=P[p + ".b"], c_layout=self.lay,
+                 **chunked)
+
+    # ---- time-pipelined stacks (slot-interleaved LSTM kernels) ---------------------------------------------------
+    def _pipelined(self, layers):
+        """ONE launch per layer for the whole sequence; layer l+1 follows layer l at a distance of ``pipe_chunk`` time
+        steps, released chunk by chunk through device-side counters (include/midivae_hip.h, 'time-pipelined stacks')
+        instead of one launch per (layer, chunk)."""
+        T = layers[0].T
+        return (self.pipeline and self.multi_stream and not self.use_graphs and len(layers) > 1 and
+                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 64 and
+                all(self._seq_layout(r) == hl.TILE16P for r in layers))
+
+    def _sync_region(self, slot, n_if, nchp):
+        """zeroed [n_if][2][nchp] int32 words (progress counters, ready flags) for pipelined stack number ``slot``"""
+        reg = self.store["sync"][slot * 1024: slot * 1024 + n_if * 2 * nchp].view(n_if, 2, nchp)
+        reg.zero_()
+        return reg
+
+    def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
+        cs = self.pipe_chunk
+        T = layers[0].T
+        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
+        L = len(layers)
+        sync = self._sync_region(slot, L - 1, nchp)          # [interface][0: hs chunks published, 1: xp chunks published][chunk]
+        status = self.store["pipe_status"]
+        lower_streams = self.s_layer[:L - 1]              # layer l < L-1 on lower_streams[l]; the top layer on this stream
+        gemm_streams = self.s_proj[:L - 1]
+        self._fork(*lower_streams, *gemm_streams)
+        for li, r in enumerate(layers):
+            top = li == L - 1
+            st = states(r) if states else {}
+            pipe = dict(chunk_steps=cs, status=status)
+            if li > 0:
+                pipe.update(wait_ready=sync[li - 1, 1], wait_value=pwaves)
+            if not top:
+                pipe["signal_done"] = sync[li, 0]
+            def run():
+                self._rec_forward(r, B, 0, 1, idx=idx, start=start, h_last=h_last if top else None,
+                                  h_last_ld=h_last_ld if top else 0, pipe=pipe, xp_external=li > 0, **st)
+            if top:
+                run()
+            else:
+                with torch.cuda.stream(lower_streams[li]):
+                    run()
+                with torch.cuda.stream(gemm_streams[li]):     # projection for the layer above: one persistent launch
+                    self._rec_xp(layers[li + 1], B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B,
+                                 chunk_wait=sync[li, 0], chunk_wait_value=nwaves, chunk_done=sync[li, 1], chunk_status=status)
+        self._join(*lower_streams, *gemm_streams)
+
+    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
+        if self._pipelined(layers):
+            return self._stack_forward_pipe(layers, B, slot, states=states, h_last=h_last, h_last_ld=h_last_ld, idx=idx,
+                                            start=start)
         nch = self._nchunks(layers)
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[torch.cuda.Event() for _ in range(nch)] for _ in layers]
@@ -516,7 +588,7 @@ class Engine(object):
             with self._on(self.s_vel):
                 self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H],
                                   h_last_ld=ldc)
-        self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc)
+        self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._join(self.s_vel, self.s_instr)
         h = cat
         if self.has_pack:
@@ -581,7 +653,7 @@ class Engine(object):
                          probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
                          dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
                          scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
-        self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout))
+        self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout), slot=1)
         top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
         ops.head(0, self.kind, T * B, H, s.Dout, top, self._v("notes.wt", self.np_notes, H), P["dec.notes.out.b"],
                  target_idx=self._v("in.y_idx", T * B) if tg else None,
@@ -600,7 +672,8 @@ class Engine(object):
         # tiles x splits ~ the CU count; more splits only add atomic traffic (212 vs 367 TFLOP/s at 64 vs 16)
         return int(min(16, max(1, K // 8192)))
 
-    def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0):
+    def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0,
+                  pipe=None):
         """BPTT over time chunk k (chunks run from the LAST to the first) + the gradient for the layer below."""
         s, p = self.spec, r.prefix
         H, GH, T = s.H, s.GH, r.T
@@ -618,9 +691,9 @@ class Engine(object):
             dc_last=(None if (first or not lstm) else sc),
             rh=self._v(p + ".rh", T, B, H)[t0:t0 + Tc] if s.cell == "GRU" else None,
             dh0=(dh0 if final else sh), dc0=((dc0 if final else sc) if lstm else None), dh0_ld=(dh0_ld if final else 0),
-            seq_layout=self._seq_layout(r)), steps=Tc)
+            seq_layout=self._seq_layout(r), **(pipe or {})), steps=Tc)
 
-    def _rec_dx(self, r, B, k=0, nch=1):
+    def _rec_dx(self, r, B, k=0, nch=1, **chunked):
         """Gradient w.r.t. the input sequence of layer ``r`` (= what the layer below receives at its h_t), time chunk k.
         Runs on the LOWER layer's stream, right before that layer's BPTT of the chunk: the upper layer's next chunk
         launches without waiting for it."""
@@ -630,7 +703,8 @@ class Engine(object):
         t0 = k * Tc
         da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
         dx = self._v(p + ".dx", T, B, H)[t0:t0 + Tc]
-        ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay)
+        ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
+                 **chunked)
 
     def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
@@ -674,9 +748,48 @@ class Engine(object):
                     lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc].reshape(R, H)
                     ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
 
+    def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
+                             xs=None, start=None):
+        cs = self.pipe_chunk
+        T = layers[0].T
+        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
+        order = list(reversed(layers))               # order[0] = top layer: runs on this stream, publishes da
+        L = len(order)
+        sync = self._sync_region(slot, L - 1, nchp)
+        status = self.store["pipe_status"]
+        lower_streams = self.s_layer[:L - 1]         # order[li], li >= 1, on lower_streams[li - 1]
+        gemm_streams = self.s_proj[:L - 1]
+        self._fork(*lower_streams, *gemm_streams)
+        for li, r in enumerate(order):
+            top = li == 0
+            ds = dstates(r) if dstates else {}
+            pipe = dict(chunk_steps=cs, status=status)
+            if li > 0:
+                pipe.update(wait_ready=sync[li - 1, 1], wait_value=pwaves)
+            if li < L - 1:
+                pipe["signal_done"] = sync[li, 0]
+            def run():
+                ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
+                self._rec_bptt(r, B, 0, 1, dhs_ext=ext, dh_last=dh_last if top else None,
+                               dh_last_ld=dh_last_ld if top else 0, pipe=pipe, **ds)
+                self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
+            if top:
+                run()
+            else:
+                with torch.cuda.stream(lower_streams[li - 1]):
+                    run()
+            if li < L - 1:
+                with torch.cuda.stream(gemm_streams[li]):     # dX for the layer below, from the last chunk to the first
+                    self._rec_dx(r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True,
+                                 chunk_wait=sync[li, 0], chunk_wait_value=nwaves, chunk_done=sync[li, 1], chunk_status=status)
+        self._join(*lower_streams, *gemm_streams)
+
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
-                        start=None):
+                        start=None, slot=0):
         """BPTT through a stack (top layer first), pipelined over time chunks in reverse order."""
+        if self._pipelined(layers):
+            return self._stack_backward_pipe(layers, B, slot, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
+                                             dstates=dstates, idx=idx, xs=xs, start=start)
         nch = self._nchunks(layers)
         order = list(reversed(layers))               # order[0] = top layer
         streams = [None] + self.s_layer[:len(layers) - 1]
@@ -752,7 +865,8 @@ class Engine(object):
                 self._stack_backward([self.dec_vel], B, dhs_ext=dext, start=self._v("in.start_vel", B, 1), dstates=dstates)
         dext = self._head_backward(B, "notes", self.dec_notes[-1], s.Dout, self.np_notes, "dec.notes.out.W",
                                    "dec.notes.out.b")
-        self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates)
+        self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates,
+                             slot=2)
         self._join(self.s_vel, self.s_instr)
         self._mark("  decoder BPTT")
         # initial-state Denses: S = tanh([z|hist] Winit + b)
@@ -822,7 +936,7 @@ class Engine(object):
             with self._on(self.s_vel):
                 self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                      xs=self._v("in.vel", T, B))
-        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B))
+        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
         self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
 
     # ------------------------------------------------------------------------------------------------------
@@ -939,10 +1053,18 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     # results
     # ------------------------------------------------------------------------------------------------------
+    def check_pipeline(self):
+        """Raises if a kernel of a time-pipelined stack gave up waiting for its input (results of that step are invalid)."""
+        if int(self.store["pipe_status"].item()) != 0:
+            self.store["pipe_status"].zero_()
+            raise RuntimeError("a time-pipelined recurrent kernel timed out waiting for its producer (stream / hardware "
+                               "queue aliasing?); set Engine.pipeline = False")
+
     def metrics(self, B) -> "OrderedDict[str, float]":
         """Losses / accuracies of the last step with the oracle's key names (one device->host copy)."""
         s = self.spec
         v = self.scal.cpu().numpy().astype(np.float64)
+        self.check_pipeline()
         m = OrderedDict()
         m["kl"] = v[S_KL]
         m["notes_loss"], m["notes_acc"] = v[S_NOTES_LOSS], v[S_NOTES_HITS] / (B * s.T)

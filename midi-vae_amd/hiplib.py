@@ -31,20 +31,26 @@ class RnnFwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("xmode", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("u_pack", _vp), ("xp", _vp), ("idx", _vp), ("table", _vp), ("xs", _vp), ("w_row", _vp),
                 ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
-                ("h_last", _vp), ("c_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32), ("seq_layout", _i32)]
+                ("h_last", _vp), ("c_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32),
+                ("chunk_steps", _i32), ("wait_ready", _vp), ("wait_value", C.c_uint32), ("signal_done", _vp), ("status", _vp),
+                ("seq_layout", _i32)]
 
 
 class RnnBwdArgs(C.Structure):
     _fields_ = [("cell", _i32), ("dtype", _i32), ("T", _i32), ("B", _i32), ("H", _i32),
                 ("ut_pack", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp), ("dhs_ext", _vp), ("dh_last", _vp),
-                ("dc_last", _vp), ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32), ("seq_layout", _i32)]
+                ("dc_last", _vp), ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32),
+                ("chunk_steps", _i32), ("wait_ready", _vp), ("wait_value", C.c_uint32), ("signal_done", _vp), ("status", _vp),
+                ("seq_layout", _i32)]
 
 
 class GemmArgs(C.Structure):
     _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("trans_a", _i32), ("trans_b", _i32),
                 ("a_kind", _i32), ("b_kind", _i32), ("c_kind", _i32), ("lda", _i32), ("ldb", _i32), ("ldc", _i32),
                 ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
-                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32)]
+                ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32),
+                ("sys_release", _i32), ("chunk_rows", _i32), ("chunk_reverse", _i32), ("chunk_wait", _vp),
+                ("chunk_wait_value", C.c_uint32), ("chunk_done", _vp), ("chunk_status", _vp)]
 
 
 class PrepJob(C.Structure):
@@ -84,6 +90,8 @@ SIGNATURES = {
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mvae_stream_wait_value32": (_i32, [_vp, _vp, C.c_uint32]),
+    "mvae_stream_write_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),

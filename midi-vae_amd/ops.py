@@ -50,7 +50,8 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
-            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, c_last=None, h0_ld=0, h_last_ld=0, seq_layout=0):
+            h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, c_last=None, h0_ld=0, h_last_ld=0, seq_layout=0,
+            chunk_steps=0, wait_ready=None, wait_value=0, signal_done=None, status=None):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -61,19 +62,22 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
         xmode = hl.X_CONST
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _pv(xp), _pv(idx), _p(table), _pv(xs), _p(w_row),
                       _p(bias), _p(xp0), _pv(h0), _pv(c0), _pv(hs), _pv(cs), _pv(acts), _pv(h_last), _pv(c_last), h0_ld, h_last_ld,
-                      seq_layout)
+                      chunk_steps, _pv(wait_ready), int(wait_value), _pv(signal_done), _pv(status), seq_layout)
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, dc_last=None, rh=None,
-            dh0=None, dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0):
+            dh0=None, dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0, chunk_steps=0, wait_ready=None, wait_value=0,
+            signal_done=None, status=None):
     a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _pv(hs), _pv(cs), _pv(acts), _pv(dhs_ext), _pv(dh_last),
-                      _pv(dc_last), _pv(da), _pv(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, seq_layout)
+                      _pv(dc_last), _pv(da), _pv(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, chunk_steps, _pv(wait_ready),
+                      int(wait_value), _pv(signal_done), _pv(status), seq_layout)
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
-         accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0):
+         accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0, sys_release=False, chunk_rows=0,
+         chunk_reverse=False, chunk_wait=None, chunk_wait_value=0, chunk_done=None, chunk_status=None):
     """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths."""
     a_kind = kind_of(A) if a_kind is None else a_kind
     if lda is None:
@@ -83,8 +87,22 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
     if ldc is None:
         ldc = N
     g = hl.GemmArgs(M, N, K, int(trans_a), int(trans_b), a_kind, kind_of(B), kind_of(C), lda, ldb, ldc,
-                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks)
+                    int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks,
+                    int(sys_release), int(chunk_rows), int(chunk_reverse), _pv(chunk_wait), int(chunk_wait_value), _pv(chunk_done),
+                    _pv(chunk_status))
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
+
+
+def stream_wait_value32(word, value, stream=None):
+    """the current (or given) stream proceeds once the 32-bit device word ``word`` (a 1-element view) is >= value"""
+    hl.check(hl.load().mvae_stream_wait_value32(_stream() if stream is None else stream.cuda_stream, _p(word), int(value)),
+             "mvae_stream_wait_value32")
+
+
+def stream_write_value32(word, value, stream=None):
+    """writes ``value`` to the 32-bit device word after everything enqueued so far on the stream"""
+    hl.check(hl.load().mvae_stream_write_value32(_stream() if stream is None else stream.cuda_stream, _p(word), int(value)),
+             "mvae_stream_write_value32")
 
 
 def colsum(X, R, N, out, ldx=None):

@@ -169,6 +169,36 @@ def test_time_chunk_pipelining_is_exact(cell, dtype):
             assert _rel_l2(g[k], res[1][1][k]) < 1e-4, k       # chunked == un-chunked up to atomic-add ordering
 
 
+def test_time_pipelined_stacks_match_chunked_launches():
+    """H=256 bf16 LSTM: the stacked layers run as ONE launch per layer with device-side hand-over every pipe_chunk steps
+    (counters + stream wait / write values).  Same kernels, same arithmetic as the chunk-per-launch schedule: the losses
+    and every gradient must agree up to the atomic-add ordering of the gradient GEMMs, for several steps in a row."""
+    B = 32
+    spec, params, batch, raw = _problem("LSTM", B, seed=31, H=256, Z=64, T=64)
+    res = {}
+    for pipe in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.pipeline, eng.pipe_chunk = pipe, 16
+        assert eng._pipelined(eng.enc_notes) == pipe
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        out = []
+        for _ in range(3):
+            eng.forward_backward(B)
+            out.append((eng.metrics(B), eng.get_grads()))
+        res[pipe] = out
+    for (m1, g1), (m0, g0) in zip(res[True], res[False]):
+        assert abs(m1["loss"] - m0["loss"]) <= 1e-5 * (1 + abs(m0["loss"]))
+        for k in g0:
+            if np.linalg.norm(g0[k]) > 1e-9:
+                assert _rel_l2(g1[k], g0[k]) < 1e-4, (k, _rel_l2(g1[k], g0[k]))
+    # and against the oracle, like every other configuration
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    assert abs(res[True][0][0]["loss"] - m_o["loss"]) <= 3e-2 * (1 + abs(m_o["loss"]))
+
+
 def test_ragged_batch_reuses_buffers():
     """A smaller last minibatch (songs are not multiples of batch_size) runs in the same engine."""
     spec, params, batch, raw = _problem("GRU", 5, seed=2)

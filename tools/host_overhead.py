@@ -11,6 +11,7 @@ from midi_vae_amd.synth import make_windows
 ap = argparse.ArgumentParser()
 ap.add_argument("--cell", default="LSTM"); ap.add_argument("--chunks", type=int, default=0)
 ap.add_argument("--no-side-grads", action="store_true");
+ap.add_argument("--pipe-chunk", type=int, default=-1, help="0 = pipeline off");
 ap.add_argument("--grad-blocks", type=int, default=0); ap.add_argument("--no-chunk-grads", action="store_true"); ap.add_argument("--one-grad-stream", action="store_true")
 a = ap.parse_args()
 T, B = 512, 256
@@ -19,6 +20,10 @@ eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
 if a.chunks:
     eng.time_chunks = a.chunks
 eng.grad_gemm_blocks = a.grad_blocks
+if a.pipe_chunk == 0:
+    eng.pipeline = False
+elif a.pipe_chunk > 0:
+    eng.pipe_chunk = a.pipe_chunk
 eng.side_grads = not a.no_side_grads
 if a.no_chunk_grads:
     eng.grad_per_chunk = False
