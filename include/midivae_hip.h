@@ -101,7 +101,7 @@ typedef struct {
     const uint32_t* wait_ready;  /* [chunks] chunk k of xp may be read once wait_ready[k] >= wait_value (kernel polls)    */
     uint32_t wait_value;         /* 0 = 1                                                                                 */
     uint32_t* signal_done;       /* [chunks] += 1 per WAVE (4 * B/16 of them) once chunk k of hs is complete and visible  */
-    uint32_t* status;            /* [1] set non-zero if a wait timed out (~2 s): results are invalid                      */
+    uint32_t* status;            /* [1] set non-zero if a wait timed out (~0.5 s): results are invalid                      */
     int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR, MVAE_TILE16 or
                               MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
                               (H=256, bf16): TILE16 the phased ones (GRU, LSTM), TILE16P the slot-interleaved LSTM

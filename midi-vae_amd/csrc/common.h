@@ -138,7 +138,7 @@ __device__ __forceinline__ void lds_barrier() {
 // increment per producer wave.
 //
 // wave_wait_ge: until *flag >= value (system-scope loads), then drop this XCD's possibly stale cache lines of the data the
-// flag guards.  Bounded (~2 s): then *status = 1 and the kernel carries on - it never hangs.
+// flag guards.  Bounded (~0.5 s): then *status = 1 and the kernel carries on - it never hangs.
 __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status) {
     unsigned tmp, spins, val;
     asm volatile(
@@ -152,14 +152,14 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         "s_cbranch_scc1 L_ready_%=\n\t"
         "s_sleep 8\n\t"
         "s_add_u32 %1, %1, 1\n\t"
-        "s_cmp_lt_u32 %1, 0x1000000\n\t"
+        "s_cmp_lt_u32 %1, 0x80000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         "buffer_inv sc0 sc1"
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(flag), "s"(value)
         : "memory", "scc");
-    if (spins >= 0x1000000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the same under a scalar condition evaluated inside the block: if (t == bound) wait
 __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status) {
@@ -177,7 +177,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         "s_cbranch_scc1 L_ready_%=\n\t"
         "s_sleep 8\n\t"
         "s_add_u32 %1, %1, 1\n\t"
-        "s_cmp_lt_u32 %1, 0x1000000\n\t"
+        "s_cmp_lt_u32 %1, 0x80000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         "buffer_inv sc0 sc1\n"
@@ -185,7 +185,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(t), "s"(bound), "s"(flag), "s"(value)
         : "memory", "scc");
-    if (spins >= 0x1000000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // This wave's global stores so far are written back to memory, then ONE increment (by its first lane) of the counter.
 __device__ __forceinline__ void wave_signal_done(uint32_t* counter) {

@@ -104,6 +104,7 @@ class Engine(object):
         self._alloc(self.maxB)
         self._views_cache = {}
         self._prep = None
+        self._pipe_verified = False
 
     def _seq_layout(self, r):
         """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM kernels (TILE16P saved
@@ -966,6 +967,23 @@ class Engine(object):
         self._mark("decoder forward + heads")
         self.backward(B)
         self._mark("backward")
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
+                                       self.backward(B)))
+
+    def _verify_pipeline(self, redo):
+        """First use of time-pipelined stacks: make sure no kernel gave up waiting for its producer (that can only happen if
+        two of the engine's streams share a hardware queue, e.g. GPU_MAX_HW_QUEUES was overridden).  If one did, fall back
+        to one launch per chunk and redo the work."""
+        if not self.pipeline or self._pipe_verified:
+            return
+        self._pipe_verified = True
+        if int(self.store["pipe_status"].item()) != 0:
+            import warnings
+            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers; falling back to chunked "
+                          "launches (Engine.pipeline = False)")
+            self.store["pipe_status"].zero_()
+            self.pipeline = False
+            redo()
 
     def train_step(self, B, allreduce=None):
         """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.
@@ -1032,6 +1050,7 @@ class Engine(object):
             self.prepare_weights()
         self.encoder_forward(B)
         self.decoder_forward(B, want_probs=want_probs)
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B), self.decoder_forward(B, want_probs=want_probs)))
 
     def encode(self, B):
         """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
@@ -1040,6 +1059,7 @@ class Engine(object):
         if self._weights_dirty:
             self.prepare_weights()
         self.encoder_forward(B)
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B)))
         return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
 
     def decode(self, B, want_probs=True):
@@ -1049,6 +1069,7 @@ class Engine(object):
         if self._weights_dirty:
             self.prepare_weights()
         self.decoder_forward(B, want_probs=want_probs)
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.decoder_forward(B, want_probs=want_probs)))
 
     # ------------------------------------------------------------------------------------------------------
     # results
