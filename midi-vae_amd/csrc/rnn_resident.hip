@@ -717,7 +717,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         // move in lockstep through 16 single-instruction stages, one stage per MFMA slot: 2 VALU per slot is what a
         // 16-cycle MFMA hides (tools/probes/slot_probe.hip), and the partner's instruction separates every exp / rcp
         // from its consumer (no hazard nops).
-        float tf[4];
         auto piece = [&](auto mc, auto slc, f32x4* P) __attribute__((always_inline)) {
             // (the tail - no MFMAs to hide under - runs each stage for all 4 elements: 4 independent chains)
             constexpr int m = decltype(mc)::value, sl = decltype(slc)::value;
@@ -736,8 +735,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
                 if constexpr (sub == 5) P[2][e] = P[2][e] + 1.0f;
                 if constexpr (sub == 6) P[2][e] = ABL_NOTRANS ? P[2][e] * 0.5f : __builtin_amdgcn_rcpf(P[2][e]);
                 if constexpr (sub == 7) P[2][e] = 1.0f - 2.0f * P[2][e];
-                if constexpr (sub == 8) tf[k] = P[1][e] * creg[m][e];
-                if constexpr (sub == 9) creg[m][e] = P[0][e] * P[2][e] + tf[k];
+                if constexpr (sub == 8) creg[m][e] = P[1][e] * creg[m][e];             // f * c_{t-1}, in place
+                if constexpr (sub == 9) creg[m][e] = P[0][e] * P[2][e] + creg[m][e];   // + i * g
                 if constexpr (sub == 10) hn[e] = creg[m][e] * K2;
                 if constexpr (sub == 11) hn[e] = ABL_NOTRANS ? hn[e] * 0.5f : __builtin_amdgcn_exp2f(hn[e]);
                 if constexpr (sub == 12) hn[e] = hn[e] + 1.0f;
