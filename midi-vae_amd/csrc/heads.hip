@@ -20,10 +20,15 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
     typedef typename op<WT>::frag frag;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
     const int R = a.R, H = a.H, N = a.N, NP = NTL * 16;
-    const int row0 = (blockIdx.x * 4 + w) * 16;
-    if (row0 >= R) return;
     const WT* __restrict__ hs = reinterpret_cast<const WT*>(a.hs);
     const WT* __restrict__ wt = reinterpret_cast<const WT*>(a.wt);
+    float loss_acc = 0.0f, hit_acc = 0.0f;
+    WT* __restrict__ dl = reinterpret_cast<WT*>(a.dlogits);
+    __shared__ float stage[KIND == 0 ? 4 * 16 * NTL * 16 : 1];       // [wave][16 rows][NP] d(logits)
+    __shared__ float wg_part[4][2];
+    // A bounded grid walks the rows (16 per wave and pass): the two loss / accuracy scalars are ONE pair of atomics per
+    // workgroup - 8192 waves adding to the same two addresses used to take 200 of this kernel's 250 us.
+    for (int row0 = (blockIdx.x * 4 + w) * 16; row0 < R; row0 += gridDim.x * 64) {
     const int ra = min(row0 + r, R - 1);
 
     f32x4 acc[NTL];
@@ -41,8 +46,6 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
 #pragma unroll
     for (int n = 0; n < NTL; ++n) bias[n] = (n * 16 + r < N) ? a.bias[n * 16 + r] : 0.0f;
 
-    float loss_acc = 0.0f, hit_acc = 0.0f;
-    WT* __restrict__ dl = reinterpret_cast<WT*>(a.dlogits);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + q * 4 + i;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
             float p[NTL], sum = 0.0f;
 #pragma unroll
             for (int n = 0; n < NTL; ++n) {
-                p[n] = expf(lg[n] - mx);
+                p[n] = __builtin_amdgcn_exp2f((lg[n] - mx) * 1.4426950408889634f);     // v_exp_f32 (rel. error ~1e-6)
                 sum += p[n];
             }
             sum = group16_sum(sum);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
             am = group16_min_i(am);                                    // first maximum (NumPy argmax tie rule)
             const bool has_t = tg < N;
             const bool inside = has_t && pt >= CE_EPS && pt <= 1.0f - CE_EPS;
-            const float ce = has_t ? -logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
+            const float ce = has_t ? -0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
             if (rv && r == 0) {
                 loss_acc += rw * ce;
                 hit_acc += (counted && am == (has_t ? tg : 0)) ? 1.0f : 0.0f;
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
                     if (a.probs && col < N) a.probs[(size_t)row * N + col] = p[n];
                     if (a.want_grad) {
                         const float g = inside ? a.grad_scale * rw * (p[n] - (col == tg ? 1.0f : 0.0f)) : 0.0f;
-                        st<WT>::store(dl + (size_t)row * NP + col, col < N ? g : 0.0f);
+                        // staged in LDS: a lane owns single columns here, the row-major rows leave as 16-byte chunks
+                        stage[(w * 16 + q * 4 + i) * NP + col] = col < N ? g : 0.0f;
                     }
                 }
             }
@@ -114,12 +118,30 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
             }
         }
     }
+    if (KIND == 0 && a.want_grad) {
+        // this wave's 16 x NP tile, row-major: 4 values (8 / 16 bytes) per lane and pass
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float* mine = stage + w * 16 * NP;
+#pragma unroll
+        for (int e = l * 4; e < 16 * NP; e += 256) {
+            const int rr = e / NP, cc = e % NP;
+            if (row0 + rr < R) st<WT>::store4(dl + (size_t)(row0 + rr) * NP + cc, *reinterpret_cast<const f32x4*>(mine + e));
+        }
+    }
+        __builtin_amdgcn_wave_barrier();        // the stage tile is reused by the next pass
+    }   // row loop
     if (a.scalars) {
         loss_acc = wave_sum(loss_acc);
         hit_acc = wave_sum(hit_acc);
         if (l == 0) {
-            atomicAdd(a.scalars, loss_acc);
-            atomicAdd(a.scalars + 1, hit_acc);
+            wg_part[w][0] = loss_acc;
+            wg_part[w][1] = hit_acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(a.scalars, wg_part[0][0] + wg_part[1][0] + wg_part[2][0] + wg_part[3][0]);
+            atomicAdd(a.scalars + 1, wg_part[0][1] + wg_part[1][1] + wg_part[2][1] + wg_part[3][1]);
         }
     }
 }
@@ -127,7 +149,8 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
 template <typename WT, int KIND>
 int launch(const mvae_head_args& a, hipStream_t s) {
     const int ntl = (a.N + 15) / 16;
-    const dim3 grid((a.R + 63) / 64), block(256);
+    const int need = (a.R + 63) / 64;
+    const dim3 grid(need < 1024 ? need : 1024), block(256);
     switch (ntl) {
         case 1: hipLaunchKernelGGL((head_k<WT, 1, KIND>), grid, block, 0, s, a); break;
         case 2: hipLaunchKernelGGL((head_k<WT, 2, KIND>), grid, block, 0, s, a); break;
