@@ -46,7 +46,12 @@ template <> struct st<bf16_t> {
 // ---- activations (Keras semantics) ---------------------------------------------------
 __device__ __forceinline__ float hard_sigmoid(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
 // derivative from the OUTPUT y: 0.2 strictly inside (0,1)
-__device__ __forceinline__ float dhard_sigmoid(float y) { return (y > 0.0f && y < 1.0f) ? 0.2f : 0.0f; }
+// derivative in terms of the OUTPUT y in [0, 1]: 0.2 * [0 < y < 1].  Without compares (2 VALU instead of 3 + 1 SALU):
+// y - y^2 > 0 exactly for the interior (0 and 1 are exact), and med3(2^100 * (y - y^2), 0, 0.2) is 0.2 times that.
+__device__ __forceinline__ float dhard_sigmoid(float y) {
+    const float sq = y - y * y;
+    return __builtin_amdgcn_fmed3f(sq * 0x1p100f, 0.0f, 0.2f);
+}
 __device__ __forceinline__ float tanh_f(float x) { return tanhf(x); }   // ocml: accurate near 0 (parity mode)
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 // bf16-mode tanh: 1 - 2/(1+e^{2x}) on the hardware exp2 / rcp units (5 VALU instead of ocml's ~40).  Absolute

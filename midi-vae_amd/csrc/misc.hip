@@ -90,9 +90,10 @@ __global__ void colsum_k(const WT* __restrict__ X, const float* __restrict__ wgt
 // bf16, N % 8 == 0, 16-byte aligned rows: each thread owns 8 columns (one 16-byte load per row), the block's 256
 // threads cover 256 / (N/8) rows at a time; partial sums meet in LDS, one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_bf16x8_k(const bf16_t* __restrict__ X, const float* __restrict__ wgt, int R, int N,
-                                                       int ldx, int rows_per_block, float* __restrict__ out) {
+                                                       int Nv /* N rounded up to 8: columns read */, int ldx, int rows_per_block,
+                                                       float* __restrict__ out) {
     __shared__ float red[256 * 8];
-    const int c8 = N / 8, lanes_r = 256 / c8;           // c8 in {1,2,4,...,256}: callers check N/8 divides 256
+    const int c8 = Nv / 8, lanes_r = 256 / c8;          // c8 in {1,2,4,...,256}: callers check Nv/8 divides 256
     const int col = (threadIdx.x % c8) * 8, rsub = threadIdx.x / c8;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -275,8 +276,9 @@ extern "C" int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream) {
 
 static int colsum_impl(const void* X, int32_t kind, const float* wgt, int32_t R, int32_t N, int32_t ldx, float* out, hipStream_t s) {
     if (!X || !out || R <= 0 || N <= 0 || ldx < N) return MVAE_E_ARG;
-    const int c8 = N / 8;
-    const bool vec = kind == MVAE_BF16 && (N % 8) == 0 && c8 <= 256 && (256 % c8) == 0 && (ldx % 8) == 0 &&
+    // (N not a multiple of 8 - 61 note classes in rows of 64: the pad columns are read and not written)
+    const int Nv = (N + 7) / 8 * 8, c8 = Nv / 8;
+    const bool vec = kind == MVAE_BF16 && Nv <= ldx && c8 <= 256 && (256 % c8) == 0 && (ldx % 8) == 0 &&
                      (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (vec) {
         // enough blocks to fill the chip, enough rows per block to amortise the LDS reduction and the atomics
@@ -284,7 +286,7 @@ static int colsum_impl(const void* X, int32_t kind, const float* wgt, int32_t R,
         const int lanes_r = 256 / c8;
         if (rpb < 16 * lanes_r) rpb = 16 * lanes_r;
         const int blocks = (R + rpb - 1) / rpb;
-        hipLaunchKernelGGL(colsum_bf16x8_k, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, wgt, R, N, ldx, rpb, out);
+        hipLaunchKernelGGL(colsum_bf16x8_k, dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, wgt, R, N, Nv, ldx, rpb, out);
         MVAE_CHECK_LAUNCH();
         return MVAE_OK;
     }

@@ -1199,10 +1199,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
             for (int i = 0; i < 4; ++i) {
                 const float tc = tanh_fast(c[i]);
                 const float dct = dc[n][i] + d[i] * og[i] * (1.0f - tc * tc);
-                di[i] = dct * gg[i] * dhard_sigmoid(ig[i]);
-                df[i] = dct * cp[i] * dhard_sigmoid(fg[i]);
+                di[i] = dct * (gg[i] * dhard_sigmoid(ig[i]));
+                df[i] = dct * (cp[i] * dhard_sigmoid(fg[i]));
                 dg[i] = dct * ig[i] * (1.0f - gg[i] * gg[i]);
-                dO[i] = d[i] * tc * dhard_sigmoid(og[i]);
+                dO[i] = d[i] * (tc * dhard_sigmoid(og[i]));
                 dc[n][i] = dct * fg[i];
             }
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);

@@ -363,7 +363,7 @@ def test_latent_block():
     close(host(dlv), dlv_o, 1e-5)
 
 
-@pytest.mark.parametrize("N,ldx", [(1024, 1024), (256, 256), (64, 64), (8, 16)])
+@pytest.mark.parametrize("N,ldx", [(1024, 1024), (256, 256), (64, 64), (8, 16), (61, 64), (1, 16)])
 def test_colsum_bf16_vector_path_plain_and_weighted(N, ldx):
     """16-byte loads, 8 columns per thread, LDS reduction + atomics; also with per-row weights (scalar-input dW)."""
     rng = np.random.default_rng(N)
