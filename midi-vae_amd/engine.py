@@ -104,6 +104,7 @@ class Engine(object):
         self._alloc(self.maxB)
         self._views_cache = {}
         self._prep = None
+        self._sync_cum = {}
         self._pipe_verified = False
 
     def _seq_layout(self, r):
@@ -505,18 +506,27 @@ class Engine(object):
                 len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 64 and
                 all(self._seq_layout(r) == hl.TILE16P for r in layers))
 
-    def _sync_region(self, slot, n_if, nchp):
-        """zeroed [n_if][2][nchp] int32 words (progress counters, ready flags) for pipelined stack number ``slot``"""
+    def _sync_region(self, slot, n_if, nchp, nwaves, pwaves):
+        """[n_if][2][nchp] 32-bit counters (hs / da chunks published, xp / dX chunks published) of pipelined stack number
+        ``slot`` and the values they will have reached when this call's producers are done.  The counters are never
+        zeroed between calls - a fill kernel in front of every stack is one more dependent launch on the critical path -
+        they count up monotonically and the thresholds move with them."""
         reg = self.store["sync"][slot * 1024: slot * 1024 + n_if * 2 * nchp].view(n_if, 2, nchp)
-        reg.zero_()
-        return reg
+        cum = self._sync_cum.setdefault(slot, [0, 0])
+        if cum[0] + nwaves >= 1 << 31 or cum[1] + pwaves >= 1 << 31:      # (once in millions of steps)
+            torch.cuda.synchronize()
+            reg.zero_()
+            cum[0] = cum[1] = 0
+        cum[0] += nwaves
+        cum[1] += pwaves
+        return reg, cum[0], cum[1]
 
     def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
         cs = self.pipe_chunk
         T = layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
         L = len(layers)
-        sync = self._sync_region(slot, L - 1, nchp)          # [interface][0: hs chunks published, 1: xp chunks published][chunk]
+        sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
         lower_streams = self.s_layer[:L - 1]              # layer l < L-1 on lower_streams[l]; the top layer on this stream
         gemm_streams = self.s_proj[:L - 1]
@@ -526,7 +536,7 @@ class Engine(object):
             st = states(r) if states else {}
             pipe = dict(chunk_steps=cs, status=status)
             if li > 0:
-                pipe.update(wait_ready=sync[li - 1, 1], wait_value=pwaves)
+                pipe.update(wait_ready=sync[li - 1, 1], wait_value=xp_target)
             if not top:
                 pipe["signal_done"] = sync[li, 0]
             def run():
@@ -539,7 +549,7 @@ class Engine(object):
                     run()
                 with torch.cuda.stream(gemm_streams[li]):     # projection for the layer above: one persistent launch
                     self._rec_xp(layers[li + 1], B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B,
-                                 chunk_wait=sync[li, 0], chunk_wait_value=nwaves, chunk_done=sync[li, 1], chunk_status=status)
+                                 chunk_wait=sync[li, 0], chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status)
         self._join(*lower_streams, *gemm_streams)
 
     def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0):
@@ -756,7 +766,7 @@ class Engine(object):
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
         order = list(reversed(layers))               # order[0] = top layer: runs on this stream, publishes da
         L = len(order)
-        sync = self._sync_region(slot, L - 1, nchp)
+        sync, da_target, dx_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
         lower_streams = self.s_layer[:L - 1]         # order[li], li >= 1, on lower_streams[li - 1]
         gemm_streams = self.s_proj[:L - 1]
@@ -766,7 +776,7 @@ class Engine(object):
             ds = dstates(r) if dstates else {}
             pipe = dict(chunk_steps=cs, status=status)
             if li > 0:
-                pipe.update(wait_ready=sync[li - 1, 1], wait_value=pwaves)
+                pipe.update(wait_ready=sync[li - 1, 1], wait_value=dx_target)
             if li < L - 1:
                 pipe["signal_done"] = sync[li, 0]
             def run():
@@ -782,7 +792,7 @@ class Engine(object):
             if li < L - 1:
                 with torch.cuda.stream(gemm_streams[li]):     # dX for the layer below, from the last chunk to the first
                     self._rec_dx(r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True,
-                                 chunk_wait=sync[li, 0], chunk_wait_value=nwaves, chunk_done=sync[li, 1], chunk_status=status)
+                                 chunk_wait=sync[li, 0], chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)
         self._join(*lower_streams, *gemm_streams)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
