@@ -601,6 +601,7 @@ class Engine(object):
                                   h_last_ld=ldc)
         self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._join(self.s_vel, self.s_instr)
+        self._mark("  encoder recurrences")
         h = cat
         if self.has_pack:
             pk = self._v("pack", B, H)
@@ -639,6 +640,7 @@ class Engine(object):
             c0 = S[:, (k + 1) * H:(k + 2) * H] if s.cell == "LSTM" else None
             return dict(h0=h0, c0=c0, h0_ld=ldS)
 
+        self._mark("  decoder initial states")
         tg = self._have_targets
         self._fork(self.s_vel, self.s_instr)
         if s.meta_instrument:
