@@ -862,6 +862,305 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GRU forward, slot-interleaved (Keras 2.0.x GRU: reset gate applied BEFORE the candidate matmul)
+// ---------------------------------------------------------------------------------------------------------
+// U is 384 KiB: the 64 z/r fragments of a wave sit in accumulator registers, its 32 candidate fragments in LDS, no
+// vector register holds weights - the working set has room, so nothing here is register-starved like the LSTM kernels.
+// Step t:  A  z, r pre-activations of tile pairs (0,1) then (2,3): 2 x 32 single-MFMA slots, B = h_{t-1} tile; the
+//             gaps of pair 1 carry pair 0's gate arithmetic (z, r, r*h -> rh tile), the gaps of pair 0 the deferred
+//             stores of the previous step and this step's row-major copy of h_{t-1}
+//          -  pair 1's gate arithmetic, barrier (the candidate needs every wave's r*h)
+//          B  candidate pre-activations, tiles (0,1) then (2,3): 2 x 16 slots, B = rh tile, fragments staged from LDS;
+//             the gaps of the second half carry tanh + the h update of tiles 0,1
+//          -  tanh + h update of tiles 2,3, barrier
+// Saved activations (z, r, candidate) stay TILE16: the phased backward kernel reads them.
+template <int XMODE, int SAVE>
+__global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a) {
+    constexpr int G = 3, GH = G * RH, NLc = RNT * RS;             // 32 candidate fragments per wave in LDS
+    static_assert(XMODE != MVAE_X_SCALAR, "scalar inputs run on the phased kernel");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* hbuf = smem;                                             // [2][16][RH] bf16, swizzled
+    unsigned char* rhbuf = smem + 2 * 16 * RH * 2;                          // [16][RH]
+    frag* ulds = reinterpret_cast<frag*>(smem + 3 * 16 * RH * 2);           // [4][NL][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
+    auto src_frag = [&](int g, int n, int ks) -> const frag* {
+        return up + (size_t)((g * (RH / 16) + w * RNT + n) * RS + ks) * 64 + l;
+    };
+    // phase A fragment f = ((np*8 + ks)*2 + nn)*2 + g  (tile 2np+nn, gate g in {z, r});  phase B fragment (LDS) i =
+    // (half*8 + ks)*2 + nn  (tile 2half+nn, candidate)
+    frag ua[64];
+    static_for<0, 16>(SF_LAMBDA(ic) {
+        constexpr int f = decltype(ic)::value * 4, np = f >> 5, ks = (f >> 2) & 7;
+        load4_agpr_nowait(ua[f], ua[f + 1], ua[f + 2], ua[f + 3], src_frag(0, 2 * np, ks), src_frag(1, 2 * np, ks),
+                          src_frag(0, 2 * np + 1, ks), src_frag(1, 2 * np + 1, ks));
+    });
+#pragma unroll
+    for (int i = 0; i < NLc; ++i) myl[(size_t)i * 64] = *src_frag(2, 2 * (i >> 4) + (i & 1), (i >> 1) & 7);
+
+    const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
+    unsigned lane8 = (unsigned)l * 8u;
+    const int ub0 = w * 64 + q * 4;
+    unsigned hw0 = (unsigned)r * 512u + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned bf4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf4[j] = (unsigned)r * 512u + ((((unsigned)j * 4u + (unsigned)q) ^ (unsigned)r) << 4);
+    const unsigned row0 = 4u * w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    unsigned tl0 = row0 * 512u + ((ch0 ^ row0) << 4);
+    unsigned tg0 = row0 * 512u + ch0 * 16u;
+
+    f32x4 hreg[RNT];
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
+        *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(hreg[n]);
+    }
+    // ---- x queue ------------------------------------------------------------------------------------------------
+    u16x4 xq[RNT][G];
+    unsigned xoff = 0;
+    int i_q = 0;
+    const unsigned char* xbase0;
+    if (XMODE == MVAE_X_DENSE) {
+        xoff = lane8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)blockIdx.x * (GH / 16) + w * RNT) * 512;
+    } else if (XMODE == MVAE_X_INDEX) {
+        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
+        i_q = a.idx[(size_t)(T > 1 ? 1 : 0) * B + b];
+    } else {
+        xoff = (unsigned)b * (GH * 2) + q * 8;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 128;
+    }
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = 0, phi = cs_steps;
+    if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready, wait_value, a.status);
+    constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;
+    constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n)
+#pragma unroll
+        for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+
+    gbyte *acts_p[G], *hs_p, *hh_prev_p;          // step t: saved gates; h_{t-1} (slot t); the candidate tiles of step t-1
+    gbyte* x_p[G];                                // step t+1: inputs
+    const size_t acts_step = tps * (GH / 16) * 512, hs_step = (size_t)B * RH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
+        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
+    }
+    hh_prev_p = acts_p[2];
+    hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
+
+    constexpr float K2 = 2.8853900817779268f;
+    f32x4 accA[4], accB[4], zg[RNT];
+    u16x4 hh_pk[RNT];                             // candidate of the previous step, stored during this step's phase A
+    frag bq[3], lt[2], cp[2];                     // B-fragment ring; LDS-fragment staging; row-major copy staging
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) hh_pk[n] = u16x4{0, 0, 0, 0};
+    vm_drain();
+    lds_barrier();
+
+    for (int t = 0; t < T; ++t) {
+        const int tstep = t;
+        (void)tstep;
+        pinu(hw0); pinu(tl0);
+        if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready && t + 1 < T && t + 1 == phi)
+            wave_wait_ge(a.wait_ready + pk + 1, wait_value, a.status);
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(hh_prev_p);
+        pins(x_p[0]); pins(x_p[1]); pins(x_p[2]);
+        unsigned char* hcur = hbuf;               // bf4 / tl0 / hw0 carry the buffer bit
+        // everything requested during the previous step (all of it in its MFMA phases) and every older store
+        vm_drain();
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) { pin1(xq[n][0]); pin1(xq[n][1]); pin1(xq[n][2]); }
+        if (XMODE == MVAE_X_INDEX) pini(i_q);
+        if (SAVE >= SAVE_HS) {
+            cp[0] = *reinterpret_cast<const frag*>(hcur + tl0);
+            cp[1] = *reinterpret_cast<const frag*>(hcur + (tl0 ^ 1056u));
+        }
+        auto request_x = [&](int n, int g) __attribute__((always_inline)) {
+            if (XMODE != MVAE_X_CONST) {
+                if (XMODE == MVAE_X_INDEX && n == 0 && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 8;
+                pinu(xoff);
+                xq[n][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + n * XN + xoff);
+            }
+        };
+        // ---- phase A ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accA[j] = unpack4(xq[j >> 1][j & 1]);             // accumulators start at x (tile j>>1, gate j&1)
+            accB[j] = unpack4(xq[2 + (j >> 1)][j & 1]);
+        }
+        bq[0] = *reinterpret_cast<const frag*>(hcur + bf4[0]);
+        bq[1] = *reinterpret_cast<const frag*>(hcur + bf4[1]);
+        asm volatile("s_nop 1" : "+v"(accA[0]), "+v"(accA[1]), "+v"(accA[2]), "+v"(accA[3]));
+        // z, r and r*h of tile n from its two accumulators; element pairs in lockstep
+        auto zr_math = [&](int n, f32x4& az, f32x4& ar, int e0, int ne) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = e0; e < e0 + ne; ++e) {
+                az[e] = hard_sigmoid(az[e]);
+                ar[e] = hard_sigmoid(ar[e]);
+            }
+        };
+        static_for<0, 64>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value, np = sl >> 5, ks = (sl >> 2) & 7, j = sl & 3, gi = sl >> 2;
+            f32x4* acc = np ? accB : accA;
+            if constexpr (j == 0 && gi + 2 < 16)
+                bq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(hcur + bf4[(ks + 2) & 3] + 256 * (((ks + 2) & 7) >> 2));
+            if constexpr (sl == 32) asm volatile("s_nop 1" : "+v"(accB[0]), "+v"(accB[1]), "+v"(accB[2]), "+v"(accB[3]));
+            mfma1<true>(acc[j], ua[sl], bq[gi % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fillers ----
+            if constexpr (np == 0) {
+                // the previous step's candidate tiles, the row-major copy of h_{t-1}, next step's z / r inputs
+                if constexpr (sl >= 2 && sl < 2 + 4 * RNT && (sl - 2) % 4 == 0) {
+                    constexpr int n = (sl - 2) / 4;
+                    if (SAVE == SAVE_ALL && t > 0) {
+                        pinu(lane8);
+                        *reinterpret_cast<g_u16x4*>(hh_prev_p + n * 512 + lane8) = hh_pk[n];
+                    }
+                }
+                if constexpr (sl == 20 || sl == 24) {
+                    if (SAVE >= SAVE_HS) {
+                        pinu(tg0);
+                        *reinterpret_cast<g_u16x8*>(hs_p + (sl == 24 ? 1024 : 0) + tg0) = cp[sl == 24 ? 1 : 0];
+                    }
+                }
+            } else {
+                // pair 0: z, r (4 slots), r*h -> rh tile (slot 36..), z / r saves, next step's inputs of every tile
+                constexpr int fs = sl - 32;
+                if constexpr (fs < 4) zr_math(fs >> 1, accA[(fs >> 1) * 2], accA[(fs >> 1) * 2 + 1], (fs & 1) * 2, 2);
+                if constexpr (fs == 4 || fs == 5) {
+                    constexpr int n = fs - 4;
+                    zg[n] = accA[n * 2];
+                    *reinterpret_cast<u16x4*>(rhbuf + (hw0 & 8191u ^ (n << 5))) = pack4(accA[n * 2 + 1] * hreg[n]);
+                }
+                if constexpr (fs >= 6 && fs < 6 + 2 * 4 && (fs - 6) % 2 == 0) {      // z, r of tiles 0, 1
+                    constexpr int k = (fs - 6) / 2, n = k >> 1, g = k & 1;
+                    if (SAVE == SAVE_ALL) {
+                        pinu(lane8);
+                        *reinterpret_cast<g_u16x4*>(acts_p[g] + n * 512 + lane8) = pack4(accA[n * 2 + g]);
+                    }
+                }
+                if constexpr (fs >= 15 && fs < 15 + 2 * 8 && (fs - 15) % 2 == 0) {   // next step's z / r inputs, all 4 tiles
+                    constexpr int k = (fs - 15) / 2;
+                    request_x(k >> 1, k & 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(accB[0]), "+v"(accB[1]), "+v"(accB[2]), "+v"(accB[3]));
+        // pair 1's gate arithmetic has nothing to hide under: the candidate needs every wave's r*h first
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            zr_math(2 + nn, accB[nn * 2], accB[nn * 2 + 1], 0, 4);
+            zg[2 + nn] = accB[nn * 2];
+            *reinterpret_cast<u16x4*>(rhbuf + (hw0 & 8191u ^ ((2 + nn) << 5))) = pack4(accB[nn * 2 + 1] * hreg[2 + nn]);
+        }
+        res_barrier();
+        // ---- phase B ------------------------------------------------------------------------------------------------
+        f32x4 accC[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) accC[n] = unpack4(xq[n][2]);
+        frag rq[3];
+        rq[0] = *reinterpret_cast<const frag*>(rhbuf + (bf4[0] & 8191u));
+        rq[1] = *reinterpret_cast<const frag*>(rhbuf + (bf4[1] & 8191u));
+        lt[0] = myl[0];
+        lt[1] = myl[64];
+        asm volatile("s_nop 1" : "+v"(accC[0]), "+v"(accC[1]), "+v"(accC[2]), "+v"(accC[3]));
+        // candidate -> h for one element of tile n
+        auto h_math = [&](int n, int e) __attribute__((always_inline)) {
+            const float ex = __builtin_amdgcn_exp2f(accC[n][e] * K2);
+            const float hh = 1.0f - 2.0f * __builtin_amdgcn_rcpf(ex + 1.0f);
+            accC[n][e] = hh;                                       // kept for the save
+            hreg[n][e] = hh + zg[n][e] * (hreg[n][e] - hh);        // z*h + (1-z)*hh
+        };
+        static_for<0, 32>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value, half = sl >> 4, ks = (sl >> 1) & 7, nn = sl & 1, n = half * 2 + nn;
+            constexpr int gi = sl >> 1;                            // group of 2 MFMAs sharing rh fragment ks
+            if constexpr (nn == 0 && gi + 2 < 16)
+                rq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(rhbuf + (bf4[(ks + 2) & 3] & 8191u) + 256 * (((ks + 2) & 7) >> 2));
+            mfma1<false>(accC[n], lt[nn], rq[gi % 3]);
+            if constexpr (sl + 2 < 32) lt[nn] = myl[(size_t)(sl + 2) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (half == 0) {
+                // z, r of tiles 2, 3; next step's candidate inputs
+                if constexpr (sl < 8 && (sl & 1) == 0) {
+                    constexpr int k = sl >> 1, nt = 2 + (k >> 1), g = k & 1;
+                    if (SAVE == SAVE_ALL) {
+                        pinu(lane8);
+                        *reinterpret_cast<g_u16x4*>(acts_p[g] + nt * 512 + lane8) = pack4(accB[(k >> 1) * 2 + g]);
+                    }
+                }
+                // (the candidate inputs were consumed when the accumulators were initialised)
+                if constexpr (sl >= 8 && (sl & 1) == 0) request_x((sl - 8) >> 1, 2);
+                if constexpr (sl == 15) {
+                    if (XMODE == MVAE_X_INDEX) i_q = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + b];
+                }
+            } else {
+                // tanh + h update of tiles 0, 1 (their accumulators were finished by slot 15): one element per 2 slots
+                constexpr int fs = sl - 16;
+                if constexpr ((fs & 1) == 0) h_math(fs >> 3, (fs >> 1) & 3);
+                if constexpr (fs == 15) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ ((m << 5) | 8192))) = pack4(hreg[m]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(accC[2]), "+v"(accC[3]));
+#pragma unroll
+        for (int n = 2; n < RNT; ++n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h_math(n, e);
+            *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ ((n << 5) | 8192))) = pack4(hreg[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) hh_pk[n] = pack4(accC[n]);
+        if (t == T - 1 && a.h_last) {
+#pragma unroll
+            for (int n = 0; n < RNT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub0 + 16 * n) = hreg[n];
+        }
+        hh_prev_p = acts_p[2];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acts_p[g] += acts_step;
+            if (XMODE == MVAE_X_DENSE && t + 2 < T) x_p[g] += acts_step;
+        }
+        hs_p += hs_step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf4[j] ^= 8192u;
+        hw0 ^= 8192u;
+        tl0 ^= 8192u;
+        res_barrier();
+        if (cs_steps && t == phi) {
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(a.signal_done + pk);
+            ++pk;
+            phi += cs_steps;
+        }
+    }
+    if (SAVE == SAVE_ALL) {
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) *reinterpret_cast<g_u16x4*>(hh_prev_p + n * 512 + lane8) = hh_pk[n];
+    }
+    if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
+        *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
+        *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
+        if (cs_steps && a.signal_done) wave_signal_done(a.signal_done + pk);
+    }
+    vm_drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward through time
 // ---------------------------------------------------------------------------------------------------------
 // The da tile in LDS is [16 rows][GH] bf16, swizzled, unpadded: LSTM needs every byte (32 KiB tile + 128 KiB of
@@ -1365,6 +1664,25 @@ int launch_lstm_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return MVAE_OK;
 }
 
+// GRU with dense / indexed / constant inputs: the slot-interleaved forward kernel (MVAE_GRU_PHASED=1 keeps the phased one)
+template <int XMODE, int SAVE>
+int launch_gru_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    const size_t lds = (size_t)3 * 16 * RH * sizeof(bf16_t) + (size_t)4 * RNT * RS * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_il_k<XMODE, SAVE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((gru_fwd_il_k<XMODE, SAVE>), dim3(a.B / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+inline bool gru_phased() {
+    static const bool v = [] { const char* e = getenv("MVAE_GRU_PHASED"); return e && e[0] == '1'; }();
+    return v;
+}
 template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.acts) {
@@ -1372,12 +1690,16 @@ int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
         if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
             if (a.seq_layout == MVAE_TILE16P) return launch_lstm_il<XMODE, SAVE_ALL>(a, s);
         if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
+        if constexpr (CELL == MVAE_GRU && XMODE != MVAE_X_SCALAR)
+            if (!gru_phased()) return launch_gru_il<XMODE, SAVE_ALL>(a, s);
         return launch_fwd_res<CELL, XMODE, SAVE_ALL>(a, s);
     }
     if (a.cs) return MVAE_E_UNSUPPORTED;
     if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
         if (a.seq_layout == MVAE_TILE16P) return a.hs ? launch_lstm_il<XMODE, SAVE_HS>(a, s) : launch_lstm_il<XMODE, SAVE_NONE>(a, s);
     if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
+    if constexpr (CELL == MVAE_GRU && XMODE != MVAE_X_SCALAR)
+        if (!gru_phased()) return a.hs ? launch_gru_il<XMODE, SAVE_HS>(a, s) : launch_gru_il<XMODE, SAVE_NONE>(a, s);
     return a.hs ? launch_fwd_res<CELL, XMODE, SAVE_HS>(a, s) : launch_fwd_res<CELL, XMODE, SAVE_NONE>(a, s);
 }
 template <int CELL>
