@@ -140,6 +140,7 @@ __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+__device__ __forceinline__ u16x8 cat8(u16x4 a, u16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pinf(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pini(int& a) { asm volatile("" : "+v"(a)); }
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
 //          B  candidate pre-activations, tiles (0,1) then (2,3): 2 x 16 slots, B = rh tile, fragments staged from LDS;
 //             the gaps of the second half carry tanh + the h update of tiles 0,1
 //          -  tanh + h update of tiles 2,3, barrier
-// Saved activations (z, r, candidate) stay TILE16: the phased backward kernel reads them.
+// Inputs are TILE16, saved activations (z, r, candidate) TILE16P: one 16-byte store per gate and tile pair.
 template <int XMODE, int SAVE>
 __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a) {
     constexpr int G = 3, GH = G * RH, NLc = RNT * RS;             // 32 candidate fragments per wave in LDS
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     for (int i = 0; i < NLc; ++i) myl[(size_t)i * 64] = *src_frag(2, 2 * (i >> 4) + (i & 1), (i >> 1) & 7);
 
     const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
-    unsigned lane8 = (unsigned)l * 8u;
+    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;      // TILE16 inputs; TILE16P saved activations
     const int ub0 = w * 64 + q * 4;
     unsigned hw0 = (unsigned)r * 512u + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
     unsigned bf4[4];
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     const size_t acts_step = tps * (GH / 16) * 512, hs_step = (size_t)B * RH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 16) + g * (RH / 16) + w * RNT) * 512;
+        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
         x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
     }
     hh_prev_p = acts_p[2];
@@ -962,10 +963,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
 
     constexpr float K2 = 2.8853900817779268f;
     f32x4 accA[4], accB[4], zg[RNT];
-    u16x4 hh_pk[RNT];                             // candidate of the previous step, stored during this step's phase A
+    u16x8 hh_pk[2];                               // candidate of the previous step (tile pairs), stored during this step's phase A
     frag bq[3], lt[2], cp[2];                     // B-fragment ring; LDS-fragment staging; row-major copy staging
-#pragma unroll
-    for (int n = 0; n < RNT; ++n) hh_pk[n] = u16x4{0, 0, 0, 0};
+    hh_pk[0] = hh_pk[1] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
     vm_drain();
     lds_barrier();
 
@@ -1022,11 +1022,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
             // ---- fillers ----
             if constexpr (np == 0) {
                 // the previous step's candidate tiles, the row-major copy of h_{t-1}, next step's z / r inputs
-                if constexpr (sl >= 2 && sl < 2 + 4 * RNT && (sl - 2) % 4 == 0) {
-                    constexpr int n = (sl - 2) / 4;
+                if constexpr (sl == 2 || sl == 10) {
+                    constexpr int pr = sl == 10;
                     if (SAVE == SAVE_ALL && t > 0) {
-                        pinu(lane8);
-                        *reinterpret_cast<g_u16x4*>(hh_prev_p + n * 512 + lane8) = hh_pk[n];
+                        pinu(lane16);
+                        *reinterpret_cast<g_u16x8*>(hh_prev_p + pr * 1024 + lane16) = hh_pk[pr];
                     }
                 }
                 if constexpr (sl == 20 || sl == 24) {
@@ -1044,11 +1044,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
                     zg[n] = accA[n * 2];
                     *reinterpret_cast<u16x4*>(rhbuf + (hw0 & 8191u ^ (n << 5))) = pack4(accA[n * 2 + 1] * hreg[n]);
                 }
-                if constexpr (fs >= 6 && fs < 6 + 2 * 4 && (fs - 6) % 2 == 0) {      // z, r of tiles 0, 1
-                    constexpr int k = (fs - 6) / 2, n = k >> 1, g = k & 1;
+                if constexpr (fs == 6 || fs == 10) {                                // z, r of the tile pair (0, 1)
+                    constexpr int g = fs == 10;
                     if (SAVE == SAVE_ALL) {
-                        pinu(lane8);
-                        *reinterpret_cast<g_u16x4*>(acts_p[g] + n * 512 + lane8) = pack4(accA[n * 2 + g]);
+                        pinu(lane16);
+                        *reinterpret_cast<g_u16x8*>(acts_p[g] + lane16) = cat8(pack4(accA[g]), pack4(accA[2 + g]));
                     }
                 }
                 if constexpr (fs >= 15 && fs < 15 + 2 * 8 && (fs - 15) % 2 == 0) {   // next step's z / r inputs, all 4 tiles
@@ -1094,11 +1094,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (half == 0) {
                 // z, r of tiles 2, 3; next step's candidate inputs
-                if constexpr (sl < 8 && (sl & 1) == 0) {
-                    constexpr int k = sl >> 1, nt = 2 + (k >> 1), g = k & 1;
+                if constexpr (sl == 0 || sl == 4) {                                 // z, r of the tile pair (2, 3)
+                    constexpr int g = sl == 4;
                     if (SAVE == SAVE_ALL) {
-                        pinu(lane8);
-                        *reinterpret_cast<g_u16x4*>(acts_p[g] + nt * 512 + lane8) = pack4(accB[(k >> 1) * 2 + g]);
+                        pinu(lane16);
+                        *reinterpret_cast<g_u16x8*>(acts_p[g] + 1024 + lane16) = cat8(pack4(accB[g]), pack4(accB[2 + g]));
                     }
                 }
                 // (the candidate inputs were consumed when the accumulators were initialised)
@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
             for (int e = 0; e < 4; ++e) h_math(n, e);
             *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ ((n << 5) | 8192))) = pack4(hreg[n]);
         }
-#pragma unroll
-        for (int n = 0; n < RNT; ++n) hh_pk[n] = pack4(accC[n]);
+        hh_pk[0] = cat8(pack4(accC[0]), pack4(accC[1]));
+        hh_pk[1] = cat8(pack4(accC[2]), pack4(accC[3]));
         if (t == T - 1 && a.h_last) {
 #pragma unroll
             for (int n = 0; n < RNT; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub0 + 16 * n) = hreg[n];
@@ -1149,8 +1149,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         }
     }
     if (SAVE == SAVE_ALL) {
-#pragma unroll
-        for (int n = 0; n < RNT; ++n) *reinterpret_cast<g_u16x4*>(hh_prev_p + n * 512 + lane8) = hh_pk[n];
+        *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = hh_pk[0];
+        *reinterpret_cast<g_u16x8*>(hh_prev_p + 1024 + lane16) = hh_pk[1];
     }
     if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
         *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
@@ -1592,6 +1592,311 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GRU backward, slot-interleaved
+// ---------------------------------------------------------------------------------------------------------
+// Step t (descending), d = dh_t (+ the gradient from the layer above), hp = h_{t-1}, saved z, r, hh:
+//   E1  dah = d (1-z)(1-hh^2) -> da tile (candidate columns);  r*hp -> rh tile (left operand of the candidate dU GEMM)
+//   M1  drh = Uh^T-fragments x dah: 32 single-MFMA slots (fragments staged from LDS - the phase is LDS-bandwidth bound,
+//       its gaps are wide); they carry daz = d (hp-hh) hs'(z) -> da tile (z columns), the row-major copies of the rh
+//       tile and of the da tile's candidate columns, and the first 8 loads of step t-1's saved values
+//   E2  dar = drh hp hs'(r) -> da tile (r columns);  part = d z + drh r
+//   M2  dh_{t-1} = part + Uzr^T-fragments x [daz|dar]: 64 slots (accumulator-register fragments); their gaps carry
+//       the other 6 loads (early: a load needs ~1500 cycles) and the row-major copy of the da tile's z, r columns
+// 64 + 32 fragments per wave: accumulator registers + LDS (24 KiB da tile + 8 KiB rh tile + 128 KiB = all of it).
+// A memory instruction occupies the CU's address unit for ~27 cycles whatever its width (4 waves: ~108 cycles per wave
+// and instruction), hence 16-byte accesses wherever the layout allows: acts TILE16P, copies in 16-byte chunks.
+#ifndef GB_NOLOAD
+#define GB_NOLOAD 0
+#endif
+#ifndef GB_NOCOPY
+#define GB_NOCOPY 0
+#endif
+#ifndef GB_NODAZ
+#define GB_NODAZ 0
+#endif
+template <bool HAS_EXT>
+__global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a) {
+    constexpr int G = 3, GH = G * RH, S2 = GH / 32, NLc = RNT * (RH / 32);      // 24 k-groups; 32 LDS fragments per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dabuf = smem;                                              // [16][GH] bf16, swizzled (24 KiB)
+    unsigned char* rhbuf = smem + 16 * GH * 2;                                // [16][RH]
+    frag* ulds = reinterpret_cast<frag*>(smem + 16 * GH * 2 + 16 * RH * 2);   // [4][NL][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = blockIdx.x * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    frag* myl = ulds + (size_t)w * NLc * 64 + l;
+    // packed fragment (unit tile w*4+n, k-group ks over the gate columns); M2 uses ks 0..15 (z, r), M1 ks 16..23
+    auto src_frag = [&](int n, int ks) -> const frag* { return up + (size_t)((w * RNT + n) * S2 + ks) * 64 + l; };
+    frag ua[64];
+    static_for<0, 16>(SF_LAMBDA(ic) {
+        constexpr int ks = decltype(ic)::value;
+        load4_agpr_nowait(ua[ks * 4], ua[ks * 4 + 1], ua[ks * 4 + 2], ua[ks * 4 + 3], src_frag(0, ks), src_frag(1, ks),
+                          src_frag(2, ks), src_frag(3, ks));
+    });
+#pragma unroll
+    for (int i = 0; i < NLc; ++i) myl[(size_t)i * 64] = *src_frag(i & 3, 16 + (i >> 2));
+
+    const int ub0 = w * 64 + q * 4;
+    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
+    // da tile (row stride 1536 B): this lane's 4 values of (gate g, tile n) at da_row + (da_ch ^ ((g*32 + n*2) << 4));
+    // B fragment of k-group ks at b_row + (b_ch ^ (ks << 6))
+    unsigned da_row = (unsigned)r * (GH * 2) + ((unsigned)q & 1u) * 8u;
+    unsigned da_ch = (((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4;
+    unsigned b_row = (unsigned)r * (GH * 2), b_ch = ((unsigned)q ^ (unsigned)r) << 4;
+    // rh tile (row stride 512 B), as the h tiles of the forward kernels
+    unsigned rw0 = (unsigned)r * 512u + ((((unsigned)w * 8u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    const unsigned row0 = 4u * w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    unsigned tl0 = row0 * 512u + ((ch0 ^ row0) << 4), tg0 = row0 * 512u + ch0 * 16u;      // rh tile copy (2 chunks per lane)
+    unsigned hp_off = (unsigned)r * (RH * 2) + (unsigned)q * 8u;                          // h_{t-1}: row r of the tile, row-major
+
+    f32x4 dh[RNT];
+    const int ldl = a.dh_last_ld ? a.dh_last_ld : RH;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * ldl + ub0 + 16 * n) : z4;
+    }
+    gbyte *acts_p[G], *hs_p, *dx_p, *da_p, *rh_p;
+    const size_t acts_step = tps * (GH / 32) * 1024, dx_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2,
+                 da_step = (size_t)B * GH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+    hs_p = to_global(a.hs) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (RH * 2) + w * 128;             // h_{t-1} = slot t
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
+    rh_p = to_global(a.rh) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (RH * 2);
+
+    // pipelined stack bookkeeping, as lstm_bwd_il_k: chunk pk (first step plo) is the one being processed
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status);
+    int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;      // step at whose start chunk pk-1 must be ready (-1: never)
+    int psig = (cs_steps && a.signal_done) ? plo : -1;                 // step after which chunk pk is published
+
+    // saved values of the step about to be processed: z, r, hh as TILE16P pairs (elements 0..3 tile 2j, 4..7 tile 2j+1);
+    // h_{t-1} (row-major) and the upstream gradient (TILE16) per tile
+    u16x8 qa[2][G];
+    u16x4 qs[RNT], qd[RNT];
+    // the 14 loads of a step, in the order their values are needed: 0..3 h_{t-1}; 4..7 z and hh (pair 0, pair 1);
+    // 8, 9 r; 10..13 upstream gradient
+    auto issue_load = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (GB_NOLOAD) return;
+        if constexpr (k < 4) {
+            pinu(hp_off);
+            qs[k] = *reinterpret_cast<const g_u16x4*>(hs_p + k * 32 + hp_off);
+        } else if constexpr (k < 10) {
+            constexpr int pr = k < 8 ? (k - 4) >> 1 : k - 8, g = k < 8 ? ((k - 4) & 1) * 2 : 1;
+            pinu(lane16);
+            qa[pr][g] = *reinterpret_cast<const g_u16x8*>(acts_p[g] + pr * 1024 + lane16);
+        } else if constexpr (HAS_EXT) {
+            pinu(lane8);
+            qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + lane8);
+        }
+    };
+    static_for<0, 14>(SF_LAMBDA(kc) { issue_load(kc); });
+#pragma unroll
+    for (int g = 0; g < G; ++g) acts_p[g] -= (T > 1 ? acts_step : 0);
+    hs_p -= (T > 1 ? hs_step : 0);
+    dx_p -= (T > 1 ? dx_step : 0);
+
+    // row-major copy of the da tile: rows 4w..4w+3, 96 chunks of 16 bytes each.  Passes 0..3: lane l copies chunk l of row
+    // 4w+pass (z, r columns); passes 4, 5: chunk 64 + l%32 of row 4w + 2(pass-4) + l/32 (candidate columns)
+    auto da_read = [&](auto jc) __attribute__((always_inline)) -> frag {
+        constexpr int j = decltype(jc)::value;
+        const unsigned row = 4u * w + (j < 4 ? (unsigned)j : 2u * (j - 4) + ((unsigned)l >> 5));
+        const unsigned ch = j < 4 ? (unsigned)l : 64u + ((unsigned)l & 31u);
+        return *reinterpret_cast<const frag*>(dabuf + row * (GH * 2) + ((ch ^ row) << 4));
+    };
+    auto da_store = [&](auto jc, frag v) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const unsigned row = j < 4 ? (unsigned)j : 2u * (j - 4) + ((unsigned)l >> 5);
+        const unsigned ch = j < 4 ? (unsigned)l : 64u + ((unsigned)l & 31u);
+        unsigned go = row * (GH * 2) + ch * 16u;
+        pinu(go);
+        *reinterpret_cast<g_u16x8*>(da_p + go) = v;
+    };
+
+    frag bq[3], lt[4], cp[4];
+    vm_drain();
+    lds_barrier();
+    // values of the step about to be processed, unpacked one step ahead (in the gaps of M2): z, hh, h_{t-1} and
+    // w1 = (1-z)(1-hh^2), the factor of the candidate gradient
+    f32x4 zv[RNT], hh[RNT], hp[RNT], w1[RNT];
+    auto half = [&](const u16x8& v, int n) __attribute__((always_inline)) -> f32x4 {
+        const int o = (n & 1) * 4;
+        return f32x4{bf2f(v[o]), bf2f(v[o + 1]), bf2f(v[o + 2]), bf2f(v[o + 3])};
+    };
+    auto pre_unpack = [&](int n, int part) __attribute__((always_inline)) {      // 4 parts per tile, ~7 VALU each
+        if (part == 0) zv[n] = half(qa[n >> 1][0], n);
+        if (part == 1) hh[n] = half(qa[n >> 1][2], n);
+        if (part == 2) hp[n] = unpack4(qs[n]);
+        if (part == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w1[n][i] = (1.0f - zv[n][i]) * (1.0f - hh[n][i] * hh[n][i]);
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < RNT; ++n)
+#pragma unroll
+        for (int part = 0; part < 4; ++part) pre_unpack(n, part);
+
+    for (int t = T - 1; t >= 0; --t) {
+        const int tstep = T - 1 - t;
+        (void)tstep;
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(da_p);
+        if (HAS_EXT) pins(dx_p);
+        if (a.rh) pins(rh_p);
+        pinu(da_ch); pinu(b_ch); pinu(rw0); pinu(tl0);
+        STAMP(0);
+        // pipelined stack: the upstream gradient of step t-1 is requested during this step's MFMA phases
+        if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
+        vm_drain();
+        STAMP(1);
+        pinq(qa[0][1]); pinq(qa[1][1]);
+        if (HAS_EXT) {
+#pragma unroll
+            for (int n = 0; n < RNT; ++n) pin1(qd[n]);
+        }
+        // ---- E1: only what M1 waits for -------------------------------------------------------------------------------
+        f32x4 d[RNT], rv[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) {
+            d[n] = dh[n];
+            if (HAS_EXT) d[n] += unpack4(qd[n]);
+            *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((2 * 32 + n * 2) << 4))) = pack4(d[n] * w1[n]);
+        }
+        STAMP(2);
+        res_barrier();
+        STAMP(3);
+        // ---- M1: drh -----------------------------------------------------------------------------------------------
+        f32x4 acc1[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (16u << 6)));
+        bq[1] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (17u << 6)));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) lt[n] = myl[(size_t)n * 64];
+        if (!GB_NOCOPY) {
+            cp[2] = da_read(std::integral_constant<int, 4>{});
+            cp[3] = da_read(std::integral_constant<int, 5>{});
+        }
+        asm volatile("s_nop 1" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+        static_for<0, 32>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value, ks = sl >> 2, n = sl & 3;
+            if constexpr (n == 0 && ks + 2 < 8)
+                bq[(ks + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((16u + ks + 2) << 6)));
+            mfma1<false>(acc1[n], lt[n], bq[ks % 3]);
+            if constexpr (sl + 4 < 32) lt[n] = myl[(size_t)(sl + 4) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            // daz = d (hp - hh) hs'(z) for tile sl/8, element (sl/2)%4
+            if constexpr (!GB_NODAZ && (sl & 1) == 0) {
+                constexpr int tn = sl >> 3, e = (sl >> 1) & 3;
+                hh[tn][e] = d[tn][e] * (hp[tn][e] - hh[tn][e]) * dhard_sigmoid(zv[tn][e]);     // hh is dead after E1: reuse as daz
+                if constexpr (e == 3)
+                    *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((0 * 32 + tn * 2) << 4))) = pack4(hh[tn]);
+            }
+            // r, and r*hp -> rh tile (nothing in this step's recurrence waits for it): tile (sl-1)/4 on slots 1, 5, 9, 13
+            if constexpr ((sl & 3) == 1 && sl < 16) {
+                constexpr int tn = sl >> 2;
+                rv[tn] = half(qa[tn >> 1][1], tn);
+                if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + (rw0 ^ (tn << 5))) = pack4(rv[tn] * hp[tn]);
+            }
+            // memory events: loads 0..7 from slot 17 on (their registers - h_{t-1}, z, hh raw - are dead once the last
+            // tile's r*hp is out; r's raw registers die in slot 13), the candidate columns of the da tile before
+            if constexpr (!GB_NOCOPY && sl == 3) da_store(std::integral_constant<int, 4>{}, cp[2]);
+            if constexpr (!GB_NOCOPY && sl == 10) da_store(std::integral_constant<int, 5>{}, cp[3]);
+            if constexpr (sl >= 16 && (sl & 1) == 0) issue_load(std::integral_constant<int, ((sl - 16) >> 1)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+        STAMP(4);
+        // ---- E2 -------------------------------------------------------------------------------------------------------
+        f32x4 part[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) {
+            f32x4 dar;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dar[i] = acc1[n][i] * hp[n][i] * dhard_sigmoid(rv[n][i]);
+                part[n][i] = d[n][i] * zv[n][i] + acc1[n][i] * rv[n][i];
+            }
+            *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((1 * 32 + n * 2) << 4))) = pack4(dar);
+        }
+        STAMP(5);
+        res_barrier();
+        STAMP(6);
+        // ---- M2: dh_{t-1} ------------------------------------------------------------------------------------------
+        f32x4 acc2[RNT];
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) acc2[n] = part[n];
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + b_ch);
+        bq[1] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (1u << 6)));
+        if (a.rh) {
+            cp[0] = *reinterpret_cast<const frag*>(rhbuf + tl0);
+            cp[1] = *reinterpret_cast<const frag*>(rhbuf + (tl0 ^ 1056u));
+        }
+        if (!GB_NOCOPY) {
+            lt[0] = da_read(std::integral_constant<int, 0>{});
+            lt[1] = da_read(std::integral_constant<int, 1>{});
+            lt[2] = da_read(std::integral_constant<int, 2>{});
+            lt[3] = da_read(std::integral_constant<int, 3>{});
+        }
+        asm volatile("s_nop 1" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]));
+        static_for<0, 64>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value, ks = sl >> 2, n = sl & 3;
+            if constexpr (n == 0 && ks + 2 < 16)
+                bq[(ks + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((unsigned)(ks + 2) << 6)));
+            mfma1<true>(acc2[n], ua[sl], bq[ks % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            // memory events: loads 8..13 first, then the copies of the rh tile and of the da tile's z, r columns
+            if constexpr ((sl & 3) == 1 && sl < 24) issue_load(std::integral_constant<int, 8 + (sl >> 2)>{});
+            if constexpr (sl == 26 || sl == 31) {
+                if (a.rh) {
+                    pinu(tg0);
+                    *reinterpret_cast<g_u16x8*>(rh_p + (sl == 31 ? 1024 : 0) + tg0) = cp[sl == 31 ? 1 : 0];
+                }
+            }
+            if constexpr (!GB_NOCOPY && sl >= 36 && (sl - 36) % 5 == 0 && sl < 36 + 20)
+                da_store(std::integral_constant<int, (sl - 36) / 5>{}, lt[(sl - 36) / 5]);
+            // step t-1's z, hh, h_{t-2} (requested in M1) unpacked, and w1: one part per 2 slots in the second half
+            if constexpr (sl >= 32 && (sl & 1) == 0) pre_unpack((sl - 32) >> 3, ((sl - 32) >> 1) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]));
+        STAMP(7);
+#pragma unroll
+        for (int n = 0; n < RNT; ++n) dh[n] = acc2[n];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acts_p[g] -= (t > 1 ? acts_step : 0);
+        hs_p -= (t > 1 ? hs_step : 0);
+        if (HAS_EXT) dx_p -= (t > 1 ? dx_step : 0);
+        da_p -= da_step;
+        if (a.rh) rh_p -= hs_step;
+        res_barrier();
+        // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
+        wave_signal_done_if(t, psig, a.signal_done + pk);
+        {
+            const bool adv = cs_steps && t == plo;
+            pk -= adv ? 1 : 0;
+            plo -= adv ? cs_steps : 0;
+            pwait = (a.wait_ready && plo > 0) ? plo : -1;
+            psig = a.signal_done ? plo : -1;
+        }
+    }
+    const int ldd = a.dh0_ld ? a.dh0_ld : RH;
+#pragma unroll
+    for (int n = 0; n < RNT; ++n)
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 16 * n) = dh[n];
+    vm_drain();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------------------
 // fragment placement per kernel: A in accumulator registers, V in vector registers, the rest in LDS (per wave)
@@ -1664,7 +1969,7 @@ int launch_lstm_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return MVAE_OK;
 }
 
-// GRU with dense / indexed / constant inputs: the slot-interleaved forward kernel (MVAE_GRU_PHASED=1 keeps the phased one)
+// GRU with dense / indexed / constant inputs and seq_layout TILE16P: the slot-interleaved kernel
 template <int XMODE, int SAVE>
 int launch_gru_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     const size_t lds = (size_t)3 * 16 * RH * sizeof(bf16_t) + (size_t)4 * RNT * RS * 64 * sizeof(frag);
@@ -1679,27 +1984,23 @@ int launch_gru_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-inline bool gru_phased() {
-    static const bool v = [] { const char* e = getenv("MVAE_GRU_PHASED"); return e && e[0] == '1'; }();
-    return v;
-}
 template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.acts) {
         if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
         if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
             if (a.seq_layout == MVAE_TILE16P) return launch_lstm_il<XMODE, SAVE_ALL>(a, s);
-        if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
         if constexpr (CELL == MVAE_GRU && XMODE != MVAE_X_SCALAR)
-            if (!gru_phased()) return launch_gru_il<XMODE, SAVE_ALL>(a, s);
+            if (a.seq_layout == MVAE_TILE16P) return launch_gru_il<XMODE, SAVE_ALL>(a, s);
+        if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
         return launch_fwd_res<CELL, XMODE, SAVE_ALL>(a, s);
     }
     if (a.cs) return MVAE_E_UNSUPPORTED;
     if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
         if (a.seq_layout == MVAE_TILE16P) return a.hs ? launch_lstm_il<XMODE, SAVE_HS>(a, s) : launch_lstm_il<XMODE, SAVE_NONE>(a, s);
-    if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     if constexpr (CELL == MVAE_GRU && XMODE != MVAE_X_SCALAR)
-        if (!gru_phased()) return a.hs ? launch_gru_il<XMODE, SAVE_HS>(a, s) : launch_gru_il<XMODE, SAVE_NONE>(a, s);
+        if (a.seq_layout == MVAE_TILE16P) return a.hs ? launch_gru_il<XMODE, SAVE_HS>(a, s) : launch_gru_il<XMODE, SAVE_NONE>(a, s);
+    if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     return a.hs ? launch_fwd_res<CELL, XMODE, SAVE_HS>(a, s) : launch_fwd_res<CELL, XMODE, SAVE_NONE>(a, s);
 }
 template <int CELL>
@@ -1729,11 +2030,28 @@ int launch_lstm_bwd_il(const mvae_rnn_bwd_args& a, hipStream_t s) {
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
+template <bool HAS_EXT>
+int launch_gru_bwd_il(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    const size_t lds = (size_t)16 * 3 * RH * sizeof(bf16_t) + (size_t)16 * RH * sizeof(bf16_t) +
+                       (size_t)4 * RNT * (RH / 32) * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_il_k<HAS_EXT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((gru_bwd_il_k<HAS_EXT>), dim3(a.B / 16), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 template <int CELL, bool HAS_EXT>
 int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
     typedef res_cfg<CELL> C;
     if constexpr (CELL == MVAE_LSTM)
         if (a.seq_layout == MVAE_TILE16P) return launch_lstm_bwd_il<HAS_EXT>(a, s);
+    if constexpr (CELL == MVAE_GRU)
+        if (a.seq_layout == MVAE_TILE16P) return launch_gru_bwd_il<HAS_EXT>(a, s);
     if (a.seq_layout == MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     constexpr int G = mvae_gates(CELL), NL = RNT * (G * RH / 32) - C::BA - C::BV;
     const size_t lds = (size_t)16 * G * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag) +

@@ -108,16 +108,17 @@ class Engine(object):
         self._pipe_verified = False
 
     def _seq_layout(self, r):
-        """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM kernels (TILE16P saved
-        activations) wherever they apply, else the phased resident kernels (TILE16), else the generic row-major ones."""
+        """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM / GRU kernels (TILE16P
+        saved activations) wherever they apply, else the phased resident kernels (TILE16), else the generic row-major
+        ones."""
         if not self.tile16:
             return hl.ROWMAJOR
-        if self.spec.cell == "LSTM":       # (a 1-feature input is expanded to x*W + b first: _scalar_as_dense)
+        if self.spec.cell in ("LSTM", "GRU"):   # (a 1-feature input is expanded to x*W + b first: _scalar_as_dense)
             return hl.TILE16P
         return hl.TILE16
 
     def _scalar_as_dense(self, r):
-        """1-feature input layers (velocity roll) of an LSTM model: x*W + b is written out (T*B*G*H bf16, one streaming
+        """1-feature input layers (velocity roll) of an LSTM / GRU model: x*W + b is written out (T*B*G*H bf16, one streaming
         kernel, ~0.1 ms) so that the layer runs on the slot-interleaved dense-input kernels (2.1 instead of 3.9 us/step)."""
         return r.xmode == hl.X_SCALAR and self._seq_layout(r) == hl.TILE16P
 

@@ -39,7 +39,7 @@ def seq_layouts(res, cellname, xmode="dense"):
     without a scalar input also the slot-interleaved kernels (TILE16P: saved activations in tile pairs)"""
     if not res:
         return [hl.ROWMAJOR]
-    return [hl.TILE16, hl.TILE16P] if (cellname == "LSTM" and xmode != "scalar") else [hl.TILE16]
+    return [hl.TILE16, hl.TILE16P] if (cellname in ("LSTM", "GRU") and xmode != "scalar") else [hl.TILE16]
 
 
 def resident(H, B, dtype, cell):

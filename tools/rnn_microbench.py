@@ -21,7 +21,7 @@ ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-ma
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
-LAY = hl.ROWMAJOR if a.rowmajor else (hl.TILE16 if (a.phased or a.cell != "LSTM") else hl.TILE16P)
+LAY = hl.ROWMAJOR if a.rowmajor else (hl.TILE16 if (a.phased or a.cell not in ("LSTM", "GRU")) else hl.TILE16P)
 G, H, T, B = hl.GATES[cell], 256, a.T, a.B
 GH = G * H
 dev = "cuda:0"

@@ -22,9 +22,9 @@ hl_ = torch.zeros((B, H), device=dev)
 kw = dict(xp=xp) if a.mode == "dense" else dict(xp0=xp0)
 for _ in range(2):
     if a.which == "fwd":
-        ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=(2 if a.cell == "LSTM" else 1), **kw)
+        ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1), **kw)
     else:
-        ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, da, dhs_ext=dext, rh=rh, dh0=hl_, seq_layout=(2 if a.cell == "LSTM" else 1))
+        ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, da, dhs_ext=dext, rh=rh, dh0=hl_, seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1))
     torch.cuda.synchronize()
 lib = hl.load()
 buf = (ctypes.c_ulonglong * 128)()
