@@ -258,6 +258,46 @@ typedef struct {
 } mvae_latent_bwd_args;
 int mvae_latent_bwd(const mvae_latent_bwd_args* a, void* stream);
 
+/* The Dense chain around the latent as ONE launch each way (reference vae_definition.py:483-516 encoder tail and
+ * latent, :519-530 decoder initial states): cat = [h_notes | h_instr | h_vel] -> pack Dense (tanh, when w_pack) -> extra
+ * Dense (tanh, when w_extra) -> z_mean / z_log_var (on the two halves of the vector when split) -> mvae_latent_fwd ->
+ * S = tanh([z | history] w_init + b_init).  Same results as the separate mvae_gemm / mvae_latent_* calls, in f32 FMAs.
+ * All matrices f32 row-major: w_pack (ncat*H, H), w_extra (H, H), w_mu / w_lv (H/2 or H, Z), w_init (zin, n_init).
+ * B % 4 == 0 (rows >= B_valid are padding: computed, excluded from scalars and gradients); H % 8, Z % 4, zin % 4 == 0. */
+typedef struct {
+    int32_t B, B_valid, H, Z, C, ncat, zin, n_init /* columns of S */, split;
+    float beta, prior_mean, prior_std, inv_batch;
+    const float* cat;             /* (B, ncat*H)                                                             */
+    const float *w_pack, *b_pack, *w_extra, *b_extra, *w_mu, *b_mu, *w_lv, *b_lv, *w_init, *b_init;
+    const float* eps;             /* (B,Z)                                                                   */
+    const uint8_t* style_target;  /* as mvae_latent_fwd_args                                                 */
+    const float* style_row_weight;
+    float *pack, *extra;          /* (B,H) out (kept for backward)                                           */
+    float *mu, *logvar;           /* (B,Z) out                                                               */
+    float* zh;                    /* (B,zin): columns [0,Z) out, [Z,zin) in (history)                        */
+    float* style_probs;           /* (B,C) out or NULL                                                       */
+    float* scalars;               /* (3) as mvae_latent_fwd_args                                             */
+    float* S;                     /* (B,n_init) out                                                          */
+} mvae_latent_chain_fwd_args;
+int mvae_latent_chain_fwd(const mvae_latent_chain_fwd_args* a, void* stream);
+
+typedef struct {
+    int32_t B, B_valid, H, Z, C, ncat, zin, n_init, split;
+    float beta, prior_mean, prior_std, style_weight, inv_batch;
+    const float *wt_pack, *wt_extra, *wt_mu, *wt_lv, *wt_init;   /* the TRANSPOSED matrices, f32 row-major: (H, ncat*H), (H,H),
+                                                                    (Z, H/2 or H) x2, (n_init, zin) - e.g. from
+                                                                    mvae_transpose_convert / mvae_prepare_batch       */
+    const float *S, *pack, *extra, *mu, *logvar, *eps, *style_probs;
+    const uint8_t* style_target;
+    const float* style_row_weight;
+    float* dS;                    /* (B,n_init) in: gradient w.r.t. S; out: w.r.t. its pre-activation         */
+    float* dzh;                   /* (B,zin) out                                                             */
+    float *dmu, *dlogvar;         /* (B,Z) out                                                               */
+    float *d_extra, *d_pack;      /* (B,H) out: gradients w.r.t. the pre-activations of the two tanh Denses   */
+    float* dcat;                  /* (B, ncat*H) out                                                         */
+} mvae_latent_chain_bwd_args;
+int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
+
 /* Every derived copy of the parameters a step needs, in ONE launch (25 tiny dependent kernels cost 0.3 - 0.8 ms of queue
  * latency per training step otherwise).  Each job is one of the single calls above:
  *   MVAE_PREP_PACK_RECURRENT   src = U (a=H, b=G*H) f32, c = direction        -> dst as mvae_pack_recurrent(kind)

@@ -140,6 +140,12 @@ __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+#ifndef GB_DRAIN
+#define GB_DRAIN 0
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int E>
+__device__ __forceinline__ f32x2 lo_hi(const f32x4& v) { return __builtin_shufflevector(v, v, E, E + 1); }
 __device__ __forceinline__ u16x8 cat8(u16x4 a, u16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pinf(float& a) { asm volatile("" : "+v"(a)); }
@@ -1469,8 +1475,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         STAMP(0);
         // pipelined stack: the upstream gradient of step t-1 is requested during this step's M phase
         if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
-        // ---- E: everything requested during the previous M phase has had that whole phase to arrive ------------
-        vm_drain();
+        // ---- E: everything requested during the previous M phase has had that whole phase to arrive (the compiler's
+        // counted waits for the loads; no drain: the da stores issued at the end of that phase may still be in flight)
+        if (GB_DRAIN) vm_drain();
         STAMP(1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1732,14 +1739,17 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         const int o = (n & 1) * 4;
         return f32x4{bf2f(v[o]), bf2f(v[o + 1]), bf2f(v[o + 2]), bf2f(v[o + 3])};
     };
-    auto pre_unpack = [&](int n, int part) __attribute__((always_inline)) {      // 4 parts per tile, ~7 VALU each
+    // (whole-vector expressions: the compiler emits packed f32 instructions, two elements each)
+    auto pre_unpack = [&](int n, int part) __attribute__((always_inline)) {      // 4 parts per tile
         if (part == 0) zv[n] = half(qa[n >> 1][0], n);
         if (part == 1) hh[n] = half(qa[n >> 1][2], n);
         if (part == 2) hp[n] = unpack4(qs[n]);
-        if (part == 3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w1[n][i] = (1.0f - zv[n][i]) * (1.0f - hh[n][i] * hh[n][i]);
-        }
+        if (part == 3) w1[n] = (1.0f - zv[n]) * (1.0f - hh[n] * hh[n]);
+    };
+    // 0.2 * [0 < y < 1] for two elements: med3(2^100 (y - y^2), 0, 0.2) as in dhard_sigmoid
+    auto dhs2 = [&](f32x2 y) __attribute__((always_inline)) -> f32x2 {
+        const f32x2 sq = (y - y * y) * 0x1p100f;
+        return f32x2{__builtin_amdgcn_fmed3f(sq[0], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[1], 0.0f, 0.2f)};
     };
 #pragma unroll
     for (int n = 0; n < RNT; ++n)
@@ -1752,11 +1762,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(da_p);
         if (HAS_EXT) pins(dx_p);
         if (a.rh) pins(rh_p);
-        pinu(da_ch); pinu(b_ch); pinu(rw0); pinu(tl0);
         STAMP(0);
         // pipelined stack: the upstream gradient of step t-1 is requested during this step's MFMA phases
         if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
-        vm_drain();
+        if (GB_DRAIN) vm_drain();       // (else the compiler's counted waits: the copy stores of M2 may still be in flight)
         STAMP(1);
         pinq(qa[0][1]); pinq(qa[1][1]);
         if (HAS_EXT) {
@@ -1776,6 +1785,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         STAMP(3);
         // ---- M1: drh -----------------------------------------------------------------------------------------------
         f32x4 acc1[RNT];
+        f32x2 dzq;
 #pragma unroll
         for (int n = 0; n < RNT; ++n) acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (16u << 6)));
@@ -1794,12 +1804,19 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             mfma1<false>(acc1[n], lt[n], bq[ks % 3]);
             if constexpr (sl + 4 < 32) lt[n] = myl[(size_t)(sl + 4) * 64];
             __builtin_amdgcn_sched_barrier(0);
-            // daz = d (hp - hh) hs'(z) for tile sl/8, element (sl/2)%4
+            // daz = d (hp - hh) hs'(z): tile sl/8, element pair (sl/4)%2, in two pieces (4 + 3 instructions)
             if constexpr (!GB_NODAZ && (sl & 1) == 0) {
-                constexpr int tn = sl >> 3, e = (sl >> 1) & 3;
-                hh[tn][e] = d[tn][e] * (hp[tn][e] - hh[tn][e]) * dhard_sigmoid(zv[tn][e]);     // hh is dead after E1: reuse as daz
-                if constexpr (e == 3)
-                    *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((0 * 32 + tn * 2) << 4))) = pack4(hh[tn]);
+                constexpr int tn = sl >> 3, e = ((sl >> 2) & 1) * 2, piece = (sl >> 1) & 1;
+                if constexpr (piece == 0) {
+                    const f32x2 dz = dhs2(lo_hi<e>(zv[tn]));
+                    dzq = dz;
+                } else {
+                    const f32x2 v = lo_hi<e>(d[tn]) * (lo_hi<e>(hp[tn]) - lo_hi<e>(hh[tn])) * dzq;
+                    hh[tn][e] = v[0];                          // hh is dead after E1: reuse as daz
+                    hh[tn][e + 1] = v[1];
+                    if constexpr (e == 2)
+                        *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((0 * 32 + tn * 2) << 4))) = pack4(hh[tn]);
+                }
             }
             // r, and r*hp -> rh tile (nothing in this step's recurrence waits for it): tile (sl-1)/4 on slots 1, 5, 9, 13
             if constexpr ((sl & 3) == 1 && sl < 16) {
@@ -1807,8 +1824,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
                 rv[tn] = half(qa[tn >> 1][1], tn);
                 if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + (rw0 ^ (tn << 5))) = pack4(rv[tn] * hp[tn]);
             }
-            // memory events: loads 0..7 from slot 17 on (their registers - h_{t-1}, z, hh raw - are dead once the last
-            // tile's r*hp is out; r's raw registers die in slot 13), the candidate columns of the da tile before
+            // memory events: loads 0..7 from slot 16 on (their registers - h_{t-1}, z, hh raw - are dead since the
+            // second half of the previous M2), the candidate columns of the da tile before.  (All 14 loads here, to give
+            // the late ones the ~2000 cycles an HBM load takes, was measured slower: the phase is LDS-bound but not idle.)
             if constexpr (!GB_NOCOPY && sl == 3) da_store(std::integral_constant<int, 4>{}, cp[2]);
             if constexpr (!GB_NOCOPY && sl == 10) da_store(std::integral_constant<int, 5>{}, cp[3]);
             if constexpr (sl >= 16 && (sl & 1) == 0) issue_load(std::integral_constant<int, ((sl - 16) >> 1)>{});
@@ -1820,12 +1838,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         f32x4 part[RNT];
 #pragma unroll
         for (int n = 0; n < RNT; ++n) {
-            f32x4 dar;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dar[i] = acc1[n][i] * hp[n][i] * dhard_sigmoid(rv[n][i]);
-                part[n][i] = d[n][i] * zv[n][i] + acc1[n][i] * rv[n][i];
-            }
+            const f32x2 s0 = dhs2(lo_hi<0>(rv[n])), s1 = dhs2(lo_hi<2>(rv[n]));
+            const f32x4 dar = acc1[n] * hp[n] * f32x4{s0[0], s0[1], s1[0], s1[1]};
+            part[n] = d[n] * zv[n] + acc1[n] * rv[n];
             *reinterpret_cast<u16x4*>(dabuf + da_row + (da_ch ^ ((1 * 32 + n * 2) << 4))) = pack4(dar);
         }
         STAMP(5);
@@ -1854,7 +1869,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
                 bq[(ks + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((unsigned)(ks + 2) << 6)));
             mfma1<true>(acc2[n], ua[sl], bq[ks % 3]);
             __builtin_amdgcn_sched_barrier(0);
-            // memory events: loads 8..13 first, then the copies of the rh tile and of the da tile's z, r columns
+            // memory events: loads 8..13 first (r, upstream gradient: used from the next E1 on), then the copies of the
+            // rh tile and of the da tile's z, r columns
             if constexpr ((sl & 3) == 1 && sl < 24) issue_load(std::integral_constant<int, 8 + (sl >> 2)>{});
             if constexpr (sl == 26 || sl == 31) {
                 if (a.rh) {

@@ -17,6 +17,8 @@ from __future__ import annotations
 from collections import OrderedDict
 
 import numpy as np
+import os
+
 import torch
 
 from . import hiplib as hl
@@ -98,6 +100,9 @@ class Engine(object):
         # beside the latency-bound recurrences slow those down by more than the ~1 ms tail they would save (measured:
         # 14.1 ms per step with per-chunk gradients, 13.0 ms without; bounding their grids is worse still).
         self.grad_per_chunk = False
+        self._deferred = None
+        self.defer_decoder_grads = False # decoder parameter-gradient GEMMs enqueued behind the latent chain (see backward)
+        self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(init_params(spec, seed))
         self._build_graph_description()
@@ -292,6 +297,15 @@ class Engine(object):
             for name, n in (("dS", self.n_init * H), ("dzh", s.zin), ("dmu", Z), ("dlv", Z), ("dtail", H),
                             ("dtail2", H), ("dcat", self.ncat * H)):
                 buf(name, B * n, **f32)
+            # transposed f32 copies of the Dense kernels around the latent (fused backward chain, csrc/latent.hip)
+            h1w = H // 2 if s.split else H
+            buf("lat.wt_init", self.n_init * H * s.zin, **f32)
+            buf("lat.wt_mu", Z * h1w, **f32)
+            buf("lat.wt_lv", Z * (H - h1w if s.split else H), **f32)
+            if s.extra_layer:
+                buf("lat.wt_extra", H * H, **f32)
+            if self.has_pack:
+                buf("lat.wt_pack", H * self.ncat * H, **f32)
         # inputs
         buf("in.x_idx", T * B, **u8)
         buf("in.y_idx", T * B, **u8)
@@ -430,6 +444,11 @@ class Engine(object):
                 pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
             if s.meta_velocity:
                 pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+            if self.training:
+                for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
+                                     ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
+                    if tname in self.store:
+                        pb.transpose_convert(P[wname], self.store[tname])
         self._prep.run()
         self._weights_dirty = False
 
@@ -582,8 +601,10 @@ class Engine(object):
         if nch > 1:
             self._join(*streams[1:])
 
-    def encoder_forward(self, B):
-        """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502."""
+    def encoder_forward(self, B, with_init=False):
+        """reference vae_definition.py:443-516 (encoder) incl. the KL layer :15-37 and sampling :498-502.  ``with_init``:
+        decoder_forward on the sampled z follows immediately - the fused latent chain also writes the decoder's initial
+        states."""
         s, P = self.spec, self.P
         H, Z = s.H, s.Z
         Breal, B = B, self.pad16(B)
@@ -603,6 +624,9 @@ class Engine(object):
         self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._join(self.s_vel, self.s_instr)
         self._mark("  encoder recurrences")
+        self._S_done = False
+        if self.fused_latent and self._latent_chain_forward(Breal, B, with_init):
+            return
         h = cat
         if self.has_pack:
             pk = self._v("pack", B, H)
@@ -625,6 +649,32 @@ class Engine(object):
                        style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
                        style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
 
+    def _latent_chain_forward(self, Breal, B, with_init):
+        """Encoder tail Denses, latent block and the decoder's initial-state Denses as ONE launch (csrc/latent.hip): six
+        dependent small kernels otherwise, in a stretch of the step where nothing else can run.  False = shape not
+        supported by the library (the separate launches follow)."""
+        s, P = self.spec, self.P
+        H, Z = s.H, s.Z
+        tg = s.style and self._have_targets
+        ok = ops.latent_chain_fwd(
+            B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, self.n_init * H, s.split, s.beta, s.prior_mean,
+            s.prior_std, 1.0 / Breal, cat=self._v("cat", B, self.ncat * H),
+            w_pack=P["enc.pack.W"] if self.has_pack else None, b_pack=P["enc.pack.b"] if self.has_pack else None,
+            w_extra=P["enc.extra.W"] if s.extra_layer else None, b_extra=P["enc.extra.b"] if s.extra_layer else None,
+            w_mu=P["enc.zmean.W"], b_mu=P["enc.zmean.b"], w_lv=P["enc.zlogvar.W"], b_lv=P["enc.zlogvar.b"],
+            w_init=P["dec.init.W"] if with_init else None, b_init=P["dec.init.b"] if with_init else None,
+            eps=self._v("in.eps", B, Z), style_target=self._v("in.c_idx", Breal) if tg else None,
+            style_row_weight=self._v("in.rw_style", Breal) if tg else None,
+            pack=self._v("pack", B, H) if self.has_pack else None, extra=self._v("extra", B, H) if s.extra_layer else None,
+            mu=self._v("mu", B, Z), logvar=self._v("lv", B, Z), zh=self._v("zh", B, s.zin),
+            style_probs=self._v("style_p", B, s.C) if s.style else None, scalars=self.scal[S_KL:S_KL + 3],
+            S=self._v("S", B, self.n_init * H) if with_init else None)
+        if ok:
+            self._tail = (self._v("extra", B, H) if s.extra_layer else self._v("pack", B, H) if self.has_pack
+                          else self._v("cat", B, H))
+            self._S_done = with_init
+        return ok
+
     def decoder_forward(self, B, want_probs=False):
         """reference vae_definition.py:519-645 (decoder heads) + losses :332-441 when targets are staged."""
         s, P = self.spec, self.P
@@ -632,7 +682,9 @@ class Engine(object):
         Breal, B = B, self.pad16(B)
         zh = self._v("zh", B, s.zin)
         S = self._v("S", B, self.n_init * H)
-        ops.gemm(zh, P["dec.init.W"], S, B, self.n_init * H, s.zin, bias=P["dec.init.b"], act=hl.ACT_TANH)
+        if not getattr(self, "_S_done", False):      # (else written by the fused latent chain of encoder_forward)
+            ops.gemm(zh, P["dec.init.W"], S, B, self.n_init * H, s.zin, bias=P["dec.init.b"], act=hl.ACT_TANH)
+        self._S_done = False
         ldS = self.n_init * H
 
         def states(r):
@@ -724,6 +776,11 @@ class Engine(object):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
+        if self._deferred is not None:     # decoder layers: enqueued behind the latent chain (see backward)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._deferred.append((ev, lambda: self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start)))
+            return
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
         Tc = T // nch
@@ -866,6 +923,10 @@ class Engine(object):
                         dh0_ld=ldS)
 
         # ---- decoder: three independent branches ---------------------------------------------------------
+        # Their parameter-gradient GEMMs fill every CU for ~1 ms; started the moment the decoder BPTT ends they are in the
+        # way of the one short kernel the encoder BPTT waits for (the latent chain: 0.08 ms alone, 0.5 ms behind them).
+        # They are collected here and enqueued once that kernel is - they then run beside the encoder BPTT as before.
+        self._deferred = [] if (self.defer_decoder_grads and self.multi_stream) else None
         self._fork(self.s_vel, self.s_instr)
         if s.meta_instrument:
             with self._on(self.s_instr):
@@ -883,6 +944,36 @@ class Engine(object):
                              slot=2)
         self._join(self.s_vel, self.s_instr)
         self._mark("  decoder BPTT")
+        deferred, self._deferred = self._deferred, None
+        dcat = self._latent_chain_backward(Breal, B) if self.fused_latent else None
+        if dcat is None:
+            dcat = self._latent_backward_unfused(Breal, B)
+        for ev, fn in deferred or ():
+            torch.cuda.current_stream().wait_event(ev)       # (no-op in time: the decoder BPTT was joined above)
+            fn()
+        ldc = self.ncat * H
+        self._mark("  latent block backward")
+        # ---- encoder recurrences: three independent branches -------------------------------------------------
+        self._fork(self.s_vel, self.s_instr)
+        k = 1
+        if s.meta_instrument:
+            with self._on(self.s_instr):
+                self._stack_backward([self.enc_instr], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                     idx=self._v("in.i_idx", V, B))
+            k += 1
+        if s.meta_velocity:
+            with self._on(self.s_vel):
+                self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                     xs=self._v("in.vel", T, B))
+        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+        self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
+
+    def _latent_backward_unfused(self, Breal, B):
+        """initial-state Denses, latent block and encoder tail Denses backward, one launch per operation; returns d(cat)"""
+        s, P, G = self.spec, self.P, self.G
+        H, Z = s.H, s.Z
+        dS = self._v("dS", B, self.n_init * H)
+        ldS = self.n_init * H
         # initial-state Denses: S = tanh([z|hist] Winit + b)
         S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
         ops.tanh_bwd(S, dS, dS)
@@ -937,21 +1028,51 @@ class Engine(object):
             ops.gemm(dt, P["enc.pack.W"], dcat, B, ldc, H, trans_b=True)
         else:
             dcat = dt
-        self._mark("  latent block backward")
-        # ---- encoder recurrences: three independent branches -------------------------------------------------
-        self._fork(self.s_vel, self.s_instr)
-        k = 1
-        if s.meta_instrument:
-            with self._on(self.s_instr):
-                self._stack_backward([self.enc_instr], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                     idx=self._v("in.i_idx", V, B))
-            k += 1
-        if s.meta_velocity:
-            with self._on(self.s_vel):
-                self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                     xs=self._v("in.vel", T, B))
-        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
-        self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
+        return dcat
+
+    def _latent_chain_backward(self, Breal, B):
+        """The same as ONE launch (csrc/latent.hip) followed by the parameter-gradient GEMMs on the side streams; None if
+        the library does not support the shape."""
+        s, P, G = self.spec, self.P, self.G
+        H, Z = s.H, s.Z
+        ldS, ldc = self.n_init * H, self.ncat * H
+        dS, S, zh = self._v("dS", B, ldS), self._v("S", B, ldS), self._v("zh", B, s.zin)
+        dmu, dlv = self._v("dmu", B, Z), self._v("dlv", B, Z)
+        d_extra, d_pack = self._v("dtail", B, H), self._v("dtail2", B, H)
+        dcat = self._v("dcat", B, ldc)
+        pk, ex, cat = self._v("pack", B, H), self._v("extra", B, H), self._v("cat", B, ldc)
+        ok = ops.latent_chain_bwd(
+            B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, ldS, s.split, s.beta, s.prior_mean, s.prior_std, s.w_style,
+            1.0 / Breal, wt_pack=self.store.get("lat.wt_pack"), wt_extra=self.store.get("lat.wt_extra"),
+            wt_mu=self.store["lat.wt_mu"], wt_lv=self.store["lat.wt_lv"], wt_init=self.store["lat.wt_init"], S=S,
+            pack=pk if self.has_pack else None,
+            extra=ex if s.extra_layer else None, mu=self._v("mu", B, Z), logvar=self._v("lv", B, Z), eps=self._v("in.eps", B, Z),
+            style_probs=self._v("style_p", B, s.C) if s.style else None,
+            style_target=self._v("in.c_idx", Breal) if s.style else None,
+            style_row_weight=self._v("in.rw_style", Breal) if s.style else None, dS=dS, dzh=self._v("dzh", B, s.zin), dmu=dmu,
+            dlogvar=dlv, d_extra=d_extra if s.extra_layer else None, d_pack=d_pack if self.has_pack else None, dcat=dcat)
+        if not ok:
+            return None
+        h = self._tail
+        h1w = H // 2 if s.split else H
+        h2w = H - h1w if s.split else H
+
+        def param_grads():
+            ops.gemm(zh, dS, G["dec.init.W"], s.zin, ldS, B, trans_a=True, accumulate=True)
+            ops.colsum(dS, B, ldS, G["dec.init.b"])
+            ops.gemm(h, dmu, G["enc.zmean.W"], h1w, Z, B, trans_a=True, lda=H, accumulate=True)
+            ops.colsum(dmu, B, Z, G["enc.zmean.b"])
+            ops.gemm(h[:, h1w:] if s.split else h, dlv, G["enc.zlogvar.W"], h2w, Z, B, trans_a=True, lda=H, accumulate=True)
+            ops.colsum(dlv, B, Z, G["enc.zlogvar.b"])
+            if s.extra_layer:
+                ops.gemm(pk if self.has_pack else cat, d_extra, G["enc.extra.W"], H, H, B, trans_a=True, accumulate=True)
+                ops.colsum(d_extra, B, H, G["enc.extra.b"])
+            if self.has_pack:
+                ops.gemm(cat, d_pack, G["enc.pack.W"], ldc, H, B, trans_a=True, accumulate=True)
+                ops.colsum(d_pack, B, H, G["enc.pack.b"])
+
+        self._side(param_grads)
+        return dcat
 
     # ------------------------------------------------------------------------------------------------------
     # steps
@@ -974,7 +1095,7 @@ class Engine(object):
         if self._weights_dirty or self.use_graphs:
             self.prepare_weights()
         self._mark("weights prepared")
-        self.encoder_forward(B)
+        self.encoder_forward(B, with_init=True)
         self._mark("encoder forward (incl. latent)")
         self.decoder_forward(B)
         self._mark("decoder forward + heads")
@@ -1061,9 +1182,10 @@ class Engine(object):
         self.scal.zero_()
         if self._weights_dirty:
             self.prepare_weights()
-        self.encoder_forward(B)
+        self.encoder_forward(B, with_init=True)
         self.decoder_forward(B, want_probs=want_probs)
-        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B), self.decoder_forward(B, want_probs=want_probs)))
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B, with_init=True),
+                                       self.decoder_forward(B, want_probs=want_probs)))
 
     def encode(self, B):
         """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
@@ -1078,6 +1200,7 @@ class Engine(object):
     def decode(self, B, want_probs=True):
         """``decoder.predict`` on the staged [z|history]; argmax note indices are always produced on device."""
         self._have_targets = False
+        self._S_done = False
         self.scal.zero_()
         if self._weights_dirty:
             self.prepare_weights()

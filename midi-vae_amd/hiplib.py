@@ -21,6 +21,7 @@ ACT_NONE, ACT_TANH = 0, 1
 ROWMAJOR, TILE16, TILE16P = 0, 1, 2
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
+E_ARG, E_UNSUPPORTED, E_LAUNCH = -1, -2, -3
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)"}
 
@@ -81,6 +82,22 @@ class LatentBwdArgs(C.Structure):
                 ("dlogvar", _vp), ("lddz", _i32)]
 
 
+class LatentChainFwdArgs(C.Structure):
+    _fields_ = ([(n, _i32) for n in ("B", "B_valid", "H", "Z", "C", "ncat", "zin", "n_init", "split")] +
+                [(n, _f32) for n in ("beta", "prior_mean", "prior_std", "inv_batch")] +
+                [(n, _vp) for n in ("cat", "w_pack", "b_pack", "w_extra", "b_extra", "w_mu", "b_mu", "w_lv", "b_lv", "w_init",
+                                    "b_init", "eps", "style_target", "style_row_weight", "pack", "extra", "mu", "logvar", "zh",
+                                    "style_probs", "scalars", "S")])
+
+
+class LatentChainBwdArgs(C.Structure):
+    _fields_ = ([(n, _i32) for n in ("B", "B_valid", "H", "Z", "C", "ncat", "zin", "n_init", "split")] +
+                [(n, _f32) for n in ("beta", "prior_mean", "prior_std", "style_weight", "inv_batch")] +
+                [(n, _vp) for n in ("wt_pack", "wt_extra", "wt_mu", "wt_lv", "wt_init", "S", "pack", "extra", "mu", "logvar", "eps",
+                                    "style_probs", "style_target", "style_row_weight", "dS", "dzh", "dmu", "dlogvar",
+                                    "d_extra", "d_pack", "dcat")])
+
+
 # name -> (restype, argtypes); every symbol include/midivae_hip.h declares
 SIGNATURES = {
     "mvae_abi_version": (_i32, []),
@@ -100,6 +117,8 @@ SIGNATURES = {
     "mvae_head_np": (_i32, [_i32]),
     "mvae_latent_fwd": (_i32, [C.POINTER(LatentFwdArgs), _vp]),
     "mvae_latent_bwd": (_i32, [C.POINTER(LatentBwdArgs), _vp]),
+    "mvae_latent_chain_fwd": (_i32, [C.POINTER(LatentChainFwdArgs), _vp]),
+    "mvae_latent_chain_bwd": (_i32, [C.POINTER(LatentChainBwdArgs), _vp]),
     "mvae_relayout": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_tanh_bwd": (_i32, [_vp, _vp, _vp, _sz, _vp]),
     "mvae_convert": (_i32, [_vp, _i32, _vp, _i32, _sz, _vp]),

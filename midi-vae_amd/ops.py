@@ -153,6 +153,31 @@ def latent_bwd(B, Z, C, beta, prior_mean, prior_std, style_weight, inv_batch, mu
     hl.check(hl.load().mvae_latent_bwd(a, _stream()), "mvae_latent_bwd")
 
 
+def latent_chain_fwd(B, B_valid, H, Z, C, ncat, zin, n_init, split, beta, prior_mean, prior_std, inv_batch, **t):
+    """Encoder tail Denses + latent block + decoder initial-state Denses in one launch (mvae_latent_chain_fwd); tensors by
+    the field names of the C struct, absent / None = NULL.  Returns False if the library does not support the shape."""
+    a = hl.LatentChainFwdArgs(B, B_valid, H, Z, C, ncat, zin, n_init, int(bool(split)), beta, prior_mean, prior_std, inv_batch)
+    for name, _ in hl.LatentChainFwdArgs._fields_[13:]:
+        setattr(a, name, _p(t.get(name)))
+    rc = hl.load().mvae_latent_chain_fwd(a, _stream())
+    if rc == hl.E_UNSUPPORTED:
+        return False
+    hl.check(rc, "mvae_latent_chain_fwd")
+    return True
+
+
+def latent_chain_bwd(B, B_valid, H, Z, C, ncat, zin, n_init, split, beta, prior_mean, prior_std, style_weight, inv_batch, **t):
+    a = hl.LatentChainBwdArgs(B, B_valid, H, Z, C, ncat, zin, n_init, int(bool(split)), beta, prior_mean, prior_std,
+                              style_weight, inv_batch)
+    for name, _ in hl.LatentChainBwdArgs._fields_[14:]:
+        setattr(a, name, _p(t.get(name)))
+    rc = hl.load().mvae_latent_chain_bwd(a, _stream())
+    if rc == hl.E_UNSUPPORTED:
+        return False
+    hl.check(rc, "mvae_latent_chain_bwd")
+    return True
+
+
 def relayout(src, dst, rows, cols, to_tile16, paired=False):
     """row-major <-> TILE16 (or TILE16P with ``paired``); ``to_tile16`` True = row-major -> tiled"""
     hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols, int(bool(to_tile16)) + (2 if paired else 0),

@@ -199,6 +199,32 @@ def test_time_pipelined_stacks_match_chunked_launches():
     assert abs(res[True][0][0]["loss"] - m_o["loss"]) <= 3e-2 * (1 + abs(m_o["loss"]))
 
 
+@pytest.mark.parametrize("cell,kw", [("LSTM", {}), ("GRU", dict(H=64, Z=8, T=8)), ("LSTM", dict(H=64, Z=16, T=8))])
+def test_fused_latent_chain_matches_separate_launches(cell, kw):
+    """The Dense chain around the latent as one launch each way (csrc/latent.hip, f32 FMAs) against the same chain as
+    separate GEMM / elementwise launches: losses, z and every gradient agree to f32 round-off; ragged batch included
+    (padding rows carry no gradient)."""
+    for B in (16, 5):
+        spec, params, batch, raw = _problem(cell, B, seed=17, **kw)
+        res = {}
+        for fused in (True, False):
+            eng = Engine(spec, max_batch=16, dtype="f32")
+            eng.fused_latent = fused
+            eng.set_params(params)
+            _stage(eng, raw, B)
+            eng.forward_backward(B)
+            res[fused] = (eng.metrics(B), eng.get_grads(), eng.latent(B).copy())
+            if fused:       # the library took the shape (no silent fallback to the separate launches)
+                assert eng._latent_chain_backward(B, eng.pad16(B)) is not None
+        (m1, g1, z1), (m0, g0, z0) = res[True], res[False]
+        np.testing.assert_allclose(z1, z0, rtol=2e-5, atol=2e-6)
+        for k in ("loss", "kl"):
+            assert abs(m1[k] - m0[k]) <= 2e-5 * (1 + abs(m0[k])), (k, m1[k], m0[k])
+        for k in g0:
+            if np.linalg.norm(g0[k]) > 1e-9:
+                assert _rel_l2(g1[k], g0[k]) < 2e-4, (B, k, _rel_l2(g1[k], g0[k]))
+
+
 def test_ragged_batch_reuses_buffers():
     """A smaller last minibatch (songs are not multiples of batch_size) runs in the same engine."""
     spec, params, batch, raw = _problem("GRU", 5, seed=2)
