@@ -231,10 +231,22 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 //     staged AS IS and read with ds_read_b64_tr_b16, the LDS transpose read of gfx950 - the generic kernel
 //     transposes with eight 2-byte LDS stores per 16 bytes loaded.
 // ===========================================================================================================
+#ifndef GEMM_ABL_NOMFMA
+#define GEMM_ABL_NOMFMA 0          // development ablations: timing only, wrong results
+#endif
+#ifndef GEMM_ABL_NOLOAD
+#define GEMM_ABL_NOLOAD 0
+#endif
+#ifndef GEMM_ABL_NOATOMIC
+#define GEMM_ABL_NOATOMIC 0
+#endif
 constexpr int FBM = 128, FBN = 128, FBK = 64;
 constexpr int F_LDK = FBK + 8;        // k-contiguous image: [row][FBK + 8]  (144 B rows: conflict-free b128 reads)
 constexpr int F_LDR = 128 + 16;       // row-contiguous image: [k][128 + 16] (288 B rows = 32 mod 256: tr reads spread)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// image row of k row k (0..63) of a row-contiguous operand tile, see f_frag
+__device__ __forceinline__ int f_krow(int k) { return (k & 32) | ((k & 4) << 2) | ((k >> 1) & 12) | (k & 3); }
 
 template <bool RC>   // element count of one operand image
 constexpr int f_img() { return RC ? FBK * F_LDR : 128 * F_LDK; }
@@ -245,10 +257,13 @@ __device__ __forceinline__ u16x8 f_frag(const bf16_t* img, int rbase, int kg, in
     if (!RC) return *reinterpret_cast<const u16x8*>(img + (rbase + r) * F_LDK + kg * 32 + q * 8);
     // lane r of a 16-lane group hands in the 8-byte chunk (k = k0 + r/4, rows rbase + 4*(r%4) ..+3); the transpose
     // read returns k0..k0+3 of row rbase + r
-    const int k0 = kg * 32 + q * 8;
-    const bf16_t* p0 = img + (k0 + (r >> 2)) * F_LDR + rbase + (r & 3) * 4;
+    // The image holds k row kg*32 + q*8 + h*4 + j at position kg*32 + h*16 + q*4 + j (f_krow): the 8 rows one half-wave
+    // pass of a transpose read touches (j = 0..3 of two neighbouring q) are then 8 CONSECUTIVE image rows, 8 banks apart
+    // (row pitch 72 dwords): all 64 banks once.  With the rows in natural order the two q of a pass are 8 rows = 576
+    // dwords = 0 banks apart: every pass a 2-way conflict (SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles).
+    const bf16_t* p0 = img + (kg * 32 + q * 4 + (r >> 2)) * F_LDR + rbase + (r & 3) * 4;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * F_LDR));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * F_LDR));
     return u16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2],
                  (bf16_t)hi[3]};
 }
@@ -261,6 +276,7 @@ struct f_stage {
     // rlim: first row index that may not be read (row-contiguous operands narrower than the tile re-read their last
     // 8 columns instead of running into the next k row; those output columns are never stored)
     __device__ __forceinline__ void load(const void* base, int ld, int row0, int k0, int tid, int rlim = 1 << 30) {
+        if (GEMM_ABL_NOLOAD) k0 = 0;           // every tile re-reads the first one (L2 hits)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * 256;
@@ -284,7 +300,7 @@ struct f_stage {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + i * 256;
-            if (RC) *reinterpret_cast<u16x8*>(img + (c >> 4) * F_LDR + (c & 15) * 8) = v[i];
+            if (RC) *reinterpret_cast<u16x8*>(img + f_krow(c >> 4) * F_LDR + (c & 15) * 8) = v[i];
             else *reinterpret_cast<u16x8*>(img + (c >> 3) * F_LDK + (c & 7) * 8) = v[i];
         }
     }
@@ -305,12 +321,23 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     // persistent chunked mode: a fixed grid walks the M tiles chunk by chunk, handing over with device-side counters
     const int tiles_mc = a.chunk_rows ? a.chunk_rows / FBM : tiles_m;          // M tiles per chunk
     const int nchunks = tiles_m / tiles_mc;
-    const int total_tiles = tiles_n * tiles_mc * splits;
+    // Split-K with >= 8 splits (the weight-gradient GEMMs: 16 output tiles, K = T*B): the tiles of one k-range share their
+    // A and B panels, so they go to ONE XCD (workgroup b runs on XCD b % 8) - spread over all eight, every XCD's L2 fetches
+    // every panel of A (2.4x the unique bytes from HBM for a 256 x 1024 output).
+    const bool xcd_split = splits >= 8 && !a.chunk_rows && (gridDim.x % 8) == 0;
+    const int total_tiles = tiles_n * tiles_mc * (xcd_split ? (splits + 7) / 8 * 8 : splits);
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
     if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
+        int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
+        if (xcd_split) {
+            const int x = tile & 7, i = tile >> 3, per_k = tiles_n * tiles_mc, within = i % per_k;
+            bz = (i / per_k) * 8 + x;
+            bx = within % tiles_n;
+            by = within / tiles_n;
+            if (bz >= splits) continue;
+        }
         const int m0 = by * FBM, n0 = bx * FBN;
         int kbeg = 0, kend = K;
         if (splits > 1) {
@@ -325,42 +352,89 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        f_stage<A_RC, ONEHOT> sa;
-        f_stage<B_RC, false> sb;
-        sa.load(a.A, a.lda, m0, kbeg, tid);
-        sb.load(a.B, a.ldb, n0, kbeg, tid, nlim);
+        // Main loop.  One wave per SIMD runs this (a 128x128 tile per CU), so nothing overlaps unless the instruction
+        // stream itself interleaves: issued in source order - 8 global loads, 16 LDS reads, wait, 16 MFMAs, 16 LDS reads,
+        // wait, 16 MFMAs, 8 LDS writes, barrier - an iteration takes ~3400 cycles for 512 cycles of MFMAs (the loads alone
+        // hold the CU's address unit for ~860).  Hence:
+        //   * prefetch distance TWO K tiles through registers (requested in iteration k, stored to LDS at the end of k+1),
+        //     and lds_barrier() instead of __syncthreads(), which drains vmcnt(0) - every prefetch in flight;
+        //   * branch-free iteration halves (clamped addresses at the tail) that the scheduler is told to interleave:
+        //     k-group 0's MFMAs carry the global loads and k-group 1's LDS reads, k-group 1's MFMAs the LDS writes.
+        f_stage<A_RC, ONEHOT> sa0, sa1;
+        f_stage<B_RC, false> sb0, sb1;
+        const int ntiles = (kend - kbeg + FBK - 1) / FBK, klast = kbeg + (ntiles - 1) * FBK;
+        sa0.load(a.A, a.lda, m0, kbeg, tid);
+        sb0.load(a.B, a.ldb, n0, kbeg, tid, nlim);
+        sa1.load(a.A, a.lda, m0, min(kbeg + FBK, klast), tid);
+        sb1.load(a.B, a.ldb, n0, min(kbeg + FBK, klast), tid, nlim);
         __syncthreads();                       // previous output tile's readers are done with both images
-        sa.store(As, tid);
-        sb.store(Bs, tid);
+        sa0.store(As, tid);
+        sb0.store(Bs, tid);
         __syncthreads();
         int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += FBK) {
-            const bool more = k0 + FBK < kend;
-            if (more) {                        // global loads for the next K tile fly under this tile's MFMAs
-                sa.load(a.A, a.lda, m0, k0 + FBK, tid);
-                sb.load(a.B, a.ldb, n0, k0 + FBK, tid, nlim);
+        auto frags = [&](int buf, int kg, u16x8 (&fa)[4], u16x8 (&fb)[4]) __attribute__((always_inline)) {
+            const bf16_t* Ai = As + buf * IA;
+            const bf16_t* Bi = Bs + buf * IB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = f_frag<A_RC>(Ai, wm * 64 + i * 16, kg, q, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = f_frag<B_RC>(Bi, wn * 64 + j * 16, kg, q, r);
+        };
+        auto mfmas = [&](u16x8 (&fa)[4], u16x8 (&fb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!GEMM_ABL_NOMFMA || (i == 0 && j == 0)) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);   // rows: n, cols: m
+        };
+        // one K tile from LDS[cur]; requests tile kreq into (la, lb); stores (sta, stb) - requested an iteration ago - into
+        // the other LDS image
+        auto half = [&](f_stage<A_RC, ONEHOT>& la, f_stage<B_RC, false>& lb, const f_stage<A_RC, ONEHOT>& sta,
+                        const f_stage<B_RC, false>& stb, int kreq) __attribute__((always_inline)) {
+            static_assert(FBK == 64, "two k-groups per tile");
+            u16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+            frags(cur, 0, fa0, fb0);
+            la.load(a.A, a.lda, m0, kreq, tid);
+            lb.load(a.B, a.ldb, n0, kreq, tid, nlim);
+            frags(cur, 1, fa1, fb1);
+            mfmas(fa0, fb0);
+            mfmas(fa1, fb1);
+            sta.store(As + (cur ^ 1) * IA, tid);
+            stb.store(Bs + (cur ^ 1) * IB, tid);
+            if (!ONEHOT && !GEMM_ABL_NOMFMA) {
+                // DS read 0x100, MFMA 0x008, VMEM read 0x020, DS write 0x200
+                __builtin_amdgcn_sched_group_barrier(0x100, (A_RC ? 8 : 4) + (B_RC ? 8 : 4), 0);      // k-group 0 fragments
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, ((A_RC ? 8 : 4) + (B_RC ? 8 : 4)) / 8, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
             }
-            const bf16_t* Ai = As + cur * IA;
-            const bf16_t* Bi = Bs + cur * IB;
+            lds_barrier();
+            cur ^= 1;
+        };
+        int t = 0, k0 = kbeg;
+        for (; t + 2 <= ntiles; t += 2, k0 += 2 * FBK) {
+            // tile t is in LDS[cur], tile t+1 in flight to (sa1, sb1): request t+2 into (sa0, sb0), store (sa1, sb1)
+            half(sa0, sb0, sa1, sb1, min(k0 + 2 * FBK, klast));
+            // tile t+1 is in LDS[cur], tile t+2 in flight to (sa0, sb0): request t+3 into (sa1, sb1), store (sa0, sb0)
+            half(sa1, sb1, sa0, sb0, min(k0 + 3 * FBK, klast));
+        }
+        if (t < ntiles) {                      // odd tile count: the last tile is in LDS[cur]
+            u16x8 fa[4], fb[4];
 #pragma unroll
             for (int kg = 0; kg < FBK / 32; ++kg) {
-                u16x8 fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = f_frag<A_RC>(Ai, wm * 64 + i * 16, kg, q, r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = f_frag<B_RC>(Bi, wn * 64 + j * 16, kg, q, r);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);   // rows: n, cols: m
+                frags(cur, kg, fa, fb);
+                mfmas(fa, fb);
             }
-            if (more) {
-                sa.store(As + (cur ^ 1) * IA, tid);
-                sb.store(Bs + (cur ^ 1) * IB, tid);
-            }
-            __syncthreads();
-            cur ^= 1;
         }
+        __syncthreads();                       // (the epilogue does not touch LDS; the next output tile's prologue does)
         // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -384,7 +458,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                     float* cp = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < N) atomicAdd(cp + e, v[e]);
+                        if (!GEMM_ABL_NOATOMIC && n + e < N) atomicAdd(cp + e, v[e]);
                 } else if (a.c_kind == MVAE_F32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n) = v;
                 } else {
@@ -409,7 +483,7 @@ int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
         raised = true;
     }
     const int sk = a.split_k > 1 ? a.split_k : 1;
-    long long tiles = (long long)((a.N + FBN - 1) / FBN) * ((a.M + FBM - 1) / FBM) * sk;
+    long long tiles = (long long)((a.N + FBN - 1) / FBN) * ((a.M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk);
     if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
     if (a.chunk_rows) tiles = a.max_blocks;          // persistent grid: every workgroup passes through every chunk
     hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT>), dim3((unsigned)tiles), dim3(256), lds, s, a);

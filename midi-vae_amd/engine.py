@@ -101,7 +101,7 @@ class Engine(object):
         # 14.1 ms per step with per-chunk gradients, 13.0 ms without; bounding their grids is worse still).
         self.grad_per_chunk = False
         self._deferred = None
-        self.defer_decoder_grads = False # decoder parameter-gradient GEMMs enqueued behind the latent chain (see backward)
+        self.defer_decoder_grads = False # decoder parameter-gradient work released once the encoder BPTT is resident (see backward)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(init_params(spec, seed))
@@ -772,14 +772,14 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None):
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
-        if self._deferred is not None:     # decoder layers: enqueued behind the latent chain (see backward)
+        if self._deferred is not None:     # decoder layers: enqueued once the encoder BPTT is running (see backward)
             ev = torch.cuda.Event()
             ev.record()
-            self._deferred.append((ev, lambda: self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start)))
+            self._deferred.append((ev, lambda: self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start, fork=False)))
             return
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
@@ -791,7 +791,8 @@ class Engine(object):
         da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
         sk = self._split_k(R)
         mb = self.grad_gemm_blocks
-        self._fork(self.s_grad, self.s_grad2)
+        if fork:
+            self._fork(self.s_grad, self.s_grad2)
         with self._on(self.s_grad):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
@@ -827,6 +828,7 @@ class Engine(object):
         order = list(reversed(layers))               # order[0] = top layer: runs on this stream, publishes da
         L = len(order)
         sync, da_target, dx_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
+        self._pipe_started = (sync[0, 0][nchp - 1:nchp], da_target)      # reached when the top layer's first chunk is out
         status = self.store["pipe_status"]
         lower_streams = self.s_layer[:L - 1]         # order[li], li >= 1, on lower_streams[li - 1]
         gemm_streams = self.s_proj[:L - 1]
@@ -923,10 +925,12 @@ class Engine(object):
                         dh0_ld=ldS)
 
         # ---- decoder: three independent branches ---------------------------------------------------------
-        # Their parameter-gradient GEMMs fill every CU for ~1 ms; started the moment the decoder BPTT ends they are in the
-        # way of the one short kernel the encoder BPTT waits for (the latent chain: 0.08 ms alone, 0.5 ms behind them).
-        # They are collected here and enqueued once that kernel is - they then run beside the encoder BPTT as before.
-        self._deferred = [] if (self.defer_decoder_grads and self.multi_stream) else None
+        # Their parameter-gradient GEMMs keep every CU supplied with workgroups for ~1 ms.  A resident-weights recurrent
+        # kernel needs whole EMPTY CUs (160 KiB LDS, 512 registers per lane): launched behind such GEMMs the encoder BPTT
+        # waits until they run out of workgroups (0.4 ms, measured on the kernel timeline).  So the decoder's gradient work is
+        # collected here and released - by a device-side wait on the encoder stack's first published chunk - once the
+        # encoder BPTT kernels are resident; it then runs beside them as before.
+        self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
         self._fork(self.s_vel, self.s_instr)
         if s.meta_instrument:
             with self._on(self.s_instr):
@@ -948,9 +952,6 @@ class Engine(object):
         dcat = self._latent_chain_backward(Breal, B) if self.fused_latent else None
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
-        for ev, fn in deferred or ():
-            torch.cuda.current_stream().wait_event(ev)       # (no-op in time: the decoder BPTT was joined above)
-            fn()
         ldc = self.ncat * H
         self._mark("  latent block backward")
         # ---- encoder recurrences: three independent branches -------------------------------------------------
@@ -966,6 +967,14 @@ class Engine(object):
                 self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                      xs=self._v("in.vel", T, B))
         self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+        if deferred:
+            word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da
+            for st in (self.s_grad, self.s_grad2):
+                for ev, _ in deferred:
+                    st.wait_event(ev)
+                ops.stream_wait_value32(word, value, stream=st)
+            for _, fn in deferred:
+                fn()
         self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
 
     def _latent_backward_unfused(self, Breal, B):

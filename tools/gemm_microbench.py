@@ -26,3 +26,15 @@ t(lambda: ops.gemm(da, wc, dx, R, H, GH, trans_b=True, c_layout=hl.TILE16), f, "
 t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=64), f, "dU = hs^T da (TN split-K 64)")
 t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=16), f, "dU = hs^T da (TN split-K 16)")
 t(lambda: ops.gemm(idx, da, dW, 61, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=64), 2.0 * R * 61 * GH, "dWtab = onehot^T da (split-K 64)")
+for sk in (8, 16, 32):
+    t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=sk), f, "dU = hs^T da (TN split-K %d)" % sk)
+# two at a time on two streams, as in the step
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+dU2 = torch.zeros((H, GH), device=dev)
+def pair():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s1): ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=16)
+    with torch.cuda.stream(s2): ops.gemm(hs, da, dU2, H, GH, R, trans_a=True, accumulate=True, split_k=16)
+    cur.wait_stream(s1); cur.wait_stream(s2)
+t(pair, 2 * f, "two dU GEMMs on two streams (split-K 16)")
