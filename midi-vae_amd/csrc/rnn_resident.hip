@@ -146,6 +146,20 @@ __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int E>
 __device__ __forceinline__ f32x2 lo_hi(const f32x4& v) { return __builtin_shufflevector(v, v, E, E + 1); }
+// 4-element forms of tanh_fast / dhard_sigmoid (common.h): the same operations per element, written on vectors so that
+// the multiplies / adds / fmas become packed instructions
+__device__ __forceinline__ f32x4 tanh_fast4(f32x4 x) {
+    const f32x4 t = x * 2.8853900817779268f;
+    const f32x4 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    const f32x4 s1 = e + 1.0f;
+    const f32x4 rc = {__builtin_amdgcn_rcpf(s1[0]), __builtin_amdgcn_rcpf(s1[1]), __builtin_amdgcn_rcpf(s1[2]), __builtin_amdgcn_rcpf(s1[3])};
+    return 1.0f - 2.0f * rc;
+}
+__device__ __forceinline__ f32x4 dhard_sigmoid4(f32x4 y) {
+    const f32x4 sq = (y - y * y) * 0x1p100f;
+    return f32x4{__builtin_amdgcn_fmed3f(sq[0], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[1], 0.0f, 0.2f),
+                 __builtin_amdgcn_fmed3f(sq[2], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[3], 0.0f, 0.2f)};
+}
 __device__ __forceinline__ u16x8 cat8(u16x4 a, u16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pinf(float& a) { asm volatile("" : "+v"(a)); }
@@ -1500,17 +1514,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
             const f32x4 c = half(carry[n >> 1]), cp = half(qs[n >> 1]);
             f32x4 d = dh[n];
             if (HAS_EXT) d += unpack4(qd[n]);
-            f32x4 di, df, dg, dO;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float tc = tanh_fast(c[i]);
-                const float dct = dc[n][i] + d[i] * og[i] * (1.0f - tc * tc);
-                di[i] = dct * (gg[i] * dhard_sigmoid(ig[i]));
-                df[i] = dct * (cp[i] * dhard_sigmoid(fg[i]));
-                dg[i] = dct * ig[i] * (1.0f - gg[i] * gg[i]);
-                dO[i] = d[i] * (tc * dhard_sigmoid(og[i]));
-                dc[n][i] = dct * fg[i];
-            }
+            // whole-vector expressions: no MFMA is in flight in this phase, so packed f32 instructions (two elements
+            // each) are pure gain here - unlike in the MFMA gaps, where they cost issue slots
+            const f32x4 tc = tanh_fast4(c);
+            const f32x4 dct = dc[n] + d * og * (1.0f - tc * tc);
+            const f32x4 di = dct * (gg * dhard_sigmoid4(ig));
+            const f32x4 df = dct * (cp * dhard_sigmoid4(fg));
+            const f32x4 dg = dct * ig * (1.0f - gg * gg);
+            const f32x4 dO = d * (tc * dhard_sigmoid4(og));
+            dc[n] = dct * fg;
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (1 * 512 + n * 32))) = pack4(df);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
