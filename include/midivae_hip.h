@@ -178,6 +178,9 @@ typedef struct {
     uint32_t chunk_wait_value;
     uint32_t* chunk_done;
     uint32_t* chunk_status;       /* [1] set non-zero if a wait timed out                                          */
+    float* colsum_b;              /* (N) f32 or NULL: += column sums of B over K (the bias gradient beside a weight-gradient
+                                     GEMM C = A^T B, whose B tiles pass through the CU anyway: no second pass over B).
+                                     Fast bf16 path with trans_a = 1, trans_b = 0 and accumulate only (else MVAE_E_UNSUPPORTED) */
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
 

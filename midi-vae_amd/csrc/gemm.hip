@@ -351,6 +351,12 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // column sums of B (bias gradient): the M tile by == 0, its waves wm == 0, multiply their B fragments by an all-ones
+        // fragment as well - 4 more MFMAs per 16, every row of the result is the column sum
+        const bool want_cs = B_RC && A_RC && !ONEHOT && a.colsum_b && by == 0 && wm == 0;
+        f32x4 accs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // Main loop.  One wave per SIMD runs this (a 128x128 tile per CU), so nothing overlaps unless the instruction
         // stream itself interleaves: issued in source order - 8 global loads, 16 LDS reads, wait, 16 MFMAs, 16 LDS reads,
@@ -386,6 +392,11 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (!GEMM_ABL_NOMFMA || (i == 0 && j == 0)) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);   // rows: n, cols: m
+            if (B_RC && A_RC && !ONEHOT && want_cs) {
+                const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accs[j] = mfma_bf16(fb[j], ones, accs[j]);
+            }
         };
         // one K tile from LDS[cur]; requests tile kreq into (la, lb); stores (sta, stb) - requested an iteration ago - into
         // the other LDS image
@@ -435,6 +446,15 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             }
         }
         __syncthreads();                       // (the epilogue does not touch LDS; the next output tile's prologue does)
+        if (B_RC && A_RC && !ONEHOT && want_cs && r == 0) {     // lane (q, r = 0) holds the sums of columns .. + q*4 + 0..3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + q * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) atomicAdd(a.colsum_b + n + e, accs[j][e]);
+            }
+        }
         // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -562,6 +582,8 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
             return MVAE_E_ARG;
         if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
     }
+    if (a->colsum_b && !(fast_ok(*a) && a->trans_a && !a->trans_b && a->accumulate && a->a_kind == MVAE_BF16 && !(a->N % FBN)))
+        return MVAE_E_UNSUPPORTED;
     if (fast_ok(*a)) return dispatch_fast(*a, s);
     // A handful of output tiles with a long K (the Dense layers around the latent: M = batch, K up to nInit*H = 2304) is
     // a few workgroups marching through K for 100+ us on an otherwise idle chip: zero C and split K over atomics.

@@ -102,6 +102,7 @@ class Engine(object):
         self.grad_per_chunk = False
         self._deferred = None
         self.defer_decoder_grads = False # decoder parameter-gradient work released once the encoder BPTT is resident (see backward)
+        self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(init_params(spec, seed))
@@ -793,15 +794,20 @@ class Engine(object):
         mb = self.grad_gemm_blocks
         if fork:
             self._fork(self.s_grad, self.s_grad2)
+        # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
+        fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
+        gb = G[p + ".b"]
         with self._on(self.s_grad):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
-                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=mb)
+                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=mb,
+                         colsum_b=gb[:2 * H] if fuse_b else None)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                         accumulate=True, split_k=sk, max_blocks=mb)
+                         accumulate=True, split_k=sk, max_blocks=mb, colsum_b=gb[2 * H:] if fuse_b else None)
             else:
-                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
+                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb,
+                         colsum_b=gb if fuse_b else None)
         with self._on(self.s_grad2):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
@@ -810,7 +816,8 @@ class Engine(object):
                     ops.colsum(dxp0, B, GH, G[p + ".b"])
                     ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=mb)
             else:
-                ops.colsum(da2, R, GH, G[p + ".b"])
+                if not fuse_b:
+                    ops.colsum(da2, R, GH, G[p + ".b"])
                 if r.xmode == hl.X_INDEX:
                     ops.gemm(idx[t0:t0 + Tc].reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
                              accumulate=True, split_k=sk)

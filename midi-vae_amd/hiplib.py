@@ -51,7 +51,7 @@ class GemmArgs(C.Structure):
                 ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
                 ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32),
                 ("sys_release", _i32), ("chunk_rows", _i32), ("chunk_reverse", _i32), ("chunk_wait", _vp),
-                ("chunk_wait_value", C.c_uint32), ("chunk_done", _vp), ("chunk_status", _vp)]
+                ("chunk_wait_value", C.c_uint32), ("chunk_done", _vp), ("chunk_status", _vp), ("colsum_b", _vp)]
 
 
 class PrepJob(C.Structure):

@@ -502,3 +502,21 @@ def test_rejects_bad_arguments_without_launching():
     assert lib.mvae_rnn_fwd(a, None) == -1
     with pytest.raises(RuntimeError):
         ops.rnn_fwd(hl.GRU, hl.F32, 4, 4, 96, torch.zeros(8, device=DEV), xp=torch.zeros(8, device=DEV))   # H=96 unsupported
+
+
+@pytest.mark.gpu
+def test_gemm_weight_gradient_with_fused_column_sums():
+    """C += A^T B over a long K with split-K, plus colsum_b += column sums of B from the same pass (the bias gradient beside
+    a recurrent-kernel gradient): against float64 on the bf16-rounded operands."""
+    rng = np.random.default_rng(5)
+    for (M, N, K, sk, ldb) in ((256, 1024, 4096, 16, None), (256, 512, 2048, 8, 768), (128, 256, 1024, 1, None)):
+        ldb_ = N if ldb is None else ldb
+        A = torch.tensor(rng.standard_normal((K, M)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+        Bf = torch.tensor(rng.standard_normal((K, ldb_)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+        C = torch.zeros((M, N), device=DEV)
+        cs = torch.full((N,), 0.25, device=DEV)
+        ops.gemm(A, Bf, C, M, N, K, trans_a=True, ldb=ldb_, accumulate=True, split_k=sk, colsum_b=cs)
+        torch.cuda.synchronize()
+        A64, B64 = A.double().cpu().numpy(), Bf.double().cpu().numpy()[:, :N]
+        np.testing.assert_allclose(C.cpu().numpy(), A64.T @ B64, rtol=2e-3, atol=2e-3 * np.sqrt(K))
+        np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + B64.sum(0), rtol=2e-3, atol=2e-3 * np.sqrt(K))
