@@ -306,8 +306,11 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *   MVAE_PREP_PACK_RECURRENT   src = U (a=H, b=G*H) f32, c = direction        -> dst as mvae_pack_recurrent(kind)
  *   MVAE_PREP_MAKE_TABLE       src = W (a=K, b=N), src2 = bias (N)            -> dst (K, N) kind     (mvae_make_table)
  *   MVAE_PREP_TRANSPOSE_CONVERT src = W (a=K, b=N), c = N_pad                 -> dst (N_pad, K) kind (mvae_transpose_convert)
- *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)     */
-enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3 };
+ *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)
+ *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros
+ *                              (the step's loss / metric accumulators: one fill launch less)                          */
+enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
+       MVAE_PREP_ZERO = 4 };
 typedef struct {
     int32_t op, kind;          /* MVAE_PREP_*, element kind of dst (MVAE_F32 / MVAE_BF16) */
     int32_t a, b, c, reserved;
@@ -340,11 +343,12 @@ int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int3
  * Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)   (epsilon outside the correction) */
 int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, int32_t t, float grad_scale, void* stream);
-/* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph */
-int mvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                       float eps, int32_t* t_done, float grad_scale, void* stream);
-int mvae_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps,
-                      float grad_scale, void* stream);
+/* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph.
+ * zero_grad != 0: g is zeroed as it is consumed (the next step accumulates into it: no separate fill launch) */
+int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream);
+int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float lr, float rho, float eps,
+                      float grad_scale, int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -225,8 +225,8 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, f
     }
 }
 // graph-replayable form: the step count lives in device memory (t_done = completed steps)
-__global__ void adam_dev_k(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                           float eps, float gs, const int* t_done) {
+__global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                           float eps, float gs, const int* t_done, int zero_g) {
     const float t = (float)(*t_done + 1);
     const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -236,15 +236,17 @@ __global__ void adam_dev_k(float* p, const float* g, float* m, float* v, size_t 
         m[e] = me;
         v[e] = ve;
         p[e] -= lr_t * me / (sqrtf(ve) + eps);
+        if (zero_g) g[e] = 0.0f;       // the next step accumulates into a clean buffer: no separate fill launch
     }
 }
 __global__ void bump_k(int* t) { *t += 1; }
-__global__ void rmsprop_k(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps, float gs) {
+__global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const float ge = g[e] * gs;
         const float ve = rho * v[e] + (1.0f - rho) * ge * ge;
         v[e] = ve;
         p[e] -= lr * ge / (sqrtf(ve) + eps);
+        if (zero_g) g[e] = 0.0f;
     }
 }
 
@@ -413,6 +415,12 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             if (bf) convert_f32_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), (size_t)job.a * job.b, bid, nb);
             else convert_f32_body<float>(src, reinterpret_cast<float*>(job.dst), (size_t)job.a * job.b, bid, nb);
             break;
+        case MVAE_PREP_ZERO: {
+            const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
+            uint32_t* d = reinterpret_cast<uint32_t*>(job.dst);
+            for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) d[e] = 0u;
+            break;
+        }
     }
 }
 extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, void* stream) {
@@ -423,8 +431,9 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
         pb.n = n_jobs - j0 < PREP_MAX_JOBS ? n_jobs - j0 : PREP_MAX_JOBS;
         for (int j = 0; j < pb.n; ++j) {
             const mvae_prep_job& job = jobs[j0 + j];
-            if (!job.src || !job.dst || job.op < 0 || job.op > MVAE_PREP_CONVERT || (job.kind != MVAE_F32 && job.kind != MVAE_BF16) ||
-                (job.op == MVAE_PREP_MAKE_TABLE && !job.src2))
+            if ((!job.src && job.op != MVAE_PREP_ZERO) || !job.dst || job.op < 0 || job.op > MVAE_PREP_ZERO ||
+                (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
+                (job.op == MVAE_PREP_ZERO && job.kind == MVAE_BF16 && (((size_t)job.a * job.b) & 1)))
                 return MVAE_E_ARG;
             if (job.op == MVAE_PREP_PACK_RECURRENT) {
                 const int K = job.c == 0 ? job.a : job.b, KG = job.kind == MVAE_BF16 ? 32 : 4;     // as mvae_pack_recurrent
@@ -491,22 +500,22 @@ extern "C" int mvae_adam_step(float* p, const float* g, float* m, float* v, size
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-extern "C" int mvae_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                                  float beta2, float eps, int32_t* t_done, float grad_scale, void* stream) {
+extern "C" int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
+                                  float beta2, float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream) {
     if (!p || !g || !m || !v || !t_done) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
-                              grad_scale, t_done);
+                              grad_scale, t_done, (int)zero_grad);
     hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
-extern "C" int mvae_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float rho, float eps,
-                                 float grad_scale, void* stream) {
+extern "C" int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float lr, float rho, float eps,
+                                 float grad_scale, int32_t zero_grad, void* stream) {
     if (!p || !g || !v) return MVAE_E_ARG;
     if (n == 0) return MVAE_OK;
     hipLaunchKernelGGL(rmsprop_k, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, v, n, lr, rho,
-                       eps, grad_scale);
+                       eps, grad_scale, (int)zero_grad);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

@@ -101,6 +101,8 @@ class Engine(object):
         # 14.1 ms per step with per-chunk gradients, 13.0 ms without; bounding their grids is worse still).
         self.grad_per_chunk = False
         self._deferred = None
+        self.zero_grads_in_optimizer = True
+        self._grads_clean = False
         self.defer_decoder_grads = False # decoder parameter-gradient work released once the encoder BPTT is resident (see backward)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
@@ -445,6 +447,7 @@ class Engine(object):
                 pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
             if s.meta_velocity:
                 pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+            pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
             if self.training:
                 for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
                                      ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
@@ -1095,21 +1098,28 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     def optimizer_step(self, grad_scale=1.0):
         s = self.spec
+        # (the gradients are zeroed as they are consumed: the next step starts without a 17 MB fill launch in front of it)
+        z = self.zero_grads_in_optimizer
         if s.optimizer == "Adam":
-            ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale)
+            ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale,
+                              zero_grad=z)
         else:
-            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale)
+            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=z)
+        self._grads_clean = z
         self._weights_dirty = True
 
     def forward_backward(self, B):
         """One pass of forward + losses + backward on the staged batch (gradients left in self.grads)."""
         assert self.training
         self._have_targets = True
-        self.scal.zero_()
-        self.grads.zero_()
         self._mark("step start")
         if self._weights_dirty or self.use_graphs:
-            self.prepare_weights()
+            self.prepare_weights()          # (also zeroes the loss / metric accumulators)
+        else:
+            self.scal.zero_()
+        if not self._grads_clean:
+            self.grads.zero_()
+        self._grads_clean = False
         self._mark("weights prepared")
         self.encoder_forward(B, with_init=True)
         self._mark("encoder forward (incl. latent)")

@@ -59,7 +59,7 @@ class PrepJob(C.Structure):
                 ("src", _vp), ("src2", _vp), ("dst", _vp)]
 
 
-PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT = 0, 1, 2, 3
+PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT, PREP_ZERO = 0, 1, 2, 3, 4
 
 
 class HeadArgs(C.Structure):
@@ -125,8 +125,8 @@ SIGNATURES = {
     "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_transpose_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_adam_step": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
-    "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _vp]),
-    "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp]),
+    "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _i32, _vp]),
+    "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _vp]),
 }
 
 _lib = None

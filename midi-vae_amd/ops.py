@@ -233,6 +233,9 @@ class PrepBatch:
     def convert(self, src, dst):
         self._add(hl.PREP_CONVERT, dst, src.numel(), 1, 0, src)
 
+    def zero(self, dst):
+        self._add(hl.PREP_ZERO, dst, dst.numel(), 1, 0, None)
+
     def run(self):
         if self._arr is None:
             self._arr = (hl.PrepJob * len(self.jobs))(*self.jobs)
@@ -244,11 +247,11 @@ def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
                                       _stream()), "mvae_adam_step")
 
 
-def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False):
     hl.check(hl.load().mvae_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(t_done),
-                                          grad_scale, _stream()), "mvae_adam_step_dev")
+                                          grad_scale, int(bool(zero_grad)), _stream()), "mvae_adam_step_dev")
 
 
-def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0):
-    hl.check(hl.load().mvae_rmsprop_step(_p(p), _p(g), _p(v), p.numel(), lr, rho, eps, grad_scale, _stream()),
+def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0, zero_grad=False):
+    hl.check(hl.load().mvae_rmsprop_step(_p(p), _p(g), _p(v), p.numel(), lr, rho, eps, grad_scale, int(bool(zero_grad)), _stream()),
              "mvae_rmsprop_step")
