@@ -58,7 +58,7 @@ enum {
  *                   one lane's 8 values of a tile pair are 16 contiguous bytes: one memory instruction instead of two
  *                   (a VMEM instruction costs the CU's address unit the same 16 cycles whatever its width).
  *                   As a seq_layout it means: xp and dhs_ext TILE16, the saved activations (acts, cs) TILE16P - the
- *                   layout the slot-interleaved LSTM kernels use; forward and backward of a layer must agree. */
+ *                   layout the slot-interleaved LSTM / GRU kernels use; forward and backward of a layer must agree. */
 enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1, MVAE_TILE16P = 2 };
 
 int mvae_abi_version(void);
@@ -104,8 +104,8 @@ typedef struct {
     uint32_t* status;            /* [1] set non-zero if a wait timed out (~0.5 s): results are invalid                      */
     int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR, MVAE_TILE16 or
                               MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
-                              (H=256, bf16): TILE16 the phased ones (GRU, LSTM), TILE16P the slot-interleaved LSTM
-                              ones (not for MVAE_X_SCALAR inputs)                                                  */
+                              (H=256, bf16): TILE16 the phased ones, TILE16P the slot-interleaved ones (LSTM, GRU; not
+                              for MVAE_X_SCALAR inputs)                                                            */
 } mvae_rnn_fwd_args;
 int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
 

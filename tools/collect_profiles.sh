@@ -1,0 +1,18 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r01f
+mkdir -p $O
+python $R/bench.py > $O/bench_lstm.json 2> $O/bench_lstm.err
+python $R/bench.py --cell GRU > $O/bench_gru.json 2> $O/bench_gru.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py > /dev/null 2>&1
+cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/bench_lstm_kernel_stats.csv
+python $R/tools/timeline.py $(find /tmp/ks -name "*kernel_trace.csv" | head -1) --min-us 25 > $O/timeline_lstm_step.txt
+i=0
+for g in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM" "FETCH_SIZE WRITE_SIZE"; do
+  for c in LSTM GRU; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_$i -- python $R/tools/rnn_microbench.py --cell $c > /dev/null 2>&1
+  done
+done
+python $R/tools/pmc_summary.py $(find /tmp/pmc_* -name "*counter_collection.csv") > $O/rnn_pmc_summary.txt 2>&1
+ls -la $O

@@ -9,11 +9,11 @@ agg = collections.defaultdict(list)
 for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(anonymous namespace\)::|void |\(mvae_rnn_\w+_args\)", "", r["Kernel_Name"])
-        if "lstm" in k or "rnn_" in k:
+        if "lstm" in k or "rnn_" in k or "gru_" in k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kernels = sorted({k for k, _ in agg})
 m = lambda k, c: (sum(agg[(k, c)]) / len(agg[(k, c)])) if (k, c) in agg else float("nan")
-print("rocprofv3 --pmc, one pass per counter group; tools/rnn_microbench.py --cell LSTM (T=%d steps, B=%d rows, H=256, bf16)" % (T, B))
+print("rocprofv3 --pmc, one pass per counter group; tools/rnn_microbench.py --cell LSTM / GRU (T=%d steps, B=%d rows, H=256, bf16)" % (T, B))
 print("per launch: %d workgroups x 4 waves; SQ_*_CYCLES counters are quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles)" % (B // 16))
 print("FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950\n")
 for k in kernels:
