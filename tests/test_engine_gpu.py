@@ -169,12 +169,13 @@ def test_time_chunk_pipelining_is_exact(cell, dtype):
             assert _rel_l2(g[k], res[1][1][k]) < 1e-4, k       # chunked == un-chunked up to atomic-add ordering
 
 
-def test_time_pipelined_stacks_match_chunked_launches():
-    """H=256 bf16 LSTM: the stacked layers run as ONE launch per layer with device-side hand-over every pipe_chunk steps
-    (counters + stream wait / write values).  Same kernels, same arithmetic as the chunk-per-launch schedule: the losses
-    and every gradient must agree up to the atomic-add ordering of the gradient GEMMs, for several steps in a row."""
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_time_pipelined_stacks_match_chunked_launches(cell):
+    """H=256 bf16: the stacked layers run as ONE launch per layer with device-side hand-over every pipe_chunk steps
+    (counters polled / published by the running kernels).  Same kernels, same arithmetic as the chunk-per-launch schedule: the
+    losses and every gradient must agree up to the atomic-add ordering of the gradient GEMMs, for several steps in a row."""
     B = 32
-    spec, params, batch, raw = _problem("LSTM", B, seed=31, H=256, Z=64, T=64)
+    spec, params, batch, raw = _problem(cell, B, seed=31, H=256, Z=64, T=64)
     res = {}
     for pipe in (True, False):
         eng = Engine(spec, max_batch=B, dtype="bf16")
