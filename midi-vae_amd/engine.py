@@ -503,7 +503,7 @@ class Engine(object):
         self._timed(("rnn_fwd", p), lambda: ops.rnn_fwd(
             self.cell, self.kind, Tc, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
             hs=self._v(p + ".hs", T + 1, B, H)[t0:t0 + Tc + 1],
-            cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None,
+            cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if (lstm and self.training) else None,   # (backward only)
             acts=self._v(p + ".acts", T, B, GH)[t0:t0 + Tc] if self.training else None,
             h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
             c_last=(sc if (lstm and not last) else None), seq_layout=self._seq_layout(r), **kw), steps=Tc)

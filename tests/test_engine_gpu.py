@@ -226,6 +226,31 @@ def test_fused_latent_chain_matches_separate_launches(cell, kw):
                 assert _rel_l2(g1[k], g0[k]) < 2e-4, (B, k, _rel_l2(g1[k], g0[k]))
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_inference_engine_matches_training_engine_h256_bf16(cell):
+    """Engine(training=False) - no saved activations, the kernels' inference variants - on the resident-weights H=256 bf16
+    path: evaluate metrics and the argmax decode must equal those of a training engine's forward pass bit for bit (same
+    kernels, same arithmetic, only the stores differ), and decoder.predict-style decode on the sampled z likewise."""
+    B = 32
+    spec, params, batch, raw = _problem(cell, B, seed=23, H=256, Z=64, T=64)
+    out = {}
+    for training in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16", training=training)
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.eval_step(B)
+        m, idx = eng.metrics(B), eng.note_indices(B).copy()
+        z = eng.latent(B).copy()
+        eng.stage_decoder_inputs(B, hist=raw["hist"], z=z)
+        eng.decode(B, want_probs=False)
+        out[training] = (m, idx, eng.note_indices(B).copy())
+    (m1, i1, d1), (m0, i0, d0) = out[True], out[False]
+    for k in m1:
+        assert m1[k] == pytest.approx(m0[k], rel=1e-6, abs=1e-7), k
+    assert np.array_equal(i1, i0) and np.array_equal(d1, d0)
+    assert np.array_equal(i0, d0)              # decode on the same z reproduces the autoencoder's notes
+
+
 def test_ragged_batch_reuses_buffers():
     """A smaller last minibatch (songs are not multiples of batch_size) runs in the same engine."""
     spec, params, batch, raw = _problem("GRU", 5, seed=2)

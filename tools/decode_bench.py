@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Decoder inference throughput (decoder forward + argmax decode, no probability tensor leaves
+the chip): windows/s of Engine.decode on one GPU.
+   python tools/decode_bench.py [--config 5|2] [--cell LSTM|GRU] [--batch N]"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import midi_vae_amd  # noqa
+from midi_vae_amd.engine import Engine
+from midi_vae_amd.layout import ModelSpec
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", type=int, default=5)
+ap.add_argument("--cell", default="LSTM")
+ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+seq, V, Z, B = {5: (512, 8, 128, 1024), 2: (128, 4, 64, 256)}[a.config]      # per-GPU share of BASELINE configs[4] / [1]
+B = a.batch or B
+T = seq * V
+spec = ModelSpec(cell=a.cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
+eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1234, training=False)
+if T // eng.pipe_chunk > 64:
+    eng.pipe_chunk = T // 64
+rng = np.random.default_rng(1234)
+z = rng.standard_normal((B, Z)).astype(np.float32)
+hist = np.concatenate([np.zeros((1, Z), np.float32), z[:-1]])             # history = z shifted by one window
+eng.stage_decoder_inputs(B, hist=hist, z=z)
+for _ in range(2):
+    eng.decode(B, want_probs=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.reps):
+    eng.decode(B, want_probs=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.reps
+idx = eng.note_indices(B)
+print("decode config %d (%s): T=%d V=%d z=%d batch=%d: %.2f ms per batch = %.0f windows/s (%.2f us per decoder time step); "
+      "argmax indices %s, %d distinct" % (a.config, a.cell, T, V, Z, B, dt * 1e3, B / dt, dt * 1e6 / T, tuple(idx.shape),
+                                           len(np.unique(idx))))
+print("device memory resident: %.1f GB" % (eng.bytes_resident() / 1e9))
