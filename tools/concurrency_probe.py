@@ -21,7 +21,7 @@ streams = [torch.cuda.Stream() for _ in range(6)]
 def fwd(s): ops.rnn_fwd(cell, hl.BF16, T, B, H, s["up"], xp=s["xp"], hs=s["hs"], cs=s["cs"], acts=s["acts"], h_last=s["hl"], seq_layout=hl.TILE16P)
 def bwd(s): ops.rnn_bwd(cell, hl.BF16, T, B, H, s["ut"], s["hs"], s["cs"], s["acts"], s["da"], dhs_ext=s["dext"], dh0=s["hl"], seq_layout=hl.TILE16P)
 for name, fn in (("fwd", fwd), ("bwd", bwd)):
-    for n in (1, 2, 3, 4, 6):
+    for n in (() if os.environ.get("NEIGHBOURS_ONLY") else (1, 2, 3, 4, 6)):
         for _ in range(2):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,3 +35,25 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
             e1.record()
             torch.cuda.synchronize()
         print("%s x%d concurrent: %.3f ms  (%.2f us per time step each)" % (name, n, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
+
+# One recurrence beside a memory streamer (device-to-device copies of 1 GiB on another stream: ~HBM speed, thrashes every
+# L2) and beside a compute-only neighbour (a GEMM whose operands fit in L2): which of the two slows it down?
+big_a = torch.empty(1 << 29, dtype=torch.int16, device=dev); big_b = torch.empty_like(big_a)
+sa = (torch.randn((4096, 1024), device=dev)).to(bf); sb = (torch.randn((1024, 1024), device=dev)).to(bf); sc = torch.zeros((4096, 1024), dtype=bf, device=dev)
+def copies():
+    for _ in range(12): big_b.copy_(big_a)
+def small_gemms():
+    for _ in range(200): ops.gemm(sa, sb, sc, 4096, 1024, 1024, trans_b=True)
+for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for bg_name, bg in (("alone", None), ("+ 1 GiB copies (HBM / L2 streamer)", copies), ("+ L2-resident GEMMs (compute neighbour)", small_gemms)):
+        for _ in range(2):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if bg is not None:
+                streams[1].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(streams[1]):
+                    bg()
+            with torch.cuda.stream(streams[0]):
+                e0.record(); fn(sets[0]); e1.record()
+            torch.cuda.synchronize()
+        print("%s %-45s %.3f ms  (%.2f us per time step)" % (name, bg_name, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T))
