@@ -223,6 +223,10 @@ typedef struct {
     float* scalars;               /* (2) accumulated atomically                                              */
     int32_t b_stride, b_valid;    /* rows are (t, b) with b = row % b_stride; rows with b >= b_valid are padding and
                                      are excluded from the metric count (0,0 = every row counts)             */
+    const void* wc;               /* (H,NP) dtype: W zero-padded to NP columns (MVAE_PREP_CONVERT_PAD), or NULL */
+    void* dhs;                    /* (R,H) dtype in MVAE_TILE16 or NULL: d(logits) W^T, the gradient w.r.t. the top cell's
+                                     h sequence, from the same launch (needs wc, want_grad, R % 16 == 0, H <= 256):
+                                     no GEMM launch between the head and the decoder's BPTT                   */
 } mvae_head_args;
 int mvae_head(const mvae_head_args* a, void* stream);
 /* padded column count NP used for `wt` rows and `dlogits` columns of an N-wide head (16/32/64/128; <0 = too wide) */
@@ -308,9 +312,10 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *   MVAE_PREP_TRANSPOSE_CONVERT src = W (a=K, b=N), c = N_pad                 -> dst (N_pad, K) kind (mvae_transpose_convert)
  *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)
  *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros
- *                              (the step's loss / metric accumulators: one fill launch less)                          */
+ *                              (the step's loss / metric accumulators: one fill launch less)
+ *   MVAE_PREP_CONVERT_PAD      src (a, b) f32, c = padded row length >= b     -> dst (a, c) kind, columns b..c-1 zero   */
 enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
-       MVAE_PREP_ZERO = 4 };
+       MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5 };
 typedef struct {
     int32_t op, kind;          /* MVAE_PREP_*, element kind of dst (MVAE_F32 / MVAE_BF16) */
     int32_t a, b, c, reserved;

@@ -14,6 +14,23 @@ namespace {
 
 constexpr float CE_EPS = 1e-7f;
 
+// fragment (8 bf16 / 4 f32 consecutive k) from f32 values, or zeros
+template <typename WT>
+__device__ __forceinline__ typename op<WT>::frag frag_from(const float* src, bool valid);
+template <>
+__device__ __forceinline__ u16x8 frag_from<bf16_t>(const float* src, bool valid) {
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(src[e]);
+    }
+    return v;
+}
+template <>
+__device__ __forceinline__ f32x4 frag_from<float>(const float* src, bool valid) {
+    return valid ? f32x4{src[0], src[1], src[2], src[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <typename WT, int NTL, int KIND>
 __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
     constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
@@ -24,7 +41,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
     const WT* __restrict__ wt = reinterpret_cast<const WT*>(a.wt);
     float loss_acc = 0.0f, hit_acc = 0.0f;
     WT* __restrict__ dl = reinterpret_cast<WT*>(a.dlogits);
-    __shared__ float stage[KIND == 0 ? 4 * 16 * NTL * 16 : 1];       // [wave][16 rows][NP] d(logits)
+    __shared__ __attribute__((aligned(16))) float stage[4 * 16 * NTL * 16];      // [wave][16 rows][NP] d(logits)
     __shared__ float wg_part[4][2];
     // A bounded grid walks the rows (16 per wave and pass): the two loss / accuracy scalars are ONE pair of atomics per
     // workgroup - 8192 waves adding to the same two addresses used to take 200 of this kernel's 250 us.
@@ -116,6 +133,8 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
                 if (a.argmax) a.argmax[row] = (uint8_t)rounded;
                 if (a.want_grad) st<WT>::store(dl + (size_t)row * NP, a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr));
             }
+            if (a.want_grad && a.dhs)      // d(logits) tile for the fused input gradient: column 0 is real
+                stage[(w * 16 + q * 4 + i) * NP + r] = (rv && r == 0) ? a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr) : 0.0f;
         }
     }
     if (KIND == 0 && a.want_grad) {
@@ -127,6 +146,40 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
         for (int e = l * 4; e < 16 * NP; e += 256) {
             const int rr = e / NP, cc = e % NP;
             if (row0 + rr < R) st<WT>::store4(dl + (size_t)(row0 + rr) * NP + cc, *reinterpret_cast<const f32x4*>(mine + e));
+        }
+    }
+    if (a.want_grad && a.dhs) {
+        // Fused gradient w.r.t. the top cell's h sequence: dhs^T tile (H x 16 rows) = Wc (H x NP) * dl^T, straight from the
+        // staged d(logits) tile - the separate GEMM launch between this kernel and the decoder BPTT (and its pass over dl)
+        // disappears.  Operand roles swapped so that a lane ends up with 4 consecutive h columns of one row: the TILE16 image.
+        if (KIND != 0) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const WT* __restrict__ wc = reinterpret_cast<const WT*>(a.wc);
+        WT* __restrict__ dhs = reinterpret_cast<WT*>(a.dhs);
+        const float* mine = stage + (w * 16 + r) * NP;
+        f32x4 dacc[16];
+        const int HT = H >> 4;                   // <= 16 (checked by the launcher)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < (NP + KG - 1) / KG; ++s2) {
+            const int k0 = s2 * KG + q * FE;
+            const frag fz = frag_from<WT>(mine, false), fd = frag_from<WT>(mine + (k0 < NP ? k0 : 0), k0 < NP);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < HT) {
+                    const frag fw = k0 < NP ? *reinterpret_cast<const frag*>(wc + (size_t)(j * 16 + r) * NP + k0) : fz;
+                    dacc[j] = op<WT>::mma(fw, fd, dacc[j]);        // C[row = h column q*4+i of tile j][col = batch-time row r]
+                }
+            }
+        }
+        if (row0 < R) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < HT)
+                    st<WT>::store4(dhs + ((((size_t)(row0 >> 4) * HT + j) * 64) + (size_t)(q * 16 + r)) * 4, dacc[j]);
         }
     }
         __builtin_amdgcn_wave_barrier();        // the stage tile is reused by the next pass
@@ -180,6 +233,8 @@ extern "C" int mvae_head_np(int32_t N) {
 extern "C" int mvae_head(const mvae_head_args* a, void* stream) {
     if (!a || !a->hs || !a->wt || !a->bias || a->R <= 0 || a->N <= 0 || a->H <= 0) return MVAE_E_ARG;
     if (a->want_grad && !a->dlogits) return MVAE_E_ARG;
+    if (a->dhs && (!a->wc || !a->want_grad || (a->R % 16) || (a->H % 16))) return MVAE_E_ARG;
+    if (a->dhs && a->H > 256) return MVAE_E_UNSUPPORTED;
     if (a->kind == 1 && a->N != 1) return MVAE_E_ARG;
     if (a->kind == 0 && a->N > 128) return MVAE_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

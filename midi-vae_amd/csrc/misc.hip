@@ -415,6 +415,16 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             if (bf) convert_f32_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), (size_t)job.a * job.b, bid, nb);
             else convert_f32_body<float>(src, reinterpret_cast<float*>(job.dst), (size_t)job.a * job.b, bid, nb);
             break;
+        case MVAE_PREP_CONVERT_PAD: {
+            const size_t n = (size_t)job.a * job.c;
+            for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
+                const int rr = (int)(e / job.c), cc = (int)(e % job.c);
+                const float v = cc < job.b ? src[(size_t)rr * job.b + cc] : 0.0f;
+                if (bf) st<bf16_t>::store(reinterpret_cast<bf16_t*>(job.dst) + e, v);
+                else reinterpret_cast<float*>(job.dst)[e] = v;
+            }
+            break;
+        }
         case MVAE_PREP_ZERO: {
             const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
             uint32_t* d = reinterpret_cast<uint32_t*>(job.dst);
@@ -431,7 +441,8 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
         pb.n = n_jobs - j0 < PREP_MAX_JOBS ? n_jobs - j0 : PREP_MAX_JOBS;
         for (int j = 0; j < pb.n; ++j) {
             const mvae_prep_job& job = jobs[j0 + j];
-            if ((!job.src && job.op != MVAE_PREP_ZERO) || !job.dst || job.op < 0 || job.op > MVAE_PREP_ZERO ||
+            if ((!job.src && job.op != MVAE_PREP_ZERO) || !job.dst || job.op < 0 || job.op > MVAE_PREP_CONVERT_PAD ||
+                (job.op == MVAE_PREP_CONVERT_PAD && job.c < job.b) ||
                 (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
                 (job.op == MVAE_PREP_ZERO && job.kind == MVAE_BF16 && (((size_t)job.a * job.b) & 1)))
                 return MVAE_E_ARG;

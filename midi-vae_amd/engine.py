@@ -104,6 +104,7 @@ class Engine(object):
         self.zero_grads_in_optimizer = True
         self._grads_clean = False
         self.defer_decoder_grads = False # decoder parameter-gradient work released once the encoder BPTT is resident (see backward)
+        self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
@@ -280,18 +281,21 @@ class Engine(object):
         if self.training:
             buf("notes.dl", T * B * self.np_notes, **esz)
             buf("notes.dhs", T * B * H, **esz)
+            buf("notes.wc", H * self.np_notes, **esz)      # W (H, NP): the head kernel's fused input gradient
         if s.meta_instrument:
             buf("instr.wt", self.np_instr * H, **esz)
             buf("instr.argmax", V * B, **u8)
             if self.training:
                 buf("instr.dl", V * B * self.np_instr, **esz)
                 buf("instr.dhs", V * B * H, **esz)
+                buf("instr.wc", H * self.np_instr, **esz)
         if s.meta_velocity:
             buf("vel.wt", 16 * H, **esz)
             buf("vel.round", T * B, **u8)
             if self.training:
                 buf("vel.dl", T * B * 16, **esz)
                 buf("vel.dhs", T * B * H, **esz)
+                buf("vel.wc", H * 16, **esz)
         # encoder tail / latent / decoder initial states (all f32, (B, .) row-major)
         for name, n in (("cat", self.ncat * H), ("pack", H), ("extra", H), ("mu", Z), ("lv", Z), ("zh", s.zin),
                         ("style_p", max(s.C, 1)), ("S", self.n_init * H)):
@@ -448,6 +452,12 @@ class Engine(object):
             if s.meta_velocity:
                 pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
             pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
+            if self.training:
+                pb.convert_pad(P["dec.notes.out.W"], self.store["notes.wc"], self.np_notes)
+                if s.meta_instrument:
+                    pb.convert_pad(P["dec.instr.out.W"], self.store["instr.wc"], self.np_instr)
+                if s.meta_velocity:
+                    pb.convert_pad(P["dec.vel.out.W"], self.store["vel.wc"], 16)
             if self.training:
                 for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
                                      ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
@@ -711,6 +721,7 @@ class Engine(object):
                          probs=self._v("out.instr_p", V * B, s.ID) if want_probs else None,
                          argmax=self._v("instr.argmax", V * B),
                          dlogits=self._v("instr.dl", V * B, self.np_instr) if (self.training and tg) else None,
+                     **self._fused_head_bwd("instr", tg),
                          scalars=self.scal[S_INSTR_LOSS:S_INSTR_LOSS + 2], b_stride=B, b_valid=Breal)
         if s.meta_velocity:
             with self._on(self.s_vel):
@@ -722,6 +733,7 @@ class Engine(object):
                          row_weight=self._v("in.rw_vel", T * B) if tg else None, grad_scale=s.w_vel,
                          probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
                          dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
+                     **self._fused_head_bwd("vel", tg),
                          scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
         self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout), slot=1)
         top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
@@ -731,6 +743,7 @@ class Engine(object):
                  probs=self._v("out.notes_p", T * B, s.Dout) if want_probs else None,
                  argmax=self._v("notes.argmax", T * B),
                  dlogits=self._v("notes.dl", T * B, self.np_notes) if (self.training and tg) else None,
+                     **self._fused_head_bwd("notes", tg),
                  scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2], b_stride=B, b_valid=Breal)
         self._join(self.s_vel, self.s_instr)
 
@@ -905,6 +918,12 @@ class Engine(object):
         if nch > 1:
             self._join(*streams[1:])
 
+    def _fused_head_bwd(self, name, tg):
+        """extra arguments of ops.head: the gradient w.r.t. the top cell's h sequence comes out of the head launch itself"""
+        if not (self.training and tg and self.fuse_head_bwd and self.lay == hl.TILE16 and self.spec.H <= 256):
+            return {}
+        return dict(wc=self.store[name + ".wc"], dhs=self.store[name + ".dhs"])
+
     def _head_backward(self, B, name, r, N, NP, outW, outb):
         """d(logits) -> gradient of the output Dense and of the top cell's h sequence."""
         s, G = self.spec, self.G
@@ -913,7 +932,8 @@ class Engine(object):
         dl = self._v(name + ".dl", R, NP)
         top = self._v(r.prefix + ".hs", T + 1, B, H)[1:].reshape(R, H)
         dhs = self._v(name + ".dhs", T, B, H)
-        ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
+        if not self._fused_head_bwd(name, True):
+            ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
         self._fork(self.s_grad)
         with self._on(self.s_grad):
             ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R),

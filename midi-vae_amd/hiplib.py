@@ -59,14 +59,14 @@ class PrepJob(C.Structure):
                 ("src", _vp), ("src2", _vp), ("dst", _vp)]
 
 
-PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT, PREP_ZERO = 0, 1, 2, 3, 4
+PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT, PREP_ZERO, PREP_CONVERT_PAD = 0, 1, 2, 3, 4, 5
 
 
 class HeadArgs(C.Structure):
     _fields_ = [("kind", _i32), ("dtype", _i32), ("R", _i32), ("H", _i32), ("N", _i32), ("want_grad", _i32),
                 ("hs", _vp), ("wt", _vp), ("bias", _vp), ("target_idx", _vp), ("target_val", _vp),
                 ("row_weight", _vp), ("grad_scale", _f32), ("probs", _vp), ("argmax", _vp), ("dlogits", _vp),
-                ("scalars", _vp), ("b_stride", _i32), ("b_valid", _i32)]
+                ("scalars", _vp), ("b_stride", _i32), ("b_valid", _i32), ("wc", _vp), ("dhs", _vp)]
 
 
 class LatentFwdArgs(C.Structure):

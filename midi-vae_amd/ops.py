@@ -133,10 +133,10 @@ def head_np(N):
 
 
 def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None, row_weight=None, grad_scale=1.0,
-         probs=None, argmax=None, dlogits=None, scalars=None, b_stride=0, b_valid=0):
+         probs=None, argmax=None, dlogits=None, scalars=None, b_stride=0, b_valid=0, wc=None, dhs=None):
     a = hl.HeadArgs(kind, dtype, R, H, N, int(dlogits is not None), hs.data_ptr(), _p(wt), _p(bias), _p(target_idx),
                     _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars),
-                    b_stride, b_valid)
+                    b_stride, b_valid, _p(wc), _p(dhs))
     hl.check(hl.load().mvae_head(a, _stream()), "mvae_head")
 
 
@@ -235,6 +235,10 @@ class PrepBatch:
 
     def zero(self, dst):
         self._add(hl.PREP_ZERO, dst, dst.numel(), 1, 0, None)
+
+    def convert_pad(self, W, out, n_pad):
+        K, N = W.shape
+        self._add(hl.PREP_CONVERT_PAD, out, K, N, n_pad, W)
 
     def run(self):
         if self._arr is None:

@@ -301,7 +301,7 @@ def test_full_size_step_properties():
     m2, idx2 = eng.metrics(B), eng.note_indices(B).copy()
     assert np.array_equal(idx1, idx2)                      # the kernels are deterministic ...
     for k in m1:                                           # ... the loss scalars are sums of atomics: equal to round-off
-        assert m1[k] == pytest.approx(m2[k], rel=1e-6, abs=1e-7), k
+        assert m1[k] == pytest.approx(m2[k], rel=1e-5, abs=1e-6), (k, m1[k], m2[k])
     assert np.isfinite(m1["loss"]) and abs(m1["notes_loss"] - np.log(61.0)) < 0.2
     z = eng.latent(B).copy()
     eng.stage_decoder_inputs(B, hist=w["hist"], z=z)
@@ -310,12 +310,12 @@ def test_full_size_step_properties():
     # f32 products summed in another order.  At random initialisation the 61 logits are nearly tied, so a last-bit
     # difference in a state flips the occasional argmax: equal up to a small fraction, not bit for bit.)
     differ = float(np.mean(eng.note_indices(B) != idx1))
-    assert differ < 0.01, differ
+    assert differ < 0.02, differ
     chunked = staged(pipeline=False)
     chunked.eval_step(B)
     mc = chunked.metrics(B)
     for k in m1:
-        assert m1[k] == pytest.approx(mc[k], rel=1e-6, abs=1e-7), k
+        assert m1[k] == pytest.approx(mc[k], rel=1e-5, abs=1e-6), (k, m1[k], mc[k])
     eng.stage_decoder_inputs(B, hist=w["hist"])
     losses = []
     for _ in range(3):

@@ -520,3 +520,39 @@ def test_gemm_weight_gradient_with_fused_column_sums():
         A64, B64 = A.double().cpu().numpy(), Bf.double().cpu().numpy()[:, :N]
         np.testing.assert_allclose(C.cpu().numpy(), A64.T @ B64, rtol=2e-3, atol=2e-3 * np.sqrt(K))
         np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + B64.sum(0), rtol=2e-3, atol=2e-3 * np.sqrt(K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
+@pytest.mark.parametrize("kind,N", [(0, 61), (0, 16), (1, 1)])
+def test_head_fused_input_gradient(dtype, tol, kind, N):
+    """mvae_head with wc / dhs: the gradient w.r.t. the h sequence, d(logits) W^T, comes out of the head launch in TILE16 -
+    against float64 on the d(logits) the same launch returned (and the zero / padded weight copies of mvae_prepare_batch)."""
+    rng = np.random.default_rng(N + kind)
+    R, H = 320, 256 if dtype == hl.BF16 else 64
+    td = ops.torch_dtype(dtype)
+    hs = dev(rng.standard_normal((R, H)) * 0.5, td)
+    W = rng.standard_normal((H, N)) * 0.3
+    NP = ops.head_np(N)
+    wt = torch.zeros((NP, H), dtype=td, device=DEV)
+    wc = torch.full((H, NP), 7.0, dtype=td, device=DEV)
+    sc_zero = torch.ones((3,), device=DEV)
+    pb = ops.PrepBatch()
+    pb.transpose_convert(dev(W), wt, n_pad=NP); pb.convert_pad(dev(W), wc, NP); pb.zero(sc_zero)
+    pb.run()
+    assert np.array_equal(host(wc)[:, :N], host(wt)[:N].T) and np.all(host(wc)[:, N:] == 0) and np.all(host(sc_zero) == 0)
+    dl = torch.zeros((R, NP), dtype=td, device=DEV)
+    dhs = torch.zeros((R, H), dtype=td, device=DEV)
+    sc = torch.zeros((2,), device=DEV)
+    rw = rng.random((R,)) / R
+    if kind == 0:
+        ops.head(0, dtype, R, H, N, hs, wt, dev(rng.standard_normal((N,)) * 0.1), target_idx=dev(rng.integers(0, N, (R,)), torch.uint8),
+                 row_weight=dev(rw), grad_scale=0.7, dlogits=dl, scalars=sc, wc=wc, dhs=dhs)
+    else:
+        ops.head(1, dtype, R, H, 1, hs, wt, dev(np.array([0.1])), target_val=dev(rng.random(R)), row_weight=dev(rw), grad_scale=1.0,
+                 dlogits=dl, scalars=sc, wc=wc, dhs=dhs)
+    torch.cuda.synchronize()
+    want = host(dl) @ host(wc).T                                   # (R,NP) (NP,H)
+    got = host(tile16(dhs, R, H, False))
+    assert np.abs(want).max() > 0
+    close(got, want, tol, "dhs")
