@@ -306,7 +306,7 @@ struct f_stage {
     }
 };
 
-template <bool A_RC, bool B_RC, bool ONEHOT>
+template <bool A_RC, bool B_RC, bool ONEHOT, bool CS = false>      // CS: also the column sums of B (mvae_gemm_args.colsum_b)
 __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IA = f_img<A_RC>(), IB = f_img<B_RC>();
@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // column sums of B (bias gradient): the M tile by == 0, its waves wm == 0, multiply their B fragments by an all-ones
         // fragment as well - 4 more MFMAs per 16, every row of the result is the column sum
-        const bool want_cs = B_RC && A_RC && !ONEHOT && a.colsum_b && by == 0 && wm == 0;
+        // (a compile-time variant, and EVERY wave of it does the 4 extra MFMAs: a run-time branch here would split the loop
+        // body into basic blocks and undo the instruction interleaving below; only the waves named above publish theirs)
+        const bool want_cs = CS && by == 0 && wm == 0;
         f32x4 accs[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (!GEMM_ABL_NOMFMA || (i == 0 && j == 0)) acc[i][j] = mfma_bf16(fb[j], fa[i], acc[i][j]);   // rows: n, cols: m
-            if (B_RC && A_RC && !ONEHOT && want_cs) {
+            if (CS) {
                 const u16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) accs[j] = mfma_bf16(fb[j], ones, accs[j]);
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             }
         }
         __syncthreads();                       // (the epilogue does not touch LDS; the next output tile's prologue does)
-        if (B_RC && A_RC && !ONEHOT && want_cs && r == 0) {     // lane (q, r = 0) holds the sums of columns .. + q*4 + 0..3
+        if (CS && want_cs && r == 0) {     // lane (q, r = 0) holds the sums of columns .. + q*4 + 0..3
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + q * 4;
@@ -492,12 +494,12 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     if (a.sys_release) __threadfence_system();
 }
 
-template <bool A_RC, bool B_RC, bool ONEHOT>
+template <bool A_RC, bool B_RC, bool ONEHOT, bool CS = false>
 int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (f_img<A_RC>() + f_img<B_RC>()) * sizeof(bf16_t);
     static bool raised = false;
     if (!raised && lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_k<A_RC, B_RC, ONEHOT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_k<A_RC, B_RC, ONEHOT, CS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MVAE_E_LAUNCH;
         raised = true;
@@ -506,7 +508,7 @@ int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
     long long tiles = (long long)((a.N + FBN - 1) / FBN) * ((a.M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk);
     if (a.max_blocks > 0 && tiles > a.max_blocks) tiles = a.max_blocks;
     if (a.chunk_rows) tiles = a.max_blocks;          // persistent grid: every workgroup passes through every chunk
-    hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT>), dim3((unsigned)tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_fast_k<A_RC, B_RC, ONEHOT, CS>), dim3((unsigned)tiles), dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
@@ -537,6 +539,7 @@ int dispatch_fast(const mvae_gemm_args& a, hipStream_t s) {
     const bool a_rc = a.trans_a != 0, b_rc = a.trans_b == 0;     // row-contiguous = [k][row] in memory
     if (a.a_kind == MVAE_A_ONEHOT)      // a full 128-row tile is computed; only rows < M are stored
         return b_rc ? launch_fast<true, true, true>(a, s) : launch_fast<true, false, true>(a, s);
+    if (a_rc && b_rc && a.colsum_b) return launch_fast<true, true, false, true>(a, s);
     if (a_rc) return b_rc ? launch_fast<true, true, false>(a, s) : launch_fast<true, false, false>(a, s);
     return b_rc ? launch_fast<false, true, false>(a, s) : launch_fast<false, false, false>(a, s);
 }

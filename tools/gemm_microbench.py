@@ -38,3 +38,9 @@ def pair():
     with torch.cuda.stream(s2): ops.gemm(hs, da, dU2, H, GH, R, trans_a=True, accumulate=True, split_k=16)
     cur.wait_stream(s1); cur.wait_stream(s2)
 t(pair, 2 * f, "two dU GEMMs on two streams (split-K 16)")
+hsT = hs.t().contiguous()
+t(lambda: ops.gemm(hsT, da, dU, H, GH, R, accumulate=True, split_k=16), f, "dU = (hs^T stored k-contiguous) da (NN split-K 16)")
+daT = da.t().contiguous()
+t(lambda: ops.gemm(hsT, daT, dU, H, GH, R, trans_b=True, accumulate=True, split_k=16), f, "dU, both operands k-contiguous (NT split-K 16)")
+cs = torch.zeros((GH,), device=dev)
+t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=16, colsum_b=cs), f, "dU + column sums of da (TN split-K 16)")
