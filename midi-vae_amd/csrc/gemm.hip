@@ -457,6 +457,32 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                     if (n + e < N) atomicAdd(a.colsum_b + n + e, accs[j][e]);
             }
         }
+        // Split-K accumulation: straight from the accumulator layout an atomic instruction touches 64 addresses in 16 rows
+        // (35 of the weight-gradient GEMM's 180 us).  The tile goes through LDS (the operand images are free now) and leaves
+        // as whole rows: one atomic instruction = 256 contiguous bytes.
+        if (a.accumulate && a.c_layout == MVAE_ROWMAJOR && !GEMM_ABL_NOATOMIC) {
+            float* ct = reinterpret_cast<float*>(smem);                    // [128][132] f32 = 66 KiB <= 2 (IA + IB) bf16
+            constexpr int CP = 132;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(ct + (wm * 64 + i * 16 + r) * CP + wn * 64 + j * 16 + q * 4) = acc[i][j] * a.alpha;
+            __syncthreads();
+            float* cb = reinterpret_cast<float*>(a.C);
+            const int mlim = ONEHOT ? M : 1 << 30;
+            for (int rr = w * 32; rr < w * 32 + 32; ++rr) {
+                const int m = m0 + rr;
+                if (m >= mlim) break;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int n = n0 + h2 * 64 + l;
+                    if (n < N) atomicAdd(cb + (size_t)m * a.ldc + n, ct[rr * CP + h2 * 64 + l]);
+                }
+            }
+            __syncthreads();                   // the next output tile's prologue writes the images
+            continue;
+        }
         // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
