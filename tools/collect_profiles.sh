@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01f
+O=$R/gpurun_out/r01g
 mkdir -p $O
 python $R/bench.py > $O/bench_lstm.json 2> $O/bench_lstm.err
 python $R/bench.py --cell GRU > $O/bench_gru.json 2> $O/bench_gru.err
@@ -16,3 +16,8 @@ for g in "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INS
 done
 python $R/tools/pmc_summary.py $(find /tmp/pmc_* -name "*counter_collection.csv") > $O/rnn_pmc_summary.txt 2>&1
 ls -la $O
+python $R/tools/decode_bench.py --config 2 > $O/decode.txt 2>&1
+python $R/tools/decode_bench.py --config 5 >> $O/decode.txt 2>&1
+python $R/tools/gemm_microbench.py > $O/gemm_microbench.txt 2>&1
+python $R/tools/rnn_microbench.py --cell LSTM > $O/rnn_microbench.txt 2>&1
+python $R/tools/rnn_microbench.py --cell GRU >> $O/rnn_microbench.txt 2>&1
