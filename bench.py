@@ -146,6 +146,7 @@ def main():
     prof = eng.prof_summary()
     eng.prof = None
     m = eng.metrics(B)
+    eng.check_pipeline()        # raises if a time-pipelined kernel ever gave up waiting for its producer (invalid results)
 
     if rank == 0:
         G, H = spec.G, spec.H
