@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                 mfmas(fa, fb);
             }
         }
-        __syncthreads();                       // (the epilogue does not touch LDS; the next output tile's prologue does)
+        __syncthreads();                       // every wave is done with the images: the epilogue / the next prologue reuse them
         if (CS && want_cs && r == 0) {     // lane (q, r = 0) holds the sums of columns .. + q*4 + 0..3
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
