@@ -143,6 +143,13 @@ __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
 #ifndef GB_DRAIN
 #define GB_DRAIN 0
 #endif
+// a wave-uniform pointer the compiler has lost track of (state captured by a step lambda), back in scalar registers
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int E>
 __device__ __forceinline__ f32x2 lo_hi(const f32x4& v) { return __builtin_shufflevector(v, v, E, E + 1); }
@@ -1699,30 +1706,38 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
 
     // saved values of the step about to be processed: z, r, hh as TILE16P pairs (elements 0..3 tile 2j, 4..7 tile 2j+1);
     // h_{t-1} (row-major) and the upstream gradient (TILE16) per tile
-    u16x8 qa[2][G];
-    u16x4 qs[RNT], qd[RNT];
-    // the 14 loads of a step, in the order their values are needed: 0..3 h_{t-1}; 4..7 z and hh (pair 0, pair 1);
-    // 8, 9 r; 10..13 upstream gradient
-    auto issue_load = [&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
+    // z, hh and h_{t-1} are requested TWO steps ahead into alternating buffers (an HBM round trip beside the gradient GEMMs
+    // takes longer than the half step they used to get); r and the upstream gradient one step ahead
+    u16x8 qzh[2][2][2], qr[2];            // [buffer][pair][z, hh];  r per pair
+    u16x4 qp[2][RNT], qd[RNT];
+    // the 14 loads: 0..3 h, 4..7 z and hh (pair 0, pair 1) of the step `back2` behind into buffer bc; 8, 9 r; 10..13 the
+    // upstream gradient of the next step.  acts_p / hs_p / dx_p point at the next step (t-1); back2 = one more step
+    // (0 where that step does not exist: the values are never used then)
+    auto issue_load = [&](auto kc, auto bc, size_t back_a, size_t back_h) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, bf_ = decltype(bc)::value;
         if constexpr (GB_NOLOAD) return;
         if constexpr (k < 4) {
             pinu(hp_off);
-            qs[k] = *reinterpret_cast<const g_u16x4*>(hs_p + k * 32 + hp_off);
-        } else if constexpr (k < 10) {
-            constexpr int pr = k < 8 ? (k - 4) >> 1 : k - 8, g = k < 8 ? ((k - 4) & 1) * 2 : 1;
+            qp[bf_][k] = *reinterpret_cast<const g_u16x4*>(hs_p - back_h + k * 32 + hp_off);
+        } else if constexpr (k < 8) {
+            constexpr int pr = (k - 4) >> 1, zh = (k - 4) & 1;
             pinu(lane16);
-            qa[pr][g] = *reinterpret_cast<const g_u16x8*>(acts_p[g] + pr * 1024 + lane16);
+            qzh[bf_][pr][zh] = *reinterpret_cast<const g_u16x8*>(acts_p[zh * 2] - back_a + pr * 1024 + lane16);
+        } else if constexpr (k < 10) {
+            pinu(lane16);
+            qr[k - 8] = *reinterpret_cast<const g_u16x8*>(acts_p[1] + (k - 8) * 1024 + lane16);
         } else if constexpr (HAS_EXT) {
             pinu(lane8);
             qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + lane8);
         }
     };
-    static_for<0, 14>(SF_LAMBDA(kc) { issue_load(kc); });
+    // step T-1 complete into buffer 0; then the pointers move to T-2 and its z, hh, h go to buffer 1
+    static_for<0, 14>(SF_LAMBDA(kc) { issue_load(kc, std::integral_constant<int, 0>{}, 0, 0); });
 #pragma unroll
     for (int g = 0; g < G; ++g) acts_p[g] -= (T > 1 ? acts_step : 0);
     hs_p -= (T > 1 ? hs_step : 0);
     dx_p -= (T > 1 ? dx_step : 0);
+    static_for<0, 8>(SF_LAMBDA(kc) { issue_load(kc, std::integral_constant<int, 1>{}, 0, 0); });
 
     // row-major copy of the da tile: rows 4w..4w+3, 96 chunks of 16 bytes each.  Passes 0..3: lane l copies chunk l of row
     // 4w+pass (z, r columns); passes 4, 5: chunk 64 + l%32 of row 4w + 2(pass-4) + l/32 (candidate columns)
@@ -1752,10 +1767,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         return f32x4{bf2f(v[o]), bf2f(v[o + 1]), bf2f(v[o + 2]), bf2f(v[o + 3])};
     };
     // (whole-vector expressions: the compiler emits packed f32 instructions, two elements each)
-    auto pre_unpack = [&](int n, int part) __attribute__((always_inline)) {      // 4 parts per tile
-        if (part == 0) zv[n] = half(qa[n >> 1][0], n);
-        if (part == 1) hh[n] = half(qa[n >> 1][2], n);
-        if (part == 2) hp[n] = unpack4(qs[n]);
+    auto pre_unpack = [&](int n, int part, int bf_) __attribute__((always_inline)) {      // 4 parts per tile
+        if (part == 0) zv[n] = half(qzh[bf_][n >> 1][0], n);
+        if (part == 1) hh[n] = half(qzh[bf_][n >> 1][1], n);
+        if (part == 2) hp[n] = unpack4(qp[bf_][n]);
         if (part == 3) w1[n] = (1.0f - zv[n]) * (1.0f - hh[n] * hh[n]);
     };
     // 0.2 * [0 < y < 1] for two elements: med3(2^100 (y - y^2), 0, 0.2) as in dhard_sigmoid
@@ -1766,20 +1781,23 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
 #pragma unroll
     for (int n = 0; n < RNT; ++n)
 #pragma unroll
-        for (int part = 0; part < 4; ++part) pre_unpack(n, part);
+        for (int part = 0; part < 4; ++part) pre_unpack(n, part, 0);
 
-    for (int t = T - 1; t >= 0; --t) {
+    // one time step; BF = the buffer that held this step's z, hh, h (consumed a step ago) = the one step t-2's go to
+    auto step = [&](const int t, auto bfc) __attribute__((always_inline)) {
+        constexpr int BF = decltype(bfc)::value;
         const int tstep = T - 1 - t;
         (void)tstep;
+        const size_t back_a = t >= 2 ? acts_step : 0, back_h = t >= 2 ? hs_step : 0;
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(da_p);
         if (HAS_EXT) pins(dx_p);
         if (a.rh) pins(rh_p);
         STAMP(0);
         // pipelined stack: the upstream gradient of step t-1 is requested during this step's MFMA phases
-        if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
+        if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status);
         if (GB_DRAIN) vm_drain();       // (else the compiler's counted waits: the copy stores of M2 may still be in flight)
         STAMP(1);
-        pinq(qa[0][1]); pinq(qa[1][1]);
+        pinq(qr[0]); pinq(qr[1]);
         if (HAS_EXT) {
 #pragma unroll
             for (int n = 0; n < RNT; ++n) pin1(qd[n]);
@@ -1833,7 +1851,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             // r, and r*hp -> rh tile (nothing in this step's recurrence waits for it): tile (sl-1)/4 on slots 1, 5, 9, 13
             if constexpr ((sl & 3) == 1 && sl < 16) {
                 constexpr int tn = sl >> 2;
-                rv[tn] = half(qa[tn >> 1][1], tn);
+                rv[tn] = half(qr[tn >> 1], tn);
                 if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + (rw0 ^ (tn << 5))) = pack4(rv[tn] * hp[tn]);
             }
             // memory events: loads 0..7 from slot 16 on (their registers - h_{t-1}, z, hh raw - are dead since the
@@ -1841,7 +1859,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             // the late ones the ~2000 cycles an HBM load takes, was measured slower: the phase is LDS-bound but not idle.)
             if constexpr (!GB_NOCOPY && sl == 3) da_store(std::integral_constant<int, 4>{}, cp[2]);
             if constexpr (!GB_NOCOPY && sl == 10) da_store(std::integral_constant<int, 5>{}, cp[3]);
-            if constexpr (sl >= 16 && (sl & 1) == 0) issue_load(std::integral_constant<int, ((sl - 16) >> 1)>{});
+            if constexpr (sl >= 16 && (sl & 1) == 0) issue_load(std::integral_constant<int, ((sl - 16) >> 1)>{}, bfc, back_a, back_h);
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_nop 9" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
@@ -1883,7 +1901,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             __builtin_amdgcn_sched_barrier(0);
             // memory events: loads 8..13 first (r, upstream gradient: used from the next E1 on), then the copies of the
             // rh tile and of the da tile's z, r columns
-            if constexpr ((sl & 3) == 1 && sl < 24) issue_load(std::integral_constant<int, 8 + (sl >> 2)>{});
+            if constexpr ((sl & 3) == 1 && sl < 24) issue_load(std::integral_constant<int, 8 + (sl >> 2)>{}, bfc, 0, 0);
             if constexpr (sl == 26 || sl == 31) {
                 if (a.rh) {
                     pinu(tg0);
@@ -1893,7 +1911,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             if constexpr (!GB_NOCOPY && sl >= 36 && (sl - 36) % 5 == 0 && sl < 36 + 20)
                 da_store(std::integral_constant<int, (sl - 36) / 5>{}, lt[(sl - 36) / 5]);
             // step t-1's z, hh, h_{t-2} (requested in M1) unpacked, and w1: one part per 2 slots in the second half
-            if constexpr (sl >= 32 && (sl & 1) == 0) pre_unpack((sl - 32) >> 3, ((sl - 32) >> 1) & 3);
+            if constexpr (sl >= 32 && (sl & 1) == 0) pre_unpack((sl - 32) >> 3, ((sl - 32) >> 1) & 3, BF ^ 1);
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_nop 9" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]));
@@ -1908,7 +1926,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         if (a.rh) rh_p -= hs_step;
         res_barrier();
         // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
-        wave_signal_done_if(t, psig, a.signal_done + pk);
+        wave_signal_done_if(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
         {
             const bool adv = cs_steps && t == plo;
             pk -= adv ? 1 : 0;
@@ -1916,7 +1934,13 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             pwait = (a.wait_ready && plo > 0) ? plo : -1;
             psig = a.signal_done ? plo : -1;
         }
+    };
+    int t = T - 1;
+    for (; t >= 1; t -= 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t - 1, std::integral_constant<int, 1>{});
     }
+    if (t == 0) step(0, std::integral_constant<int, 0>{});
     const int ldd = a.dh0_ld ? a.dh0_ld : RH;
 #pragma unroll
     for (int n = 0; n < RNT; ++n)

@@ -137,7 +137,19 @@ def test_rnn_forward_zero_initial_state_and_inference_mode():
 @pytest.mark.parametrize("H,B,ext", [(64, 5, True), (128, 20, False), (256, 19, True), (256, 33, False), (256, 32, True),
                                      (256, 16, False)])
 def test_rnn_backward(cellname, cell, dtype, tol, H, B, ext):
-    T = 8
+    _rnn_backward_case(cellname, cell, dtype, tol, H, B, ext, T=8)
+
+
+@pytest.mark.parametrize("cellname,cell", [c for c in CELLS if c[0] in ("GRU", "LSTM")])
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_rnn_backward_resident_kernels_short_and_odd_lengths(cellname, cell, T):
+    """The slot-interleaved backward kernels process time steps in pairs (alternating prefetch buffers) with a single
+    trailing step for odd T: lengths 1, 2, 3 and 7 at H=256 bf16, with and without an upstream gradient."""
+    for ext in (True, False):
+        _rnn_backward_case(cellname, cell, hl.BF16, dict(DTYPES)[hl.BF16], 256, 32, ext, T=T)
+
+
+def _rnn_backward_case(cellname, cell, dtype, tol, H, B, ext, T):
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=11 + H)
     GH = G * H
     td = ops.torch_dtype(dtype)
