@@ -150,6 +150,9 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
+#ifndef GRU_NVB
+#define GRU_NVB 32     // candidate fragments of the GRU forward kernel held in vector registers (of 32)
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int E>
 __device__ __forceinline__ f32x2 lo_hi(const f32x4& v) { return __builtin_shufflevector(v, v, E, E + 1); }
@@ -892,8 +895,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
 // ---------------------------------------------------------------------------------------------------------
 // GRU forward, slot-interleaved (Keras 2.0.x GRU: reset gate applied BEFORE the candidate matmul)
 // ---------------------------------------------------------------------------------------------------------
-// U is 384 KiB: the 64 z/r fragments of a wave sit in accumulator registers, its 32 candidate fragments in LDS, no
-// vector register holds weights - the working set has room, so nothing here is register-starved like the LSTM kernels.
+// U is 384 KiB: the 64 z/r fragments of a wave sit in accumulator registers, its 32 candidate fragments in vector
+// registers (GRU_NVB; the rest, if any, in LDS) - the whole recurrent kernel in registers, nothing here is starved like the
+// LSTM kernels.
 // Step t:  A  z, r pre-activations of tile pairs (0,1) then (2,3): 2 x 32 single-MFMA slots, B = h_{t-1} tile; the
 //             gaps of pair 1 carry pair 0's gate arithmetic (z, r, r*h -> rh tile), the gaps of pair 0 the deferred
 //             stores of the previous step and this step's row-major copy of h_{t-1}
@@ -929,8 +933,16 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         load4_agpr_nowait(ua[f], ua[f + 1], ua[f + 2], ua[f + 3], src_frag(0, 2 * np, ks), src_frag(1, 2 * np, ks),
                           src_frag(0, 2 * np + 1, ks), src_frag(1, 2 * np + 1, ks));
     });
+    // candidate fragments: the first NVB of phase B's 32 slots read theirs from vector registers (the kernel has them to
+    // spare: four waves streaming all 32 from LDS made the phase LDS-bandwidth bound), the rest from LDS
+    constexpr int NVB = GRU_NVB;
+    frag uv[NVB > 0 ? NVB : 1];
 #pragma unroll
-    for (int i = 0; i < NLc; ++i) myl[(size_t)i * 64] = *src_frag(2, 2 * (i >> 4) + (i & 1), (i >> 1) & 7);
+    for (int i = 0; i < NLc; ++i) {
+        const frag f = *src_frag(2, 2 * (i >> 4) + (i & 1), (i >> 1) & 7);
+        if (i < NVB) uv[i] = f;
+        else myl[(size_t)i * 64] = f;
+    }
 
     const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
     unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;      // TILE16 inputs; TILE16P saved activations
@@ -1101,8 +1113,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         frag rq[3];
         rq[0] = *reinterpret_cast<const frag*>(rhbuf + (bf4[0] & 8191u));
         rq[1] = *reinterpret_cast<const frag*>(rhbuf + (bf4[1] & 8191u));
-        lt[0] = myl[0];
-        lt[1] = myl[64];
+        if (NVB < 1) lt[0] = myl[0];
+        if (NVB < 2) lt[1] = myl[64];
         asm volatile("s_nop 1" : "+v"(accC[0]), "+v"(accC[1]), "+v"(accC[2]), "+v"(accC[3]));
         // candidate -> h for one element of tile n
         auto h_math = [&](int n, int e) __attribute__((always_inline)) {
@@ -1116,8 +1128,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
             constexpr int gi = sl >> 1;                            // group of 2 MFMAs sharing rh fragment ks
             if constexpr (nn == 0 && gi + 2 < 16)
                 rq[(gi + 2) % 3] = *reinterpret_cast<const frag*>(rhbuf + (bf4[(ks + 2) & 3] & 8191u) + 256 * (((ks + 2) & 7) >> 2));
-            mfma1<false>(accC[n], lt[nn], rq[gi % 3]);
-            if constexpr (sl + 2 < 32) lt[nn] = myl[(size_t)(sl + 2) * 64];
+            if constexpr (sl < NVB) mfma1<false>(accC[n], uv[sl < NVB ? sl : 0], rq[gi % 3]);
+            else mfma1<false>(accC[n], lt[nn], rq[gi % 3]);
+            if constexpr (sl + 2 < 32 && sl + 2 >= NVB) lt[nn] = myl[(size_t)(sl + 2) * 64];
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (half == 0) {
                 // z, r of tiles 2, 3; next step's candidate inputs
