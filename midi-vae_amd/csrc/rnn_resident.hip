@@ -574,6 +574,32 @@ typedef __attribute__((address_space(1))) u16x8 g_u16x8;
 __device__ __forceinline__ gbyte* to_global(const void* p) { return (gbyte*)(const_cast<void*>(p)); }
 __device__ __forceinline__ void pins(gbyte*& p) { asm volatile("" : "+s"(p)); }
 
+// Residency class of the 32 fragment groups of a step (group = the 4 gate fragments of one k-group of one unit tile, in
+// order of use).  CLS_T: group 7 (tile 0's last).  With the NLG groups that live in LDS all at the end of the step (F0 = 32 -
+// NLG) four waves stream 1 KiB per slot from LDS for 36 slots in a row and those slots take ~50 cycles instead of 16;
+// spread evenly over groups F0..31 they overlap with the register-fed slots.  The training variants cannot afford it (the
+// LDS-staging registers would be live through tile 2 as well: 17-21 registers spilled); the inference variants can.
+enum { CLS_A = 0, CLS_V = 1, CLS_L = 2, CLS_T = 3 };
+template <int NAG, int NVG, int NLG, int F0>       // numbers of groups per class (NAG + NVG + NLG + 1 == 32)
+struct lstm_group_map {
+    int cls[32], ord[32];
+    constexpr lstm_group_map() : cls{}, ord{} {
+        bool isl[32] = {};
+        constexpr int SPAN = 32 - F0;
+        for (int k = 0; k < NLG; ++k) isl[F0 + (k * SPAN + SPAN / 2) / (NLG > 0 ? NLG : 1)] = true;
+        int na = 0, nv = 0, nl = 0;
+        for (int g = 0; g < 32; ++g) {
+            if (g == 7) { cls[g] = CLS_T; ord[g] = 0; }
+            else if (isl[g]) { cls[g] = CLS_L; ord[g] = nl++; }
+            else if (na < NAG) { cls[g] = CLS_A; ord[g] = na++; }
+            else { cls[g] = CLS_V; ord[g] = nv++; }
+        }
+    }
+};
+#ifndef LSTM_L_FIRST
+#define LSTM_L_FIRST 12
+#endif
+
 template <int XMODE, int SAVE, int NA, int NV>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args a) {
     constexpr int G = 4, GH = G * RH;
@@ -585,6 +611,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     constexpr int TB = 28, NT = 4, NLc = FPW - NT - NA - NV;
     static_assert(XMODE != MVAE_X_SCALAR, "scalar inputs run on the phased kernel");
     static_assert(NA % 4 == 0 && NV % 4 == 0 && NLc >= 0 && NA <= 64, "fragment classes");
+    constexpr lstm_group_map<NA / 4, NV / 4, NLc / 4, (SAVE == SAVE_ALL ? 32 - NLc / 4 : LSTM_L_FIRST)> GM{};
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* hbuf = smem;                                             // [2][16][RH] bf16, swizzled
@@ -602,15 +629,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         return up + (size_t)((g * (RH / 16) + w * RNT + n) * RS + ks) * 64 + l;
     };
     frag ua[NA > 0 ? NA : 4], uv[NV > 0 ? NV : 4];
-    static_for<0, (FPW - NT) / 4>(SF_LAMBDA(ic) {
-        constexpr int i = decltype(ic)::value * 4;                 // class index of 4 consecutive fragments
-        constexpr int f = i < TB ? i : i + NT;
-        if constexpr (i < NA) load4_agpr_nowait(ua[i], ua[i + 1], ua[i + 2], ua[i + 3], frag_ptr(f), frag_ptr(f + 1), frag_ptr(f + 2), frag_ptr(f + 3));
-        else if constexpr (i < NA + NV) {
-            uv[i - NA] = *frag_ptr(f); uv[i - NA + 1] = *frag_ptr(f + 1); uv[i - NA + 2] = *frag_ptr(f + 2); uv[i - NA + 3] = *frag_ptr(f + 3);
-        } else {
-            myl[(size_t)(i - NA - NV) * 64] = *frag_ptr(f); myl[(size_t)(i - NA - NV + 1) * 64] = *frag_ptr(f + 1);
-            myl[(size_t)(i - NA - NV + 2) * 64] = *frag_ptr(f + 2); myl[(size_t)(i - NA - NV + 3) * 64] = *frag_ptr(f + 3);
+    static_for<0, NGRP>(SF_LAMBDA(gc) {
+        constexpr int gi = decltype(gc)::value, f = gi * 4, c = GM.cls[gi], i = GM.ord[gi] * 4;     // i: index within the class
+        if constexpr (c == CLS_A) load4_agpr_nowait(ua[i], ua[i + 1], ua[i + 2], ua[i + 3], frag_ptr(f), frag_ptr(f + 1), frag_ptr(f + 2), frag_ptr(f + 3));
+        else if constexpr (c == CLS_V) {
+            uv[i] = *frag_ptr(f); uv[i + 1] = *frag_ptr(f + 1); uv[i + 2] = *frag_ptr(f + 2); uv[i + 3] = *frag_ptr(f + 3);
+        } else if constexpr (c == CLS_L) {
+            myl[(size_t)i * 64] = *frag_ptr(f); myl[(size_t)(i + 1) * 64] = *frag_ptr(f + 1);
+            myl[(size_t)(i + 2) * 64] = *frag_ptr(f + 2); myl[(size_t)(i + 3) * 64] = *frag_ptr(f + 3);
         }
     });
     const frag* tsrc = frag_ptr(TB);            // T fragments: gates 0..3 are (RH/16)*RS*64 fragments apart
@@ -821,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
                 constexpr int sl = decltype(slc)::value;
                 if constexpr (n < RNT) {
                     constexpr int ks = sl >> 2, g = sl & 3, gi = n * RS + ks, f = gi * 4 + g;
-                    constexpr int ci = f < TB ? f : f - NT;                       // class index (T excluded)
+                    constexpr int cl = GM.cls[gi], ci = GM.ord[gi] * 4 + g;      // class, index within the class
                     if constexpr (n == 0 && sl == TB) {
                         // One wait per step: this step's x and T fragments (requested during the previous step) and
                         // every older store.  The saved-sequence row-major copy of h_{t-1} follows it.
@@ -843,14 +869,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
                     if constexpr (sl == 0)    // VALU-initialised accumulators -> first MFMA of the tile
                         asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
                     constexpr int bi = ABL_NOB ? (gi & 1) : gi % 3;
-                    if constexpr (f >= TB && f < TB + NT) mfma1<false>(acc[g], __builtin_bit_cast(frag, accB[g]), bq[bi]);
-                    else if constexpr (ci < NA) mfma1<true>(acc[g], ua[ci], bq[bi]);
-                    else if constexpr (ci < NA + NV) mfma1<false>(acc[g], uv[ci - NA], bq[bi]);
+                    if constexpr (cl == CLS_T) mfma1<false>(acc[g], __builtin_bit_cast(frag, accB[g]), bq[bi]);
+                    else if constexpr (cl == CLS_A) mfma1<true>(acc[g], ua[ci], bq[bi]);
+                    else if constexpr (cl == CLS_V) mfma1<false>(acc[g], uv[ci], bq[bi]);
                     else mfma1<false>(acc[g], lt[g], bq[bi]);
-                    // fragments of the next group that live in LDS: into the register this MFMA just read
-                    constexpr int fn = f + 4, cn = fn - NT;
-                    if constexpr (fn < FPW && fn >= TB + NT && cn >= NA + NV && !ABL_NOL)
-                        lt[g] = myl[(size_t)(cn - NA - NV) * 64];
+                    // the next group's fragments, if they live in LDS: into the staging register (idle, or just read)
+                    if constexpr (gi + 1 < NGRP && !ABL_NOL) {
+                        if constexpr (GM.cls[gi + 1 < NGRP ? gi + 1 : 0] == CLS_L)
+                            lt[g] = myl[(size_t)(GM.ord[gi + 1 < NGRP ? gi + 1 : 0] * 4 + g) * 64];
+                    }
                     if constexpr (n >= 1 && (sl & 3) == 1 && sl < 16) request_x(nc, std::integral_constant<int, (sl >> 2) & 3>{});
                     __builtin_amdgcn_sched_barrier(0);   // MFMA first, then the slot's fillers: strict alternation
                 }
