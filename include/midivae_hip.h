@@ -348,8 +348,7 @@ int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int3
  * Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)   (epsilon outside the correction) */
 int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, int32_t t, float grad_scale, void* stream);
-/* same, with the count of COMPLETED steps in device memory: t_done[0], incremented by the kernel itself after the update
- * (replayable in a hipGraph); t_done[1] is scratch of the kernel and must be zero on the first call (two int32 in all).
+/* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph.
  * zero_grad != 0: g is zeroed as it is consumed (the next step accumulates into it: no separate fill launch) */
 int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                        float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream);

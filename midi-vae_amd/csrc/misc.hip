@@ -226,7 +226,7 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, f
 }
 // graph-replayable form: the step count lives in device memory (t_done = completed steps)
 __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                           float eps, float gs, int* t_done, int zero_g) {
+                           float eps, float gs, const int* t_done, int zero_g) {
     const float t = (float)(*t_done + 1);
     const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -238,17 +238,8 @@ __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, flo
         p[e] -= lr_t * me / (sqrtf(ve) + eps);
         if (zero_g) g[e] = 0.0f;       // the next step accumulates into a clean buffer: no separate fill launch
     }
-    // The step count is bumped by the LAST workgroup to finish (every other one has read it by then): no dependent one-thread
-    // launch between two steps.  t_done[1] counts finished workgroups and is left at zero.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(t_done + 1, 1) == (int)gridDim.x - 1) {
-            t_done[1] = 0;
-            t_done[0] += 1;
-        }
-    }
 }
+__global__ void bump_k(int* t) { *t += 1; }
 __global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const float ge = g[e] * gs;
@@ -524,8 +515,9 @@ extern "C" int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t
                                   float beta2, float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream) {
     if (!p || !g || !m || !v || !t_done) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
+    if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
                               grad_scale, t_done, (int)zero_grad);
+    hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

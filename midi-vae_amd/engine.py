@@ -73,7 +73,7 @@ class Engine(object):
         self.grads = torch.zeros(L.total, **f32)
         self.opt_m = torch.zeros(L.total, **f32)
         self.opt_v = torch.zeros(L.total, **f32)
-        self.t_done = torch.zeros(2, dtype=torch.int32, device=dev)     # [completed steps, scratch of the optimizer kernel]
+        self.t_done = torch.zeros(1, dtype=torch.int32, device=dev)
         self.P = {n: L.view(self.params, n) for n in L.entries}
         self.G = {n: L.view(self.grads, n) for n in L.entries}
         self.scal = torch.zeros(N_SCALARS, **f32)
