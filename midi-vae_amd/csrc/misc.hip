@@ -388,7 +388,7 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
 }
 
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
-constexpr int PREP_MAX_JOBS = 32, PREP_BLOCKS_PER_JOB = 64;
+constexpr int PREP_MAX_JOBS = 64, PREP_BLOCKS_PER_JOB = 64;      // (64 x 48-byte jobs = 3 KiB of kernel arguments; the limit is 4 KiB)
 struct prep_batch {
     int32_t n;
     mvae_prep_job jobs[PREP_MAX_JOBS];
