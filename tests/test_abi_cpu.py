@@ -46,3 +46,33 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(hl, "LIB_PATH", "/nonexistent/libmidivae_hip.so")
     with pytest.raises(hl.HipLibraryMissing):
         hl.load()
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every argument struct of include/midivae_hip.h against its ctypes mirror: size and the offset of every field, from a
+    C program compiled with the same header (a field added on one side only would silently shift everything after it)."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"mvae_rnn_fwd_args": hl.RnnFwdArgs, "mvae_rnn_bwd_args": hl.RnnBwdArgs, "mvae_gemm_args": hl.GemmArgs,
+             "mvae_head_args": hl.HeadArgs, "mvae_latent_fwd_args": hl.LatentFwdArgs, "mvae_latent_bwd_args": hl.LatentBwdArgs,
+             "mvae_latent_chain_fwd_args": hl.LatentChainFwdArgs, "mvae_latent_chain_bwd_args": hl.LatentChainBwdArgs,
+             "mvae_prep_job": hl.PrepJob}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "midivae_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs.items():
+        assert got[(cname, "sizeof")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
