@@ -242,18 +242,19 @@ __device__ __forceinline__ void pack_recurrent_body(const float* __restrict__ U,
     const int rowsA = direction == 0 ? GH : H;   // A rows
     const int K = direction == 0 ? H : GH;       // contraction length
     const int S = K / KG;
-    const size_t total = (size_t)rowsA * K;
-    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < total; e += (size_t)nb * blockDim.x) {
-        const int j = (int)(e % FE);
-        const int l = (int)((e / FE) % 64);
-        const size_t f = e / (FE * 64);
-        const int s = (int)(f % S);
-        const int mt = (int)(f / S);
-        const int arow = mt * 16 + (l & 15);
-        const int k = s * KG + (l >> 4) * FE + j;
-        const float v = direction == 0 ? U[(size_t)k * GH + arow]      // A[gate col][h]   = U[h][gate col]
-                                       : U[(size_t)arow * GH + k];     // A[unit][gate col] = U[unit][gate col]
-        st<WT>::store(out + e, v);
+    // one thread = one lane's fragment (FE consecutive k): 32-bit index arithmetic once per FE elements, one 16-byte store
+    const unsigned groups = (unsigned)((size_t)rowsA * K / FE);
+    for (unsigned g = (unsigned)bid * blockDim.x + threadIdx.x; g < groups; g += (unsigned)nb * blockDim.x) {
+        const unsigned l = g & 63u, f = g >> 6, s = f % (unsigned)S, mt = f / (unsigned)S;
+        const unsigned arow = mt * 16 + (l & 15), k0 = s * KG + (l >> 4) * FE;
+        typename op<WT>::frag v;
+#pragma unroll
+        for (int j = 0; j < FE; ++j) {
+            const float x = direction == 0 ? U[(size_t)(k0 + j) * GH + arow]      // A[gate col][h]   = U[h][gate col]
+                                           : U[(size_t)arow * GH + k0 + j];      // A[unit][gate col] = U[unit][gate col]
+            st<WT>::store(reinterpret_cast<WT*>(&v) + j, x);
+        }
+        *reinterpret_cast<typename op<WT>::frag*>(out + (size_t)g * FE) = v;
     }
 }
 template <typename D>
