@@ -151,7 +151,7 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 #ifndef GRU_NVB
-#define GRU_NVB 32     // candidate fragments of the GRU forward kernel held in vector registers (of 32)
+#define GRU_NVB 24     // candidate fragments of the GRU forward kernel held in vector registers (of 32; the rest in LDS)
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int E>
@@ -990,9 +990,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(hreg[n]);
     }
     // ---- x queue ------------------------------------------------------------------------------------------------
-    u16x4 xq[RNT][G];
+    // Inputs are requested TWO steps ahead into alternating buffers (the step loop is unrolled by two): beside the gradient
+    // GEMMs an HBM round trip takes longer than the one step they used to get (in-step 3.3 us per time step against 1.8 alone)
+    u16x4 xq[2][RNT][G];
     unsigned xoff = 0;
-    int i_q = 0;
+    int i_q = 0;                                  // X_INDEX: the index of step min(t+2, T-1)
     const unsigned char* xbase0;
     if (XMODE == MVAE_X_DENSE) {
         xoff = lane8;
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     } else if (XMODE == MVAE_X_INDEX) {
         xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
-        i_q = a.idx[(size_t)(T > 1 ? 1 : 0) * B + b];
+        i_q = a.idx[(size_t)(T > 2 ? 2 : T - 1) * B + b];
     } else {
         xoff = (unsigned)b * (GH * 2) + q * 8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 128;
@@ -1011,18 +1013,23 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready, wait_value, a.status);
     constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;
     constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
+    const size_t x_step1 = (XMODE == MVAE_X_DENSE && T > 1) ? tps * (GH / 16) * 512 : 0;       // step 1 (buffer 1)
+    const unsigned xoff1 = XMODE == MVAE_X_INDEX ? (unsigned)a.idx[(size_t)(T > 1 ? 1 : 0) * B + b] * (GH * 2) + q * 8 : xoff;
 #pragma unroll
     for (int n = 0; n < RNT; ++n)
 #pragma unroll
-        for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+        for (int g = 0; g < G; ++g) {
+            xq[0][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+            if (XMODE != MVAE_X_CONST) xq[1][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + x_step1 + g * XG + n * XN + xoff1);
+        }
 
     gbyte *acts_p[G], *hs_p, *hh_prev_p;          // step t: saved gates; h_{t-1} (slot t); the candidate tiles of step t-1
-    gbyte* x_p[G];                                // step t+1: inputs
+    gbyte* x_p[G];                                // step min(t+2, T-1): inputs
     const size_t acts_step = tps * (GH / 16) * 512, hs_step = (size_t)B * RH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
-        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
+        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE ? (T > 2 ? 2 : T - 1) * acts_step : 0);
     }
     hh_prev_p = acts_p[2];
     hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
@@ -1035,19 +1042,21 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     vm_drain();
     lds_barrier();
 
-    for (int t = 0; t < T; ++t) {
+    auto step = [&](const int t, auto xbc) __attribute__((always_inline)) {
+        constexpr int XB = XMODE == MVAE_X_CONST ? 0 : decltype(xbc)::value;       // the buffer holding this step's inputs
         const int tstep = t;
         (void)tstep;
         pinu(hw0); pinu(tl0);
-        if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready && t + 1 < T && t + 1 == phi)
-            wave_wait_ge(a.wait_ready + pk + 1, wait_value, a.status);
+        // pipelined stack: x of step t+2 is requested during this step - its chunk must have been published
+        if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready && t + 2 < T && t + 2 == phi)
+            wave_wait_ge(uniform_ptr(a.wait_ready + pk + 1), wait_value, a.status);
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(hh_prev_p);
         pins(x_p[0]); pins(x_p[1]); pins(x_p[2]);
         unsigned char* hcur = hbuf;               // bf4 / tl0 / hw0 carry the buffer bit
-        // everything requested during the previous step (all of it in its MFMA phases) and every older store
-        vm_drain();
+        // (no drain: the compiler's counted waits cover this step's inputs, requested two steps ago; younger requests and
+        // stores stay in flight)
 #pragma unroll
-        for (int n = 0; n < RNT; ++n) { pin1(xq[n][0]); pin1(xq[n][1]); pin1(xq[n][2]); }
+        for (int n = 0; n < RNT; ++n) { pin1(xq[XB][n][0]); pin1(xq[XB][n][1]); pin1(xq[XB][n][2]); }
         if (XMODE == MVAE_X_INDEX) pini(i_q);
         if (SAVE >= SAVE_HS) {
             cp[0] = *reinterpret_cast<const frag*>(hcur + tl0);
@@ -1057,14 +1066,14 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
             if (XMODE != MVAE_X_CONST) {
                 if (XMODE == MVAE_X_INDEX && n == 0 && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 8;
                 pinu(xoff);
-                xq[n][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + n * XN + xoff);
+                xq[XB][n][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + n * XN + xoff);
             }
         };
         // ---- phase A ------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            accA[j] = unpack4(xq[j >> 1][j & 1]);             // accumulators start at x (tile j>>1, gate j&1)
-            accB[j] = unpack4(xq[2 + (j >> 1)][j & 1]);
+            accA[j] = unpack4(xq[XB][j >> 1][j & 1]);         // accumulators start at x (tile j>>1, gate j&1)
+            accB[j] = unpack4(xq[XB][2 + (j >> 1)][j & 1]);
         }
         bq[0] = *reinterpret_cast<const frag*>(hcur + bf4[0]);
         bq[1] = *reinterpret_cast<const frag*>(hcur + bf4[1]);
@@ -1136,7 +1145,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         // ---- phase B ------------------------------------------------------------------------------------------------
         f32x4 accC[RNT];
 #pragma unroll
-        for (int n = 0; n < RNT; ++n) accC[n] = unpack4(xq[n][2]);
+        for (int n = 0; n < RNT; ++n) accC[n] = unpack4(xq[XB][n][2]);
         frag rq[3];
         rq[0] = *reinterpret_cast<const frag*>(rhbuf + (bf4[0] & 8191u));
         rq[1] = *reinterpret_cast<const frag*>(rhbuf + (bf4[1] & 8191u));
@@ -1171,7 +1180,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
                 // (the candidate inputs were consumed when the accumulators were initialised)
                 if constexpr (sl >= 8 && (sl & 1) == 0) request_x((sl - 8) >> 1, 2);
                 if constexpr (sl == 15) {
-                    if (XMODE == MVAE_X_INDEX) i_q = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + b];
+                    if (XMODE == MVAE_X_INDEX) i_q = a.idx[(size_t)(t + 3 < T ? t + 3 : T - 1) * B + b];
                 }
             } else {
                 // tanh + h update of tiles 0, 1 (their accumulators were finished by slot 15): one element per 2 slots
@@ -1201,7 +1210,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             acts_p[g] += acts_step;
-            if (XMODE == MVAE_X_DENSE && t + 2 < T) x_p[g] += acts_step;
+            if (XMODE == MVAE_X_DENSE && t + 3 < T) x_p[g] += acts_step;
         }
         hs_p += hs_step;
 #pragma unroll
@@ -1210,11 +1219,17 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         tl0 ^= 8192u;
         res_barrier();
         if (cs_steps && t == phi) {
-            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(a.signal_done + pk);
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(uniform_ptr(a.signal_done + pk));
             ++pk;
             phi += cs_steps;
         }
+    };
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
     }
+    if (t < T) step(t, std::integral_constant<int, 0>{});
     if (SAVE == SAVE_ALL) {
         *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = hh_pk[0];
         *reinterpret_cast<g_u16x8*>(hh_prev_p + 1024 + lane16) = hh_pk[1];
@@ -1222,7 +1237,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
         *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
         *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
-        if (cs_steps && a.signal_done) wave_signal_done(a.signal_done + pk);
+        if (cs_steps && a.signal_done) wave_signal_done(uniform_ptr(a.signal_done + pk));
     }
     vm_drain();
 }
