@@ -351,3 +351,32 @@ def test_h256_one_step_bf16_runs_and_is_finite():
     eng.train_step(32)
     m = eng.metrics(32)
     assert np.isfinite(m["loss"]) and abs(m["loss"] - m_o["loss"]) < 3e-2 * (1 + abs(m_o["loss"]))
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_baseline_config0_elbo_within_1e3_of_oracle(cell):
+    """BASELINE configs[0] (seq_len 32 x 4 voices = 128 rows, z=16, 8 windows, H=256, 2+2 layers, every default head) on
+    the bf16 resident-weights path: the ELBO of three consecutive optimizer steps within 1e-3 of the float64 oracle - the
+    north-star tolerance (tools/config0_parity.py prints the parts and the f32 path as well)."""
+    from midi_vae_amd.synth import make_windows
+    B, T, V, Z = 8, 128, 4, 16
+    spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
+    params = init_params(spec, 3)
+    w = make_windows(B, T, 61, V, 16, 2, Z, seed=1234, epsilon_std=spec.epsilon_std)
+    oh = lambda idx, n: np.eye(n)[idx.astype(np.int64)]
+    batch = dict(X=oh(w["x_idx"], 61), I=oh(w["i_idx"], 16), Vel=w["vel"][..., None].astype(np.float64),
+                 Hist=w["hist"].astype(np.float64), Y=oh(w["x_idx"], 61), C=oh(w["c_idx"], 2))
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    st = orc.new_opt_state(p64)
+    eng = Engine(spec, max_batch=B, dtype="bf16")
+    eng.set_params(params)
+    eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
+    eng.stage_decoder_inputs(B, hist=w["hist"])
+    eng.stage_targets(B, w["x_idx"], w["c_idx"])
+    for _ in range(3):
+        want = orc.train_step(p64, st, batch, w["eps"].astype(np.float64))
+        eng.train_step(B)
+        got = eng.metrics(B)
+        assert abs(got["loss"] - want["loss"]) < 1e-3, (got["loss"], want["loss"])
+        assert abs(got["kl"] - want["kl"]) < 1e-4 and abs(got["notes_loss"] - want["notes_loss"]) < 1e-3
