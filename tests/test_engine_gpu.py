@@ -380,3 +380,34 @@ def test_baseline_config0_elbo_within_1e3_of_oracle(cell):
         got = eng.metrics(B)
         assert abs(got["loss"] - want["loss"]) < 1e-3, (got["loss"], want["loss"])
         assert abs(got["kl"] - want["kl"]) < 1e-4 and abs(got["notes_loss"] - want["notes_loss"]) < 1e-3
+
+
+@pytest.mark.parametrize("kw", [dict(meta_instrument=False, meta_velocity=False), dict(split=False), dict(extra_layer=False),
+                                dict(history=False), dict(C=4), dict(Le=3, Ld=1), dict(Le=1, Ld=3, meta_velocity=False),
+                                dict(style=False), dict(extra_layer=False, split=False, meta_instrument=False)])
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_model_switches_match_oracle(cell, kw):
+    """The settings.py switches that change the graph around the latent and the stacks (no meta encoders / decoders and so no
+    pack Dense, un-split or missing extra Dense, no history input, 4 styles, no style head, 1- and 3-layer stacks): losses and
+    every gradient of one forward + backward pass against the oracle in f32 - also the fused latent chain's variants."""
+    B = 8
+    spec, params, batch, raw = _problem(cell, B, seed=3, H=64, Z=16, T=8, **kw)
+    if not spec.history:
+        batch = {k: v for k, v in batch.items() if k != "Hist"}
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    eng = Engine(spec, max_batch=B, dtype="f32", seed=0)
+    eng.set_params(params)
+    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"])
+    eng.stage_decoder_inputs(B, hist=raw["hist"] if spec.history else None)
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"])
+    eng.forward_backward(B)
+    m, g = eng.metrics(B), eng.get_grads()
+    for k in m_o:
+        if not k.endswith("_acc"):
+            assert abs(m[k] - m_o[k]) <= 2e-4 * (1 + abs(m_o[k])), (k, m[k], m_o[k])
+    for k in g_o:
+        err = np.abs(g[k] - g_o[k])
+        assert np.all(err <= 2e-6 + 2e-4 * np.abs(g_o[k]) + 2e-4 * np.abs(g_o[k]).max()), (k, err.max())
