@@ -411,3 +411,28 @@ def test_model_switches_match_oracle(cell, kw):
     for k in g_o:
         err = np.abs(g[k] - g_o[k])
         assert np.all(err <= 2e-6 + 2e-4 * np.abs(g_o[k]) + 2e-4 * np.abs(g_o[k]).max()), (k, err.max())
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_three_layer_stacks_pipelined_h256_bf16(cell):
+    """3 + 3 stacked layers on the resident bf16 path: two hand-over interfaces per time-pipelined stack.  Loss against the
+    oracle, and against the chunk-per-launch schedule of the same kernels."""
+    B = 16
+    spec, params, batch, raw = _problem(cell, B, seed=13, H=256, Z=32, T=64, Le=3, Ld=3)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    m_o, _ = orc.forward({k: v.astype(np.float64) for k, v in params.items()}, batch, raw["eps"].astype(np.float64))
+    out = {}
+    for pipe in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.pipeline, eng.pipe_chunk = pipe, 16
+        assert eng._pipelined(eng.enc_notes) == pipe and eng._pipelined(eng.dec_notes) == pipe
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        eng.check_pipeline()
+        out[pipe] = (eng.metrics(B), eng.get_grads())
+    assert abs(out[True][0]["loss"] - m_o["loss"]) <= 3e-2 * (1 + abs(m_o["loss"]))
+    assert abs(out[True][0]["loss"] - out[False][0]["loss"]) <= 1e-5 * (1 + abs(m_o["loss"]))
+    for k, g0 in out[False][1].items():
+        if np.linalg.norm(g0) > 1e-9:
+            assert _rel_l2(out[True][1][k], g0) < 1e-4, (k, _rel_l2(out[True][1][k], g0))
