@@ -96,26 +96,34 @@ template <> struct op<float> {
 
 __host__ __device__ constexpr int mvae_gates(int cell) { return cell == MVAE_GRU ? 3 : (cell == MVAE_LSTM ? 4 : 1); }
 
-// 16-lane-group reductions (lanes sharing l>>4)
+// 16-lane-group reductions (lanes sharing l>>4 = one DPP row), every lane gets the result.  Data-parallel-primitive
+// moves instead of __shfl_xor (= ds_bpermute: an LDS round trip per step - the head kernels' softmax is a chain of 20 of
+// them per row): xor 1, xor 2 inside the quads, then the half-row and the row mirrored.  Both operands of every step are
+// the two partial results swapped, so all 16 lanes end up with the same bits.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
 __device__ __forceinline__ float group16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
     return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ int group16_min_i(int v) {
-    v = min(v, __shfl_xor(v, 1));
-    v = min(v, __shfl_xor(v, 2));
-    v = min(v, __shfl_xor(v, 4));
-    v = min(v, __shfl_xor(v, 8));
+    v = min(v, dpp_i<DPP_XOR1>(v));
+    v = min(v, dpp_i<DPP_XOR2>(v));
+    v = min(v, dpp_i<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -17,3 +17,29 @@ for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 print("notes head: %.1f us  (reads %.0f MB, writes %.0f MB -> %.2f TB/s)" % (us, R * H * 2 / 1e6, R * NP * 2 / 1e6, (R * H * 2 + R * NP * 2) / us / 1e6))
+wc = (torch.randn((H, NP), device=dev) * 0.1).to(bf); dhs = torch.zeros((R, H), dtype=bf, device=dev)
+def run2(): ops.head(0, hl.BF16, R, H, N, hs, wt, bias, target_idx=tgt, grad_scale=1.0 / R, argmax=am, dlogits=dl, scalars=sc, wc=wc, dhs=dhs)
+run2(); torch.cuda.synchronize()
+e0.record()
+for _ in range(20): run2()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print("notes head + fused input gradient: %.1f us  (reads %.0f MB, writes %.0f MB -> %.2f TB/s)" % (
+    us, R * H * 2 / 1e6, (R * NP * 2 + R * H * 2) / 1e6, (2 * R * H * 2 + R * NP * 2) / us / 1e6))
+def run3(): ops.head(0, hl.BF16, R, H, N, hs, wt, bias, target_idx=tgt, grad_scale=1.0 / R, argmax=am, dlogits=dl, scalars=None, wc=wc, dhs=dhs)
+run3(); torch.cuda.synchronize()
+e0.record()
+for _ in range(20): run3()
+e1.record(); torch.cuda.synchronize()
+print("  the same without the two loss / accuracy atomics per workgroup: %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
+def run4(): ops.head(0, hl.BF16, R, H, N, hs, wt, bias, target_idx=tgt, grad_scale=1.0 / R, argmax=am, scalars=None)
+run4(); torch.cuda.synchronize()
+e0.record()
+for _ in range(20): run4()
+e1.record(); torch.cuda.synchronize()
+print("  logits + softmax + argmax only (no gradient, no scalars): %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))
+x = torch.empty_like(hs)
+e0.record()
+for _ in range(20): x.copy_(hs)
+e1.record(); torch.cuda.synchronize()
+print("  (a 67 MB device copy for scale: %.1f us)" % (e0.elapsed_time(e1) / 20 * 1e3))
