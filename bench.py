@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--dp-overlap", type=int, default=0,
+                    help="N>1: 1 = reduce the decoder gradient bucket beside the encoder BPTT (dp.BucketedAllReduce)")
     ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
     args = ap.parse_args()
 
@@ -89,7 +91,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # MVAE_BENCH_FORCE_DIST=1: go through RCCL even with one rank (checks the collective path on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("MVAE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -106,9 +110,9 @@ def main():
     eng.stage_targets(B, w["x_idx"], w["c_idx"])
 
     allreduce = None
-    if world > 1:
+    if use_dist:
         from midi_vae_amd.dp import make_allreduce
-        allreduce = make_allreduce(eng, dist, world)
+        allreduce = make_allreduce(eng, dist, world, overlap=args.dp_overlap)
 
     def step():
         eng.train_step(B, allreduce=allreduce)

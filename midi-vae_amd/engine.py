@@ -86,6 +86,8 @@ class Engine(object):
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
+        self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
+        self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
         # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
         self.time_chunks = 4
@@ -148,6 +150,12 @@ class Engine(object):
         cur = torch.cuda.current_stream()
         for st in streams:
             cur.wait_stream(st)
+
+    def _join_into(self, stream):
+        """``stream`` waits for everything enqueued so far on the current stream and on every side stream"""
+        stream.wait_stream(torch.cuda.current_stream())
+        for st in (self.s_vel, self.s_instr, self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
+            stream.wait_stream(st)
 
     def _side(self, fn):
         """Run ``fn`` (parameter-gradient work nobody waits for before the optimizer) on the second gradient stream,
@@ -984,6 +992,16 @@ class Engine(object):
             dcat = self._latent_backward_unfused(Breal, B)
         ldc = self.ncat * H
         self._mark("  latent block backward")
+        hook = self._bucket_hook
+        if hook is not None and self.multi_stream and not deferred and self.layout.dec_begin > 0:
+            # data parallel: every decoder-side gradient [dec_begin, total) is queued by now - start its all-reduce on the
+            # communication stream, beside the encoder BPTT (dp.BucketedAllReduce)
+            if self.s_comm is None:
+                with torch.cuda.device(self.device):
+                    self.s_comm = torch.cuda.Stream()
+            self._join_into(self.s_comm)
+            with torch.cuda.stream(self.s_comm):
+                hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: three independent branches -------------------------------------------------
         self._fork(self.s_vel, self.s_instr)
         k = 1
@@ -1171,7 +1189,11 @@ class Engine(object):
         per batch size into a hipGraph and replayed: the step is otherwise bound by host-side launch issue."""
         if self.use_graphs and self.prof is None:
             return self._graph_step(B, allreduce)
-        self.forward_backward(B)
+        self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
+        try:
+            self.forward_backward(B)
+        finally:
+            self._bucket_hook = None
         gs = 1.0
         if allreduce is not None:
             gs = allreduce(self.grads)

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import midi_vae_amd  # noqa: F401
-from midi_vae_amd.dp import make_allreduce, shard_bounds
+from midi_vae_amd.dp import BucketedAllReduce, make_allreduce, shard_bounds
 from tests.oracle_util import tiny_problem
 
 
@@ -44,6 +44,13 @@ def _worker(rank, world, port, out):
         flat = torch.from_numpy(np.concatenate([g[k].ravel() for k in names]))
         hook = make_allreduce(None, dist, world)
         scale = hook(flat)
+        # the same reduction in two buckets (decoder side early, the rest after the backward pass) - engine.backward's use
+        flat2 = torch.from_numpy(np.concatenate([g[k].ravel() for k in names]))
+        cut = flat2.numel() // 3
+        hook2 = BucketedAllReduce(dist, world, cut)
+        hook2.early(flat2[cut:])
+        assert hook2(flat2) == scale and hook2._work is None
+        assert torch.equal(flat2, flat)
         loss = torch.tensor([met["loss"]], dtype=torch.float64)
         dist.all_reduce(loss)
         if rank == 0:

@@ -1,0 +1,52 @@
+"""Data-parallel hook on the GPU: a one-rank RCCL group (torch.distributed backend "nccl") - all a 1-GPU box can hold -
+drives the engine's bucketed gradient all-reduce (decoder bucket started on the communication stream beside the encoder
+BPTT, midi_vae_amd.dp.BucketedAllReduce) and must leave the same losses as the step without a hook."""
+import os
+import socket
+
+import pytest
+import torch
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd.dp import make_allreduce
+from midi_vae_amd.engine import Engine
+from tests.test_engine_gpu import _problem, _stage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_rccl():
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_bucketed_allreduce_beside_the_encoder_bptt(one_rank_rccl, cell):
+    dist = one_rank_rccl
+    B = 32
+    spec, params, batch, raw = _problem(cell, B, seed=43, H=256, Z=64, T=64)
+    losses = {}
+    for mode in ("none", "bucketed", "single"):
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        hook = None if mode == "none" else make_allreduce(eng, dist, 1, overlap=(mode == "bucketed"))
+        out = []
+        for _ in range(3):
+            eng.train_step(B, allreduce=hook)
+            out.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        if mode == "bucketed":
+            assert 0 < eng.layout.dec_begin < eng.layout.total and eng.s_comm is not None and hook._work is None
+        losses[mode] = out
+    for mode in ("bucketed", "single"):
+        for a, b in zip(losses[mode], losses["none"]):
+            assert abs(a - b) <= 2e-3 * (1 + abs(b)), losses
+    assert losses["bucketed"][2] < losses["bucketed"][0]
