@@ -31,8 +31,12 @@ __device__ __forceinline__ f32x4 frag_from<float>(const float* src, bool valid) 
     return valid ? f32x4{src[0], src[1], src[2], src[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// row tiles per wave and pass (bf16 softmax heads up to 64 padded columns: registers and the 64 KiB of static LDS allow two)
 template <typename WT, int NTL, int KIND>
-__global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
+__host__ __device__ constexpr int head_rb() { return (sizeof(WT) == 2 && KIND == 0 && NTL <= 4) ? 2 : 1; }
+
+template <typename WT, int NTL, int KIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(head_rb<WT, NTL, KIND>()))) void head_k(const mvae_head_args a) {
     constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS;
     typedef typename op<WT>::frag frag;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
@@ -41,28 +45,39 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
     const WT* __restrict__ wt = reinterpret_cast<const WT*>(a.wt);
     float loss_acc = 0.0f, hit_acc = 0.0f;
     WT* __restrict__ dl = reinterpret_cast<WT*>(a.dlogits);
-    __shared__ __attribute__((aligned(16))) float stage[4 * 16 * NTL * 16];      // [wave][16 rows][NP] d(logits)
+    // RB row tiles per wave and pass share every weight fragment: the weight-fragment loads (all L1 / L2 hits, but each one
+    // an instruction of the CU's address unit) are what this kernel waits for - 64 of the 92 VMEM instructions per 16 rows.
+    constexpr int RB = head_rb<WT, NTL, KIND>();
+    __shared__ __attribute__((aligned(16))) float stage[4 * RB * 16 * NTL * 16];      // [wave][RB][16 rows][NP] d(logits)
     __shared__ float wg_part[4][2];
-    // A bounded grid walks the rows (16 per wave and pass): the two loss / accuracy scalars are ONE pair of atomics per
+    // A bounded grid walks the rows (16*RB per wave and pass): the two loss / accuracy scalars are ONE pair of atomics per
     // workgroup - 8192 waves adding to the same two addresses used to take 200 of this kernel's 250 us.
-    for (int row0 = (blockIdx.x * 4 + w) * 16; row0 < R; row0 += gridDim.x * 64) {
-    const int ra = min(row0 + r, R - 1);
-
-    f32x4 acc[NTL];
+    for (int row00 = (blockIdx.x * 4 + w) * 16 * RB; row00 < R; row00 += gridDim.x * 64 * RB) {
+    f32x4 acc_[RB][NTL];
 #pragma unroll
-    for (int n = 0; n < NTL; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int n = 0; n < NTL; ++n) acc_[b][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < H / KG; ++s) {
-        const frag fa = *reinterpret_cast<const frag*>(hs + (size_t)ra * H + s * KG + q * FE);
+        frag fa[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            fa[b] = *reinterpret_cast<const frag*>(hs + (size_t)min(row00 + b * 16 + r, R - 1) * H + s * KG + q * FE);
 #pragma unroll
         for (int n = 0; n < NTL; ++n) {
             const frag fb = *reinterpret_cast<const frag*>(wt + (size_t)(n * 16 + r) * H + s * KG + q * FE);
-            acc[n] = op<WT>::mma(fa, fb, acc[n]);     // C[row = q*4+i][col = n*16 + r]
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc_[b][n] = op<WT>::mma(fa[b], fb, acc_[b][n]);     // C[row = q*4+i][col = n*16 + r]
         }
     }
     float bias[NTL];
 #pragma unroll
     for (int n = 0; n < NTL; ++n) bias[n] = (n * 16 + r < N) ? a.bias[n * 16 + r] : 0.0f;
 
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+    const int row0 = row00 + b * 16, wb = w * RB + b;
+    const f32x4 (&acc)[NTL] = acc_[b];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = row0 + q * 4 + i;
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
                     if (a.want_grad) {
                         const float g = inside ? a.grad_scale * rw * (p[n] - (col == tg ? 1.0f : 0.0f)) : 0.0f;
                         // staged in LDS: a lane owns single columns here, the row-major rows leave as 16-byte chunks
-                        stage[(w * 16 + q * 4 + i) * NP + col] = col < N ? g : 0.0f;
+                        stage[(wb * 16 + q * 4 + i) * NP + col] = col < N ? g : 0.0f;
                     }
                 }
             }
@@ -134,20 +149,21 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
                 if (a.want_grad) st<WT>::store(dl + (size_t)row * NP, a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr));
             }
             if (a.want_grad && a.dhs)      // d(logits) tile for the fused input gradient: column 0 is real
-                stage[(w * 16 + q * 4 + i) * NP + r] = (rv && r == 0) ? a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr) : 0.0f;
+                stage[(wb * 16 + q * 4 + i) * NP + r] = (rv && r == 0) ? a.grad_scale * rw * 2.0f * (pr - y) * pr * (1.0f - pr) : 0.0f;
         }
     }
     if (KIND == 0 && a.want_grad) {
         // this wave's 16 x NP tile, row-major: 4 values (8 / 16 bytes) per lane and pass
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const float* mine = stage + w * 16 * NP;
+        const float* mine = stage + wb * 16 * NP;
 #pragma unroll
         for (int e = l * 4; e < 16 * NP; e += 256) {
             const int rr = e / NP, cc = e % NP;
             if (row0 + rr < R) st<WT>::store4(dl + (size_t)(row0 + rr) * NP + cc, *reinterpret_cast<const f32x4*>(mine + e));
         }
     }
+    }   // row tiles of this pass
     if (a.want_grad && a.dhs) {
         // Fused gradient w.r.t. the top cell's h sequence: dhs^T tile (H x 16 rows) = Wc (H x NP) * dl^T, straight from the
         // staged d(logits) tile - the separate GEMM launch between this kernel and the decoder BPTT (and its pass over dl)
@@ -158,28 +174,39 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
         }
         const WT* __restrict__ wc = reinterpret_cast<const WT*>(a.wc);
         WT* __restrict__ dhs = reinterpret_cast<WT*>(a.dhs);
-        const float* mine = stage + (w * 16 + r) * NP;
-        f32x4 dacc[16];
+        f32x4 dacc[RB][16];
         const int HT = H >> 4;                   // <= 16 (checked by the launcher)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dacc[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < (NP + KG - 1) / KG; ++s2) {
             const int k0 = s2 * KG + q * FE;
-            const frag fz = frag_from<WT>(mine, false), fd = frag_from<WT>(mine + (k0 < NP ? k0 : 0), k0 < NP);
+            const frag fz = frag_from<WT>(stage, false);
+            frag fd[RB];
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                fd[b] = frag_from<WT>(stage + ((w * RB + b) * 16 + r) * NP + (k0 < NP ? k0 : 0), k0 < NP);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (j < HT) {
                     const frag fw = k0 < NP ? *reinterpret_cast<const frag*>(wc + (size_t)(j * 16 + r) * NP + k0) : fz;
-                    dacc[j] = op<WT>::mma(fw, fd, dacc[j]);        // C[row = h column q*4+i of tile j][col = batch-time row r]
+#pragma unroll
+                    for (int b = 0; b < RB; ++b)
+                        dacc[b][j] = op<WT>::mma(fw, fd[b], dacc[b][j]);   // C[row = h column q*4+i of tile j][col = batch-time row r]
                 }
             }
         }
-        if (row0 < R) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < HT)
-                    st<WT>::store4(dhs + ((((size_t)(row0 >> 4) * HT + j) * 64) + (size_t)(q * 16 + r)) * 4, dacc[j]);
+        for (int b = 0; b < RB; ++b) {
+            const int row0 = row00 + b * 16;
+            if (row0 < R) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < HT)
+                        st<WT>::store4(dhs + ((((size_t)(row0 >> 4) * HT + j) * 64) + (size_t)(q * 16 + r)) * 4, dacc[b][j]);
+            }
         }
     }
         __builtin_amdgcn_wave_barrier();        // the stage tile is reused by the next pass
@@ -202,15 +229,19 @@ __global__ __launch_bounds__(256) void head_k(const mvae_head_args a) {
 template <typename WT, int KIND>
 int launch(const mvae_head_args& a, hipStream_t s) {
     const int ntl = (a.N + 15) / 16;
-    const int need = (a.R + 63) / 64;
-    const dim3 grid(need < 1024 ? need : 1024), block(256);
+    const dim3 block(256);
+    auto grid = [&](int rb) {
+        const int need = (a.R + 64 * rb - 1) / (64 * rb);
+        const int cap = rb == 2 ? 512 : 1024;       // rb == 2: two workgroups per CU are resident - one round, half the atomics
+        return dim3(need < cap ? need : cap);
+    };
     switch (ntl) {
-        case 1: hipLaunchKernelGGL((head_k<WT, 1, KIND>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((head_k<WT, 2, KIND>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((head_k<WT, 1, KIND>), grid(head_rb<WT, 1, KIND>()), block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((head_k<WT, 2, KIND>), grid(head_rb<WT, 2, KIND>()), block, 0, s, a); break;
         case 3:
-        case 4: hipLaunchKernelGGL((head_k<WT, 4, KIND>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((head_k<WT, 4, KIND>), grid(head_rb<WT, 4, KIND>()), block, 0, s, a); break;
         case 5: case 6: case 7:
-        case 8: hipLaunchKernelGGL((head_k<WT, 8, KIND>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((head_k<WT, 8, KIND>), grid(head_rb<WT, 8, KIND>()), block, 0, s, a); break;
         default: return MVAE_E_UNSUPPORTED;
     }
     MVAE_CHECK_LAUNCH();
