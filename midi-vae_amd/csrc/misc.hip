@@ -226,17 +226,44 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, f
 }
 // graph-replayable form: the step count lives in device memory (t_done = completed steps)
 __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                           float eps, float gs, const int* t_done, int zero_g) {
+                           float eps, float gs, const int* t_done, int zero_g, int vec) {
     const float t = (float)(*t_done + 1);
     const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const float ge = g[e] * gs;
-        const float me = b1 * m[e] + (1.0f - b1) * ge;
-        const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;
+    auto one = [&](float ge, float& me, float& ve, float& pe) {
+        ge *= gs;
+        me = b1 * me + (1.0f - b1) * ge;
+        ve = b2 * ve + (1.0f - b2) * ge * ge;
+        pe -= lr_t * me / (sqrtf(ve) + eps);
+    };
+    // 16 bytes per lane and access: four streams in, four out - the kernel is the HBM pass over 32 bytes per parameter
+    const size_t n4 = vec ? n >> 2 : 0;          // vec: all four buffers 16-byte aligned
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 ge = g4[e];
+        f32x4 me = m4[e], ve = v4[e], pe = p4[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float mi = me[i], vi = ve[i], pi = pe[i];
+            one(ge[i], mi, vi, pi);
+            me[i] = mi;
+            ve[i] = vi;
+            pe[i] = pi;
+        }
+        m4[e] = me;
+        v4[e] = ve;
+        p4[e] = pe;
+        if (zero_g) g4[e] = f32x4{0.f, 0.f, 0.f, 0.f};       // the next step accumulates into a clean buffer: no fill launch
+    }
+    for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float me = m[e], ve = v[e], pe = p[e];
+        one(g[e], me, ve, pe);
         m[e] = me;
         v[e] = ve;
-        p[e] -= lr_t * me / (sqrtf(ve) + eps);
-        if (zero_g) g[e] = 0.0f;       // the next step accumulates into a clean buffer: no separate fill launch
+        p[e] = pe;
+        if (zero_g) g[e] = 0.0f;
     }
 }
 __global__ void bump_k(int* t) { *t += 1; }
@@ -515,8 +542,10 @@ extern "C" int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t
                                   float beta2, float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream) {
     if (!p || !g || !m || !v || !t_done) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps,
-                              grad_scale, t_done, (int)zero_grad);
+    const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                      reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(vec ? (n + 3) / 4 : n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
+                              eps, grad_scale, t_done, (int)zero_grad, vec);
     hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
