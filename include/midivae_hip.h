@@ -313,9 +313,11 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)
  *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros
  *                              (the step's loss / metric accumulators: one fill launch less)
- *   MVAE_PREP_CONVERT_PAD      src (a, b) f32, c = padded row length >= b     -> dst (a, c) kind, columns b..c-1 zero   */
+ *   MVAE_PREP_CONVERT_PAD      src (a, b) f32, c = padded row length >= b     -> dst (a, c) kind, columns b..c-1 zero
+ *   MVAE_PREP_ADD_I32          (no src)                                       -> *(int32_t*)dst += a  (the optimizer's step
+ *                              count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own)            */
 enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
-       MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5 };
+       MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5, MVAE_PREP_ADD_I32 = 6 };
 typedef struct {
     int32_t op, kind;          /* MVAE_PREP_*, element kind of dst (MVAE_F32 / MVAE_BF16) */
     int32_t a, b, c, reserved;
@@ -349,7 +351,10 @@ int mvae_transpose_convert(const float* W, void* out, int32_t K, int32_t N, int3
 int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, int32_t t, float grad_scale, void* stream);
 /* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph.
- * zero_grad != 0: g is zeroed as it is consumed (the next step accumulates into it: no separate fill launch) */
+ * zero_grad = flags: MVAE_ADAM_ZERO_GRAD: g is zeroed as it is consumed (the next step accumulates into it: no separate
+ * fill launch); MVAE_ADAM_KEEP_COUNT: *t_done is left alone - the caller adds 1 before the next step, e.g. as a
+ * MVAE_PREP_ADD_I32 job of the weight-preparation launch that follows anyway (one dependent launch less per step). */
+enum { MVAE_ADAM_ZERO_GRAD = 1, MVAE_ADAM_KEEP_COUNT = 2 };
 int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                        float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream);
 int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float lr, float rho, float eps,

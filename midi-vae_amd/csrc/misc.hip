@@ -452,6 +452,9 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             }
             break;
         }
+        case MVAE_PREP_ADD_I32:
+            if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<int32_t*>(job.dst) += job.a;
+            break;
         case MVAE_PREP_ZERO: {
             const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
             uint32_t* d = reinterpret_cast<uint32_t*>(job.dst);
@@ -468,7 +471,8 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
         pb.n = n_jobs - j0 < PREP_MAX_JOBS ? n_jobs - j0 : PREP_MAX_JOBS;
         for (int j = 0; j < pb.n; ++j) {
             const mvae_prep_job& job = jobs[j0 + j];
-            if ((!job.src && job.op != MVAE_PREP_ZERO) || !job.dst || job.op < 0 || job.op > MVAE_PREP_CONVERT_PAD ||
+            if ((!job.src && job.op != MVAE_PREP_ZERO && job.op != MVAE_PREP_ADD_I32) || !job.dst || job.op < 0 ||
+                job.op > MVAE_PREP_ADD_I32 ||
                 (job.op == MVAE_PREP_CONVERT_PAD && job.c < job.b) ||
                 (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
                 (job.op == MVAE_PREP_ZERO && job.kind == MVAE_BF16 && (((size_t)job.a * job.b) & 1)))
@@ -545,8 +549,8 @@ extern "C" int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t
     const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
     if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(vec ? (n + 3) / 4 : n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
-                              eps, grad_scale, t_done, (int)zero_grad, vec);
-    hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
+                              eps, grad_scale, t_done, (int)(zero_grad & MVAE_ADAM_ZERO_GRAD), vec);
+    if (!(zero_grad & MVAE_ADAM_KEEP_COUNT)) hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

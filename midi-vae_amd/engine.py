@@ -115,6 +115,9 @@ class Engine(object):
         self._alloc(self.maxB)
         self._views_cache = {}
         self._prep = None
+        self._prep_count = None
+        self._count_only = None
+        self._count_pending = False
         self._sync_cum = {}
         self._pipe_verified = False
 
@@ -209,6 +212,7 @@ class Engine(object):
         self.opt_m.zero_()
         self.opt_v.zero_()
         self.t_done.zero_()
+        self._count_pending = False
 
     # ------------------------------------------------------------------------------------------------------
     # static description of the recurrent layers
@@ -442,36 +446,42 @@ class Engine(object):
         s, P = self.spec, self.P
 
         if self._prep is None:          # built once: every source / destination is a fixed view
-            pb = self._prep = ops.PrepBatch()
-            for r in self.all_rec:
-                p = r.prefix
-                pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
-                if r.xmode == hl.X_INDEX:
-                    pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
-                elif r.xmode == hl.X_DENSE:
-                    pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
-                if self.training:
-                    pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
-                    if r.xmode == hl.X_DENSE:
-                        pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
-            pb.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
-            if s.meta_instrument:
-                pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
-            if s.meta_velocity:
-                pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
-            pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
-            if self.training:
-                pb.convert_pad(P["dec.notes.out.W"], self.store["notes.wc"], self.np_notes)
+            self._prep, self._prep_count = ops.PrepBatch(), ops.PrepBatch()
+            self._prep_count.add_i32(self.t_done)       # ... the optimizer's step count rides along after an eager step
+            for pb in (self._prep, self._prep_count):
+                for r in self.all_rec:
+                    p = r.prefix
+                    pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
+                    if r.xmode == hl.X_INDEX:
+                        pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+                    elif r.xmode == hl.X_DENSE:
+                        pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
+                    if self.training:
+                        pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
+                        if r.xmode == hl.X_DENSE:
+                            pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
+                pb.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
                 if s.meta_instrument:
-                    pb.convert_pad(P["dec.instr.out.W"], self.store["instr.wc"], self.np_instr)
+                    pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
                 if s.meta_velocity:
-                    pb.convert_pad(P["dec.vel.out.W"], self.store["vel.wc"], 16)
-            if self.training:
-                for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
-                                     ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
-                    if tname in self.store:
-                        pb.transpose_convert(P[wname], self.store[tname])
-        self._prep.run()
+                    pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+                pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
+                if self.training:
+                    pb.convert_pad(P["dec.notes.out.W"], self.store["notes.wc"], self.np_notes)
+                    if s.meta_instrument:
+                        pb.convert_pad(P["dec.instr.out.W"], self.store["instr.wc"], self.np_instr)
+                    if s.meta_velocity:
+                        pb.convert_pad(P["dec.vel.out.W"], self.store["vel.wc"], 16)
+                if self.training:
+                    for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
+                                         ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
+                        if tname in self.store:
+                            pb.transpose_convert(P[wname], self.store[tname])
+        if self._count_pending:
+            self._prep_count.run()
+            self._count_pending = False
+        else:
+            self._prep.run()
         self._weights_dirty = False
 
     # ------------------------------------------------------------------------------------------------------
@@ -1134,13 +1144,28 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     # steps
     # ------------------------------------------------------------------------------------------------------
+    def _flush_count(self):
+        """apply a step-count increment still owed to ``t_done`` (see optimizer_step)"""
+        if self._count_pending:
+            if self._count_only is None:
+                self._count_only = ops.PrepBatch()
+                self._count_only.add_i32(self.t_done)
+            self._count_only.run()
+            self._count_pending = False
+
     def optimizer_step(self, grad_scale=1.0):
         s = self.spec
         # (the gradients are zeroed as they are consumed: the next step starts without a 17 MB fill launch in front of it)
         z = self.zero_grads_in_optimizer
         if s.optimizer == "Adam":
+            # eager: the step count is bumped by the weight-preparation launch that follows anyway (one dependent launch
+            # less between two steps); under graph capture the optimizer graph bumps it itself
+            keep = not self.use_graphs
+            if self._count_pending:
+                self._flush_count()
             ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale,
-                              zero_grad=z)
+                              zero_grad=z, keep_count=keep)
+            self._count_pending = keep
         else:
             ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=z)
         self._grads_clean = z

@@ -60,6 +60,8 @@ class PrepJob(C.Structure):
 
 
 PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT, PREP_ZERO, PREP_CONVERT_PAD = 0, 1, 2, 3, 4, 5
+PREP_ADD_I32 = 6
+ADAM_ZERO_GRAD, ADAM_KEEP_COUNT = 1, 2
 
 
 class HeadArgs(C.Structure):

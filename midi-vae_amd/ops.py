@@ -236,6 +236,13 @@ class PrepBatch:
     def zero(self, dst):
         self._add(hl.PREP_ZERO, dst, dst.numel(), 1, 0, None)
 
+    def add_i32(self, counter, value=1):
+        """*counter (int32 device scalar) += value"""
+        assert counter.dtype == torch.int32
+        self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, None, None, _p(counter)))
+        self._keep.append(counter)
+        self._arr = None
+
     def convert_pad(self, W, out, n_pad):
         K, N = W.shape
         self._add(hl.PREP_CONVERT_PAD, out, K, N, n_pad, W)
@@ -251,9 +258,11 @@ def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
                                       _stream()), "mvae_adam_step")
 
 
-def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False):
+def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False,
+                  keep_count=False):
+    flags = (hl.ADAM_ZERO_GRAD if zero_grad else 0) | (hl.ADAM_KEEP_COUNT if keep_count else 0)
     hl.check(hl.load().mvae_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(t_done),
-                                          grad_scale, int(bool(zero_grad)), _stream()), "mvae_adam_step_dev")
+                                          grad_scale, flags, _stream()), "mvae_adam_step_dev")
 
 
 def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0, zero_grad=False):

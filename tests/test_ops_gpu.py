@@ -476,6 +476,33 @@ def test_reductions_and_elementwise():
     close(host(tab), W + b, 1e-6)
 
 
+def test_adam_keep_count_and_prep_add_i32_job():
+    """mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT | MVAE_ADAM_ZERO_GRAD) leaves the step count to a MVAE_PREP_ADD_I32 job of the
+    next weight-preparation launch: three such steps (odd length: vector body + scalar tail; unaligned views: scalar path)
+    equal the oracle's Keras Adam, the gradients come back zeroed and the count ends at 3."""
+    rng = np.random.default_rng(18)
+    for n, off in ((5003, 0), (4099, 1)):
+        p0, m = rng.standard_normal(n), vo.OracleVAE(vo.make_cfg(lr=1e-3))
+        p_o = {"w": p0.copy()}
+        st = m.new_opt_state(p_o)
+        buf = [torch.zeros(n + off, device=DEV) for _ in range(4)]
+        p, g_d, mm, vv = [b[off:] for b in buf]
+        p.copy_(dev(p0))
+        t_done = torch.zeros(1, dtype=torch.int32, device=DEV)
+        bump = ops.PrepBatch()
+        bump.add_i32(t_done)
+        for t in range(1, 4):
+            g = rng.standard_normal(n)
+            m.opt_step(p_o, {"w": g}, st)
+            g_d.copy_(dev(g))
+            ops.adam_step_dev(p, g_d, mm, vv, 1e-3, t_done, zero_grad=True, keep_count=True)
+            assert int(t_done.item()) == t - 1
+            bump.run()
+            assert float(g_d.abs().max()) == 0.0
+        close(host(p), p_o["w"], 1e-5)
+        assert int(t_done.item()) == 3
+
+
 def test_keras_adam_and_rmsprop_match_oracle():
     rng = np.random.default_rng(8)
     n = 5000
