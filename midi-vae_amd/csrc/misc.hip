@@ -267,12 +267,35 @@ __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, flo
     }
 }
 __global__ void bump_k(int* t) { *t += 1; }
-__global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const float ge = g[e] * gs;
-        const float ve = rho * v[e] + (1.0f - rho) * ge * ge;
+__global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g, int vec) {
+    auto one = [&](float ge, float& ve, float& pe) {
+        ge *= gs;
+        ve = rho * ve + (1.0f - rho) * ge * ge;
+        pe -= lr * ge / (sqrtf(ve) + eps);
+    };
+    const size_t n4 = vec ? n >> 2 : 0;          // vec: all three buffers 16-byte aligned
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 ge = g4[e];
+        f32x4 ve = v4[e], pe = p4[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float vi = ve[i], pi = pe[i];
+            one(ge[i], vi, pi);
+            ve[i] = vi;
+            pe[i] = pi;
+        }
+        v4[e] = ve;
+        p4[e] = pe;
+        if (zero_g) g4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (size_t e = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        float ve = v[e], pe = p[e];
+        one(g[e], ve, pe);
         v[e] = ve;
-        p[e] -= lr * ge / (sqrtf(ve) + eps);
+        p[e] = pe;
         if (zero_g) g[e] = 0.0f;
     }
 }
@@ -558,8 +581,9 @@ extern "C" int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float l
                                  float grad_scale, int32_t zero_grad, void* stream) {
     if (!p || !g || !v) return MVAE_E_ARG;
     if (n == 0) return MVAE_OK;
-    hipLaunchKernelGGL(rmsprop_k, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, v, n, lr, rho,
-                       eps, grad_scale, (int)zero_grad);
+    const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    hipLaunchKernelGGL(rmsprop_k, dim3(nblocks(vec ? (n + 3) / 4 : n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, v,
+                       n, lr, rho, eps, grad_scale, (int)zero_grad, vec);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
