@@ -86,6 +86,7 @@ class Engine(object):
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
+        self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
@@ -146,11 +147,23 @@ class Engine(object):
     # ---- stream helpers -------------------------------------------------------------------------------------
     def _fork(self, *streams):
         cur = torch.cuda.current_stream()
+        if self.lean_sync and len(streams) > 1:
+            ev = cur.record_event()         # ONE marker packet on this queue, however many streams branch off
+            for st in streams:
+                st.wait_event(ev)
+            return
         for st in streams:
             st.wait_stream(cur)
 
     def _join(self, *streams):
         cur = torch.cuda.current_stream()
+        if self.lean_sync and len(streams) > 1:
+            # chained: every side queue takes its barrier packet when ITS work ends; the joining queue (the critical one)
+            # processes one barrier packet instead of len(streams)
+            for a, b in zip(streams, streams[1:]):
+                b.wait_stream(a)
+            cur.wait_stream(streams[-1])
+            return
         for st in streams:
             cur.wait_stream(st)
 
