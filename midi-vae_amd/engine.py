@@ -86,6 +86,7 @@ class Engine(object):
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
+        self._prefork = None
         self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
@@ -146,6 +147,9 @@ class Engine(object):
 
     # ---- stream helpers -------------------------------------------------------------------------------------
     def _fork(self, *streams):
+        if self._prefork is not None and streams == self._prefork:
+            self._prefork = None            # already forked by _fork_with_stack
+            return
         cur = torch.cuda.current_stream()
         if self.lean_sync and len(streams) > 1:
             ev = cur.record_event()         # ONE marker packet on this queue, however many streams branch off
@@ -154,6 +158,17 @@ class Engine(object):
             return
         for st in streams:
             st.wait_stream(cur)
+
+    def _fork_with_stack(self, layers, *streams):
+        """fork ``streams`` AND the streams a pipelined stack over ``layers`` will use with one event; that stack's own
+        fork - the next _fork() call for exactly those streams - is then skipped (nothing may be launched on the current
+        stream in between)."""
+        extra = ()
+        if self.lean_sync and self._pipelined(layers):
+            L = len(layers)
+            extra = (*self.s_layer[:L - 1], *self.s_proj[:L - 1])
+        self._fork(*streams, *extra)
+        self._prefork = extra if extra else None
 
     def _join(self, *streams):
         cur = torch.cuda.current_stream()
@@ -655,7 +670,7 @@ class Engine(object):
         Breal, B = B, self.pad16(B)
         cat = self._v("cat", B, self.ncat * H)
         ldc = self.ncat * H
-        self._fork(self.s_vel, self.s_instr)
+        self._fork_with_stack(self.enc_notes, self.s_vel, self.s_instr)
         k = 1
         if s.meta_instrument:
             with self._on(self.s_instr):
@@ -667,6 +682,7 @@ class Engine(object):
                 self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H],
                                   h_last_ld=ldc)
         self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
+        self._prefork = None
         self._join(self.s_vel, self.s_instr)
         self._mark("  encoder recurrences")
         self._S_done = False
@@ -740,7 +756,7 @@ class Engine(object):
 
         self._mark("  decoder initial states")
         tg = self._have_targets
-        self._fork(self.s_vel, self.s_instr)
+        self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr)
         if s.meta_instrument:
             with self._on(self.s_instr):
                 r = self.dec_instr
@@ -767,6 +783,7 @@ class Engine(object):
                      **self._fused_head_bwd("vel", tg),
                          scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
         self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout), slot=1)
+        self._prefork = None
         top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
         ops.head(0, self.kind, T * B, H, s.Dout, top, self._v("notes.wt", self.np_notes, H), P["dec.notes.out.b"],
                  target_idx=self._v("in.y_idx", T * B) if tg else None,
@@ -1026,7 +1043,7 @@ class Engine(object):
             with torch.cuda.stream(self.s_comm):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: three independent branches -------------------------------------------------
-        self._fork(self.s_vel, self.s_instr)
+        self._fork_with_stack(self.enc_notes, self.s_vel, self.s_instr)
         k = 1
         if s.meta_instrument:
             with self._on(self.s_instr):
@@ -1038,6 +1055,7 @@ class Engine(object):
                 self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                      xs=self._v("in.vel", T, B))
         self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+        self._prefork = None
         if deferred:
             word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da
             for st in (self.s_grad, self.s_grad2):
