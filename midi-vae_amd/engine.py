@@ -1064,7 +1064,10 @@ class Engine(object):
                 ops.stream_wait_value32(word, value, stream=st)
             for _, fn in deferred:
                 fn()
-        self._join(self.s_vel, self.s_instr, self.s_grad, self.s_grad2)
+        # the two gradient queues finish last and together: chained, they would put two cross-queue hops in series - the
+        # early finishers are chained into one of them, the other is waited for directly
+        self._join(self.s_vel, self.s_instr, self.s_grad)
+        self._join(self.s_grad2)
 
     def _latent_backward_unfused(self, Breal, B):
         """initial-state Denses, latent block and encoder tail Denses backward, one launch per operation; returns d(cat)"""
