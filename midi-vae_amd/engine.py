@@ -147,8 +147,10 @@ class Engine(object):
 
     # ---- stream helpers -------------------------------------------------------------------------------------
     def _fork(self, *streams):
-        if self._prefork is not None and streams == self._prefork:
-            self._prefork = None            # already forked by _fork_with_stack
+        if self._prefork is not None and self._prefork[0] == torch.cuda.current_stream() and \
+                all(any(st is p for p in self._prefork[1]) for st in streams):
+            for st in streams:              # already forked by _fork_with_stack
+                self._prefork[1].remove(st)
             return
         cur = torch.cuda.current_stream()
         if self.lean_sync and len(streams) > 1:
@@ -159,16 +161,16 @@ class Engine(object):
         for st in streams:
             st.wait_stream(cur)
 
-    def _fork_with_stack(self, layers, *streams):
-        """fork ``streams`` AND the streams a pipelined stack over ``layers`` will use with one event; that stack's own
-        fork - the next _fork() call for exactly those streams - is then skipped (nothing may be launched on the current
-        stream in between)."""
+    def _fork_with_stack(self, layers, *streams, also=()):
+        """fork ``streams`` AND the streams a pipelined stack over ``layers`` will use (and ``also``) with one event; the
+        forks the callees then ask for from THIS stream for those streams are skipped, once each (nothing they depend on
+        may be launched on the current stream in between; the caller clears ``_prefork`` after the stack)."""
         extra = ()
         if self.lean_sync and self._pipelined(layers):
             L = len(layers)
-            extra = (*self.s_layer[:L - 1], *self.s_proj[:L - 1])
+            extra = (*self.s_layer[:L - 1], *self.s_proj[:L - 1], *also)
         self._fork(*streams, *extra)
-        self._prefork = extra if extra else None
+        self._prefork = (torch.cuda.current_stream(), list(extra)) if extra else None
 
     def _join(self, *streams):
         cur = torch.cuda.current_stream()
@@ -1009,7 +1011,8 @@ class Engine(object):
         # collected here and released - by a device-side wait on the encoder stack's first published chunk - once the
         # encoder BPTT kernels are resident; it then runs beside them as before.
         self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
-        self._fork(self.s_vel, self.s_instr)
+        # (one event for the three branches, the notes head's gradient GEMM and the notes stack's lower layers)
+        self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr, also=(self.s_grad,))
         if s.meta_instrument:
             with self._on(self.s_instr):
                 dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
@@ -1024,6 +1027,7 @@ class Engine(object):
                                    "dec.notes.out.b")
         self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates,
                              slot=2)
+        self._prefork = None
         self._join(self.s_vel, self.s_instr)
         self._mark("  decoder BPTT")
         deferred, self._deferred = self._deferred, None
