@@ -87,6 +87,7 @@ class Engine(object):
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
         self._prefork = None
+        self._branches_stay_forked = False
         self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
@@ -795,7 +796,8 @@ class Engine(object):
                  dlogits=self._v("notes.dl", T * B, self.np_notes) if (self.training and tg) else None,
                      **self._fused_head_bwd("notes", tg),
                  scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2], b_stride=B, b_valid=Breal)
-        self._join(self.s_vel, self.s_instr)
+        if not self._branches_stay_forked:
+            self._join(self.s_vel, self.s_instr)
 
     # ------------------------------------------------------------------------------------------------------
     # backward
@@ -1012,7 +1014,10 @@ class Engine(object):
         # encoder BPTT kernels are resident; it then runs beside them as before.
         self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
         # (one event for the three branches, the notes head's gradient GEMM and the notes stack's lower layers)
-        self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr, also=(self.s_grad,))
+        if self._branches_stay_forked:      # (train step: the velocity / instrument queues go straight on with their own backward)
+            self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
+        else:
+            self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr, also=(self.s_grad,))
         if s.meta_instrument:
             with self._on(self.s_instr):
                 dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
@@ -1224,9 +1229,16 @@ class Engine(object):
         self._mark("weights prepared")
         self.encoder_forward(B, with_init=True)
         self._mark("encoder forward (incl. latent)")
-        self.decoder_forward(B)
-        self._mark("decoder forward + heads")
-        self.backward(B)
+        # The velocity / instrument branches' backward depends on nothing the notes branch does in between: no join at
+        # the end of the decoder forward pass and no fork at the start of the backward pass (two packets less on the
+        # critical queue); they are joined where the decoder BPTT ends.
+        self._branches_stay_forked = self.lean_sync and self.multi_stream
+        try:
+            self.decoder_forward(B)
+            self._mark("decoder forward + heads")
+            self.backward(B)
+        finally:
+            self._branches_stay_forked = False
         self._mark("backward")
         self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
                                        self.backward(B)))
