@@ -930,7 +930,8 @@ class Engine(object):
                 with torch.cuda.stream(gemm_streams[li]):     # dX for the layer below, from the last chunk to the first
                     self._rec_dx(r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True,
                                  chunk_wait=sync[li, 0], chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)
-        self._join(*lower_streams, *gemm_streams)
+        # chained join: the latest finisher (the bottom layer) last - ahead of the dX GEMMs it would put two hops in series
+        self._join(*gemm_streams, *lower_streams)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
                         start=None, slot=0):
