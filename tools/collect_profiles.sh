@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01k
+O=$R/gpurun_out/r01l
 mkdir -p $O
 python $R/bench.py > $O/bench_lstm.json 2> $O/bench_lstm.err
 python $R/bench.py --cell GRU > $O/bench_gru.json 2> $O/bench_gru.err
