@@ -314,6 +314,55 @@ def test_softmax_head(dtype, tol, N):
     assert host(sc)[1] == hits
 
 
+@pytest.mark.parametrize("dtype", [hl.F32, hl.BF16])
+@pytest.mark.parametrize("want_probs", [True, False])
+@pytest.mark.parametrize("N,H", [(61, 64), (61, 256), (16, 256)])
+def test_softmax_head_argmax_planted_ties(dtype, want_probs, N, H):
+    """The fused argmax follows the reference's decode rule (reference vae_definition.py:1048-1067: np.argmax = FIRST maximum;
+    a row that sums to zero -> index 0) with ties PLANTED on the device: identical weight columns give bit-identical logits, so
+    the maximum is shared by 2 / 3 / all columns - with and without the probability output (the decode-only path writes no
+    probabilities), in both arithmetic modes, across both 16-column halves of a lane group and the 64-column boundary."""
+    rng = np.random.default_rng(7 + N)
+    R = 16 * 9 + 5
+    td = ops.torch_dtype(dtype)
+    hs_h = rng.standard_normal((R, H))
+    W = rng.standard_normal((H, N)) * 0.3
+    bias = rng.standard_normal((N,)) * 0.1
+    # columns that tie: (a) two adjacent, (b) two across the 16-column boundary, (c) three incl. the last column
+    groups = [(3, 4), (5, N - 1)] if N <= 16 else [(3, 4), (14, 17), (20, 40, N - 1)]
+    Wt = W.copy()
+    bt = bias.copy()
+    big = 5.0 * np.abs(hs_h @ W + bias).max()
+    for gi, grp in enumerate(groups):
+        for c in grp:
+            Wt[:, c] = W[:, grp[0]]
+            bt[c] = bias[grp[0]]
+    NP = ops.head_np(N)
+    am_all = {}
+    for gi, grp in enumerate(groups + [tuple(range(N))]):
+        Wg, bg = Wt.copy(), bt.copy()
+        if len(grp) == N:                          # every logit equal: all-zero weights and equal biases -> index 0
+            Wg[:], bg[:] = 0.0, 0.25
+        else:
+            for c in grp:                          # lift the tied columns above every other column of every row
+                bg[c] = bt[grp[0]] + big
+        wt = torch.zeros((NP, H), dtype=td, device=DEV)
+        ops.transpose_convert(dev(Wg), wt, n_pad=NP)
+        hs = dev(hs_h, td)
+        probs = torch.zeros((R, N), device=DEV) if want_probs else None
+        am = torch.full((R,), 255, dtype=torch.uint8, device=DEV)
+        sc = torch.zeros((2,), device=DEV)
+        ops.head(0, dtype, R, H, N, hs, wt, dev(bg), probs=probs, argmax=am, scalars=sc)
+        torch.cuda.synchronize()
+        got = am.cpu().numpy()
+        assert np.all(got == min(grp)), (grp, np.unique(got))
+        if want_probs:
+            p = probs.cpu().numpy()
+            for c in grp[1:]:
+                assert np.array_equal(p[:, c], p[:, grp[0]])          # the tie is exact on the device
+            assert np.array_equal(got, np.argmax(p, axis=1).astype(np.uint8))
+
+
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
 def test_sigmoid_head(dtype, tol):
     rng = np.random.default_rng(2)
