@@ -33,9 +33,10 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 1
+#define MVAE_ABI_VERSION 2
 
-enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3 };
+enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
+       MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
 enum { MVAE_GRU = 0, MVAE_LSTM = 1, MVAE_RNN = 2 };
 enum { MVAE_F32 = 0, MVAE_BF16 = 1 };
 /* where x_t W + b comes from in a recurrent layer */
@@ -314,8 +315,8 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros
  *                              (the step's loss / metric accumulators: one fill launch less)
  *   MVAE_PREP_CONVERT_PAD      src (a, b) f32, c = padded row length >= b     -> dst (a, c) kind, columns b..c-1 zero
- *   MVAE_PREP_ADD_I32          (no src)                                       -> *(int32_t*)dst += a  (the optimizer's step
- *                              count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own)            */
+ *   MVAE_PREP_ADD_I32          src = NULL or a guard word (uint32)            -> *(int32_t*)dst += a unless *src != 0 (the
+ *                              optimizer's step count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own) */
 enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
        MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5, MVAE_PREP_ADD_I32 = 6 };
 typedef struct {
@@ -353,12 +354,46 @@ int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
 /* same, with the count of COMPLETED steps in device memory (incremented after the update): replayable in a hipGraph.
  * zero_grad = flags: MVAE_ADAM_ZERO_GRAD: g is zeroed as it is consumed (the next step accumulates into it: no separate
  * fill launch); MVAE_ADAM_KEEP_COUNT: *t_done is left alone - the caller adds 1 before the next step, e.g. as a
- * MVAE_PREP_ADD_I32 job of the weight-preparation launch that follows anyway (one dependent launch less per step). */
+ * MVAE_PREP_ADD_I32 job of the weight-preparation launch that follows anyway (one dependent launch less per step).
+ * guard (NULL = none): a device word, e.g. the `status` word of the time-pipelined stacks - while it is non-zero the update
+ * (and the step count) is SKIPPED on the device, so a step whose gradients are invalid never reaches the parameters or the
+ * moments; the gradients are still zeroed. */
 enum { MVAE_ADAM_ZERO_GRAD = 1, MVAE_ADAM_KEEP_COUNT = 2 };
 int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                       float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream);
+                       float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, const uint32_t* guard, void* stream);
 int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float lr, float rho, float eps,
-                      float grad_scale, int32_t zero_grad, void* stream);
+                      float grad_scale, int32_t zero_grad, const uint32_t* guard, void* stream);
+
+/* Epoch accumulators of the per-step loss / metric scalars - what Keras' BaseLogger keeps on the host for the `history` of
+ * autoencoder.fit (reference vae_training.py:817-864 reads it per song): acc[i] += (bit i of plain_mask ? 1 : alpha) * x[i],
+ * n <= 32.  One tiny launch behind the step instead of a device->host read (a full synchronisation) per minibatch. */
+int mvae_scalars_accumulate(float* acc, const float* x, int32_t n, float alpha, uint32_t plain_mask, void* stream);
+/* dst (rows, cols; row stride ldd) = src rows src_row0 .. (row stride lds); the first zero_rows rows of dst are ZERO instead
+ * (their source row index may be negative).  Places the history latent - the previous window's z, zeros for the first
+ * window (reference vae_training.py:795-798: H[1:] = z[:-1]) - or a caller's z into the [z | history] decoder input. */
+int mvae_copy2d_f32(float* dst, int32_t ldd, const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_row0,
+                    int32_t zero_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * HOST-side packers (csrc/hostpack.cpp): every pointer below is a HOST pointer, nothing touches the device.
+ * The reference hands the Keras Models float64 NumPy windows - one-hot rows (n, T, K) (reference import_midi.py:245-286,
+ * lists built by vae_definition.py:880-1045) - the engine consumes ONE BYTE per row, time-major, padded to 16 windows.
+ * One multi-threaded pass over the caller's array validates, converts, transposes and pads, straight into the pinned
+ * staging block the engine uploads with a single asynchronous copy (64 MB of float64 -> 128 KB per 256 x 512 rows).
+ * --------------------------------------------------------------------------------------------------------- */
+enum { MVAE_HOST_F64 = 0, MVAE_HOST_F32 = 1, MVAE_HOST_U8 = 2 };
+/* size of the worker pool: n > 0 sets it, 0 restores the default (min(16, cores)), < 0 only queries; returns the size */
+int mvae_host_threads(int32_t n);
+/* windows [lo, hi) of x (n, T, K) one-hot rows of xkind -> out (T, Bp) uint8: out[t*Bp + (b-lo)] = position of the 1;
+ * columns hi-lo .. Bp-1 = fill.  A row that is not exactly one 1 among zeros: MVAE_E_FORMAT, *bad_row = its flat row. */
+int mvae_host_onehot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_t T, int32_t K, int64_t lo, int64_t hi,
+                                 uint8_t* out, int32_t Bp, uint8_t fill, int64_t* bad_row);
+/* the same for rows that already are indices: idx (n, T) uint8 */
+int mvae_host_index_to_tm(const uint8_t* idx, int64_t n, int32_t T, int64_t lo, int64_t hi, uint8_t* out, int32_t Bp,
+                          uint8_t fill);
+/* windows [lo, hi) of v (n, T) of vkind -> out (T, Bp) f32 = scale * v, pad columns zero (velocity roll, sample weights) */
+int mvae_host_rows_to_tm_f32(const void* v, int32_t vkind, int64_t n, int32_t T, int64_t lo, int64_t hi, float scale,
+                             float* out, int32_t Bp);
 
 #ifdef __cplusplus
 }

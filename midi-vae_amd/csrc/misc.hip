@@ -225,11 +225,15 @@ __global__ void adam_k(float* p, const float* g, float* m, float* v, size_t n, f
     }
 }
 // graph-replayable form: the step count lives in device memory (t_done = completed steps)
+// ``guard``: status word of the time-pipelined stacks - non-zero means a kernel of THIS step gave up waiting for its producer and
+// the gradients are garbage: the update is skipped (parameters and moments stay valid), the gradients are still zeroed.
 __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                           float eps, float gs, const int* t_done, int zero_g, int vec) {
+                           float eps, float gs, const int* t_done, int zero_g, int vec, const uint32_t* guard) {
+    const bool skip = guard && *guard != 0u;
     const float t = (float)(*t_done + 1);
     const float lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
     auto one = [&](float ge, float& me, float& ve, float& pe) {
+        if (skip) return;
         ge *= gs;
         me = b1 * me + (1.0f - b1) * ge;
         ve = b2 * ve + (1.0f - b2) * ge * ge;
@@ -266,9 +270,12 @@ __global__ void adam_dev_k(float* p, float* g, float* m, float* v, size_t n, flo
         if (zero_g) g[e] = 0.0f;
     }
 }
-__global__ void bump_k(int* t) { *t += 1; }
-__global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g, int vec) {
+__global__ void bump_k(int* t, const uint32_t* guard) { if (!(guard && *guard != 0u)) *t += 1; }
+__global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, float rho, float eps, float gs, int zero_g, int vec,
+                          const uint32_t* guard) {
+    const bool skip = guard && *guard != 0u;
     auto one = [&](float ge, float& ve, float& pe) {
+        if (skip) return;
         ge *= gs;
         ve = rho * ve + (1.0f - rho) * ge * ge;
         pe -= lr * ge / (sqrtf(ve) + eps);
@@ -297,6 +304,20 @@ __global__ void rmsprop_k(float* p, float* g, float* v, size_t n, float lr, floa
         v[e] = ve;
         p[e] = pe;
         if (zero_g) g[e] = 0.0f;
+    }
+}
+
+// epoch accumulators of the per-step loss / metric scalars (Keras BaseLogger: batch-size weighted means): one tiny launch
+// after the step instead of a device->host read (= a full synchronisation) per minibatch
+__global__ void scalars_accumulate_k(float* acc, const float* x, int n, float alpha, uint32_t plain_mask) {
+    const int i = threadIdx.x;
+    if (i < n) acc[i] += ((plain_mask >> i) & 1u) ? x[i] : alpha * x[i];
+}
+__global__ void copy2d_f32_k(float* dst, int ldd, const float* src, int lds, int rows, int cols, int src_row0, int zero_rows) {
+    // dst[r, c] = src[src_row0 + r, c]; rows whose source index is negative (r < zero_rows) become zero
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)rows * cols; e += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        dst[(size_t)r * ldd + c] = r < zero_rows ? 0.0f : src[(size_t)(src_row0 + r) * lds + c];
     }
 }
 
@@ -475,8 +496,9 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             }
             break;
         }
-        case MVAE_PREP_ADD_I32:
-            if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<int32_t*>(job.dst) += job.a;
+        case MVAE_PREP_ADD_I32:        // (src = optional guard word: no increment while it is non-zero - the update was skipped too)
+            if (bid == 0 && threadIdx.x == 0 && !(job.src && *reinterpret_cast<const uint32_t*>(job.src) != 0u))
+                *reinterpret_cast<int32_t*>(job.dst) += job.a;
             break;
         case MVAE_PREP_ZERO: {
             const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
@@ -555,6 +577,23 @@ extern "C" int mvae_transpose_convert(const float* W, void* out, int32_t K, int3
     return MVAE_OK;
 }
 
+extern "C" int mvae_scalars_accumulate(float* acc, const float* x, int32_t n, float alpha, uint32_t plain_mask, void* stream) {
+    if (!acc || !x || n < 0 || n > 32) return MVAE_E_ARG;
+    if (n) hipLaunchKernelGGL(scalars_accumulate_k, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), acc, x, n, alpha,
+                              plain_mask);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_copy2d_f32(float* dst, int32_t ldd, const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_row0,
+                               int32_t zero_rows, void* stream) {
+    if (!dst || !src || rows < 0 || cols < 0 || ldd < cols || lds < cols || zero_rows < 0 || src_row0 + zero_rows < 0)
+        return MVAE_E_ARG;
+    if (rows && cols)
+        hipLaunchKernelGGL(copy2d_f32_k, dim3(nblocks((size_t)rows * cols)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst,
+                           ldd, src, lds, rows, cols, src_row0, zero_rows);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 extern "C" int mvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                               float eps, int32_t t, float grad_scale, void* stream) {
     if (!p || !g || !m || !v || t < 1) return MVAE_E_ARG;
@@ -566,24 +605,25 @@ extern "C" int mvae_adam_step(float* p, const float* g, float* m, float* v, size
     return MVAE_OK;
 }
 extern "C" int mvae_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
-                                  float beta2, float eps, int32_t* t_done, float grad_scale, int32_t zero_grad, void* stream) {
+                                  float beta2, float eps, int32_t* t_done, float grad_scale, int32_t zero_grad,
+                                  const uint32_t* guard, void* stream) {
     if (!p || !g || !m || !v || !t_done) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
     if (n) hipLaunchKernelGGL(adam_dev_k, dim3(nblocks(vec ? (n + 3) / 4 : n)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
-                              eps, grad_scale, t_done, (int)(zero_grad & MVAE_ADAM_ZERO_GRAD), vec);
-    if (!(zero_grad & MVAE_ADAM_KEEP_COUNT)) hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done);
+                              eps, grad_scale, t_done, (int)(zero_grad & MVAE_ADAM_ZERO_GRAD), vec, guard);
+    if (!(zero_grad & MVAE_ADAM_KEEP_COUNT)) hipLaunchKernelGGL(bump_k, dim3(1), dim3(1), 0, s, t_done, guard);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
 extern "C" int mvae_rmsprop_step(float* p, float* g, float* v, size_t n, float lr, float rho, float eps,
-                                 float grad_scale, int32_t zero_grad, void* stream) {
+                                 float grad_scale, int32_t zero_grad, const uint32_t* guard, void* stream) {
     if (!p || !g || !v) return MVAE_E_ARG;
     if (n == 0) return MVAE_OK;
     const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
     hipLaunchKernelGGL(rmsprop_k, dim3(nblocks(vec ? (n + 3) / 4 : n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, v,
-                       n, lr, rho, eps, grad_scale, (int)zero_grad, vec);
+                       n, lr, rho, eps, grad_scale, (int)zero_grad, vec, guard);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

@@ -18,6 +18,29 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class DataParallel:
+    """What ``Autoencoder.fit(dp=...)`` / ``VAE.set_data_parallel`` take: the process group the minibatches are sharded over.
+
+    fit splits every global minibatch of <= batch_size consecutive windows contiguously over the ranks (shard_bounds) and
+    normalises every loss by the GLOBAL counts (staging.Norm), so each rank's gradient is its SHARE of the single-process
+    gradient: ``allreduce_grads`` sums the flat f32 gradient buffer (one collective per optimizer step, every rank, every
+    minibatch - also ranks whose shard is empty) and returns the scale 1.0; ``allreduce_sum`` sums the loss / metric
+    accumulators once per fit call.  ``dist`` is torch.distributed (backend "nccl" = RCCL over xGMI on a node of MI355X;
+    "gloo" in the CPU / single-GPU tests)."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce_grads(self, grads):
+        self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM, group=self.group)
+        return 1.0
+
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
 class BucketedAllReduce:
     """The hook ``engine.train_step(allreduce=...)`` expects, in two buckets.
 

@@ -96,7 +96,7 @@ class Engine(object):
         self.time_chunks = 4
         # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
         # every pipe_chunk time steps (no relaunch, no weight reload, layers 32 steps apart instead of T/4)
-        self.pipeline = True
+        self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
         self.pipe_chunk = 32
         self.pipe_gemm_blocks = 64       # persistent grid of the projection / dX GEMM between two pipelined layers
         # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
@@ -123,6 +123,9 @@ class Engine(object):
         self._count_pending = False
         self._sync_cum = {}
         self._pipe_verified = False
+        self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
+        self._have_staged_targets = False
+        self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)     # epoch accumulators (accumulate_metrics)
 
     def _seq_layout(self, r):
         """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM / GRU kernels (TILE16P
@@ -356,20 +359,23 @@ class Engine(object):
                 buf("lat.wt_extra", H * H, **f32)
             if self.has_pack:
                 buf("lat.wt_pack", H * self.ncat * H, **f32)
-        # inputs
-        buf("in.x_idx", T * B, **u8)
-        buf("in.y_idx", T * B, **u8)
-        buf("in.i_idx", V * B, **u8)
-        buf("in.vel", T * B, **f32)
-        buf("in.eps", B * Z, **f32)
-        buf("in.c_idx", B, **u8)
-        buf("in.rw_notes", T * B, **f32)
-        buf("in.rw_instr", V * B, **f32)
-        buf("in.rw_vel", T * B, **f32)
-        buf("in.rw_style", B, **f32)
-        buf("in.start_notes", B * s.Dout, **f32)
-        buf("in.start_instr", B * s.ID, **f32)
-        buf("in.start_vel", B, **f32)
+        # inputs: ONE contiguous block (staging.Stager uploads it with a single copy from a pinned mirror); the "in.*"
+        # buffers are typed views of it.  Regions are sized for max_batch; smaller batches use a prefix of each region.
+        regions = [("in.x_idx", T * B, torch.uint8), ("in.y_idx", T * B, torch.uint8), ("in.i_idx", V * B, torch.uint8),
+                   ("in.c_idx", B, torch.uint8), ("in.vel", T * B, torch.float32), ("in.eps", B * Z, torch.float32),
+                   ("in.rw_notes", T * B, torch.float32), ("in.rw_instr", V * B, torch.float32),
+                   ("in.rw_vel", T * B, torch.float32), ("in.rw_style", B, torch.float32),
+                   ("in.start_notes", B * s.Dout, torch.float32), ("in.start_instr", B * s.ID, torch.float32),
+                   ("in.start_vel", B, torch.float32), ("in.hist", B * Z, torch.float32), ("in.z", B * Z, torch.float32)]
+        self._in_regions, off = {}, 0
+        for name, n, tdt in regions:
+            nbytes = int(n) * (1 if tdt == torch.uint8 else 4)
+            self._in_regions[name] = (off, nbytes, tdt)
+            off += (nbytes + 255) // 256 * 256
+        self._in_block = torch.zeros(off, dtype=torch.uint8, device=dev)
+        for name, (o, nbytes, tdt) in self._in_regions.items():
+            st[name] = self._in_block[o:o + nbytes].view(tdt)
+        self._stager = None
         # inference outputs on request
         buf("out.notes_p", T * B * s.Dout, **f32)
         buf("out.instr_p", V * B * s.ID, **f32)
@@ -416,6 +422,7 @@ class Engine(object):
         """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; eps (B,Z) f32 ALREADY scaled by
         epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
         B = x_idx.shape[0]
+        self.norm_B = float(B)
         self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
         if self.spec.meta_instrument:
             self._up_tm("in.i_idx", np.asarray(i_idx, np.uint8), torch.uint8)
@@ -447,6 +454,7 @@ class Engine(object):
         rows get target 255 ("no target") and weight 0."""
         s = self.spec
         T, V = s.T, s.V
+        self.norm_B = float(B)
         self._up_tm("in.y_idx", np.asarray(y_idx, np.uint8), torch.uint8, fill=255)
 
         def norm(w, n_other):
@@ -478,7 +486,7 @@ class Engine(object):
 
         if self._prep is None:          # built once: every source / destination is a fixed view
             self._prep, self._prep_count = ops.PrepBatch(), ops.PrepBatch()
-            self._prep_count.add_i32(self.t_done)       # ... the optimizer's step count rides along after an eager step
+            self._prep_count.add_i32(self.t_done, guard=self._guard())   # ... the optimizer's step count rides along after an eager step
             for pb in (self._prep, self._prep_count):
                 for r in self.all_rec:
                     p = r.prefix
@@ -707,7 +715,7 @@ class Engine(object):
         ops.gemm(h, P["enc.zmean.W"], mu, B, Z, h1w, lda=H, bias=P["enc.zmean.b"])
         ops.gemm(h2, P["enc.zlogvar.W"], lv, B, Z, H - h1w if s.split else H, lda=H, bias=P["enc.zlogvar.b"])
         zh = self._v("zh", B, s.zin)
-        ops.latent_fwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / Breal, mu, lv,
+        ops.latent_fwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / self.norm_B, mu, lv,
                        self._v("in.eps", B, Z), zh, self.scal[S_KL:S_KL + 3],
                        style_target=self._v("in.c_idx", Breal) if (s.style and self._have_targets) else None,
                        style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
@@ -722,7 +730,7 @@ class Engine(object):
         tg = s.style and self._have_targets
         ok = ops.latent_chain_fwd(
             B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, self.n_init * H, s.split, s.beta, s.prior_mean,
-            s.prior_std, 1.0 / Breal, cat=self._v("cat", B, self.ncat * H),
+            s.prior_std, 1.0 / self.norm_B, cat=self._v("cat", B, self.ncat * H),
             w_pack=P["enc.pack.W"] if self.has_pack else None, b_pack=P["enc.pack.b"] if self.has_pack else None,
             w_extra=P["enc.extra.W"] if s.extra_layer else None, b_extra=P["enc.extra.b"] if s.extra_layer else None,
             w_mu=P["enc.zmean.W"], b_mu=P["enc.zmean.b"], w_lv=P["enc.zlogvar.W"], b_lv=P["enc.zlogvar.b"],
@@ -1098,7 +1106,7 @@ class Engine(object):
         if B > Breal:            # padding rows carry no gradient
             dmu[Breal:].zero_()
             dlv[Breal:].zero_()
-        ops.latent_bwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / Breal, mu, lv,
+        ops.latent_bwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / self.norm_B, mu, lv,
                        self._v("in.eps", B, Z), dzh, dmu, dlv, style_probs=self._v("style_p", B, s.C) if s.style else None,
                        style_target=self._v("in.c_idx", Breal) if s.style else None,
                        style_row_weight=self._v("in.rw_style", Breal) if s.style else None, lddz=s.zin)
@@ -1154,7 +1162,7 @@ class Engine(object):
         pk, ex, cat = self._v("pack", B, H), self._v("extra", B, H), self._v("cat", B, ldc)
         ok = ops.latent_chain_bwd(
             B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, ldS, s.split, s.beta, s.prior_mean, s.prior_std, s.w_style,
-            1.0 / Breal, wt_pack=self.store.get("lat.wt_pack"), wt_extra=self.store.get("lat.wt_extra"),
+            1.0 / self.norm_B, wt_pack=self.store.get("lat.wt_pack"), wt_extra=self.store.get("lat.wt_extra"),
             wt_mu=self.store["lat.wt_mu"], wt_lv=self.store["lat.wt_lv"], wt_init=self.store["lat.wt_init"], S=S,
             pack=pk if self.has_pack else None,
             extra=ex if s.extra_layer else None, mu=self._v("mu", B, Z), logvar=self._v("lv", B, Z), eps=self._v("in.eps", B, Z),
@@ -1193,9 +1201,25 @@ class Engine(object):
         if self._count_pending:
             if self._count_only is None:
                 self._count_only = ops.PrepBatch()
-                self._count_only.add_i32(self.t_done)
+                self._count_only.add_i32(self.t_done, guard=self._guard())
             self._count_only.run()
             self._count_pending = False
+
+    def _guard(self):
+        """The status word of the time-pipelined stacks as the optimizer's guard: while it is non-zero (a kernel gave up waiting
+        for its producer: that step's gradients are invalid) the update and the step count are skipped ON THE DEVICE, so the
+        parameters and moments stay valid until the host notices (check_pipeline / metrics raise)."""
+        return self.store["pipe_status"] if self.pipeline else None
+
+    def get_optimizer_state(self):
+        return dict(m=self.opt_m.clone(), v=self.opt_v.clone(), t=self.t_done.clone(), pending=self._count_pending)
+
+    def set_optimizer_state(self, st):
+        """moments / step count of another Engine of the same spec (the flat layout is identical whatever the batch size)"""
+        self.opt_m.copy_(st["m"])
+        self.opt_v.copy_(st["v"])
+        self.t_done.copy_(st["t"])
+        self._count_pending = bool(st["pending"])
 
     def optimizer_step(self, grad_scale=1.0):
         s = self.spec
@@ -1208,10 +1232,10 @@ class Engine(object):
             if self._count_pending:
                 self._flush_count()
             ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale,
-                              zero_grad=z, keep_count=keep)
+                              zero_grad=z, keep_count=keep, guard=self._guard())
             self._count_pending = keep
         else:
-            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=z)
+            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=z, guard=self._guard())
         self._grads_clean = z
         self._weights_dirty = True
 
@@ -1274,6 +1298,48 @@ class Engine(object):
         if allreduce is not None:
             gs = allreduce(self.grads)
         self.optimizer_step(gs if gs is not None else 1.0)
+
+    def train_step_empty(self, allreduce):
+        """Data parallel, ragged minibatch: this rank's shard is EMPTY (fewer windows than ranks) - contribute zero gradients to
+        the collective and apply the same update as everybody else."""
+        assert self.training and allreduce is not None
+        if self._weights_dirty:
+            self.prepare_weights()
+        else:
+            self.scal.zero_()
+        if not self._grads_clean:
+            self.grads.zero_()
+        self._grads_clean = False
+        gs = allreduce(self.grads)
+        self.optimizer_step(gs if gs is not None else 1.0)
+
+    def stager(self):
+        if self._stager is None:
+            from .staging import Stager
+            self._stager = Stager(self)
+        return self._stager
+
+    # hit-count slots of the scalar block (accumulated as counts; everything else as batch-size weighted means)
+    HIT_MASK = (1 << S_NOTES_HITS) | (1 << S_INSTR_HITS) | (1 << S_VEL_HITS) | (1 << S_STYLE_HITS)
+
+    def reset_accumulated(self):
+        self.acc.zero_()
+
+    def accumulate_metrics(self, B_global):
+        """acc += B_global * (loss slots), += (hit slots) of the step just enqueued - Keras' BaseLogger on the device, no read"""
+        ops.scalars_accumulate(self.acc, self.scal, float(B_global), self.HIT_MASK)
+
+    def read_accumulated(self, n_windows, allreduce_sum=None):
+        """means over ``n_windows`` windows of everything accumulated since reset_accumulated (ONE device->host read; with
+        ``allreduce_sum`` the per-rank shares are summed first)"""
+        if allreduce_sum is not None:
+            allreduce_sum(self.acc)
+        v = self.acc.cpu().numpy().astype(np.float64)
+        self.check_pipeline()
+        n = max(float(n_windows), 1.0)
+        hit = np.array([(self.HIT_MASK >> i) & 1 for i in range(N_SCALARS)], bool)
+        v = np.where(hit, v, v / n)
+        return self._metrics_from(v, n)
 
     def _graph_step(self, B, allreduce):
         key = (B, allreduce is not None)
@@ -1366,6 +1432,13 @@ class Engine(object):
         s = self.spec
         v = self.scal.cpu().numpy().astype(np.float64)
         self.check_pipeline()
+        if B is not None and self.norm_B != B:
+            B = self.norm_B             # a shard of a global minibatch: this rank's SHARE of the global means
+        return self._metrics_from(v, B)
+
+    def _metrics_from(self, v, B):
+        """metric dict from the scalar slots: loss slots hold batch means already, hit slots counts over ``B`` windows"""
+        s = self.spec
         m = OrderedDict()
         m["kl"] = v[S_KL]
         m["notes_loss"], m["notes_acc"] = v[S_NOTES_LOSS], v[S_NOTES_HITS] / (B * s.T)

@@ -21,11 +21,13 @@ ACT_NONE, ACT_TANH = 0, 1
 ROWMAJOR, TILE16, TILE16P = 0, 1, 2
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
-E_ARG, E_UNSUPPORTED, E_LAUNCH = -1, -2, -3
+E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
+HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
+ABI_VERSION = 2
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
-          -3: "MVAE_E_LAUNCH (HIP launch failed)"}
+          -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
-_i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+_i32, _f32, _vp, _sz, _i64 = C.c_int32, C.c_float, C.c_void_p, C.c_size_t, C.c_int64
 
 
 class RnnFwdArgs(C.Structure):
@@ -127,8 +129,14 @@ SIGNATURES = {
     "mvae_make_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_transpose_convert": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_adam_step": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
-    "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _i32, _vp]),
-    "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "mvae_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _vp, _f32, _i32, _vp, _vp]),
+    "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "mvae_scalars_accumulate": (_i32, [_vp, _vp, _i32, _f32, C.c_uint32, _vp]),
+    "mvae_copy2d_f32": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_host_threads": (_i32, [_i32]),
+    "mvae_host_onehot_to_index_tm": (_i32, [_vp, _i32, _i64, _i32, _i32, _i64, _i64, _vp, _i32, C.c_uint8, C.POINTER(_i64)]),
+    "mvae_host_index_to_tm": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _i32, C.c_uint8]),
+    "mvae_host_rows_to_tm_f32": (_i32, [_vp, _i32, _i64, _i32, _i64, _i64, _f32, _vp, _i32]),
 }
 
 _lib = None
@@ -152,8 +160,9 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = ABI drift between header and library
         fn.restype = res
         fn.argtypes = args
-    if lib.mvae_abi_version() != 1:
-        raise HipLibraryMissing("ABI version mismatch: library %d, binding 1" % lib.mvae_abi_version())
+    if lib.mvae_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing("ABI version mismatch: library %d, binding %d - rebuild with `make -C midi-vae_amd/csrc`"
+                                % (lib.mvae_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

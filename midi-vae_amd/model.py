@@ -12,10 +12,13 @@ Keeps the surface the reference's scripts use (reference vae_definition.py:39-44
     model.autoencoder.predict(x_list, batch_size=...)                     -> [notes, instrument, velocity, style]
     .save_weights(path) / .load_weights(path, by_name=False) / .reset_states() / .summary()
 
-Inputs are the host NumPy lists built by the packers (packers.py); they are never mutated.  The engine is created on
-first use, sized for the largest batch seen.  Differences from Keras, stated plainly: weights are stored in this
-repo's own container (``.npz`` content under whatever file name the caller passes - the reference's ``*.pickle``
-files are Keras-HDF5, which cannot be read here); optimizer state is not saved (same as the reference).
+Inputs are the host NumPy lists built by the packers (packers.py); they are never mutated.  They are converted by the
+multi-threaded host packers of the C ABI (staging.py / csrc/hostpack.cpp) straight into a pinned staging block, one
+asynchronous upload per minibatch; losses and metrics accumulate on the device and are read back once per fit call.
+The engine is created on first use, sized for the ``batch_size`` of the call.  Differences from Keras, stated plainly:
+weights are stored in this repo's own container (``.npz`` content under whatever file name the caller passes - the
+reference's ``*.pickle`` files are Keras-HDF5, which cannot be read here); optimizer state is not saved (same as the
+reference).
 """
 from __future__ import annotations
 
@@ -33,18 +36,33 @@ class History(object):
         self.epoch = []
 
 
-def _is_onehot(a):
-    a = np.asarray(a)
-    return bool(np.all((a == 0) | (a == 1)) and np.all(a.sum(-1) == 1))
+class DeviceLatent(object):
+    """Sampled z of every window of a song, resident in HBM - what ``encoder.predict(..., device=True)`` returns instead of a
+    host array.  Passed in the history slot of the fit / evaluate input list it stands for the ROLLED history of reference
+    vae_training.py:795-798 (H[1:] = z[:-1], H[0] = 0): the engine places row i-1 beside window i on the device, so the
+    history pre-pass costs no device->host->device round trip.  ``numpy()`` gives the rolled host array the reference builds."""
 
+    def __init__(self, z_dev):
+        self.z = z_dev                    # (n, Z) f32 device tensor, UNROLLED
+        self.shape = tuple(z_dev.shape)
 
-def _to_index(a, what):
-    """(..., K) one-hot float array -> uint8 indices; anything else is outside the implemented input format."""
-    a = np.asarray(a)
-    if a.shape[-1] > 255 or not _is_onehot(a):
-        raise NotImplementedError("%s must be one-hot rows of width <= 255 (reference layout, import_midi.py:255-262); "
-                                  "dense / multi-hot rows need the dense input projection, which is not built" % what)
-    return np.argmax(a, axis=-1).astype(np.uint8)
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, sl):
+        """prefix slices only (the packers drop the last window when the next-notes head is on: H[:-1])"""
+        if not (isinstance(sl, slice) and sl.start in (None, 0) and sl.step in (None, 1)):
+            raise IndexError("DeviceLatent supports prefix slices only; use .numpy() for anything else")
+        return DeviceLatent(self.z[sl])
+
+    def latent(self):
+        return self.z.cpu().numpy()
+
+    def numpy(self):
+        z = self.latent()
+        H = np.zeros_like(z)
+        H[1:] = z[:-1]
+        return H
 
 
 class _Shared(object):
@@ -56,15 +74,25 @@ class _Shared(object):
         self.params_host = init_params(spec, seed)     # authoritative copy until an engine exists
         self.engine = None
         self.rng = np.random.default_rng(seed + 1)
+        self.dp = None                    # dp.DataParallel: minibatches are sharded over its ranks inside fit
 
     def get_engine(self, batch, training=True):
+        """The engine, sized for ``batch`` windows on first use (callers pass their ``batch_size``, not the length of the song
+        at hand, so that songs of different lengths do not rebuild it).  A larger request rebuilds it; parameters AND
+        optimizer state (Adam moments, step count) move to the new engine - Keras keeps both across fit calls."""
         from .engine import Engine                      # imported lazily: needs the HIP library and a GPU
         need = max(int(batch), 16)
         if self.engine is None or self.engine.maxB < need or (training and not self.engine.training):
-            params = self.engine.get_params() if self.engine is not None else self.params_host
+            old = self.engine
+            params = old.get_params() if old is not None else self.params_host
+            opt = old.get_optimizer_state() if (old is not None and old.training) else None
+            self.engine = None
+            del old
             self.engine = Engine(self.spec, max_batch=need, dtype=self.dtype, device=self.device, seed=self.seed,
                                  training=True)
             self.engine.set_params(params)
+            if opt is not None:
+                self.engine.set_optimizer_state(opt)
         return self.engine
 
     def current_params(self):
@@ -139,28 +167,36 @@ class Encoder(_ModelView):
     name = "encoder"
 
     def _unpack(self, x):
+        """[X, I_tiled (n,V,ID), Vel (n,T,1)] or bare X without meta heads (reference vae_definition.py:797-808)"""
         sp = self._s.spec
         x = _as_list(x)
         i = 0
-        X = x[i]; i += 1
+        X = x[i]
+        i += 1
         I = x[i] if sp.meta_instrument else None
         i += int(sp.meta_instrument)
         V = x[i] if sp.meta_velocity else None
-        return (_to_index(X, "notes input"), _to_index(I, "instrument input") if I is not None else None,
-                np.asarray(V, np.float32)[..., 0] if V is not None else None)
+        return X, I, V
 
-    def predict(self, x, batch_size=32, verbose=0):
-        """Sampled z for every window (fresh epsilon per call, reference vae_definition.py:498-502)."""
-        x_idx, i_idx, vel = self._unpack(x)
-        n = x_idx.shape[0]
-        out = np.zeros((n, self._s.spec.Z), np.float32)
-        eng = self._s.get_engine(min(batch_size, max(n, 1)))
+    def predict(self, x, batch_size=32, verbose=0, device=False):
+        """Sampled z for every window (fresh epsilon per call, reference vae_definition.py:498-502).  The batches run back to
+        back on the device; z is read back once.  ``device=True``: no read-back at all - a DeviceLatent for the history slot of
+        the next fit / evaluate (the history pre-pass of reference vae_training.py:788-798, kept in HBM)."""
+        import torch
+        X, I, Vel = self._unpack(x)
+        n = np.asarray(X).shape[0]
+        eng = self._s.get_engine(batch_size)
+        st = eng.stager()
+        out = torch.empty((n, self._s.spec.Z), dtype=torch.float32, device=eng.device)
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
-            B = eng.stage_encoder_inputs(x_idx[lo:hi], None if i_idx is None else i_idx[lo:hi],
-                                         None if vel is None else vel[lo:hi], self._s.epsilon(hi - lo))
-            out[lo:hi] = eng.encode(B).cpu().numpy()
-        return out
+            B = st.stage(lo, hi, X=X, I=I, Vel=Vel, eps=self._s.epsilon(hi - lo))
+            out[lo:hi].copy_(eng.encode(B))
+        if device:
+            return DeviceLatent(out)
+        res = out.cpu().numpy()
+        eng.check_pipeline()
+        return res
 
 
 class Decoder(_ModelView):
@@ -183,13 +219,14 @@ class Decoder(_ModelView):
     def _run(self, x, batch_size, want_probs=True):
         sp = self._s.spec
         start, z, hist, istart, vstart = self._unpack(x)
-        n = np.asarray(z).shape[0]
-        eng = self._s.get_engine(min(batch_size, max(n, 1)))
+        z = np.asarray(z)
+        n = z.shape[0]
+        eng = self._s.get_engine(batch_size)
         outs, idxs = [], []
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
             B = hi - lo
-            eng.stage_decoder_inputs(B, hist=None if hist is None else np.asarray(hist)[lo:hi], z=np.asarray(z)[lo:hi],
+            eng.stage_decoder_inputs(B, hist=None if hist is None else np.asarray(hist)[lo:hi], z=z[lo:hi],
                                      start_notes=np.asarray(start)[lo:hi],
                                      start_instr=None if istart is None else np.asarray(istart)[lo:hi],
                                      start_vel=None if vstart is None else np.asarray(vstart)[lo:hi])
@@ -280,105 +317,134 @@ class Autoencoder(_ModelView):
         return Y, C
 
     def _unpack_w(self, w, n):
-        """[w_notes (n,T), w_style, w_instr, w_vel] - the reference's order (vae_definition.py:930-1004)."""
+        """Keras maps a ``sample_weight`` LIST to the model's outputs BY POSITION: [notes, instrument, velocity, style].  (The
+        reference builds its list as notes / style / instrument / velocity, vae_definition.py:930-1004 - every entry but the
+        first is all-ones of shape (n,), so the mismatch is invisible there; it is applied here as Keras would apply it.)
+        Returns (w_notes (n,T), w_instr, w_vel, w_style); None = all ones."""
         sp = self._s.spec
         if w is None:
             return None, None, None, None
-        w = _as_list(w) if isinstance(w, (list, tuple)) else [w]
-        wn = w[0]
-        i = 1
-        ws = w[i] if sp.style and len(w) > i else None
-        i += int(sp.style)
-        wi = w[i] if sp.meta_instrument and len(w) > i else None
-        i += int(sp.meta_instrument)
-        wv = w[i] if sp.meta_velocity and len(w) > i else None
-        return wn, ws, wi, wv
+        w = list(w) if isinstance(w, (list, tuple)) else [w]
+        outs = (["notes"] + (["instr"] if sp.meta_instrument else []) + (["vel"] if sp.meta_velocity else []) +
+                (["style"] if sp.style else []))
+        if len(w) != len(outs):
+            raise ValueError("sample_weight has %d entries for the %d outputs %s" % (len(w), len(outs), outs))
+        by = dict(zip(outs, w))
+        wn = np.asarray(by["notes"])
+        if wn.shape != (n, sp.T):
+            raise ValueError("the notes output uses sample_weight_mode='temporal': weights of shape %s expected, got %s"
+                             % ((n, sp.T), wn.shape))
+        res = [None if np.all(wn == 1) else wn]
+        for k in ("instr", "vel", "style"):
+            v = by.get(k)
+            if v is not None:
+                v = np.asarray(v)
+                if v.shape != (n,):
+                    raise ValueError("sample_weight of output %r must have shape (%d,), got %s" % (k, n, v.shape))
+                if np.all(v == 1):
+                    v = None
+            res.append(v)
+        return tuple(res)
 
-    def _stage(self, eng, lo, hi, xs, ys, ws):
-        X_idx, start, hist, istart, I_idx, vstart, vel, Y_idx, C_idx = xs + ys
-        sl = slice(lo, hi)
-        B = eng.stage_encoder_inputs(X_idx[sl], None if I_idx is None else I_idx[sl], None if vel is None else vel[sl],
-                                     self._s.epsilon(hi - lo))
-        eng.stage_decoder_inputs(B, hist=None if hist is None else np.asarray(hist)[sl], start_notes=np.asarray(start)[sl],
-                                 start_instr=None if istart is None else np.asarray(istart)[sl],
-                                 start_vel=None if vstart is None else np.asarray(vstart)[sl])
-        if Y_idx is not None:
-            wn, wst, wi, wv = ws
-            eng.stage_targets(B, Y_idx[sl], None if C_idx is None else C_idx[sl],
-                              w_notes=None if wn is None else np.asarray(wn)[sl],
-                              w_instr=None if wi is None else np.asarray(wi)[sl],
-                              w_vel=None if wv is None else np.asarray(wv)[sl],
-                              w_style=None if wst is None else np.asarray(wst)[sl])
-        return B
+    def _dp(self, dp):
+        dp = dp if dp is not None else self._s.dp
+        return dp if (dp is not None and dp.world > 1) else None
 
-    def _prepare(self, x, y):
-        X, start, hist, istart, I, vstart, V = self._unpack_x(x)
-        xs = (_to_index(X, "notes input"), start, hist, istart, _to_index(I, "instrument input") if I is not None else None,
-              vstart, np.asarray(V, np.float32)[..., 0] if V is not None else None)
-        if y is None:
-            return xs, (None, None)
-        Y, C = self._unpack_y(y)
-        return xs, (_to_index(Y, "notes target"), _to_index(C, "style target") if C is not None else None)
+    @staticmethod
+    def _history_source(hist):
+        if isinstance(hist, DeviceLatent):
+            return None, hist.z
+        return hist, None
 
     # ---- Keras methods -----------------------------------------------------------------------------------------
-    def fit(self, x, y, epochs=1, batch_size=32, shuffle=False, sample_weight=None, verbose=0, allreduce=None):
-        """One optimizer step per minibatch of consecutive windows (reference vae_training.py:804-809).  History
-        values are batch-size-weighted means over the minibatches of each epoch (Keras BaseLogger semantics)."""
+    def fit(self, x, y, epochs=1, batch_size=32, shuffle=False, sample_weight=None, verbose=0, dp=None, allreduce=None):
+        """One optimizer step per minibatch of <= batch_size consecutive windows (reference vae_training.py:804-809).  History
+        values are batch-size-weighted means over the minibatches of each epoch (Keras BaseLogger semantics), accumulated on
+        the device and read back ONCE per epoch.
+
+        Data parallel (``dp``: dp.DataParallel, or VAE.set_data_parallel): every rank calls fit with the SAME arguments; each
+        global minibatch is split contiguously over the ranks (dp.shard_bounds), the losses are normalised by the GLOBAL counts,
+        gradients are summed by one all-reduce per step - the parameters after every step equal the single-process run's (to
+        f32 summation order), ragged last minibatches and empty shards included, and every rank executes the same number of
+        collectives by construction.  ``allreduce`` (legacy hook: each rank trains on its OWN minibatches, mean of gradients)
+        is kept for bench-style callers."""
         if shuffle:
             raise NotImplementedError("shuffle=True (the reference always passes shuffle=False)")
-        xs, ys = self._prepare(x, y)
-        n = xs[0].shape[0]
-        ws = self._unpack_w(sample_weight, n)
-        eng = self._s.get_engine(min(batch_size, max(n, 1)), training=True)
-        hist = History()
+        from .dp import shard_bounds
+        from .staging import Norm
+        sp = self._s.spec
+        X, start, hist, istart, I, vstart, V = self._unpack_x(x)
+        Y, Cc = self._unpack_y(y)
+        n = np.asarray(X).shape[0]
+        wn, wi, wv, ws = self._unpack_w(sample_weight, n)
+        dp = self._dp(dp)
+        eng = self._s.get_engine(batch_size, training=True)
+        st = eng.stager()
+        hist_host, hist_dev = self._history_source(hist)
+        history = History()
         keys = self._history_keys()
         for e in range(epochs):
-            tot = OrderedDict((k, 0.0) for k, _ in keys)
+            eng.reset_accumulated()
             for lo in range(0, n, batch_size):
                 hi = min(n, lo + batch_size)
-                B = self._stage(eng, lo, hi, xs, ys, ws)
-                eng.train_step(B, allreduce=allreduce)
-                m = eng.metrics(B)
-                for k, src in keys:
-                    tot[k] += m[src] * B
-            for k in tot:
-                hist.history.setdefault(k, []).append(tot[k] / max(n, 1))
-            hist.epoch.append(e)
-        return hist
+                eps = self._s.epsilon(hi - lo)               # one draw per GLOBAL minibatch: every rank holds the same stream
+                a, b = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
+                if b > a:
+                    norm = Norm.of(lo, hi, sp.T, wn, wi, wv, ws)
+                    B = st.stage(lo + a, lo + b, X=X, I=I, Vel=V, eps=eps[a:b], hist=hist_host, hist_dev=hist_dev, Y=Y, C_=Cc,
+                                 start_notes=start, start_instr=istart, start_vel=vstart, w_notes=wn, w_instr=wi, w_vel=wv,
+                                 w_style=ws, norm=norm)
+                    eng.train_step(B, allreduce=dp.allreduce_grads if dp is not None else allreduce)
+                    eng.accumulate_metrics(hi - lo)
+                else:
+                    eng.train_step_empty(dp.allreduce_grads)
+            m = eng.read_accumulated(n, allreduce_sum=dp.allreduce_sum if dp is not None else None)
+            for k, src in keys:
+                history.history.setdefault(k, []).append(m[src])
+            history.epoch.append(e)
+        return history
 
     def _forward_all(self, x, y, batch_size, want_probs):
-        xs, ys = self._prepare(x, y)
-        n = xs[0].shape[0]
-        eng = self._s.get_engine(min(batch_size, max(n, 1)))
-        keys = self._history_keys()
-        tot = OrderedDict((k, 0.0) for k, _ in keys)
+        from .staging import Norm
+        sp = self._s.spec
+        X, start, hist, istart, I, vstart, V = self._unpack_x(x)
+        Y, Cc = self._unpack_y(y) if y is not None else (None, None)
+        n = np.asarray(X).shape[0]
+        eng = self._s.get_engine(batch_size)
+        st = eng.stager()
+        hist_host, hist_dev = self._history_source(hist)
         outs = []
+        eng.reset_accumulated()
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
-            B = self._stage(eng, lo, hi, xs, ys, (None, None, None, None))
+            B = st.stage(lo, hi, X=X, I=I, Vel=V, eps=self._s.epsilon(hi - lo), hist=hist_host, hist_dev=hist_dev, Y=Y, C_=Cc,
+                         start_notes=start, start_instr=istart, start_vel=vstart,
+                         norm=Norm.of(lo, hi, sp.T) if Y is not None else None)
             if y is None:
                 eng._have_targets = False
                 eng.scal.zero_()
                 if eng._weights_dirty:
                     eng.prepare_weights()
-                eng.encoder_forward(B)
+                eng.encoder_forward(B, with_init=True)
                 eng.decoder_forward(B, want_probs=True)
             else:
                 eng.eval_step(B, want_probs=want_probs)
-                m = eng.metrics(B)
-                for k, src in keys:
-                    tot[k] += m[src] * B
+                eng.accumulate_metrics(hi - lo)
             if want_probs:
                 outs.append(eng.outputs(B))
+        tot = eng.read_accumulated(n) if y is not None else None
         return tot, outs, n
 
     def evaluate(self, x, y, batch_size=32, verbose=0, sample_weight=None):
-        tot, _, n = self._forward_all(x, y, batch_size, want_probs=False)
-        by_key = {k: v / max(n, 1) for k, v in tot.items()}
-        keys = [k for k, _ in self._history_keys()]
-        losses = [k for k in keys if "loss" in k]
-        accs = [k for k in keys if "acc" in k]
-        return [by_key[k] for k in losses + accs]
+        """Forward + losses over the song's minibatches (reference vae_training.py:300); the list is aligned with
+        ``metrics_names``."""
+        if sample_weight is not None:
+            raise NotImplementedError("evaluate(sample_weight=...): the reference never passes it (vae_training.py:300)")
+        m, _, n = self._forward_all(x, y, batch_size, want_probs=False)
+        pairs = self._history_keys()
+        losses = [src for k, src in pairs if "loss" in k]
+        accs = [src for k, src in pairs if "acc" in k]
+        return [m[k] for k in losses + accs]
 
     def predict(self, x, batch_size=32, verbose=0):
         sp = self._s.spec
@@ -410,4 +476,9 @@ class VAE(object):
         self.decoder = Decoder(shared)
         self.autoencoder = Autoencoder(shared, self.encoder)
         self.composer_decoder = None     # parameter-free softmax over z[:, :C]; reported through the autoencoder
+        return self
+
+    def set_data_parallel(self, dp):
+        """dp.DataParallel (or None): ``autoencoder.fit`` shards every minibatch over its ranks from now on."""
+        self._shared.dp = dp
         return self

@@ -236,11 +236,11 @@ class PrepBatch:
     def zero(self, dst):
         self._add(hl.PREP_ZERO, dst, dst.numel(), 1, 0, None)
 
-    def add_i32(self, counter, value=1):
-        """*counter (int32 device scalar) += value"""
+    def add_i32(self, counter, value=1, guard=None):
+        """*counter (int32 device scalar) += value  (not while the device word ``guard`` is non-zero)"""
         assert counter.dtype == torch.int32
-        self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, None, None, _p(counter)))
-        self._keep.append(counter)
+        self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, _p(guard), None, _p(counter)))
+        self._keep += [counter, guard]
         self._arr = None
 
     def convert_pad(self, W, out, n_pad):
@@ -259,12 +259,25 @@ def adam_step(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
 
 
 def adam_step_dev(p, g, m, v, lr, t_done, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False,
-                  keep_count=False):
+                  keep_count=False, guard=None):
     flags = (hl.ADAM_ZERO_GRAD if zero_grad else 0) | (hl.ADAM_KEEP_COUNT if keep_count else 0)
     hl.check(hl.load().mvae_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(t_done),
-                                          grad_scale, flags, _stream()), "mvae_adam_step_dev")
+                                          grad_scale, flags, _p(guard), _stream()), "mvae_adam_step_dev")
 
 
-def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0, zero_grad=False):
-    hl.check(hl.load().mvae_rmsprop_step(_p(p), _p(g), _p(v), p.numel(), lr, rho, eps, grad_scale, int(bool(zero_grad)), _stream()),
-             "mvae_rmsprop_step")
+def rmsprop_step(p, g, v, lr, rho=0.9, eps=1e-8, grad_scale=1.0, zero_grad=False, guard=None):
+    hl.check(hl.load().mvae_rmsprop_step(_p(p), _p(g), _p(v), p.numel(), lr, rho, eps, grad_scale, int(bool(zero_grad)),
+                                         _p(guard), _stream()), "mvae_rmsprop_step")
+
+
+def scalars_accumulate(acc, x, alpha, plain_mask=0):
+    """acc[i] += (bit i of plain_mask ? 1 : alpha) * x[i]"""
+    hl.check(hl.load().mvae_scalars_accumulate(_p(acc), _p(x), x.numel(), float(alpha), int(plain_mask), _stream()),
+             "mvae_scalars_accumulate")
+
+
+def copy2d(dst, src, rows, cols, src_row0=0, zero_rows=0):
+    """dst[:rows, :cols] = src[src_row0 : src_row0 + rows, :cols] (f32, row strides from the views); the first ``zero_rows`` rows
+    of dst are zeroed instead"""
+    hl.check(hl.load().mvae_copy2d_f32(_pv(dst), dst.stride(0), _pv(src), src.stride(0), int(rows), int(cols), int(src_row0),
+                                       int(zero_rows), _stream()), "mvae_copy2d_f32")

@@ -1,0 +1,229 @@
+"""Input staging of the device engine: the caller's host arrays -> ONE pinned block -> ONE asynchronous upload.
+
+What the reference's callers hand to ``autoencoder.fit`` / ``evaluate`` / ``predict`` (reference vae_training.py:802-809,
+lists built by vae_definition.py:880-1045) are float64 NumPy windows: one-hot note rows (n, T, 61), one-hot instrument
+rows (n, V, 16), velocity (n, T, 1), the history latent (n, Z), one-hot style targets, sample weights.  The engine consumes
+one byte per row, time-major, padded to 16 windows, plus f32 side inputs.  ``Stager.stage`` converts one minibatch
+[lo, hi) of such a song with the multi-threaded host packers of the C ABI (csrc/hostpack.cpp: validation + argmax +
+transpose + padding in one pass over the caller's array), writes everything into a pinned mirror of the engine's contiguous
+input block and uploads it with a single stream-ordered copy.  Two pinned mirrors alternate, so the host prepares minibatch
+k+1 while the device still runs step k; nothing here synchronises the device.
+
+Data parallelism: every Keras loss of this graph is a (weighted) batch mean.  ``norm`` carries the
+GLOBAL minibatch size and non-zero weight counts, so that a rank staging only its shard of the minibatch produces its
+share of the global-mean gradient: summing over ranks (all-reduce) gives exactly the single-process gradient, ragged
+shards included ("sum, then divide by the global count").
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hiplib as hl
+
+_KIND = {np.dtype(np.float64): hl.HOST_F64, np.dtype(np.float32): hl.HOST_F32, np.dtype(np.uint8): hl.HOST_U8}
+
+
+class Norm(object):
+    """Normalisers of one GLOBAL minibatch (Keras weighted objectives, SURVEY Appendix A.7: score*w / mean(w != 0), then
+    the mean over the remaining axes): B windows, and the number of non-zero sample weights per output."""
+
+    def __init__(self, B, nz_notes, nz_instr, nz_vel, nz_style):
+        self.B, self.nz_notes, self.nz_instr, self.nz_vel, self.nz_style = int(B), nz_notes, nz_instr, nz_vel, nz_style
+
+    @staticmethod
+    def of(lo, hi, T, w_notes=None, w_instr=None, w_vel=None, w_style=None):
+        B = hi - lo
+
+        def nz(w, full):
+            if w is None:
+                return full
+            c = int(np.count_nonzero(np.asarray(w)[lo:hi]))
+            return max(c, 1)
+
+        return Norm(B, nz(w_notes, B * T), nz(w_instr, B), nz(w_vel, B), nz(w_style, B))
+
+
+def _host_kind(a):
+    k = _KIND.get(a.dtype)
+    if k is None:
+        raise TypeError("host arrays must be float64, float32 or uint8 (got %s)" % a.dtype)
+    return k
+
+
+def _c(a):
+    a = np.asarray(a)
+    if a.dtype not in _KIND:
+        a = a.astype(np.float64)
+    return a if a.flags.c_contiguous else np.ascontiguousarray(a)
+
+
+def host_onehot_to_index(a, what="input"):
+    """(n, T, K) one-hot rows (float64 / float32 / uint8) -> (n, T) uint8 indices through the C ABI's host packer; raises
+    NotImplementedError for anything that is not exactly one 1 among zeros per row (no device needed)."""
+    a = _c(a)
+    if a.ndim != 3:
+        raise ValueError("%s: expected (n, T, K) one-hot rows, got %s" % (what, a.shape))
+    n, T, K = a.shape
+    out = np.empty((T, max(n, 1)), np.uint8)
+    bad = C.c_int64(-1)
+    rc = hl.load().mvae_host_onehot_to_index_tm(a.ctypes.data, _host_kind(a), n, T, K, 0, n, out.ctypes.data, max(n, 1), 0,
+                                                C.byref(bad))
+    if rc == hl.E_FORMAT:
+        raise NotImplementedError("%s must be one-hot rows of width <= 255 (reference layout, import_midi.py:255-262): row %d of "
+                                  "window %d is not; dense / multi-hot rows need the dense input projection, which is not built"
+                                  % (what, bad.value % T, bad.value // T))
+    hl.check(rc, "mvae_host_onehot_to_index_tm")
+    return np.ascontiguousarray(out[:, :n].T)
+
+
+class Stager(object):
+    def __init__(self, engine):
+        self.eng = engine
+        self.lib = hl.load()
+        self.regions = engine._in_regions            # name -> (byte offset, byte length, torch dtype)
+        nbytes = engine._in_block.numel()
+        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.np_host = [h.numpy() for h in self.host]
+        for h in self.np_host:
+            h[:] = 0
+        self.done = [None, None]                     # event after the last upload from each mirror
+        self.k = 0
+
+    def _view(self, k, name, dtype, n):
+        off, length, _ = self.regions[name]
+        item = np.dtype(dtype).itemsize
+        assert n * item <= length, (name, n, length)
+        return self.np_host[k][off:off + n * item].view(dtype)
+
+    # ---- converters (write into the pinned mirror) ----------------------------------------------------------------
+    def _rows_u8(self, k, name, arr, lo, hi, steps, width, Bp, fill, what):
+        """one-hot (n, steps, width) or index (n, steps) rows -> (steps, Bp) uint8 time-major"""
+        a = _c(arr)
+        out = self._view(k, name, np.uint8, steps * Bp)
+        if a.ndim == 3 or (a.ndim == 2 and steps == 1 and a.shape[1] == width and a.dtype != np.uint8):
+            if a.shape[-1] != width or a.size != a.shape[0] * steps * width:
+                raise ValueError("%s: expected (n, %d, %d) one-hot rows, got %s" % (what, steps, width, a.shape))
+            bad = C.c_int64(-1)
+            rc = self.lib.mvae_host_onehot_to_index_tm(a.ctypes.data, _host_kind(a), a.shape[0], steps, width, lo, hi,
+                                                       out.ctypes.data, Bp, fill, C.byref(bad))
+            if rc == hl.E_FORMAT:
+                raise NotImplementedError(
+                    "%s must be one-hot rows (reference layout, import_midi.py:255-262): row %d of window %d is not; dense / "
+                    "multi-hot rows need the dense input projection, which is not built" % (what, bad.value % steps, bad.value // steps))
+            hl.check(rc, "mvae_host_onehot_to_index_tm")
+        else:
+            a = a.reshape(a.shape[0], -1)
+            if a.dtype != np.uint8 or a.shape[1] != steps:
+                raise ValueError("%s: expected (n, %d) uint8 indices or one-hot rows, got %s %s" % (what, steps, a.shape, a.dtype))
+            hl.check(self.lib.mvae_host_index_to_tm(a.ctypes.data, a.shape[0], steps, lo, hi, out.ctypes.data, Bp, fill),
+                     "mvae_host_index_to_tm")
+
+    def _rows_f32(self, k, name, arr, lo, hi, steps, Bp, scale=1.0):
+        a = _c(arr)
+        a = a.reshape(a.shape[0], -1)
+        if a.shape[1] != steps:
+            raise ValueError("%s: expected (n, %d) values, got %s" % (name, steps, a.shape))
+        out = self._view(k, name, np.float32, steps * Bp)
+        hl.check(self.lib.mvae_host_rows_to_tm_f32(a.ctypes.data, _host_kind(a), a.shape[0], steps, lo, hi, float(scale),
+                                                   out.ctypes.data, Bp), "mvae_host_rows_to_tm_f32")
+
+    def _per_window(self, k, name, w, lo, hi, steps, Bp, scale):
+        """per-window weight (n,) (None = ones) -> (steps, Bp) f32 = scale * w repeated over the steps, pad columns 0"""
+        B = hi - lo
+        out = self._view(k, name, np.float32, steps * Bp).reshape(steps, Bp)
+        if w is None:
+            out[:, :B] = scale
+        else:
+            out[:, :B] = (np.asarray(w, np.float64)[lo:hi] * scale).astype(np.float32)[None, :]
+        out[:, B:] = 0.0
+
+    def _rows_bm(self, k, name, arr, lo, hi, width, Bp):
+        """(n, width) -> first B rows of (Bp, width) f32, pad rows zero; None = zeros"""
+        B = hi - lo
+        out = self._view(k, name, np.float32, Bp * width).reshape(Bp, width)
+        if arr is None:
+            out[:] = 0.0
+        else:
+            out[:B] = np.asarray(arr).reshape(-1, width)[lo:hi]
+            out[B:] = 0.0
+
+    # ---- one minibatch ------------------------------------------------------------------------------------------
+    def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
+              start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
+              norm=None, batch_local=False):
+        """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
+        window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
+        ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
+        a DEVICE tensor (n, Z) of sampled z whose row i-1 is the history of window i (zeros for window 0) - the fused history
+        pre-pass; neither: zeros.  Returns the number of windows staged."""
+        eng, s = self.eng, self.eng.spec
+        if batch_local:
+            lo, hi = 0, hi - lo
+        B = hi - lo
+        if B <= 0 or B > eng.maxB:
+            raise ValueError("batch of %d windows does not fit the engine (max %d)" % (B, eng.maxB))
+        Bp = eng.pad16(B)
+        T, V = s.T, s.V
+        k = self.k
+        self.k ^= 1
+        if self.done[k] is not None:
+            self.done[k].synchronize()              # the upload that last read this mirror has completed
+        self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
+        if s.meta_instrument:
+            self._rows_u8(k, "in.i_idx", I, lo, hi, V, s.ID, Bp, 0, "instrument input")
+        if s.meta_velocity:
+            self._rows_f32(k, "in.vel", Vel, lo, hi, T, Bp)
+        self._rows_bm(k, "in.eps", eps, 0, B, s.Z, Bp)
+        self._rows_bm(k, "in.start_notes", start_notes, lo, hi, s.Dout, Bp)
+        if s.meta_instrument:
+            self._rows_bm(k, "in.start_instr", start_instr, lo, hi, s.ID, Bp)
+        if s.meta_velocity:
+            self._rows_bm(k, "in.start_vel", start_vel, lo, hi, 1, Bp)
+        if s.history and hist_dev is None:
+            self._rows_bm(k, "in.hist", hist, lo, hi, s.Z, Bp)
+        if z is not None:
+            self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
+        have_targets = Y is not None
+        if have_targets:
+            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style)
+            self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
+            if w_notes is None:
+                out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
+                out[:, :B] = 1.0 / nm.nz_notes
+                out[:, B:] = 0.0
+            else:
+                self._rows_f32(k, "in.rw_notes", w_notes, lo, hi, T, Bp, scale=1.0 / nm.nz_notes)
+            if s.meta_instrument:
+                self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
+            if s.meta_velocity:
+                self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
+            if s.style:
+                self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
+                self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 0, "style target")
+            eng.norm_B = float(nm.B)
+        else:
+            eng.norm_B = float(B)
+        # ---- ONE upload, ordered on the current stream behind whatever still reads the block -------------------------------
+        eng._in_block.copy_(self.host[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[k] = ev
+        # [z | history]: the decoder's initial-state Denses read one (Bp, zin) operand
+        zh = eng._v("zh", Bp, s.zin)
+        from . import ops
+        if s.history:
+            if hist_dev is not None:
+                # history of window i = sampled z of window i-1, zeros for the first window of the song
+                first = 1 if lo == 0 else 0
+                ops.copy2d(zh[:, s.Z:], hist_dev, B, s.Z, src_row0=lo - 1, zero_rows=first)
+                if Bp > B:
+                    zh[B:, s.Z:].zero_()
+            else:
+                ops.copy2d(zh[:, s.Z:], eng._v("in.hist", Bp, s.Z), Bp, s.Z)
+        if z is not None:
+            ops.copy2d(zh[:, :s.Z], eng._v("in.z", Bp, s.Z), Bp, s.Z)
+        eng._have_staged_targets = have_targets
+        return B

@@ -118,7 +118,7 @@ def test_root_modules_are_drop_in(golden):
 
 
 def test_non_onehot_input_is_rejected_not_silently_accepted():
-    from midi_vae_amd.model import _to_index
+    from midi_vae_amd.staging import host_onehot_to_index as _to_index
     with pytest.raises(NotImplementedError):
         _to_index(np.full((2, 3, 4), 0.25), "notes input")
     assert _to_index(np.eye(4)[None], "x").tolist() == [[0, 1, 2, 3]]

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the DROP-IN path: windows/s through ``autoencoder.fit`` on reference-format arrays (float64 one-hot
+rolls, the lists of vae_definition.prepare_autoencoder_input_and_output_list, reference vae_training.py:802-809) at BASELINE
+configs[1] (T=512, z=64, batch 256, LSTM, bf16) - host conversion + upload + train step + history read-back, next to the engine
+number of bench.py (inputs resident in HBM).
+   python tools/fit_e2e_bench.py [--songs 4] [--windows 1024] [--cell LSTM] [--with-prepass]"""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import midi_vae_amd  # noqa
+from midi_vae_amd import hiplib as hl, packers as pk
+from midi_vae_amd.config import build_settings, create_kwargs
+from midi_vae_amd.model import VAE
+from midi_vae_amd.synth import make_windows, to_reference_format
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--songs", type=int, default=4)
+ap.add_argument("--windows", type=int, default=1024, help="windows per song (a fit call = one song)")
+ap.add_argument("--cell", default="LSTM")
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--with-prepass", action="store_true", help="history pre-pass (encoder.predict, kept on the device) before every fit")
+ap.add_argument("--host-history", action="store_true", help="... through host arrays, as the reference does")
+a = ap.parse_args()
+import torch
+s = build_settings(cell_type=a.cell, input_length=128, output_length=128, latent_dim=64, batch_size=a.batch)
+m = VAE().create(compute_dtype="bf16", seed=0, **create_kwargs(s))
+n = a.windows
+songs = []
+for i in range(a.songs):
+    w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=10 + i)
+    X, Y, C, I, V, D = to_reference_format(w)
+    songs.append((X, Y, C, I, V, D, np.zeros((n, s["signature_vector_length"]))))
+print("host packer threads: %d; one song = %d windows = %.0f MB of float64 one-hot rows (X) + as much again (Y)" % (
+    hl.load().mvae_host_threads(-1), n, songs[0][0].nbytes / 1e6))
+
+
+def one_song(sg, epoch):
+    X, Y, C, I, V, D, S = sg
+    t0 = time.perf_counter()
+    if a.with_prepass and epoch > 0:
+        enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+        H = m.encoder.predict(enc_in, batch_size=a.batch, device=not a.host_history)
+        if a.host_history:
+            H = np.concatenate([np.zeros((1, H.shape[1])), H[:-1]])
+    else:
+        H = np.zeros((n, s["latent_dim"]))
+    t1 = time.perf_counter()
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+    t2 = time.perf_counter()
+    h = m.autoencoder.fit(x, y, epochs=1, batch_size=a.batch, shuffle=False, sample_weight=sw, verbose=False)
+    t3 = time.perf_counter()
+    return h.history["loss"][0], t1 - t0, t2 - t1, t3 - t2
+
+
+one_song(songs[0], 0)          # engine construction, first launches
+for ep in (1, 2):
+    tp = tk = tf = 0.0
+    t0 = time.perf_counter()
+    for sg in songs:
+        loss, a_, b_, c_ = one_song(sg, ep)
+        tp, tk, tf = tp + a_, tk + b_, tf + c_
+    dt = time.perf_counter() - t0
+    nw = n * len(songs)
+    print("epoch %d: %d windows in %.3f s = %.0f windows/s end to end | fit alone %.0f windows/s (%.2f ms per %d-window step) | "
+          "pre-pass %.3f s, python packers %.3f s, fit %.3f s | loss %.4f" % (
+              ep, nw, dt, nw / dt, nw / tf, tf / (nw / a.batch) * 1e3, a.batch, tp, tk, tf, loss))

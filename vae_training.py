@@ -9,7 +9,8 @@ saved by a user's own importer (an ``.npz`` with X, C, I, V per song).  Plots / 
 the reference are not reproduced.
 
     python vae_training.py --epochs 3 --songs 6                         (single GPU)
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 vae_training.py --epochs 3   (DP)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 vae_training.py --epochs 3   (DP: every
+        rank walks the same songs; each minibatch of <= batch_size windows is sharded over the ranks inside fit)
 """
 import argparse
 import os
@@ -37,19 +38,23 @@ def synthetic_songs(n_songs, s, seed):
     return songs
 
 
-def history_for(model, song, s, use_encoder):
-    """reference vae_training.py:788-798 - zeros in epoch 0, else the previous window's SAMPLED z."""
+def history_for(model, song, s, use_encoder, on_device=True):
+    """reference vae_training.py:788-798 - zeros in epoch 0, else the previous window's SAMPLED z (a fresh epsilon: one
+    extra encoder forward per song).  ``on_device``: the z of the pre-pass stays in HBM (model.DeviceLatent) and the roll
+    H[1:] = z[:-1], H[0] = 0 happens where the train step reads it; else the reference's host arrays."""
     n = song["X"].shape[0]
     if not (s["history"] and use_encoder):
         return np.zeros((n, s["latent_dim"]))
     enc_in = vae_definition.prepare_encoder_input_list(song["X"], song["I"], song["V"], song["D"])
+    if on_device:
+        return model.encoder.predict(enc_in, batch_size=s["batch_size"], verbose=False, device=True)
     z = model.encoder.predict(enc_in, batch_size=s["batch_size"], verbose=False)
     H = np.zeros(z.shape)
     H[1:] = z[:-1]
     return H
 
 
-def run_epoch(model, songs, s, epoch, train, allreduce=None):
+def run_epoch(model, songs, s, epoch, train):
     names = model.autoencoder.metrics_names
     enum, seen, total = [], {}, {n: names.count(n) for n in names}
     for n in names:                                            # reference vae_training.py:172-187
@@ -62,7 +67,7 @@ def run_epoch(model, songs, s, epoch, train, allreduce=None):
             x, y, w = vae_definition.prepare_autoencoder_input_and_output_list(
                 song["X"], song["Y"], song["C"], song["I"], song["V"], song["D"], song["S"], H, return_sample_weight=True)
             hist = model.autoencoder.fit(x, y, epochs=1, batch_size=s["batch_size"], shuffle=False, sample_weight=w,
-                                         verbose=False, allreduce=allreduce)
+                                         verbose=False)
             if s["reset_states"]:
                 model.autoencoder.reset_states()
             vals = {k: float(np.mean(v)) for k, v in hist.history.items()}
@@ -91,41 +96,47 @@ def main():
     ap.add_argument("--test-songs", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model-path", default="models/autoencode/vae/")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend when WORLD_SIZE > 1")
     args = ap.parse_args()
     s = vars(settings)
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
-    allreduce = None
+    dp = None
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        from midi_vae_amd.dp import make_allreduce
-        allreduce = make_allreduce(None, dist, world)
+        dist.init_process_group(args.backend, **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
+        from midi_vae_amd.dp import DataParallel
+        dp = DataParallel(dist)
 
     print("creating model...")
     model = VAE()
     model.create(compute_dtype=args.dtype, device="cuda:%d" % local, **create_kwargs(s))
+    # Data parallel: EVERY rank walks the same song list in the same order and calls fit with the same arguments; fit splits
+    # each minibatch of <= batch_size consecutive windows over the ranks (dp.shard_bounds).  All ranks therefore run the same
+    # number of optimizer steps and collectives by construction - ragged songs and ranks with empty shards included.
+    model.set_data_parallel(dp)
     if rank == 0:
         print(model.autoencoder.summary())
     if s["load_previous_checkpoint"]:
         for view, name in ((model.autoencoder, "autoencoder"), (model.encoder, "encoder"), (model.decoder, "decoder")):
             view.load_weights(s["previous_checkpoint_path"] + name + "Epoch" + str(s["previous_epoch"]) + ".pickle", by_name=False)
-    train = synthetic_songs(args.songs, s, seed=1 + rank)      # each rank trains on its own songs (data parallel)
+    train = synthetic_songs(args.songs, s, seed=1)             # the SAME songs on every rank (sharded inside fit)
     test = synthetic_songs(args.test_songs, s, seed=999)
+    order_rng = np.random.default_rng(4321)                     # ... in the SAME order (the reference's shuffle is unseeded)
     path = os.path.join(args.model_path, "%s-_ls_inlen_%d_outlen_%d_beta_%s_lr_%s_lstmsize_%d_latent_%d" % (
         s["t"], s["input_length"], s["output_length"], s["beta"], s["learning_rate"], s["lstm_size"], s["latent_dim"]))
     start = s["previous_epoch"] if s["load_previous_checkpoint"] else 0
     for e in range(start, start + args.epochs):
         t0 = time.time()
-        order = np.random.permutation(len(train)) if s["shuffle_train_set"] else np.arange(len(train))
-        tr = run_epoch(model, [train[i] for i in order], s, e, train=True, allreduce=allreduce)
+        order = order_rng.permutation(len(train)) if s["shuffle_train_set"] else np.arange(len(train))
+        tr = run_epoch(model, [train[i] for i in order], s, e, train=True)
         n_win = sum(sg["X"].shape[0] for sg in train)
         if rank == 0:
             print("Epoch %d: train loss %.4f notes %.4f acc %.4f kl %.5f | %.0f windows/s" % (
                 e, tr["loss"], tr.get("decoder_loss_1", tr["loss"]), tr.get("decoder_acc_1", 0.0), tr["kl_loss"],
-                n_win * world / (time.time() - t0)))
+                n_win / (time.time() - t0)))
         if e % s["test_step"] == 0 and rank == 0:
             te = run_epoch(model, test, s, e, train=False)
             print("         test  loss %.4f notes %.4f acc %.4f kl %.5f" % (
