@@ -12,7 +12,8 @@ update on one minibatch of synthetic piano-roll windows already resident in HBM.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     dominant kernel (the T-step recurrent kernels) measured live with HIP events on the launch stream
-  cpu_baseline the oracle (NumPy port of the same step) timed on the host cores, rank 0 / N=1 only, bounded sample
+  cpu_baseline the same step as float32 torch-CPU tensor operations on all host cores (oracle/torch_cpu.py), rank 0 / N=1 only,
+               bounded sample, timed BEFORE the GPU phase
 """
 import argparse
 import json
@@ -30,40 +31,80 @@ PEAK_F32_TFLOPS = 157.3
 
 
 def cpu_baseline(spec, budget_s=20.0):
-    """Oracle train step (float32 NumPy, BLAS threads = all host cores) on a bounded sample of the same workload."""
-    from oracle.vae_oracle import OracleVAE, make_cfg
+    """The identical train step (forward + losses + analytic backward + Keras-Adam) as float32 torch-CPU tensor operations on ALL
+    host cores (oracle/torch_cpu.py, pinned to the NumPy oracle by tests/test_torch_port_cpu.py) - the reference's own Keras CPU
+    path cannot run here.  SURVEY 8(d): the largest batch under a time bound - here the largest of 16..256 windows
+    whose step is expected to fit ``budget_s`` seconds (a step at B=16 is timed first; cost grows at most linearly in B), one
+    untimed + one timed step at that size.  Runs BEFORE the GPU phase."""
+    import torch
+    from oracle.torch_cpu import TorchCPUVAE
+    from oracle.vae_oracle import make_cfg
     from midi_vae_amd.layout import init_params
     from midi_vae_amd.synth import make_windows
-    Bs = 8
-    orc = OracleVAE(make_cfg(**spec.oracle_cfg()), dtype=np.float32)
-    p = {k: v.astype(np.float32) for k, v in init_params(spec, 1234).items()}
-    w = make_windows(Bs, spec.T, spec.Dout, spec.V, spec.ID, spec.C, spec.Z, seed=1234, epsilon_std=spec.epsilon_std)
-    oh = lambda idx, n: np.eye(n, dtype=np.float32)[idx.astype(np.int64)]
-    batch = dict(X=oh(w["x_idx"], spec.Din), I=oh(w["i_idx"], spec.ID), Vel=w["vel"][..., None], Hist=w["hist"],
-                 Y=oh(w["x_idx"], spec.Dout), C=oh(w["c_idx"], spec.C))
-    st = orc.new_opt_state(p)
-    t0 = time.perf_counter()
-    orc.train_step(p, st, batch, w["eps"])          # warm-up (BLAS thread pools, page faults)
-    first = time.perf_counter() - t0
-    n = int(max(1, min(5, (budget_s - first) // max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        orc.train_step(p, st, batch, w["eps"])
-    dt = (time.perf_counter() - t0) / n
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    return {"value": Bs / dt, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": "%d windows x %d timed step(s) of the identical train step (T=%d,H=%d,%s) in float32 NumPy "
-                      "(oracle/vae_oracle.py), %.2f s/step" % (Bs, n, spec.T, spec.H, spec.cell, dt)}
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    tv = TorchCPUVAE(make_cfg(**spec.oracle_cfg()))
+    oh = lambda idx, n: np.eye(n, dtype=np.float32)[idx.astype(np.int64)]
+
+    def problem(Bs):
+        w = make_windows(Bs, spec.T, spec.Dout, spec.V, spec.ID, spec.C, spec.Z, seed=1234, epsilon_std=spec.epsilon_std)
+        batch = dict(X=oh(w["x_idx"], spec.Din), I=oh(w["i_idx"], spec.ID), Vel=w["vel"][..., None], Hist=w["hist"],
+                     Y=oh(w["x_idx"], spec.Dout), C=oh(w["c_idx"], spec.C))
+        P = tv.tensors(init_params(spec, 1234))
+        return P, tv.new_opt_state(P), batch, w["eps"]
+
+    def one(Bs, reps):
+        P, st, batch, eps = problem(Bs)
+        tv.train_step(P, st, batch, eps)                 # untimed: thread pools, page faults
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tv.train_step(P, st, batch, eps)
+        return (time.perf_counter() - t0) / reps
+
+    t16 = one(16, 1)
+    Bs = 16
+    for cand in (32, 64, 128, 256):
+        if t16 * cand / 16 * 2 <= budget_s:              # (x2: the untimed step at that size)
+            Bs = cand
+    dt = one(Bs, 1) if Bs > 16 else t16
+    torch.set_num_threads(threads_before)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": Bs / dt, "unit": "windows/s", "cores": cores, "kind": "port", "cpu": model,
+            "sample": "1 timed step of the identical train step (T=%d,H=%d,%s) at %d windows in float32 torch-CPU on %d threads "
+                      "(oracle/torch_cpu.py; largest batch of 16..256 expected to fit %.0f s: a 16-window step took %.2f s), "
+                      "%.2f s/step" % (spec.T, spec.H, spec.cell, Bs, cores, budget_s, t16, dt)}
+
+
+def algorithmic_flops_per_window(spec):
+    """Forward FLOPs of one window, SURVEY section 8(d) formula (mm(k,n) = 2kn; decoder input projections counted once per window:
+    the decoder input is constant over the steps, F9; the one-hot x W of encoder layer 1 counted as the GEMM it replaces).
+    A train step is 3x this (1 forward + 2 backward GEMMs)."""
+    mm = lambda k, n: 2.0 * k * n
+    H, GH, Z, T, V, D, ID = spec.H, spec.GH, spec.Z, spec.T, spec.V, spec.Dout, spec.ID
+    s_ = spec.nstate
+    f_enc = (T * (mm(spec.Din, GH) + mm(H, GH)) + (spec.Le - 1) * T * 2 * mm(H, GH) + V * (mm(ID, GH) + mm(H, GH)) +
+             T * (mm(1, GH) + mm(H, GH)) + mm(3 * H, H) + mm(H, H) + 2 * mm(H // 2, Z))
+    f_dec = ((spec.Ld + 2) * s_ * mm(spec.zin, H) + (mm(D, GH) + T * mm(H, GH)) + (spec.Ld - 1) * T * 2 * mm(H, GH) +
+             T * mm(H, D) + (mm(ID, GH) + V * (mm(H, GH) + mm(H, ID))) + (mm(1, GH) + T * (mm(H, GH) + mm(H, 1))))
+    return f_enc + f_dec
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
@@ -103,6 +144,9 @@ def main():
     T = args.seq_len * args.voices
     spec = ModelSpec(cell=args.cell, H=256, Z=args.latent, Din=61, Dout=61, T=T, V=args.voices, ID=16, C=2, Le=2, Ld=2)
     B = args.batch
+    # the CPU baseline FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
+    # process sees the GPU busy at the end of the run rather than idle
+    cpu = cpu_baseline(spec) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
     eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234, use_graphs=args.graphs)
     if args.chunks:
         eng.time_chunks = args.chunks
@@ -141,7 +185,8 @@ def main():
     # The warmup steps run exactly what the timed steps run - including the HIP-event brackets around the dominant kernel
     # (their first use costs tens of milliseconds in the first GPU process of a freshly started box: measured 12.9 instead
     # of 9.1 ms per step over 10 timed steps when the brackets first appeared inside the timed region).
-    eng.prof_kinds = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0")}
+    KINDS = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1")}
+    eng.prof_kinds = KINDS
     if not args.graphs and args.warmup:
         eng.prof = {}
     for _ in range(args.warmup):
@@ -152,26 +197,32 @@ def main():
         eng.prof = None
     first_loss = eng.metrics(B)["loss"] if args.warmup else float("nan")
 
-    # Bracket only the dominant kernel's launches, and of those the two stacked decoder layers (8 of the 26 BPTT launches
-    # of a step): every event pair costs launch slots - all 26 bracketed slow the step by 0.5 ms.
-    eng.prof_kinds = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0")}
+    # Bracket only the dominant kernel's launches, and of those the two stacked decoder layers (plus one forward layer for the
+    # critical-path figure): every event pair costs launch slots - all 26 BPTT launches bracketed slow the step by 0.5 ms.
+    # One more event per step boundary on the critical stream gives the per-step times (median).
+    eng.prof_kinds = KINDS
     if not args.graphs:
         eng.prof = {}           # HIP events on the launch streams; with graph replay: timed in a second pass
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if args.steps % 2 else 0.5 * (step_ms[args.steps // 2 - 1] + step_ms[args.steps // 2])
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed, median_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
     if args.graphs:
         # same process, same inputs, same K steps, launched eagerly so individual launches can be bracketed with events
         eng.prof = {}
@@ -188,7 +239,7 @@ def main():
         # region was bracketed with HIP events on its stream).  Algorithmic work = the recurrent GEMM only:
         # 2 * B * H * (G*H) flop per time step (da U^T), summed over the steps each launch covers (the stacked layers
         # run as time chunks) - SURVEY section 8d.
-        longk = {k: v for k, v in prof.items() if "instr" not in k[1]}
+        longk = {k: v for k, v in prof.items() if k[0] == "rnn_bwd"}
         launches = sum(n for n, _, _ in longk.values())
         tot_ms = sum(n * ms for n, ms, _ in longk.values())
         tot_steps = sum(n * st for n, _, st in longk.values())
@@ -198,10 +249,27 @@ def main():
         achieved = flop_step * tot_steps / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         cus = Bp // 16                      # one workgroup (= one CU) per 16 batch rows
+        us_bwd = tot_ms * 1e3 / tot_steps
+        fwdk = [v for k, v in prof.items() if k[0] == "rnn_fwd"]
+        us_fwd = sum(n * ms for n, ms, _ in fwdk) * 1e3 / max(sum(n * st for n, _, st in fwdk), 1) if fwdk else float("nan")
+        ms_step = elapsed / args.steps * 1e3
+        # HBM traffic of the dominant kernel from the PMC counters: bench.py cannot run a counter pass over itself, so the pass over
+        # THIS command (tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
+        # doubled as MI355X_MICROARCH.md prescribes for gfx950) is committed as profiles/<round>_bench_traffic.json and embedded
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf)).get("%s_%s" % (args.cell, args.dtype))
+                if rec and rec.get("T") == T and rec.get("B") == B:
+                    traffic, traffic_src = rec["bytes_per_launch"], rec
+            except (ValueError, OSError):
+                pass
+        step_flop = 3.0 * algorithmic_flops_per_window(spec) * B
         out = {
             "metric": "MIDI roll windows/sec (train step)", "value": B * world * args.steps / elapsed,
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 2-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU %s "
                                    "H=256 2+2 layers, notes+instrument+velocity+style heads, Keras-Adam"
@@ -211,16 +279,28 @@ def main():
                      "notes_loss": m["notes_loss"]},
             "roofline": {"bound": "mfma", "kernel": "rnn_bwd (BPTT, %s %s, resident recurrent weights)" % (args.cell, args.dtype),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
-                         "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": tot_ms * 1e3 / tot_steps,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         # per time step and row: LSTM reads gates 4H + cell state H + upstream gradient H, writes da 4H;
+                         # GRU reads gates 3H + h H + upstream gradient H, writes da 3H + r*h H
+                         "algorithmic_bytes_per_launch": Bp * T * H * (10 if args.cell == "LSTM" else 9) * (2 if args.dtype == "bf16" else 4),
+                         "avg_launch_ms": avg_ms, "launches": launches,
+                         "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": us_bwd,
                          "flop_per_time_step": flop_step,
                          # the recurrence is latency-bound by design: B/16 workgroups, one per CU, step after step
                          "cus_occupied": cus, "frac_of_occupied_cus": achieved / (peak * cus / 256.0),
-                         "launch_ms_per_step_by_layer": {k[1]: n * ms / args.steps for k, (n, ms, _) in prof.items()}},
+                         "launch_ms_per_step_by_layer": {"%s:%s" % k: n * ms / args.steps for k, (n, ms, _) in prof.items()},
+                         # the two figures beside the per-kernel fraction
+                         "whole_step": {"algorithmic_tflop": step_flop / 1e12, "tflops": step_flop / (ms_step * 1e-3) / 1e12,
+                                        "frac_of_peak": step_flop / (ms_step * 1e-3) / 1e12 / peak},
+                         "critical_path": {"what": "the four serial recurrence phases of a step (encoder forward, decoder forward, "
+                                                   "decoder BPTT, encoder BPTT): T x the measured time per time step of a stacked layer",
+                                           "us_per_step_fwd": us_fwd, "us_per_step_bwd": us_bwd,
+                                           "bound_ms": 2.0 * T * (us_fwd + us_bwd) * 1e-3,
+                                           "frac_of_step": 2.0 * T * (us_fwd + us_bwd) * 1e-3 / ms_step}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = out["value"] / cpu["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
