@@ -27,6 +27,7 @@ from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
 
 # slots of the scalar accumulator
 S_NOTES_LOSS, S_NOTES_HITS, S_INSTR_LOSS, S_INSTR_HITS, S_VEL_LOSS, S_VEL_HITS, S_KL, S_STYLE_LOSS, S_STYLE_HITS = range(9)
+S_HELD_LOSS, S_HELD_HITS, S_NEXT_LOSS, S_NEXT_HITS = 10, 11, 12, 13          # (slot 9: third word of the latent kernels' block)
 N_SCALARS = 16
 
 
@@ -45,6 +46,18 @@ class _Rec(object):
         self.prefix, self.T, self.xmode, self.K = prefix, T, xmode, K
         self.init_block = init_block      # first column block of dec.init holding this cell's initial state(s)
         self.lower = lower                # the layer whose h sequence feeds this one (X_DENSE)
+
+
+class _Head(object):
+    """One decoder head (reference vae_definition.py:521-726): a cell stack stepped ``T`` times on a constant input, a Dense with
+    softmax (kind 0, N classes, categorical cross-entropy) or sigmoid (kind 1, squared error) on the top cell's output."""
+
+    def __init__(self, name, layers, kind, N, weight, slot, target, stream=None):
+        self.name, self.layers, self.kind, self.N, self.weight, self.slot, self.target = name, layers, kind, N, weight, slot, target
+        self.T = layers[0].T
+        self.out = "dec.%s.out" % name
+        self.stream = stream              # None = the critical stream (the notes stack)
+        self.NP = None
 
 
 class Engine(object):
@@ -82,6 +95,8 @@ class Engine(object):
         # (needed only by the optimizer) go to a fourth stream off the critical path.  Fork / join is event based.
         with torch.cuda.device(self.device):
             self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+            self.s_held = torch.cuda.Stream() if spec.meta_held else None
+            self.s_next = torch.cuda.Stream() if spec.meta_next else None
             self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
@@ -191,8 +206,12 @@ class Engine(object):
     def _join_into(self, stream):
         """``stream`` waits for everything enqueued so far on the current stream and on every side stream"""
         stream.wait_stream(torch.cuda.current_stream())
-        for st in (self.s_vel, self.s_instr, self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
+        for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
             stream.wait_stream(st)
+
+    def _side_streams(self):
+        """the streams of the independent encoder / decoder branches beside the notes stack"""
+        return [st for st in (self.s_vel, self.s_instr, self.s_held, self.s_next) if st is not None]
 
     def _side(self, fn):
         """Run ``fn`` (parameter-gradient work nobody waits for before the optimizer) on the second gradient stream,
@@ -259,6 +278,10 @@ class Engine(object):
                                        s.Din if l == 0 else s.H, lower=self.enc_notes[-1] if l else None))
         self.enc_instr = _Rec("enc.instr", s.V, hl.X_INDEX, s.ID) if s.meta_instrument else None
         self.enc_vel = _Rec("enc.vel", s.T, hl.X_SCALAR, 1) if s.meta_velocity else None
+        self.enc_held = _Rec("enc.held", s.T, hl.X_INDEX, 2) if s.meta_held else None
+        # (record, stream, input buffer): the meta rolls beside the notes stack, in the order they are concatenated
+        self.enc_meta = [m for m in ((self.enc_instr, self.s_instr, "in.i_idx"), (self.enc_vel, self.s_vel, "in.vel"),
+                                     (self.enc_held, self.s_held, "in.d_idx")) if m[0] is not None]
         blocks = dec_init_blocks(s)
         self.n_init = len(blocks)
         self.dec_notes = []
@@ -270,10 +293,28 @@ class Engine(object):
                           if s.meta_instrument else None)
         self.dec_vel = (_Rec("dec.vel.cell", s.T, hl.X_CONST, 1, init_block=blocks.index("dec.vel.init.0"))
                         if s.meta_velocity else None)
-        self.all_rec = (self.enc_notes + [r for r in (self.enc_instr, self.enc_vel) if r] + self.dec_notes +
-                        [r for r in (self.dec_instr, self.dec_vel) if r])
-        self.ncat = 1 + int(s.meta_instrument) + int(s.meta_velocity)
-        self.has_pack = s.meta_instrument or s.meta_velocity
+        self.dec_held = (_Rec("dec.held.cell", s.T, hl.X_CONST, 2, init_block=blocks.index("dec.held.init.0"))
+                         if s.meta_held else None)
+        self.dec_next = []
+        if s.meta_next:
+            for l in range(s.Ld):
+                self.dec_next.append(_Rec("dec.next.%d" % l, s.T, hl.X_CONST if l == 0 else hl.X_DENSE,
+                                          s.Dout if l == 0 else s.H, init_block=blocks.index("dec.next.init.%d.0" % l),
+                                          lower=self.dec_next[-1] if l else None))
+        # decoder heads: the notes stack on the critical stream, every other head on its own
+        self.heads = [_Head("notes", self.dec_notes, 0, s.Dout, 1.0, S_NOTES_LOSS, "in.y_idx")]
+        if s.meta_instrument:
+            self.heads.append(_Head("instr", [self.dec_instr], 0, s.ID, s.w_instr, S_INSTR_LOSS, "in.i_idx", self.s_instr))
+        if s.meta_velocity:
+            self.heads.append(_Head("vel", [self.dec_vel], 1, 1, s.w_vel, S_VEL_LOSS, "in.vel", self.s_vel))
+        if s.meta_held:
+            self.heads.append(_Head("held", [self.dec_held], 0, 2, s.w_held, S_HELD_LOSS, "in.d_idx", self.s_held))
+        if s.meta_next:
+            self.heads.append(_Head("next", self.dec_next, 0, s.Dout, s.w_next, S_NEXT_LOSS, "in.n_idx", self.s_next))
+        self.head = {h.name: h for h in self.heads}
+        self.all_rec = (self.enc_notes + [m[0] for m in self.enc_meta] + [r for h in self.heads for r in h.layers])
+        self.ncat = s.ncat
+        self.has_pack = s.has_pack
 
     # ------------------------------------------------------------------------------------------------------
     # buffers (sized for max_batch; smaller batches reinterpret the same storage with a smaller row stride)
@@ -321,27 +362,17 @@ class Engine(object):
                 if self.training:
                     buf(p + ".dxp0", B * GH, **f32)
         # heads
-        self.np_notes, self.np_instr = ops.head_np(s.Dout), ops.head_np(s.ID)
-        buf("notes.wt", self.np_notes * H, **esz)
-        buf("notes.argmax", T * B, **u8)
-        if self.training:
-            buf("notes.dl", T * B * self.np_notes, **esz)
-            buf("notes.dhs", T * B * H, **esz)
-            buf("notes.wc", H * self.np_notes, **esz)      # W (H, NP): the head kernel's fused input gradient
-        if s.meta_instrument:
-            buf("instr.wt", self.np_instr * H, **esz)
-            buf("instr.argmax", V * B, **u8)
+        for h in self.heads:
+            h.NP = ops.head_np(h.N)
+            n = h.name
+            buf(n + ".wt", h.NP * H, **esz)
+            buf(n + ".argmax", h.T * B, **u8)              # (the velocity head: round(p))
             if self.training:
-                buf("instr.dl", V * B * self.np_instr, **esz)
-                buf("instr.dhs", V * B * H, **esz)
-                buf("instr.wc", H * self.np_instr, **esz)
-        if s.meta_velocity:
-            buf("vel.wt", 16 * H, **esz)
-            buf("vel.round", T * B, **u8)
-            if self.training:
-                buf("vel.dl", T * B * 16, **esz)
-                buf("vel.dhs", T * B * H, **esz)
-                buf("vel.wc", H * 16, **esz)
+                buf(n + ".dl", h.T * B * h.NP, **esz)
+                buf(n + ".dhs", h.T * B * H, **esz)
+                buf(n + ".wc", H * h.NP, **esz)            # W (H, NP): the head kernel's fused input gradient
+            buf("out.%s_p" % n, h.T * B * h.N, **f32)      # inference outputs on request
+        self.np_notes = self.head["notes"].NP
         # encoder tail / latent / decoder initial states (all f32, (B, .) row-major)
         for name, n in (("cat", self.ncat * H), ("pack", H), ("extra", H), ("mu", Z), ("lv", Z), ("zh", s.zin),
                         ("style_p", max(s.C, 1)), ("S", self.n_init * H)):
@@ -356,7 +387,7 @@ class Engine(object):
             buf("lat.wt_mu", Z * h1w, **f32)
             buf("lat.wt_lv", Z * (H - h1w if s.split else H), **f32)
             if s.extra_layer:
-                buf("lat.wt_extra", H * H, **f32)
+                buf("lat.wt_extra", H * s.tail_in, **f32)
             if self.has_pack:
                 buf("lat.wt_pack", H * self.ncat * H, **f32)
         # inputs: ONE contiguous block (staging.Stager uploads it with a single copy from a pinned mirror); the "in.*"
@@ -367,6 +398,11 @@ class Engine(object):
                    ("in.rw_vel", T * B, torch.float32), ("in.rw_style", B, torch.float32),
                    ("in.start_notes", B * s.Dout, torch.float32), ("in.start_instr", B * s.ID, torch.float32),
                    ("in.start_vel", B, torch.float32), ("in.hist", B * Z, torch.float32), ("in.z", B * Z, torch.float32)]
+        if s.meta_held:
+            regions += [("in.d_idx", T * B, torch.uint8), ("in.rw_held", T * B, torch.float32), ("in.start_held", B * 2, torch.float32)]
+        if s.meta_next:
+            regions += [("in.n_idx", T * B, torch.uint8), ("in.rw_next", T * B, torch.float32),
+                        ("in.start_next", B * s.Dout, torch.float32)]
         self._in_regions, off = {}, 0
         for name, n, tdt in regions:
             nbytes = int(n) * (1 if tdt == torch.uint8 else 4)
@@ -376,10 +412,6 @@ class Engine(object):
         for name, (o, nbytes, tdt) in self._in_regions.items():
             st[name] = self._in_block[o:o + nbytes].view(tdt)
         self._stager = None
-        # inference outputs on request
-        buf("out.notes_p", T * B * s.Dout, **f32)
-        buf("out.instr_p", V * B * s.ID, **f32)
-        buf("out.vel_p", T * B, **f32)
 
     def bytes_resident(self):
         return (sum(t.numel() * t.element_size() for t in self.store.values()) +
@@ -418,9 +450,9 @@ class Engine(object):
         out[:B] = arr
         self._up(name, out, tdtype)
 
-    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None):
-        """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; eps (B,Z) f32 ALREADY scaled by
-        epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
+    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None, d_idx=None):
+        """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; d_idx (B,T) uint8 held-notes flag; eps (B,Z)
+        f32 ALREADY scaled by epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
         B = x_idx.shape[0]
         self.norm_B = float(B)
         self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
@@ -428,11 +460,14 @@ class Engine(object):
             self._up_tm("in.i_idx", np.asarray(i_idx, np.uint8), torch.uint8)
         if self.spec.meta_velocity:
             self._up_tm("in.vel", np.asarray(vel, np.float32), torch.float32)
+        if self.spec.meta_held:
+            self._up_tm("in.d_idx", np.asarray(d_idx, np.uint8), torch.uint8)
         self._up_rows("in.eps", np.zeros((B, self.spec.Z), np.float32) if eps is None else np.asarray(eps, np.float32),
                       self.spec.Z)
         return B
 
-    def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None):
+    def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None, start_held=None,
+                             start_next=None):
         s = self.spec
         Bp = self.pad16(B)
         zh = self._v("zh", Bp, s.zin)
@@ -445,10 +480,14 @@ class Engine(object):
         if z is not None:
             zh[:B, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
         for name, val, width in (("in.start_notes", start_notes, s.Dout), ("in.start_instr", start_instr, s.ID),
-                                 ("in.start_vel", start_vel, 1)):
+                                 ("in.start_vel", start_vel, 1), ("in.start_held", start_held, 2),
+                                 ("in.start_next", start_next, s.Dout)):
+            if name not in self.store:
+                continue
             self._up_rows(name, np.zeros((B, width), np.float32) if val is None else np.asarray(val, np.float32), width)
 
-    def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None):
+    def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None, n_idx=None,
+                      w_held=None, w_next=None):
         """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
         (score*w / mean(w != 0), then the mean over the axes) into one factor per row; padding
         rows get target 255 ("no target") and weight 0."""
@@ -470,6 +509,13 @@ class Engine(object):
         if s.meta_velocity:
             wv = np.ones((B,)) if w_vel is None else w_vel
             self._up_tm("in.rw_vel", np.repeat(norm(wv, T)[:, None], T, axis=1), torch.float32)
+        if s.meta_held:          # (the target is the held-notes roll staged with the encoder inputs)
+            wh = np.ones((B,)) if w_held is None else w_held
+            self._up_tm("in.rw_held", np.repeat(norm(wh, T)[:, None], T, axis=1), torch.float32)
+        if s.meta_next:
+            wx = np.ones((B,)) if w_next is None else w_next
+            self._up_tm("in.rw_next", np.repeat(norm(wx, T)[:, None], T, axis=1), torch.float32)
+            self._up_tm("in.n_idx", np.asarray(n_idx, np.uint8), torch.uint8, fill=255)
         if s.style:
             ws = np.ones((B,)) if w_style is None else w_style
             self._up("in.rw_style", norm(ws, 1), torch.float32)
@@ -499,18 +545,12 @@ class Engine(object):
                         pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
                         if r.xmode == hl.X_DENSE:
                             pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
-                pb.transpose_convert(P["dec.notes.out.W"], self._v("notes.wt", self.np_notes, s.H), n_pad=self.np_notes)
-                if s.meta_instrument:
-                    pb.transpose_convert(P["dec.instr.out.W"], self._v("instr.wt", self.np_instr, s.H), n_pad=self.np_instr)
-                if s.meta_velocity:
-                    pb.transpose_convert(P["dec.vel.out.W"], self._v("vel.wt", 16, s.H), n_pad=16)
+                for h in self.heads:
+                    pb.transpose_convert(P[h.out + ".W"], self._v(h.name + ".wt", h.NP, s.H), n_pad=h.NP)
                 pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
                 if self.training:
-                    pb.convert_pad(P["dec.notes.out.W"], self.store["notes.wc"], self.np_notes)
-                    if s.meta_instrument:
-                        pb.convert_pad(P["dec.instr.out.W"], self.store["instr.wc"], self.np_instr)
-                    if s.meta_velocity:
-                        pb.convert_pad(P["dec.vel.out.W"], self.store["vel.wc"], 16)
+                    for h in self.heads:
+                        pb.convert_pad(P[h.out + ".W"], self.store[h.name + ".wc"], h.NP)
                 if self.training:
                     for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
                                          ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
@@ -681,23 +721,17 @@ class Engine(object):
         Breal, B = B, self.pad16(B)
         cat = self._v("cat", B, self.ncat * H)
         ldc = self.ncat * H
-        self._fork_with_stack(self.enc_notes, self.s_vel, self.s_instr)
-        k = 1
-        if s.meta_instrument:
-            with self._on(self.s_instr):
-                self._rec_forward(self.enc_instr, B, idx=self._v("in.i_idx", s.V, B), h_last=cat[:, k * H:(k + 1) * H],
-                                  h_last_ld=ldc)
-            k += 1
-        if s.meta_velocity:
-            with self._on(self.s_vel):
-                self._rec_forward(self.enc_vel, B, xs=self._v("in.vel", s.T, B), h_last=cat[:, k * H:(k + 1) * H],
-                                  h_last_ld=ldc)
+        self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
+        for k, (r, st, src) in enumerate(self.enc_meta, 1):
+            with self._on(st):
+                inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
+                self._rec_forward(r, B, h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc, **inp)
         self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._prefork = None
-        self._join(self.s_vel, self.s_instr)
+        self._join(*[st for _, st, _ in self.enc_meta])
         self._mark("  encoder recurrences")
         self._S_done = False
-        if self.fused_latent and self._latent_chain_forward(Breal, B, with_init):
+        if self.fused_latent and (self.has_pack or self.ncat == 1) and self._latent_chain_forward(Breal, B, with_init):
             return
         h = cat
         if self.has_pack:
@@ -706,7 +740,7 @@ class Engine(object):
             h = pk
         if s.extra_layer:
             ex = self._v("extra", B, H)
-            ops.gemm(h, P["enc.extra.W"], ex, B, H, H, bias=P["enc.extra.b"], act=hl.ACT_TANH)
+            ops.gemm(h, P["enc.extra.W"], ex, B, H, s.tail_in, bias=P["enc.extra.b"], act=hl.ACT_TANH)
             h = ex
         self._tail = h
         h1w = H // 2 if s.split else H
@@ -767,45 +801,36 @@ class Engine(object):
 
         self._mark("  decoder initial states")
         tg = self._have_targets
-        self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr)
-        if s.meta_instrument:
-            with self._on(self.s_instr):
-                r = self.dec_instr
-                self._rec_forward(r, B, start=self._v("in.start_instr", B, s.ID), **states(r))
-                top = self._v(r.prefix + ".hs", V + 1, B, H)[1:]
-                ops.head(0, self.kind, V * B, H, s.ID, top, self._v("instr.wt", self.np_instr, H), P["dec.instr.out.b"],
-                         target_idx=self._v("in.i_idx", V * B) if tg else None,
-                         row_weight=self._v("in.rw_instr", V * B) if tg else None, grad_scale=s.w_instr,
-                         probs=self._v("out.instr_p", V * B, s.ID) if want_probs else None,
-                         argmax=self._v("instr.argmax", V * B),
-                         dlogits=self._v("instr.dl", V * B, self.np_instr) if (self.training and tg) else None,
-                     **self._fused_head_bwd("instr", tg),
-                         scalars=self.scal[S_INSTR_LOSS:S_INSTR_LOSS + 2], b_stride=B, b_valid=Breal)
-        if s.meta_velocity:
-            with self._on(self.s_vel):
-                r = self.dec_vel
-                self._rec_forward(r, B, start=self._v("in.start_vel", B, 1), **states(r))
-                top = self._v(r.prefix + ".hs", T + 1, B, H)[1:]
-                ops.head(1, self.kind, T * B, H, 1, top, self._v("vel.wt", 16, H), P["dec.vel.out.b"],
-                         target_val=self._v("in.vel", T * B) if tg else None,
-                         row_weight=self._v("in.rw_vel", T * B) if tg else None, grad_scale=s.w_vel,
-                         probs=self._v("out.vel_p", T * B) if want_probs else None, argmax=self._v("vel.round", T * B),
-                         dlogits=self._v("vel.dl", T * B, 16) if (self.training and tg) else None,
-                     **self._fused_head_bwd("vel", tg),
-                         scalars=self.scal[S_VEL_LOSS:S_VEL_LOSS + 2], b_stride=B, b_valid=Breal)
-        self._stack_forward(self.dec_notes, B, states=states, start=self._v("in.start_notes", B, s.Dout), slot=1)
+        side = [h for h in self.heads if h.stream is not None]
+        self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
+        for h in side:
+            with self._on(h.stream):
+                self._head_forward(h, B, Breal, states, tg, want_probs, slot=None)
+        self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs, slot=1)
         self._prefork = None
-        top = self._v(self.dec_notes[-1].prefix + ".hs", T + 1, B, H)[1:]
-        ops.head(0, self.kind, T * B, H, s.Dout, top, self._v("notes.wt", self.np_notes, H), P["dec.notes.out.b"],
-                 target_idx=self._v("in.y_idx", T * B) if tg else None,
-                 row_weight=self._v("in.rw_notes", T * B) if tg else None, grad_scale=1.0,
-                 probs=self._v("out.notes_p", T * B, s.Dout) if want_probs else None,
-                 argmax=self._v("notes.argmax", T * B),
-                 dlogits=self._v("notes.dl", T * B, self.np_notes) if (self.training and tg) else None,
-                     **self._fused_head_bwd("notes", tg),
-                 scalars=self.scal[S_NOTES_LOSS:S_NOTES_LOSS + 2], b_stride=B, b_valid=Breal)
         if not self._branches_stay_forked:
-            self._join(self.s_vel, self.s_instr)
+            self._join(*[h.stream for h in side])
+
+    def _head_forward(self, h, B, Breal, states, tg, want_probs, slot):
+        """cell stack + output Dense / activation / loss / accuracy / argmax of one decoder head (B = padded batch)"""
+        s, P = self.spec, self.P
+        H, n = s.H, h.name
+        start = self._v("in.start_" + n, B, h.layers[0].K)
+        if len(h.layers) > 1 and slot is not None:
+            self._stack_forward(h.layers, B, states=states, start=start, slot=slot)
+        else:
+            for r in h.layers:           # (a stack off the critical stream - the next-notes head - runs layer after layer)
+                self._rec_forward(r, B, start=start, **states(r))
+        top = self._v(h.layers[-1].prefix + ".hs", h.T + 1, B, H)[1:]
+        R = h.T * B
+        tgt = {}
+        if tg:
+            tgt = (dict(target_val=self._v(h.target, R)) if h.kind == 1 else dict(target_idx=self._v(h.target, R)))
+            tgt["row_weight"] = self._v("in.rw_" + n, R)
+        ops.head(h.kind, self.kind, R, H, h.N, top, self._v(n + ".wt", h.NP, H), P[h.out + ".b"], grad_scale=h.weight,
+                 probs=self._v("out.%s_p" % n, R, h.N) if want_probs else None, argmax=self._v(n + ".argmax", R),
+                 dlogits=self._v(n + ".dl", R, h.NP) if (self.training and tg) else None, **self._fused_head_bwd(n, tg),
+                 scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=Breal, **tgt)
 
     # ------------------------------------------------------------------------------------------------------
     # backward
@@ -985,6 +1010,19 @@ class Engine(object):
             return {}
         return dict(wc=self.store[name + ".wc"], dhs=self.store[name + ".dhs"])
 
+    def _head_stack_backward(self, h, B, dstates, slot):
+        """output Dense backward + BPTT through one decoder head's cell stack"""
+        dext = self._head_backward(B, h.name, h.layers[-1], h.N, h.NP, h.out + ".W", h.out + ".b")
+        start = self._v("in.start_" + h.name, B, h.layers[0].K)
+        if len(h.layers) > 1 and slot is not None:
+            self._stack_backward(h.layers, B, dhs_ext=dext, start=start, dstates=dstates, slot=slot)
+            return
+        for r in reversed(h.layers):
+            self._stack_backward([r], B, dhs_ext=dext, start=start, dstates=dstates)
+            if r.lower is not None:
+                self._rec_dx(r, B)
+                dext = self._v(r.prefix + ".dx", r.T, B, self.spec.H)
+
     def _head_backward(self, B, name, r, N, NP, outW, outb):
         """d(logits) -> gradient of the output Dense and of the top cell's h sequence."""
         s, G = self.spec, self.G
@@ -1023,29 +1061,20 @@ class Engine(object):
         # encoder BPTT kernels are resident; it then runs beside them as before.
         self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
         # (one event for the three branches, the notes head's gradient GEMM and the notes stack's lower layers)
-        if self._branches_stay_forked:      # (train step: the velocity / instrument queues go straight on with their own backward)
+        side = [h for h in self.heads if h.stream is not None]
+        if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
             self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
         else:
-            self._fork_with_stack(self.dec_notes, self.s_vel, self.s_instr, also=(self.s_grad,))
-        if s.meta_instrument:
-            with self._on(self.s_instr):
-                dext = self._head_backward(B, "instr", self.dec_instr, s.ID, self.np_instr, "dec.instr.out.W",
-                                           "dec.instr.out.b")
-                self._stack_backward([self.dec_instr], B, dhs_ext=dext, start=self._v("in.start_instr", B, s.ID),
-                                     dstates=dstates)
-        if s.meta_velocity:
-            with self._on(self.s_vel):
-                dext = self._head_backward(B, "vel", self.dec_vel, 1, 16, "dec.vel.out.W", "dec.vel.out.b")
-                self._stack_backward([self.dec_vel], B, dhs_ext=dext, start=self._v("in.start_vel", B, 1), dstates=dstates)
-        dext = self._head_backward(B, "notes", self.dec_notes[-1], s.Dout, self.np_notes, "dec.notes.out.W",
-                                   "dec.notes.out.b")
-        self._stack_backward(self.dec_notes, B, dhs_ext=dext, start=self._v("in.start_notes", B, s.Dout), dstates=dstates,
-                             slot=2)
+            self._fork_with_stack(self.dec_notes, *[h.stream for h in side], also=(self.s_grad,))
+        for h in side:
+            with self._on(h.stream):
+                self._head_stack_backward(h, B, dstates, slot=None)
+        self._head_stack_backward(self.head["notes"], B, dstates, slot=2)
         self._prefork = None
-        self._join(self.s_vel, self.s_instr)
+        self._join(*[h.stream for h in side])
         self._mark("  decoder BPTT")
         deferred, self._deferred = self._deferred, None
-        dcat = self._latent_chain_backward(Breal, B) if self.fused_latent else None
+        dcat = self._latent_chain_backward(Breal, B) if (self.fused_latent and (self.has_pack or self.ncat == 1)) else None
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
         ldc = self.ncat * H
@@ -1061,17 +1090,11 @@ class Engine(object):
             with torch.cuda.stream(self.s_comm):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: three independent branches -------------------------------------------------
-        self._fork_with_stack(self.enc_notes, self.s_vel, self.s_instr)
-        k = 1
-        if s.meta_instrument:
-            with self._on(self.s_instr):
-                self._stack_backward([self.enc_instr], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                     idx=self._v("in.i_idx", V, B))
-            k += 1
-        if s.meta_velocity:
-            with self._on(self.s_vel):
-                self._stack_backward([self.enc_vel], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                     xs=self._v("in.vel", T, B))
+        self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
+        for k, (r, st, src) in enumerate(self.enc_meta, 1):
+            with self._on(st):
+                inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
+                self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc, **inp)
         self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
         self._prefork = None
         if deferred:
@@ -1084,7 +1107,7 @@ class Engine(object):
                 fn()
         # the two gradient queues finish last and together: chained, they would put two cross-queue hops in series - the
         # early finishers are chained into one of them, the other is waited for directly
-        self._join(self.s_vel, self.s_instr, self.s_grad)
+        self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
         self._join(self.s_grad2)
 
     def _latent_backward_unfused(self, Breal, B):
@@ -1130,12 +1153,12 @@ class Engine(object):
         # ---- encoder tail ------------------------------------------------------------------------------
         if s.extra_layer:
             ex = self._v("extra", B, H)
-            src = self._v("pack", B, H) if self.has_pack else self._v("cat", B, H)
+            src = self._v("pack", B, H) if self.has_pack else self._v("cat", B, self.ncat * H)
             ops.tanh_bwd(ex, dt, dt)
-            self._side(lambda dt=dt: (ops.gemm(src, dt, G["enc.extra.W"], H, H, B, trans_a=True, accumulate=True),
+            self._side(lambda dt=dt: (ops.gemm(src, dt, G["enc.extra.W"], s.tail_in, H, B, trans_a=True, accumulate=True),
                                       ops.colsum(dt, B, H, G["enc.extra.b"])))
-            dt2 = self._v("dtail2", B, H)
-            ops.gemm(dt, P["enc.extra.W"], dt2, B, H, H, trans_b=True)
+            dt2 = self._v("dcat", B, s.tail_in) if not self.has_pack else self._v("dtail2", B, H)
+            ops.gemm(dt, P["enc.extra.W"], dt2, B, s.tail_in, H, trans_b=True)
             dt = dt2
         ldc = self.ncat * H
         if self.has_pack:
@@ -1320,7 +1343,8 @@ class Engine(object):
         return self._stager
 
     # hit-count slots of the scalar block (accumulated as counts; everything else as batch-size weighted means)
-    HIT_MASK = (1 << S_NOTES_HITS) | (1 << S_INSTR_HITS) | (1 << S_VEL_HITS) | (1 << S_STYLE_HITS)
+    HIT_MASK = ((1 << S_NOTES_HITS) | (1 << S_INSTR_HITS) | (1 << S_VEL_HITS) | (1 << S_STYLE_HITS) | (1 << S_HELD_HITS) |
+                (1 << S_NEXT_HITS))
 
     def reset_accumulated(self):
         self.acc.zero_()
@@ -1449,6 +1473,12 @@ class Engine(object):
         if s.meta_velocity:
             m["vel_loss"], m["vel_acc"] = v[S_VEL_LOSS], v[S_VEL_HITS] / (B * s.T)
             total += s.w_vel * m["vel_loss"]
+        if s.meta_held:
+            m["held_loss"], m["held_acc"] = v[S_HELD_LOSS], v[S_HELD_HITS] / (B * s.T)
+            total += s.w_held * m["held_loss"]
+        if s.meta_next:
+            m["next_loss"], m["next_acc"] = v[S_NEXT_LOSS], v[S_NEXT_HITS] / (B * s.T)
+            total += s.w_next * m["next_loss"]
         if s.style:
             m["style_loss"], m["style_acc"] = v[S_STYLE_LOSS], v[S_STYLE_HITS] / B
             total += s.w_style * m["style_loss"]
@@ -1460,11 +1490,8 @@ class Engine(object):
         s = self.spec
         Bp = self.pad16(B)
         out = OrderedDict()
-        out["notes"] = self._v("out.notes_p", s.T, Bp, s.Dout)[:, :B].permute(1, 0, 2).cpu().numpy()
-        if s.meta_instrument:
-            out["instr"] = self._v("out.instr_p", s.V, Bp, s.ID)[:, :B].permute(1, 0, 2).cpu().numpy()
-        if s.meta_velocity:
-            out["vel"] = self._v("out.vel_p", s.T, Bp, 1)[:, :B].permute(1, 0, 2).cpu().numpy()
+        for h in self.heads:
+            out[h.name] = self._v("out.%s_p" % h.name, h.T, Bp, h.N)[:, :B].permute(1, 0, 2).cpu().numpy()
         if s.style:
             out["style"] = self._v("style_p", Bp, s.C)[:B].cpu().numpy()
         return out

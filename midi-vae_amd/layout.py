@@ -50,6 +50,12 @@ class ModelSpec:
     epsilon_std: float = 0.01
     lr: float = 2e-4
     optimizer: str = "Adam"
+    # off by default in the reference (settings.py:217,227): held-notes roll through the encoder + a 2-way decoder head
+    # (vae_definition.py:476-480,648-683), a second notes stack predicting the NEXT window (:685-726)
+    meta_held: bool = False
+    w_held: float = 1.0
+    meta_next: bool = False
+    w_next: float = 1.0
 
     def oracle_cfg(self):
         """dict accepted by oracle.vae_oracle.make_cfg (tests only)."""
@@ -73,12 +79,26 @@ class ModelSpec:
     def zin(self):
         return 2 * self.Z if self.history else self.Z
 
+    @property
+    def ncat(self):
+        return 1 + int(self.meta_instrument) + int(self.meta_velocity) + int(self.meta_held)
+
+    @property
+    def has_pack(self):
+        """the pack Dense exists when instrument or velocity rolls are on - the reference's condition repeats meta_instrument and
+        omits meta_held_notes (vae_definition.py:483), reproduced as written"""
+        return self.meta_instrument or self.meta_velocity
+
+    @property
+    def tail_in(self):
+        """width of what the extra Dense (or, without it, the split) receives"""
+        return self.H if self.has_pack else self.ncat * self.H
+
 
 _UNSUPPORTED_SWITCHES = (
-    ("use_embedding", False), ("bidirectional", False), ("teacher_force", False), ("decoder_additional_input", False),
+    ("use_embedding", False), ("bidirectional", False), ("decoder_additional_input", False),
     ("signature_decoder", False), ("composer_decoder_at_notes_output", False),
-    ("composer_decoder_at_instrument_output", False), ("meta_held_notes", False), ("meta_next_notes", False),
-    ("meta_next_notes_teacher_force", False),
+    ("composer_decoder_at_instrument_output", False),
 )
 
 
@@ -116,7 +136,9 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         style=bool(g("include_composer_decoder", False)), w_instr=float(g("meta_instrument_weight", 1.0)),
         w_vel=float(g("meta_velocity_weight", 1.0)), w_style=float(g("composer_weight", 1.0)), beta=float(g("beta", 0.01)),
         prior_mean=float(g("prior_mean", 0.0)), prior_std=float(g("prior_std", 1.0)),
-        epsilon_std=float(g("epsilon_std", 1.0)), lr=float(g("learning_rate", 0.001)), optimizer=opt)
+        epsilon_std=float(g("epsilon_std", 1.0)), lr=float(g("learning_rate", 0.001)), optimizer=opt,
+        meta_held=bool(g("meta_held_notes", False)), w_held=float(g("meta_held_notes_weight", 1.0)),
+        meta_next=bool(g("meta_next_notes", False)), w_next=float(g("meta_next_notes_weight", 1.0)))
     # the asserts of reference vae_definition.py:177-208
     assert s.Le > 0 and s.Ld > 0 and s.T > 0 and s.H > 0 and s.Z > 0 and s.beta > 0
     assert int(g("input_length", s.T)) > 0
@@ -130,6 +152,21 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         assert s.w_vel > 0 and g("meta_velocity_length", 0) > 0
         if int(g("meta_velocity_length")) != s.T:
             raise NotImplementedError("meta_velocity_length != output_length")
+    if s.meta_held:
+        assert s.w_held > 0 and g("meta_held_notes_length", 0) > 0
+        if int(g("meta_held_notes_length")) != s.T:
+            raise NotImplementedError("meta_held_notes_length != output_length")
+        if g("meta_held_notes_activation", "softmax") != "softmax":
+            raise NotImplementedError("meta_held_notes_activation: only 'softmax' is implemented")
+        if not s.has_pack and not s.extra_layer:
+            raise NotImplementedError("meta_held_notes without instrument / velocity rolls and without extra_layer: the reference "
+                                      "then splits an un-packed 2H vector (vae_definition.py:483-492), which is not built")
+    if s.meta_next:
+        assert s.w_next > 0 and g("meta_next_notes_output_length", 0) > 0
+        if int(g("meta_next_notes_output_length")) != s.T:
+            raise NotImplementedError("meta_next_notes_output_length != output_length")
+    # (teacher forcing - teacher_force / meta_next_notes_teacher_force - only changes what the unused readout state holds,
+    #  the cell graph never reads it, so the switch is accepted and has no effect, as in the reference)
     if s.style:
         assert 0 < s.C <= min(s.Z, 64)
     if s.H % 64 or s.H > 256:
@@ -149,6 +186,11 @@ def dec_init_blocks(spec: ModelSpec):
         out += ["dec.instr.init.%d" % s for s in range(spec.nstate)]
     if spec.meta_velocity:
         out += ["dec.vel.init.%d" % s for s in range(spec.nstate)]
+    if spec.meta_held:
+        out += ["dec.held.init.%d" % s for s in range(spec.nstate)]
+    if spec.meta_next:
+        for l in range(spec.Ld):
+            out += ["dec.next.init.%d.%d" % (l, s) for s in range(spec.nstate)]
     return out
 
 
@@ -193,11 +235,14 @@ class ParamLayout:
         if spec.meta_velocity:
             rnn("enc.vel", 1, "enc")
             ncat += 1
-        if spec.meta_instrument or spec.meta_velocity:
+        if spec.meta_held:
+            rnn("enc.held", 2, "enc")
+            ncat += 1
+        if spec.has_pack:
             add("enc.pack.W", (ncat * H, H), "enc")
             add("enc.pack.b", (H,), "enc")
         if spec.extra_layer:
-            add("enc.extra.W", (H, H), "enc")
+            add("enc.extra.W", (spec.tail_in, H), "enc")
             add("enc.extra.b", (H,), "enc")
         h1 = H // 2 if spec.split else H
         h2 = H - H // 2 if spec.split else H
@@ -226,6 +271,15 @@ class ParamLayout:
             rnn("dec.vel.cell", 1, "dec")
             add("dec.vel.out.W", (H, 1), "dec")
             add("dec.vel.out.b", (1,), "dec")
+        if spec.meta_held:
+            rnn("dec.held.cell", 2, "dec")
+            add("dec.held.out.W", (H, 2), "dec")
+            add("dec.held.out.b", (2,), "dec")
+        if spec.meta_next:
+            for l in range(spec.Ld):
+                rnn("dec.next.%d" % l, spec.Dout if l == 0 else H, "dec")
+            add("dec.next.out.W", (H, spec.Dout), "dec")
+            add("dec.next.out.b", (spec.Dout,), "dec")
         L.total = cur
         return L
 

@@ -74,6 +74,8 @@ class _Shared(object):
         self.params_host = init_params(spec, seed)     # authoritative copy until an engine exists
         self.engine = None
         self.rng = np.random.default_rng(seed + 1)
+        self.teacher_force = False        # extra ground-truth inputs in the lists (no effect on the graph)
+        self.next_teacher_force = False
         self.dp = None                    # dp.DataParallel: minibatches are sharded over its ranks inside fit
 
     def get_engine(self, batch, training=True):
@@ -105,6 +107,12 @@ class _Shared(object):
 
     def epsilon(self, n):
         return (self.rng.standard_normal((n, self.spec.Z)) * self.spec.epsilon_std).astype(np.float32)
+
+    def head_names(self):
+        """decoder outputs in the reference's order (vae_definition.py:341-351): notes, instrument, velocity, held, next"""
+        sp = self.spec
+        return (["notes"] + (["instr"] if sp.meta_instrument else []) + (["vel"] if sp.meta_velocity else []) +
+                (["held"] if sp.meta_held else []) + (["next"] if sp.meta_next else []))
 
 
 class _ModelView(object):
@@ -176,21 +184,23 @@ class Encoder(_ModelView):
         I = x[i] if sp.meta_instrument else None
         i += int(sp.meta_instrument)
         V = x[i] if sp.meta_velocity else None
-        return X, I, V
+        i += int(sp.meta_velocity)
+        D = x[i] if sp.meta_held else None
+        return X, I, V, D
 
     def predict(self, x, batch_size=32, verbose=0, device=False):
         """Sampled z for every window (fresh epsilon per call, reference vae_definition.py:498-502).  The batches run back to
         back on the device; z is read back once.  ``device=True``: no read-back at all - a DeviceLatent for the history slot of
         the next fit / evaluate (the history pre-pass of reference vae_training.py:788-798, kept in HBM)."""
         import torch
-        X, I, Vel = self._unpack(x)
+        X, I, Vel, Held = self._unpack(x)
         n = np.asarray(X).shape[0]
         eng = self._s.get_engine(batch_size)
         st = eng.stager()
         out = torch.empty((n, self._s.spec.Z), dtype=torch.float32, device=eng.device)
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
-            B = st.stage(lo, hi, X=X, I=I, Vel=Vel, eps=self._s.epsilon(hi - lo))
+            B = st.stage(lo, hi, X=X, I=I, Vel=Vel, Held=Held, eps=self._s.epsilon(hi - lo))
             out[lo:hi].copy_(eng.encode(B))
         if device:
             return DeviceLatent(out)
@@ -204,32 +214,33 @@ class Decoder(_ModelView):
     name = "decoder"
 
     def _unpack(self, x):
-        """[start, z, (history), instr_start, vel_start]  (reference vae_definition.py:820-865)"""
+        """[start, z, (ground truth), (history), instr_start, vel_start, held_start, next_start, (next ground truth)]
+        (reference vae_definition.py:253-327, built by prepare_decoder_input :820-865)"""
         sp = self._s.spec
         x = _as_list(x)
         start, z = x[0], x[1]
-        i = 2
+        i = 2 + int(bool(self._s.teacher_force))           # (the ground-truth input feeds the unused readout state: SURVEY F9)
         hist = x[i] if sp.history else None
         i += int(sp.history)
-        istart = x[i] if sp.meta_instrument else None
-        i += int(sp.meta_instrument)
-        vstart = x[i] if sp.meta_velocity else None
-        return start, z, hist, istart, vstart
+        res = dict(start_notes=start, z=z, hist=hist)
+        for flag, key in ((sp.meta_instrument, "start_instr"), (sp.meta_velocity, "start_vel"), (sp.meta_held, "start_held"),
+                          (sp.meta_next, "start_next")):
+            if flag:
+                res[key] = x[i]
+                i += 1
+        return res
 
     def _run(self, x, batch_size, want_probs=True):
         sp = self._s.spec
-        start, z, hist, istart, vstart = self._unpack(x)
-        z = np.asarray(z)
+        a = self._unpack(x)
+        z = np.asarray(a.pop("z"))
         n = z.shape[0]
         eng = self._s.get_engine(batch_size)
         outs, idxs = [], []
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
             B = hi - lo
-            eng.stage_decoder_inputs(B, hist=None if hist is None else np.asarray(hist)[lo:hi], z=z[lo:hi],
-                                     start_notes=np.asarray(start)[lo:hi],
-                                     start_instr=None if istart is None else np.asarray(istart)[lo:hi],
-                                     start_vel=None if vstart is None else np.asarray(vstart)[lo:hi])
+            eng.stage_decoder_inputs(B, z=z[lo:hi], **{k: (None if v is None else np.asarray(v)[lo:hi]) for k, v in a.items()})
             eng.decode(B, want_probs=want_probs)
             if want_probs:
                 outs.append(eng.outputs(B))
@@ -237,13 +248,8 @@ class Decoder(_ModelView):
         return outs, np.concatenate(idxs, 0) if idxs else np.zeros((0, sp.T), np.uint8)
 
     def predict(self, x, batch_size=32, verbose=0):
-        sp = self._s.spec
         outs, _ = self._run(x, batch_size)
-        res = [np.concatenate([o["notes"] for o in outs], 0)]
-        if sp.meta_instrument:
-            res.append(np.concatenate([o["instr"] for o in outs], 0))
-        if sp.meta_velocity:
-            res.append(np.concatenate([o["vel"] for o in outs], 0))
+        res = [np.concatenate([o[h] for o in outs], 0) for h in self._s.head_names()]
         return res if len(res) > 1 else res[0]
 
     def predict_note_indices(self, x, batch_size=32):
@@ -261,8 +267,7 @@ class Autoencoder(_ModelView):
 
     # ---- names -------------------------------------------------------------------------------------------
     def _decoder_outputs(self):
-        sp = self._s.spec
-        return ["notes"] + (["instr"] if sp.meta_instrument else []) + (["vel"] if sp.meta_velocity else [])
+        return self._s.head_names()
 
     @property
     def metrics_names(self):
@@ -294,57 +299,59 @@ class Autoencoder(_ModelView):
 
     # ---- list unpacking (orders of reference vae_definition.py:924-1040) -------------------------------------
     def _unpack_x(self, x):
+        """[X, Y_start, (Y ground truth), H, instr_start, I, vel_start, V, held_start, D, next_start, (next ground truth)]
+        (reference vae_definition.py:924-1028) -> dict of Stager.stage keyword arguments"""
         sp = self._s.spec
         x = _as_list(x)
-        X, start = x[0], x[1]
-        i = 2
-        hist = x[i] if sp.history else None
+        a = dict(X=x[0], start_notes=x[1])
+        i = 2 + int(bool(self._s.teacher_force))
+        a["hist"] = x[i] if sp.history else None
         i += int(sp.history)
-        istart = I = vstart = V = None
-        if sp.meta_instrument:
-            istart, I = x[i], x[i + 1]
-            i += 2
-        if sp.meta_velocity:
-            vstart, V = x[i], x[i + 1]
-        return X, start, hist, istart, I, vstart, V
+        for flag, k_start, k_in in ((sp.meta_instrument, "start_instr", "I"), (sp.meta_velocity, "start_vel", "Vel"),
+                                    (sp.meta_held, "start_held", "Held")):
+            if flag:
+                a[k_start], a[k_in] = x[i], x[i + 1]
+                i += 2
+        if sp.meta_next:
+            a["start_next"] = x[i]
+        return a
 
     def _unpack_y(self, y):
+        """[Y, I, V, D, N, C] (reference vae_definition.py:926-1031) -> targets as Stager.stage keyword arguments (the instrument,
+        velocity and held-notes targets are the encoder inputs themselves)"""
         sp = self._s.spec
         y = _as_list(y)
-        Y = y[0]
-        i = 1 + int(sp.meta_instrument) + int(sp.meta_velocity)
-        C = y[i] if sp.style else None
-        return Y, C
+        i = 1 + int(sp.meta_instrument) + int(sp.meta_velocity) + int(sp.meta_held)
+        t = dict(Y=y[0])
+        if sp.meta_next:
+            t["Next"] = y[i]
+            i += 1
+        if sp.style:
+            t["C_"] = y[i]
+        return t
 
     def _unpack_w(self, w, n):
-        """Keras maps a ``sample_weight`` LIST to the model's outputs BY POSITION: [notes, instrument, velocity, style].  (The
-        reference builds its list as notes / style / instrument / velocity, vae_definition.py:930-1004 - every entry but the
-        first is all-ones of shape (n,), so the mismatch is invisible there; it is applied here as Keras would apply it.)
-        Returns (w_notes (n,T), w_instr, w_vel, w_style); None = all ones."""
+        """Keras maps a ``sample_weight`` LIST to the model's outputs BY POSITION: [notes, instrument, velocity, held, next,
+        style].  (The reference builds its list as notes / style / ... / instrument / velocity / held / next,
+        vae_definition.py:930-1028 - every entry but the first is all-ones of shape (n,), so the mismatch is invisible there; it
+        is applied here as Keras would apply it.)  Returns Stager.stage keyword arguments; all-ones weights are dropped."""
         sp = self._s.spec
         if w is None:
-            return None, None, None, None
+            return {}
         w = list(w) if isinstance(w, (list, tuple)) else [w]
-        outs = (["notes"] + (["instr"] if sp.meta_instrument else []) + (["vel"] if sp.meta_velocity else []) +
-                (["style"] if sp.style else []))
+        outs = self._s.head_names() + (["style"] if sp.style else [])
         if len(w) != len(outs):
             raise ValueError("sample_weight has %d entries for the %d outputs %s" % (len(w), len(outs), outs))
-        by = dict(zip(outs, w))
-        wn = np.asarray(by["notes"])
-        if wn.shape != (n, sp.T):
-            raise ValueError("the notes output uses sample_weight_mode='temporal': weights of shape %s expected, got %s"
-                             % ((n, sp.T), wn.shape))
-        res = [None if np.all(wn == 1) else wn]
-        for k in ("instr", "vel", "style"):
-            v = by.get(k)
-            if v is not None:
-                v = np.asarray(v)
-                if v.shape != (n,):
-                    raise ValueError("sample_weight of output %r must have shape (%d,), got %s" % (k, n, v.shape))
-                if np.all(v == 1):
-                    v = None
-            res.append(v)
-        return tuple(res)
+        res = {}
+        for k, v in zip(outs, w):
+            v = np.asarray(v)
+            want = (n, sp.T) if k == "notes" else (n,)
+            if v.shape != want:
+                raise ValueError("sample_weight of output %r must have shape %s (the notes output uses sample_weight_mode="
+                                 "'temporal'), got %s" % (k, want, v.shape))
+            if not np.all(v == 1):
+                res["w_" + k] = v
+        return res
 
     def _dp(self, dp):
         dp = dp if dp is not None else self._s.dp
@@ -373,14 +380,15 @@ class Autoencoder(_ModelView):
         from .dp import shard_bounds
         from .staging import Norm
         sp = self._s.spec
-        X, start, hist, istart, I, vstart, V = self._unpack_x(x)
-        Y, Cc = self._unpack_y(y)
-        n = np.asarray(X).shape[0]
-        wn, wi, wv, ws = self._unpack_w(sample_weight, n)
+        a = self._unpack_x(x)
+        a.update(self._unpack_y(y))
+        n = np.asarray(a["X"]).shape[0]
+        ws = self._unpack_w(sample_weight, n)
+        a.update(ws)
         dp = self._dp(dp)
         eng = self._s.get_engine(batch_size, training=True)
         st = eng.stager()
-        hist_host, hist_dev = self._history_source(hist)
+        a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
         history = History()
         keys = self._history_keys()
         for e in range(epochs):
@@ -388,12 +396,10 @@ class Autoencoder(_ModelView):
             for lo in range(0, n, batch_size):
                 hi = min(n, lo + batch_size)
                 eps = self._s.epsilon(hi - lo)               # one draw per GLOBAL minibatch: every rank holds the same stream
-                a, b = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
-                if b > a:
-                    norm = Norm.of(lo, hi, sp.T, wn, wi, wv, ws)
-                    B = st.stage(lo + a, lo + b, X=X, I=I, Vel=V, eps=eps[a:b], hist=hist_host, hist_dev=hist_dev, Y=Y, C_=Cc,
-                                 start_notes=start, start_instr=istart, start_vel=vstart, w_notes=wn, w_instr=wi, w_vel=wv,
-                                 w_style=ws, norm=norm)
+                a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
+                if b0 > a0:
+                    norm = Norm.of(lo, hi, sp.T, **ws)
+                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, **a)
                     eng.train_step(B, allreduce=dp.allreduce_grads if dp is not None else allreduce)
                     eng.accumulate_metrics(hi - lo)
                 else:
@@ -407,19 +413,18 @@ class Autoencoder(_ModelView):
     def _forward_all(self, x, y, batch_size, want_probs):
         from .staging import Norm
         sp = self._s.spec
-        X, start, hist, istart, I, vstart, V = self._unpack_x(x)
-        Y, Cc = self._unpack_y(y) if y is not None else (None, None)
-        n = np.asarray(X).shape[0]
+        a = self._unpack_x(x)
+        if y is not None:
+            a.update(self._unpack_y(y))
+        n = np.asarray(a["X"]).shape[0]
         eng = self._s.get_engine(batch_size)
         st = eng.stager()
-        hist_host, hist_dev = self._history_source(hist)
+        a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
         outs = []
         eng.reset_accumulated()
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
-            B = st.stage(lo, hi, X=X, I=I, Vel=V, eps=self._s.epsilon(hi - lo), hist=hist_host, hist_dev=hist_dev, Y=Y, C_=Cc,
-                         start_notes=start, start_instr=istart, start_vel=vstart,
-                         norm=Norm.of(lo, hi, sp.T) if Y is not None else None)
+            B = st.stage(lo, hi, eps=self._s.epsilon(hi - lo), norm=Norm.of(lo, hi, sp.T) if y is not None else None, **a)
             if y is None:
                 eng._have_targets = False
                 eng.scal.zero_()
@@ -449,13 +454,7 @@ class Autoencoder(_ModelView):
     def predict(self, x, batch_size=32, verbose=0):
         sp = self._s.spec
         _, outs, _ = self._forward_all(x, None, batch_size, want_probs=True)
-        res = [np.concatenate([o["notes"] for o in outs], 0)]
-        if sp.meta_instrument:
-            res.append(np.concatenate([o["instr"] for o in outs], 0))
-        if sp.meta_velocity:
-            res.append(np.concatenate([o["vel"] for o in outs], 0))
-        if sp.style:
-            res.append(np.concatenate([o["style"] for o in outs], 0))
+        res = [np.concatenate([o[h] for o in outs], 0) for h in self._s.head_names() + (["style"] if sp.style else [])]
         return res if len(res) > 1 else res[0]
 
 
@@ -471,6 +470,8 @@ class VAE(object):
             setattr(self, k, v)
         self.spec = spec_from_create_kwargs(kw)
         shared = _Shared(self.spec, compute_dtype, seed, device)
+        shared.teacher_force = bool(kw.get("teacher_force", False))
+        shared.next_teacher_force = bool(kw.get("meta_next_notes_teacher_force", False))
         self._shared = shared
         self.encoder = Encoder(shared)
         self.decoder = Decoder(shared)

@@ -30,11 +30,13 @@ class Norm(object):
     """Normalisers of one GLOBAL minibatch (Keras weighted objectives, SURVEY Appendix A.7: score*w / mean(w != 0), then
     the mean over the remaining axes): B windows, and the number of non-zero sample weights per output."""
 
-    def __init__(self, B, nz_notes, nz_instr, nz_vel, nz_style):
+    def __init__(self, B, nz_notes, nz_instr, nz_vel, nz_style, nz_held=None, nz_next=None):
         self.B, self.nz_notes, self.nz_instr, self.nz_vel, self.nz_style = int(B), nz_notes, nz_instr, nz_vel, nz_style
+        self.nz_held = int(B) if nz_held is None else nz_held
+        self.nz_next = int(B) if nz_next is None else nz_next
 
     @staticmethod
-    def of(lo, hi, T, w_notes=None, w_instr=None, w_vel=None, w_style=None):
+    def of(lo, hi, T, w_notes=None, w_instr=None, w_vel=None, w_style=None, w_held=None, w_next=None):
         B = hi - lo
 
         def nz(w, full):
@@ -43,7 +45,7 @@ class Norm(object):
             c = int(np.count_nonzero(np.asarray(w)[lo:hi]))
             return max(c, 1)
 
-        return Norm(B, nz(w_notes, B * T), nz(w_instr, B), nz(w_vel, B), nz(w_style, B))
+        return Norm(B, nz(w_notes, B * T), nz(w_instr, B), nz(w_vel, B), nz(w_style, B), nz(w_held, B), nz(w_next, B))
 
 
 def _host_kind(a):
@@ -153,7 +155,7 @@ class Stager(object):
     # ---- one minibatch ------------------------------------------------------------------------------------------
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
-              norm=None, batch_local=False):
+              norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
@@ -176,6 +178,11 @@ class Stager(object):
             self._rows_u8(k, "in.i_idx", I, lo, hi, V, s.ID, Bp, 0, "instrument input")
         if s.meta_velocity:
             self._rows_f32(k, "in.vel", Vel, lo, hi, T, Bp)
+        if s.meta_held:
+            self._rows_u8(k, "in.d_idx", Held, lo, hi, T, 2, Bp, 0, "held-notes input")
+            self._rows_bm(k, "in.start_held", start_held, lo, hi, 2, Bp)
+        if s.meta_next:
+            self._rows_bm(k, "in.start_next", start_next, lo, hi, s.Dout, Bp)
         self._rows_bm(k, "in.eps", eps, 0, B, s.Z, Bp)
         self._rows_bm(k, "in.start_notes", start_notes, lo, hi, s.Dout, Bp)
         if s.meta_instrument:
@@ -188,7 +195,7 @@ class Stager(object):
             self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
         have_targets = Y is not None
         if have_targets:
-            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style)
+            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next)
             self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
             if w_notes is None:
                 out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
@@ -200,6 +207,11 @@ class Stager(object):
                 self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
             if s.meta_velocity:
                 self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
+            if s.meta_held:
+                self._per_window(k, "in.rw_held", w_held, lo, hi, T, Bp, 1.0 / (nm.nz_held * T))
+            if s.meta_next:
+                self._per_window(k, "in.rw_next", w_next, lo, hi, T, Bp, 1.0 / (nm.nz_next * T))
+                self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
             if s.style:
                 self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
                 self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 0, "style target")

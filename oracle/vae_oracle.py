@@ -45,6 +45,7 @@ DEFAULT_CFG = dict(
     Le=2, Ld=2, meta_instrument=True, meta_velocity=True, extra_layer=True, split=True, history=True,
     style=True, w_instr=0.1, w_vel=1.0, w_style=0.1, beta=0.1, prior_mean=0.0, prior_std=1.0,
     lr=2e-4, optimizer="Adam",
+    meta_held=False, w_held=1.0, meta_next=False, w_next=1.0,      # reference settings.py:217,227 (off by default)
 )
 
 
@@ -79,10 +80,14 @@ def param_shapes(cfg):
     if cfg["meta_velocity"]:
         rnn("enc.vel", 1)
         ncat += 1
-    if cfg["meta_instrument"] or cfg["meta_velocity"]:      # reference :483 (condition as written)
+    if cfg["meta_held"]:                                    # reference :476-480: RNN over the (T,2) held-notes roll
+        rnn("enc.held", 2)
+        ncat += 1
+    packed = cfg["meta_instrument"] or cfg["meta_velocity"]   # reference :483 (condition as written: held alone does not pack)
+    if packed:
         P["enc.pack.W"], P["enc.pack.b"] = (ncat * H, H), (H,)
     if cfg["extra_layer"]:
-        P["enc.extra.W"], P["enc.extra.b"] = (H, H), (H,)
+        P["enc.extra.W"], P["enc.extra.b"] = (H if packed else ncat * H, H), (H,)
     h1 = H // 2 if cfg["split"] else H
     h2 = H - H // 2 if cfg["split"] else H
     P["enc.zmean.W"], P["enc.zmean.b"] = (h1, Z), (Z,)
@@ -106,6 +111,16 @@ def param_shapes(cfg):
         init("dec.vel.init")
         rnn("dec.vel.cell", 1)
         P["dec.vel.out.W"], P["dec.vel.out.b"] = (H, 1), (1,)
+    if cfg["meta_held"]:                                    # reference :648-683: one cell, Dense(2, softmax)
+        init("dec.held.init")
+        rnn("dec.held.cell", 2)
+        P["dec.held.out.W"], P["dec.held.out.b"] = (H, 2), (2,)
+    if cfg["meta_next"]:                                    # reference :685-726: a second Ld-layer stack, Dense(D, softmax)
+        for l in range(cfg["Ld"]):
+            init("dec.next.init.%d" % l)
+        for l in range(cfg["Ld"]):
+            rnn("dec.next.%d" % l, cfg["Dout"] if l == 0 else H)
+        P["dec.next.out.W"], P["dec.next.out.b"] = (H, cfg["Dout"]), (cfg["Dout"],)
     return P
 
 
@@ -257,8 +272,8 @@ class OracleVAE(object):
         return hs, cs, acts
 
     # ---- encoder --------------------------------------------------------------------------------
-    def encode(self, p, X, I=None, Vel=None, eps=None, cache=None):
-        """X (B,T,Din), I (B,V,ID), Vel (B,T,1), eps (B,Z) ALREADY scaled by epsilon_std.
+    def encode(self, p, X, I=None, Vel=None, eps=None, cache=None, Held=None):
+        """X (B,T,Din), I (B,V,ID), Vel (B,T,1), Held (B,T,2) one-hot, eps (B,Z) ALREADY scaled by epsilon_std.
         Returns z (B,Z); fills cache with mu, logvar and everything backward needs."""
         cfg, dt = self.cfg, self.dtype
         c = {} if cache is None else cache
@@ -279,6 +294,11 @@ class OracleVAE(object):
             xv = np.asarray(Vel, dt).transpose(1, 0, 2)
             hs, cs, acts = self._enc_rnn(p, "enc.vel", xv)
             c["enc_vel"] = (xv, hs, cs, acts)
+            feats.append(hs[-1])
+        if cfg["meta_held"]:
+            xd = np.asarray(Held, dt).transpose(1, 0, 2)
+            hs, cs, acts = self._enc_rnn(p, "enc.held", xd)
+            c["enc_held"] = (xd, hs, cs, acts)
             feats.append(hs[-1])
         h = np.concatenate(feats, axis=1)
         c["cat"] = h
@@ -340,6 +360,15 @@ class OracleVAE(object):
             lg = self._dec_head(p, ["dec.vel.cell"], ["dec.vel.init"], "dec.vel.out",
                                 np.asarray(starts["vel"], dt).reshape(-1, 1), zh, cfg["T"], c, "dec_vel")
             out["vel"] = sigmoid(lg).transpose(1, 0, 2)
+        if cfg["meta_held"]:
+            lg = self._dec_head(p, ["dec.held.cell"], ["dec.held.init"], "dec.held.out",
+                                np.asarray(starts.get("held", np.zeros((z.shape[0], 2))), dt), zh, cfg["T"], c, "dec_held")
+            out["held"] = softmax(lg).transpose(1, 0, 2)
+        if cfg["meta_next"]:
+            lg = self._dec_head(p, ["dec.next.%d" % l for l in range(Ld)], ["dec.next.init.%d" % l for l in range(Ld)],
+                                "dec.next.out", np.asarray(starts.get("next", np.zeros((z.shape[0], cfg["Dout"]))), dt), zh,
+                                cfg["T"], c, "dec_next")
+            out["next"] = softmax(lg).transpose(1, 0, 2)
         return out
 
     # ---- full forward with losses ---------------------------------------------------------------
@@ -350,10 +379,12 @@ class OracleVAE(object):
         cfg, dt = self.cfg, self.dtype
         c = {}
         B = np.asarray(batch["X"]).shape[0]
-        z = self.encode(p, batch["X"], batch.get("I"), batch.get("Vel"), eps, c)
+        z = self.encode(p, batch["X"], batch.get("I"), batch.get("Vel"), eps, c, Held=batch.get("Held"))
         starts = dict(notes=batch.get("start_notes", np.zeros((B, cfg["Dout"]))),
                       instr=batch.get("start_instr", np.zeros((B, cfg["ID"]))),
-                      vel=batch.get("start_vel", np.zeros((B,))))
+                      vel=batch.get("start_vel", np.zeros((B,))),
+                      held=batch.get("start_held", np.zeros((B, 2))),
+                      next=batch.get("start_next", np.zeros((B, cfg["Dout"]))))
         c["starts"] = starts
         out = self.decode(p, z, batch.get("Hist", np.zeros((B, cfg["Z"]))), starts, c)
         c["out"] = out
@@ -388,6 +419,22 @@ class OracleVAE(object):
             c["g_vel"] = g[:, None] / cfg["T"] * np.ones((1, cfg["T"]))
             m["vel_acc"] = np.mean(np.round(out["vel"]) == Vt)      # Keras binary_accuracy
             total = total + cfg["w_vel"] * m["vel_loss"]
+        if cfg["meta_held"]:                                 # target = the held-notes roll itself (reference :1006-1016)
+            Dt = np.asarray(batch["Held"], dt)
+            wh = np.asarray(batch.get("w_held", ones), dt)
+            sc = np.mean(_cce(out["held"], Dt), axis=1)
+            m["held_loss"], g = _weighted_mean(sc, wh)
+            c["g_held"] = g[:, None] / cfg["T"] * np.ones((1, cfg["T"]))
+            m["held_acc"] = np.mean(np.argmax(out["held"], -1) == np.argmax(Dt, -1))
+            total = total + cfg["w_held"] * m["held_loss"]
+        if cfg["meta_next"]:                                 # target = the NEXT window's notes (reference :882-891,1018-1028)
+            Nt = np.asarray(batch["Next"], dt)
+            wx = np.asarray(batch.get("w_next", ones), dt)
+            sc = np.mean(_cce(out["next"], Nt), axis=1)
+            m["next_loss"], g = _weighted_mean(sc, wx)
+            c["g_next"] = g[:, None] / cfg["T"] * np.ones((1, cfg["T"]))
+            m["next_acc"] = np.mean(np.argmax(out["next"], -1) == np.argmax(Nt, -1))
+            total = total + cfg["w_next"] * m["next_loss"]
         if cfg["style"]:
             Ct = np.asarray(batch["C"], dt)
             ws = np.asarray(batch.get("w_style", ones), dt)
@@ -460,6 +507,14 @@ class OracleVAE(object):
             dl = (2.0 * (pv - Vt) * pv * (1.0 - pv) * (cfg["w_vel"] * c["g_vel"])[..., None]).transpose(1, 0, 2)
             self._dec_head_backward(p, g, c["dec_vel"], dl, "dec.vel.out",
                                     np.asarray(c["starts"]["vel"], dt).reshape(-1, 1), dzh)
+        if cfg["meta_held"]:
+            Dt = np.asarray(b["Held"], dt)
+            dl = (_cce_grad_logits(out["held"], Dt) * (cfg["w_held"] * c["g_held"])[..., None]).transpose(1, 0, 2)
+            self._dec_head_backward(p, g, c["dec_held"], dl, "dec.held.out", np.asarray(c["starts"]["held"], dt), dzh)
+        if cfg["meta_next"]:
+            Nt = np.asarray(b["Next"], dt)
+            dl = (_cce_grad_logits(out["next"], Nt) * (cfg["w_next"] * c["g_next"])[..., None]).transpose(1, 0, 2)
+            self._dec_head_backward(p, g, c["dec_next"], dl, "dec.next.out", np.asarray(c["starts"]["next"], dt), dzh)
         dz = dzh[:, :Z].copy()
         if cfg["style"]:
             Ct = np.asarray(b["C"], dt)
@@ -489,6 +544,9 @@ class OracleVAE(object):
             k += H
         if cfg["meta_velocity"]:
             self._enc_rnn_backward(p, g, "enc.vel", c["enc_vel"], None, dh[:, k:k + H], False)
+            k += H
+        if cfg["meta_held"]:
+            self._enc_rnn_backward(p, g, "enc.held", c["enc_held"], None, dh[:, k:k + H], False)
             k += H
         dext, dlast = None, d_notes
         for l in range(cfg["Le"] - 1, -1, -1):

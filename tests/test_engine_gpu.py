@@ -37,16 +37,19 @@ def _problem(cell, B, seed=0, H=64, Z=32, T=12, V=4, C=2, **kw):
     eps = (rng.standard_normal((B, Z)) * spec.epsilon_std).astype(np.float32)
     c_idx = rng.integers(0, C, (B,)).astype(np.uint8)
     w_notes = np.where(x_idx == spec.Dout - 1, 0.5, 1.0)
+    d_idx = (rng.random((B, T)) < 0.4).astype(np.uint8)                   # held-notes roll (reference import_midi.py:267-286)
+    n_idx = rng.integers(0, spec.Dout, (B, T)).astype(np.uint8)          # the next window's notes
     batch = dict(X=_onehot(x_idx, spec.Din), I=_onehot(i_idx, spec.ID), Vel=vel[..., None].astype(np.float64),
-                 Hist=hist.astype(np.float64), Y=_onehot(x_idx, spec.Dout), C=_onehot(c_idx, C), w_notes=w_notes)
-    raw = dict(x_idx=x_idx, i_idx=i_idx, vel=vel, hist=hist, eps=eps, c_idx=c_idx, w_notes=w_notes)
+                 Hist=hist.astype(np.float64), Y=_onehot(x_idx, spec.Dout), C=_onehot(c_idx, C), w_notes=w_notes,
+                 Held=_onehot(d_idx, 2), Next=_onehot(n_idx, spec.Dout))
+    raw = dict(x_idx=x_idx, i_idx=i_idx, vel=vel, hist=hist, eps=eps, c_idx=c_idx, w_notes=w_notes, d_idx=d_idx, n_idx=n_idx)
     return spec, params, batch, raw
 
 
 def _stage(eng, raw, B):
-    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"])
+    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"], d_idx=raw["d_idx"])
     eng.stage_decoder_inputs(B, hist=raw["hist"])
-    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"])
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"])
 
 
 def _rel_l2(a, b):
@@ -384,12 +387,17 @@ def test_baseline_config0_elbo_within_1e3_of_oracle(cell):
 
 @pytest.mark.parametrize("kw", [dict(meta_instrument=False, meta_velocity=False), dict(split=False), dict(extra_layer=False),
                                 dict(history=False), dict(C=4), dict(Le=3, Ld=1), dict(Le=1, Ld=3, meta_velocity=False),
-                                dict(style=False), dict(extra_layer=False, split=False, meta_instrument=False)])
+                                dict(style=False), dict(extra_layer=False, split=False, meta_instrument=False),
+                                dict(meta_held=True, w_held=0.7), dict(meta_next=True, w_next=0.3),
+                                dict(meta_held=True, meta_next=True, Ld=1, C=3),
+                                dict(meta_held=True, meta_instrument=False, meta_velocity=False)])
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 def test_model_switches_match_oracle(cell, kw):
     """The settings.py switches that change the graph around the latent and the stacks (no meta encoders / decoders and so no
-    pack Dense, un-split or missing extra Dense, no history input, 4 styles, no style head, 1- and 3-layer stacks): losses and
-    every gradient of one forward + backward pass against the oracle in f32 - also the fused latent chain's variants."""
+    pack Dense, un-split or missing extra Dense, no history input, 4 styles, no style head, 1- and 3-layer stacks; the held-notes
+    roll + head and the next-notes head of reference vae_definition.py:476-480,648-726, alone - where the reference's pack-Dense
+    condition does not fire and the extra Dense takes the 2H concatenation - and together): losses and every gradient of one
+    forward + backward pass against the oracle in f32 - also the fused latent chain's variants."""
     B = 8
     spec, params, batch, raw = _problem(cell, B, seed=3, H=64, Z=16, T=8, **kw)
     if not spec.history:
@@ -400,9 +408,9 @@ def test_model_switches_match_oracle(cell, kw):
     g_o = orc.backward(p64, cache)
     eng = Engine(spec, max_batch=B, dtype="f32", seed=0)
     eng.set_params(params)
-    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"])
+    eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"], d_idx=raw["d_idx"])
     eng.stage_decoder_inputs(B, hist=raw["hist"] if spec.history else None)
-    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"])
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"])
     eng.forward_backward(B)
     m, g = eng.metrics(B), eng.get_grads()
     for k in m_o:

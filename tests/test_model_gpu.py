@@ -92,3 +92,57 @@ def test_weights_survive_engine_regrowth(tmp_path):
     m._shared.rng = np.random.default_rng(0)
     z2 = m.encoder.predict(enc_in, batch_size=20)          # bigger batch -> engine is rebuilt, weights carried over
     assert np.allclose(z1[:4], z2[:4], atol=1e-5)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_held_and_next_heads_through_the_reference_lists(cell):
+    """meta_held_notes + meta_next_notes (+ the teacher-forcing switches, which add inputs but do not reach the cell graph -
+    SURVEY F9) through the reference's own list layout (vae_definition.py:880-1045: the next-notes target is the NEXT window,
+    the last window is dropped): evaluate equals the oracle's forward pass on the same lists, fit reports
+    decoder_loss_1..5 / decoder_acc_1..5, predict returns the five decoder outputs + style."""
+    s = build_settings(cell_type=cell, lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=8,
+                       learning_rate=1e-3, meta_held_notes=True, meta_next_notes=True, teacher_force=True,
+                       meta_next_notes_teacher_force=False, epsilon_std=0.0)
+    m = VAE().create(compute_dtype="f32", seed=2, **create_kwargs(s))
+    n = 13
+    w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=8)
+    X, Y, C, I, V, D = to_reference_format(w)
+    rng = np.random.default_rng(3)
+    D = (rng.random(D.shape) < 0.4).astype(np.float64)
+    Hh = rng.standard_normal((n, s["latent_dim"])) * 0.1
+    S = np.zeros((n, s["signature_vector_length"]))
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, Hh, return_sample_weight=True)
+    assert x[0].shape[0] == n - 1 and len(y) == 6 and len(sw) == 6
+    names = m.autoencoder.metrics_names
+    assert names.count("decoder_loss") == 5 and names.count("decoder_acc") == 5
+    res = dict(zip(["loss"] + ["l%d" % i for i in range(1, 6)] + ["ls"] + ["a%d" % i for i in range(1, 6)] + ["as"],
+                   m.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)))
+    # the oracle on the same lists (epsilon_std = 0: z = z_mean, no noise to reproduce)
+    spec = m.spec
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    from midi_vae_amd.layout import init_params
+    p = {k: v.astype(np.float64) for k, v in init_params(spec, 2).items()}
+    nb = n - 1
+    tot = {}
+    for lo in range(0, nb, s["batch_size"]):
+        hi = min(nb, lo + s["batch_size"])
+        b = dict(X=x[0][lo:hi], Hist=x[3][lo:hi], I=x[5][lo:hi], Vel=x[7][lo:hi], Held=x[9][lo:hi],
+                 Y=y[0][lo:hi], Next=y[4][lo:hi], C=y[5][lo:hi])
+        mo, _ = orc.forward(p, b, np.zeros((hi - lo, spec.Z)))
+        for k, v in mo.items():
+            tot[k] = tot.get(k, 0.0) + v * (hi - lo) / nb
+    for got, want in (("loss", "loss"), ("l1", "notes_loss"), ("l2", "instr_loss"), ("l3", "vel_loss"), ("l4", "held_loss"),
+                      ("l5", "next_loss"), ("ls", "style_loss"), ("a4", "held_acc"), ("a5", "next_acc")):
+        assert abs(res[got] - tot[want]) <= 2e-4 * (1 + abs(tot[want])), (got, res[got], tot[want])
+    hist = m.autoencoder.fit(x, y, epochs=2, batch_size=s["batch_size"], shuffle=False, sample_weight=sw, verbose=False)
+    for k in ("decoder_loss_4", "decoder_acc_4", "decoder_loss_5", "decoder_acc_5"):
+        assert len(hist.history[k]) == 2
+    assert hist.history["loss"][1] < hist.history["loss"][0]
+    outs = m.autoencoder.predict(x, batch_size=s["batch_size"])
+    assert [o.shape for o in outs] == [(nb, 16, 61), (nb, 4, 16), (nb, 16, 1), (nb, 16, 2), (nb, 16, 61), (nb, 2)]
+    enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+    assert len(enc_in) == 4
+    z = m.encoder.predict(enc_in, batch_size=s["batch_size"])
+    dec_in = pk.prepare_decoder_input(s, z, C, S, None)
+    d_out = m.decoder.predict(dec_in, batch_size=s["batch_size"])
+    assert [o.shape for o in d_out] == [(n, 16, 61), (n, 4, 16), (n, 16, 1), (n, 16, 2), (n, 16, 61)]
