@@ -75,7 +75,7 @@ class Engine(object):
         self.tile16 = (spec.H == 256 and self.kind == hl.BF16 and spec.cell in ("GRU", "LSTM"))
         self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR          # what the GEMM epilogues write (xp, dX)
         self.maxB = (int(max_batch) + 15) // 16 * 16
-        self.layout = ParamLayout.build(spec)
+        self.layout = self._make_layout()
         self.use_graphs = use_graphs
         self._graphs = {}
         self.prof = None       # dict -> per-kernel HIP-event pairs are recorded on the launch stream (bench.py)
@@ -128,7 +128,7 @@ class Engine(object):
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
-        self.set_params(init_params(spec, seed))
+        self.set_params(self._initial_params(seed))
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
@@ -141,6 +141,13 @@ class Engine(object):
         self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
         self._have_staged_targets = False
         self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)     # epoch accumulators (accumulate_metrics)
+
+    # (hooks of the style-classifier engine, classifier.py: the same recurrent / head / optimizer machinery on another graph)
+    def _make_layout(self):
+        return ParamLayout.build(self.spec)
+
+    def _initial_params(self, seed):
+        return init_params(self.spec, seed)
 
     def _seq_layout(self, r):
         """Sequence layout (= kernel family) of one recurrent layer: the slot-interleaved LSTM / GRU kernels (TILE16P
@@ -319,9 +326,10 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     # buffers (sized for max_batch; smaller batches reinterpret the same storage with a smaller row stride)
     # ------------------------------------------------------------------------------------------------------
-    def _alloc(self, B):
+    def _alloc_common(self, B):
+        """buffers of the recurrent layers (self.all_rec) and of the output heads (self.heads), sized for B rows"""
         s, dev, dt = self.spec, self.device, self.dt
-        H, GH, Z, T, V = s.H, s.GH, s.Z, s.T, s.V
+        H, GH = s.H, s.GH
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         st = self.store = {}
@@ -372,6 +380,14 @@ class Engine(object):
                 buf(n + ".dhs", h.T * B * H, **esz)
                 buf(n + ".wc", H * h.NP, **esz)            # W (H, NP): the head kernel's fused input gradient
             buf("out.%s_p" % n, h.T * B * h.N, **f32)      # inference outputs on request
+        return buf
+
+    def _alloc(self, B):
+        s, dev, dt = self.spec, self.device, self.dt
+        H, GH, Z, T, V = s.H, s.GH, s.Z, s.T, s.V
+        f32 = dict(dtype=torch.float32, device=dev)
+        buf = self._alloc_common(B)
+        st = self.store
         self.np_notes = self.head["notes"].NP
         # encoder tail / latent / decoder initial states (all f32, (B, .) row-major)
         for name, n in (("cat", self.ncat * H), ("pack", H), ("extra", H), ("mu", Z), ("lv", Z), ("zh", s.zin),

@@ -316,6 +316,69 @@ class ParamLayout:
         return OrderedDict((n, np.array(self.view(flat, n))) for n in self.oracle_names())
 
 
+@dataclass
+class ClassifierSpec:
+    """One of the reference's three style classifiers (pitch_classifier.py:89-103, velocity_classifier.py:110-125,
+    instrument_classifier.py:93-107): ``L`` Keras GRU(H) layers over a roll -> Dense(C, softmax).  ``K`` = input width; ``xmode``
+    'index' for one-hot rolls (pitch: K=61, instrument: K=16), 'scalar' for the velocity roll (K=1)."""
+    K: int = 61
+    T: int = 64
+    C: int = 2
+    H: int = 256
+    L: int = 2
+    cell: str = "GRU"
+    xmode: str = "index"
+    lr: float = 2e-5
+    optimizer: str = "Adam"
+    # what the shared engine code reads off a spec
+    meta_held: bool = False
+    meta_next: bool = False
+
+    @property
+    def G(self):
+        return GATES[self.cell]
+
+    @property
+    def GH(self):
+        return GATES[self.cell] * self.H
+
+    @property
+    def Le(self):
+        return self.L
+
+    @property
+    def Ld(self):
+        return 1
+
+    def oracle_cfg(self):
+        return dict(cell=self.cell, H=self.H, K=self.K, L=self.L, C=self.C)
+
+
+def classifier_layout(spec: ClassifierSpec) -> ParamLayout:
+    """rnn.<l>.{W,U,b}, cls.out.{W,b} in one flat f32 buffer (names shared with oracle/classifier_oracle.py)"""
+    L = ParamLayout(spec)
+    cur = 0
+    for l in range(spec.L):
+        for suffix, shape in ((".W", (spec.K if l == 0 else spec.H, spec.GH)), (".U", (spec.H, spec.GH)), (".b", (spec.GH,))):
+            L.entries["rnn.%d%s" % (l, suffix)] = Entry(cur, tuple(shape), shape[-1], "enc")
+            cur += (int(np.prod(shape)) + _ALIGN - 1) // _ALIGN * _ALIGN
+    for name, shape in (("cls.out.W", (spec.H, spec.C)), ("cls.out.b", (spec.C,))):
+        L.entries[name] = Entry(cur, tuple(shape), shape[-1], "enc")
+        cur += (int(np.prod(shape)) + _ALIGN - 1) // _ALIGN * _ALIGN
+    L.total, L.dec_begin = cur, 0
+    return L
+
+
+def init_classifier_params(spec: ClassifierSpec, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Keras defaults: kernels glorot_uniform, recurrent kernels orthogonal, biases zero"""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for n, e in classifier_layout(spec).entries.items():
+        out[n] = (_orthogonal(rng, e.shape) if n.endswith(".U") else _glorot_uniform(rng, e.shape) if n.endswith(".W")
+                  else np.zeros(e.shape)).astype(np.float32)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------
 # Keras / recurrentshop initialisers (SURVEY Appendix A.9)
 # ----------------------------------------------------------------------------------------------------------
