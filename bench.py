@@ -30,48 +30,16 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICRO
 PEAK_F32_TFLOPS = 157.3
 
 
-def cpu_baseline(spec, budget_s=20.0):
-    """The identical train step (forward + losses + analytic backward + Keras-Adam) as float32 torch-CPU tensor operations on ALL
+def cpu_baseline(spec, B, budget_s=15.0, hard_limit_s=150.0):
+    """The identical train step (forward + losses + analytic backward + Keras-Adam) as float32 torch-CPU tensor operations on the
     host cores (oracle/torch_cpu.py, pinned to the NumPy oracle by tests/test_torch_port_cpu.py) - the reference's own Keras CPU
-    path cannot run here.  SURVEY 8(d): the largest batch under a time bound - here the largest of 16..256 windows
-    whose step is expected to fit ``budget_s`` seconds (a step at B=16 is timed first; cost grows at most linearly in B), one
-    untimed + one timed step at that size.  Runs BEFORE the GPU phase."""
-    import torch
-    from oracle.torch_cpu import TorchCPUVAE
-    from oracle.vae_oracle import make_cfg
-    from midi_vae_amd.layout import init_params
-    from midi_vae_amd.synth import make_windows
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
-    threads_before = torch.get_num_threads()
-    torch.set_num_threads(cores)
-    tv = TorchCPUVAE(make_cfg(**spec.oracle_cfg()))
-    oh = lambda idx, n: np.eye(n, dtype=np.float32)[idx.astype(np.int64)]
-
-    def problem(Bs):
-        w = make_windows(Bs, spec.T, spec.Dout, spec.V, spec.ID, spec.C, spec.Z, seed=1234, epsilon_std=spec.epsilon_std)
-        batch = dict(X=oh(w["x_idx"], spec.Din), I=oh(w["i_idx"], spec.ID), Vel=w["vel"][..., None], Hist=w["hist"],
-                     Y=oh(w["x_idx"], spec.Dout), C=oh(w["c_idx"], spec.C))
-        P = tv.tensors(init_params(spec, 1234))
-        return P, tv.new_opt_state(P), batch, w["eps"]
-
-    def one(Bs, reps):
-        P, st, batch, eps = problem(Bs)
-        tv.train_step(P, st, batch, eps)                 # untimed: thread pools, page faults
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            tv.train_step(P, st, batch, eps)
-        return (time.perf_counter() - t0) / reps
-
-    t16 = one(16, 1)
-    Bs = 16
-    for cand in (32, 64, 128, 256):
-        if t16 * cand / 16 * 2 <= budget_s:              # (x2: the untimed step at that size)
-            Bs = cand
-    dt = one(Bs, 1) if Bs > 16 else t16
-    torch.set_num_threads(threads_before)
+    path cannot run here.  Full batch (B windows), bounded in TIME: the step is timed on the first T_s of the T time
+    steps and scaled by T / T_s (the step's cost is linear in T), T_s chosen to fit ``budget_s``; the thread count is calibrated
+    (all cores is not the fastest for ~10^5 small tensor operations per step).  Runs in a SUBPROCESS with a hard wall-clock limit,
+    BEFORE the GPU phase."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "torch_cpu.py"), "--cell", spec.cell, "--T", str(spec.T), "--B", str(B),
+           "--V", str(spec.V), "--Z", str(spec.Z), "--C", str(spec.C), "--budget", str(budget_s)]
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -80,10 +48,14 @@ def cpu_baseline(spec, budget_s=20.0):
                 break
     except OSError:
         pass
-    return {"value": Bs / dt, "unit": "windows/s", "cores": cores, "kind": "port", "cpu": model,
-            "sample": "1 timed step of the identical train step (T=%d,H=%d,%s) at %d windows in float32 torch-CPU on %d threads "
-                      "(oracle/torch_cpu.py; largest batch of 16..256 expected to fit %.0f s: a 16-window step took %.2f s), "
-                      "%.2f s/step" % (spec.T, spec.H, spec.cell, Bs, cores, budget_s, t16, dt)}
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=hard_limit_s, cwd=ROOT)
+        rec = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError, IndexError) as e:
+        rec = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port",
+               "sample": "oracle/torch_cpu.py did not finish within %.0f s on this host (%r)" % (hard_limit_s, type(e).__name__)}
+    rec["cpu"] = model
+    return rec
 
 
 def algorithmic_flops_per_window(spec):
@@ -146,7 +118,7 @@ def main():
     B = args.batch
     # the CPU baseline FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
     # process sees the GPU busy at the end of the run rather than idle
-    cpu = cpu_baseline(spec) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    cpu = cpu_baseline(spec, B) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
     eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234, use_graphs=args.graphs)
     if args.chunks:
         eng.time_chunks = args.chunks
@@ -300,7 +272,7 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-            out["gpu_over_cpu"] = out["value"] / cpu["value"]
+            out["gpu_over_cpu"] = out["value"] / cpu["value"] if cpu.get("value") else None
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -138,6 +138,7 @@ class Engine(object):
         self._count_pending = False
         self._sync_cum = {}
         self._pipe_verified = False
+        self._dxp0_clean = False
         self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
         self._have_staged_targets = False
         self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)     # epoch accumulators (accumulate_metrics)
@@ -567,6 +568,9 @@ class Engine(object):
                 if self.training:
                     for h in self.heads:
                         pb.convert_pad(P[h.out + ".W"], self.store[h.name + ".wc"], h.NP)
+                    for r in self.all_rec:      # sum over time of da of the constant-input cells: accumulated into a buffer this
+                        if r.xmode == hl.X_CONST:       # launch zeroes (a hipMemsetAsync per layer and step otherwise)
+                            pb.zero(self.store[r.prefix + ".dxp0"])
                 if self.training:
                     for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
                                          ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
@@ -928,7 +932,7 @@ class Engine(object):
         with self._on(self.s_grad2):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
-                ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1))
+                ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1) or self._dxp0_clean)
                 if k == 0:
                     ops.colsum(dxp0, B, GH, G[p + ".b"])
                     ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=mb)
@@ -1284,9 +1288,11 @@ class Engine(object):
         self._have_targets = True
         self._mark("step start")
         if self._weights_dirty or self.use_graphs:
-            self.prepare_weights()          # (also zeroes the loss / metric accumulators)
+            self.prepare_weights()          # (also zeroes the loss / metric accumulators and the constant-input cells' dxp0 sums)
+            self._dxp0_clean = True
         else:
             self.scal.zero_()
+            self._dxp0_clean = False
         if not self._grads_clean:
             self.grads.zero_()
         self._grads_clean = False
@@ -1320,6 +1326,7 @@ class Engine(object):
                           "launches (Engine.pipeline = False)")
             self.store["pipe_status"].zero_()
             self.pipeline = False
+            self._dxp0_clean = False
             redo()
 
     def train_step(self, B, allreduce=None):

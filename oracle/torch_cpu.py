@@ -291,3 +291,77 @@ class TorchCPUVAE(object):
             g = self.backward(p, c)
             self.opt_step(p, g, st)
         return m
+
+
+def timed_sample(cell, T, B, V, Z, C, budget_s=15.0, threads=0):
+    """windows/s of the full train step at B windows, from a BOUNDED sample: the same step on the first T_s of the T time steps
+    (every cost of the step but the latent block and the optimizer is linear in T, so the rate is scaled by T_s / T).  T_s is the
+    largest power of two whose two steps (one untimed, one timed) are expected to fit ``budget_s`` after a T_s = 8 calibration.
+    Returns a dict for bench.py's ``cpu_baseline``."""
+    import os
+    import time
+
+    import numpy as np
+
+    from midi_vae_amd.layout import ModelSpec, init_params
+    from midi_vae_amd.synth import make_windows
+    from oracle.vae_oracle import make_cfg
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    oh = lambda idx, n: np.eye(n, dtype=np.float32)[idx.astype(np.int64)]
+
+    def run(Ts, reps):
+        spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=Ts, V=V, ID=16, C=C, Le=2, Ld=2)
+        tv = TorchCPUVAE(make_cfg(**spec.oracle_cfg()))
+        w = make_windows(B, Ts, 61, V, 16, C, Z, seed=1234, epsilon_std=spec.epsilon_std)
+        batch = dict(X=oh(w["x_idx"], 61), I=oh(w["i_idx"], 16), Vel=w["vel"][..., None], Hist=w["hist"], Y=oh(w["x_idx"], 61),
+                     C=oh(w["c_idx"], C))
+        P = tv.tensors(init_params(spec, 1234))
+        st = tv.new_opt_state(P)
+        tv.train_step(P, st, batch, w["eps"])                 # untimed: thread pools, page faults
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tv.train_step(P, st, batch, w["eps"])
+        return (time.perf_counter() - t0) / reps
+
+    # thread count: all cores is not always the fastest for 10^5 small tensor operations per step - calibrate
+    best = None
+    for n in sorted({cores, min(cores, 64), min(cores, 16)} if not threads else {threads}, reverse=True):
+        torch.set_num_threads(n)
+        t8 = run(8, 1)
+        if best is None or t8 < best[1]:
+            best = (n, t8)
+    n_thr, t8 = best
+    torch.set_num_threads(n_thr)
+    Ts = 8
+    while Ts * 2 <= T and t8 * (Ts * 2 / 8.0) * 2 <= budget_s:
+        Ts *= 2
+    dt = run(Ts, 1) if Ts > 8 else t8
+    step_s = dt * T / Ts
+    return {"value": B / step_s, "unit": "windows/s", "cores": n_thr, "host_cores": cores, "kind": "port",
+            "sample": "the identical train step (%s, H=256, B=%d windows) in float32 torch-CPU tensor operations on %d threads "
+                      "(oracle/torch_cpu.py), timed on the first %d of the T=%d time steps: %.2f s, scaled by T/T_s to %.1f s per "
+                      "full step (thread count picked from {all, 64, 16} by a T_s=8 calibration: %.2f s)"
+                      % (cell, B, n_thr, Ts, T, dt, step_s, t8)}
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import midi_vae_amd  # noqa: F401
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cell", default="LSTM")
+    ap.add_argument("--T", type=int, default=512)
+    ap.add_argument("--B", type=int, default=256)
+    ap.add_argument("--V", type=int, default=4)
+    ap.add_argument("--Z", type=int, default=64)
+    ap.add_argument("--C", type=int, default=2)
+    ap.add_argument("--budget", type=float, default=15.0)
+    ap.add_argument("--threads", type=int, default=0)
+    a = ap.parse_args()
+    print(json.dumps(timed_sample(a.cell, a.T, a.B, a.V, a.Z, a.C, a.budget, a.threads)))

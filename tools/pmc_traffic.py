@@ -24,7 +24,10 @@ pat = "lstm_bwd_il_k" if a.cell == "LSTM" else "gru_bwd_il_k"
 def per_launch(path, counter):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
             if pat in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    big = [v for v in vals if v > 0.3 * max(vals)]              # the T-step launches (the 4-step instrument layers are 100x smaller)
+    srt = sorted(vals)
+    med_top = srt[int(0.9 * len(srt))]                          # (robust against a single outlier launch)
+    big = [v for v in vals if v > 0.3 * med_top]                # the T-step launches (the 4-step instrument layers are 100x smaller)
+    print("%s %s: %d launches; deciles %s" % (pat, counter, len(vals), ["%.3g" % srt[int(q * (len(srt) - 1) / 10)] for q in range(11)]))
     return sum(big) / len(big), len(big), len(vals)
 
 
