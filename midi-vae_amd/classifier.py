@@ -93,12 +93,8 @@ class ClassifierEngine(Engine):
             self.prepare_weights()
         else:
             self.scal.zero_()
-        inp = (dict(idx=self._v("in.x_idx", s.T, B)) if s.xmode == "index" else None)
-        h_last = self._v("h_last", B, s.H)
-        if s.xmode == "index":
-            self._stack_forward(self.layers, B, idx=inp["idx"], h_last=h_last, h_last_ld=s.H, slot=0)
-        else:
-            self._stack_forward_scalar(B, h_last)
+        inp = (dict(idx=self._v("in.x_idx", s.T, B)) if s.xmode == "index" else dict(xs=self._v("in.x_val", s.T, B)))
+        self._stack_forward(self.layers, B, h_last=self._v("h_last", B, s.H), h_last_ld=s.H, slot=0, **inp)
         self._prefork = None
         top = self._v(self.layers[-1].prefix + ".hs", s.T + 1, B, s.H)[s.T]      # (B,H) in the compute dtype
         h = self.head["cls"]
@@ -108,19 +104,6 @@ class ClassifierEngine(Engine):
                  grad_scale=1.0, probs=self._v("out.cls_p", B, s.C) if want_probs else None, argmax=self._v("cls.argmax", B),
                  dlogits=self._v("cls.dl", B, h.NP) if (self.training and tg) else None, scalars=self.scal[S_LOSS:S_LOSS + 2],
                  b_stride=B, b_valid=Breal)
-
-    def _stack_forward_scalar(self, B, h_last):
-        """velocity roll: the first layer reads a 1-wide input (x*W + b written out for the dense-input kernels)"""
-        s = self.spec
-        xs = self._v("in.x_val", s.T, B)
-        if len(self.layers) == 1:
-            self._rec_forward(self.layers[0], B, xs=xs, h_last=h_last, h_last_ld=s.H)
-            return
-        # (the pipelined stack entry takes idx / start inputs only: run the layers one after the other)
-        self._rec_forward(self.layers[0], B, xs=xs)
-        for r in self.layers[1:]:
-            top = r is self.layers[-1]
-            self._rec_forward(r, B, h_last=h_last if top else None, h_last_ld=s.H if top else 0)
 
     def backward(self, B):
         s, P, G = self.spec, self.P, self.G
@@ -134,18 +117,8 @@ class ClassifierEngine(Engine):
         with self._on(self.s_grad):
             ops.gemm(top, dl, G["cls.out.W"], s.H, s.C, B, trans_a=True, ldb=h.NP, accumulate=True)
             ops.colsum(dl, B, s.C, G["cls.out.b"], ldx=h.NP)
-        if s.xmode == "index":
-            self._stack_backward(self.layers, B, dh_last=dh, dh_last_ld=s.H, idx=self._v("in.x_idx", s.T, B), slot=3)
-        else:
-            xs = self._v("in.x_val", s.T, B)
-            order = list(reversed(self.layers))
-            dext = None
-            for i, r in enumerate(order):
-                self._stack_backward([r], B, dhs_ext=dext, dh_last=dh if i == 0 else None, dh_last_ld=s.H if i == 0 else 0,
-                                     xs=xs)
-                if r.lower is not None:
-                    self._rec_dx(r, B)
-                    dext = self._v(r.prefix + ".dx", r.T, B, s.H)
+        inp = (dict(idx=self._v("in.x_idx", s.T, B)) if s.xmode == "index" else dict(xs=self._v("in.x_val", s.T, B)))
+        self._stack_backward(self.layers, B, dh_last=dh, dh_last_ld=s.H, slot=3, **inp)
         self._prefork = None
         self._join(self.s_grad)
         self._join(self.s_grad2)

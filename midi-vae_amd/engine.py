@@ -672,7 +672,7 @@ class Engine(object):
         cum[1] += pwaves
         return reg, cum[0], cum[1]
 
-    def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
+    def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None):
         cs = self.pipe_chunk
         T = layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
@@ -691,7 +691,7 @@ class Engine(object):
             if not top:
                 pipe["signal_done"] = sync[li, 0]
             def run():
-                self._rec_forward(r, B, 0, 1, idx=idx, start=start, h_last=h_last if top else None,
+                self._rec_forward(r, B, 0, 1, idx=idx, start=start, xs=xs, h_last=h_last if top else None,
                                   h_last_ld=h_last_ld if top else 0, pipe=pipe, xp_external=li > 0, **st)
             if top:
                 run()
@@ -703,11 +703,11 @@ class Engine(object):
                                  chunk_wait=sync[li, 0], chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status)
         self._join(*lower_streams, *gemm_streams)
 
-    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0):
+    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0, xs=None):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
         if self._pipelined(layers):
             return self._stack_forward_pipe(layers, B, slot, states=states, h_last=h_last, h_last_ld=h_last_ld, idx=idx,
-                                            start=start)
+                                            start=start, xs=xs)
         nch = self._nchunks(layers)
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[torch.cuda.Event() for _ in range(nch)] for _ in layers]
@@ -720,7 +720,7 @@ class Engine(object):
                 def run():
                     if li > 0 and nch > 1:
                         torch.cuda.current_stream().wait_event(done[li - 1][k])
-                    self._rec_forward(r, B, k, nch, idx=idx, start=start, h_last=h_last if top else None,
+                    self._rec_forward(r, B, k, nch, idx=idx, start=start, xs=xs, h_last=h_last if top else None,
                                       h_last_ld=h_last_ld if top else 0, **st)
                     if nch > 1:
                         done[li][k].record()

@@ -67,7 +67,7 @@ def test_classifier_resident_path_matches_oracle_bf16(xmode, K, T):
     probs_o, m_o, cache = orc.forward(p64, X, Y)
     g_o = orc.backward(p64, cache)
     eng = ClassifierEngine(spec, max_batch=B, dtype="bf16")
-    assert eng.tile16 and (eng._pipelined(eng.layers) == (xmode == "index" and T % eng.pipe_chunk == 0))
+    assert eng.tile16 and (eng._pipelined(eng.layers) == (T % eng.pipe_chunk == 0))
     eng.set_params(params)
     eng.stage(x, c)
     eng.grads.zero_()

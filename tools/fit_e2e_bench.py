@@ -34,6 +34,28 @@ print("host packer threads: %d; one song = %d windows = %.0f MB of float64 one-h
     hl.load().mvae_host_threads(-1), n, songs[0][0].nbytes / 1e6))
 
 
+# host-side wall time inside fit, by part (the device runs asynchronously beside all of it)
+from midi_vae_amd import staging as _st, engine as _en
+HOST = {"stage": 0.0, "train_step enqueue": 0.0, "read-back": 0.0}
+
+
+def _timed(cls, name, key):
+    fn = getattr(cls, name)
+
+    def wrap(*a_, **k_):
+        t = time.perf_counter()
+        try:
+            return fn(*a_, **k_)
+        finally:
+            HOST[key] += time.perf_counter() - t
+    setattr(cls, name, wrap)
+
+
+_timed(_st.Stager, "stage", "stage")
+_timed(_en.Engine, "train_step", "train_step enqueue")
+_timed(_en.Engine, "read_accumulated", "read-back")
+
+
 def one_song(sg, epoch):
     X, Y, C, I, V, D, S = sg
     t0 = time.perf_counter()
@@ -55,6 +77,8 @@ def one_song(sg, epoch):
 one_song(songs[0], 0)          # engine construction, first launches
 for ep in (1, 2):
     tp = tk = tf = 0.0
+    for k_ in HOST:
+        HOST[k_] = 0.0
     t0 = time.perf_counter()
     for sg in songs:
         loss, a_, b_, c_ = one_song(sg, ep)
@@ -64,3 +88,5 @@ for ep in (1, 2):
     print("epoch %d: %d windows in %.3f s = %.0f windows/s end to end | fit alone %.0f windows/s (%.2f ms per %d-window step) | "
           "pre-pass %.3f s, python packers %.3f s, fit %.3f s | loss %.4f" % (
               ep, nw, dt, nw / dt, nw / tf, tf / (nw / a.batch) * 1e3, a.batch, tp, tk, tf, loss))
+    print("         host time inside fit per %d-window step: %s" % (a.batch, ", ".join(
+        "%s %.2f ms" % (k_, v_ / (nw / a.batch) * 1e3) for k_, v_ in HOST.items())))
