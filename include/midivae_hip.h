@@ -374,6 +374,18 @@ int mvae_scalars_accumulate(float* acc, const float* x, int32_t n, float alpha, 
 int mvae_copy2d_f32(float* dst, int32_t ldd, const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_row0,
                     int32_t zero_rows, void* stream);
 
+/* Signature head (reference vae_definition.py:737-745, loss :409-416; off by default): out (B,SD) = tanh(zh[:, off:off+SD]);
+ * with a target (B,SD): scalars[0] += sum_b row_weight[b] * mean_j (out - target)^2, scalars[1] += rows whose argmax matches the
+ * target's (Keras 'accuracy' on this output).  bwd: dz[b, off+j] += weight * row_weight[b] * 2 (out - target) / SD * (1 - out^2). */
+int mvae_signature_head_fwd(const float* zh, int32_t ldz, int32_t off, int32_t SD, int32_t B, const float* target,
+                            const float* row_weight, float* out, float* scalars, void* stream);
+int mvae_signature_head_bwd(float* dz, int32_t lddz, int32_t off, int32_t SD, int32_t B, const float* out, const float* target,
+                            const float* row_weight, float weight, void* stream);
+/* dlogits (R,NP) kind += probs * (dprobs - rowsum(probs * dprobs)): a gradient that arrives at a softmax output - the classifiers
+ * the reference can hang on the decoder's notes / instrument probabilities (vae_definition.py:747-761) - folded into d(logits) */
+int mvae_softmax_bwd_add(const float* probs, const float* dprobs, void* dlogits, int32_t kind, int32_t R, int32_t N, int32_t NP,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * HOST-side packers (csrc/hostpack.cpp): every pointer below is a HOST pointer, nothing touches the device.
  * The reference hands the Keras Models float64 NumPy windows - one-hot rows (n, T, K) (reference import_midi.py:245-286,

@@ -321,6 +321,53 @@ __global__ void copy2d_f32_k(float* dst, int ldd, const float* src, int lds, int
     }
 }
 
+// ---- signature head: activation(z[:, off:off+SD]) against the song's signature vector, mean squared error ------------------
+// one thread per window (B is a minibatch: a few hundred rows); loss / hits added to scalars[0..1]
+__global__ void sig_head_fwd_k(const float* zh, int ldz, int off, int SD, int B, const float* target, const float* row_weight,
+                               float* out, float* scalars) {
+    float loss = 0.0f, hits = 0.0f;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        float se = 0.0f, best_p = -INFINITY, best_t = -INFINITY;
+        int arg_p = 0, arg_t = 0;
+        for (int j = 0; j < SD; ++j) {
+            const float p = tanhf(zh[(size_t)b * ldz + off + j]);
+            const float t = target ? target[(size_t)b * SD + j] : 0.0f;
+            out[(size_t)b * SD + j] = p;
+            se += (p - t) * (p - t);
+            if (p > best_p) { best_p = p; arg_p = j; }
+            if (t > best_t) { best_t = t; arg_t = j; }
+        }
+        const float rw = row_weight ? row_weight[b] : 0.0f;
+        loss += rw * se / (float)SD;                        // Keras mse: mean over the last axis, then the weighted batch mean
+        hits += (rw != 0.0f && arg_p == arg_t) ? 1.0f : 0.0f;     // 'accuracy' on a non-categorical output = categorical_accuracy
+    }
+    if (target && scalars) {
+        if (loss != 0.0f) atomicAdd(scalars, loss);
+        if (hits != 0.0f) atomicAdd(scalars + 1, hits);
+    }
+}
+// dz[b, off + j] += weight * rw[b] * 2 (p - t) / SD * (1 - p^2)
+__global__ void sig_head_bwd_k(float* dz, int lddz, int off, int SD, int B, const float* out, const float* target,
+                               const float* row_weight, float weight) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * SD) return;
+    const int b = e / SD, j = e % SD;
+    const float p = out[e];
+    dz[(size_t)b * lddz + off + j] += weight * row_weight[b] * 2.0f * (p - target[e]) / (float)SD * (1.0f - p * p);
+}
+// dl[r, n] += p[r, n] * (dp[r, n] - sum_j p[r, j] dp[r, j]): a gradient arriving at softmax PROBABILITIES folded into d(logits)
+template <typename WT>
+__global__ void softmax_bwd_add_k(const float* __restrict__ p, const float* __restrict__ dp, WT* __restrict__ dl, int R, int N, int NP) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const float* pr = p + (size_t)r * N;
+        const float* dr = dp + (size_t)r * N;
+        float dot = 0.0f;
+        for (int j = 0; j < N; ++j) dot += pr[j] * dr[j];
+        WT* out = dl + (size_t)r * NP;
+        for (int j = 0; j < N; ++j) st<WT>::store(out + j, st<WT>::load(out + j) + pr[j] * (dr[j] - dot));
+    }
+}
+
 inline int nblocks(size_t n, int per = 256, int cap = 2048) {
     size_t b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -577,6 +624,35 @@ extern "C" int mvae_transpose_convert(const float* W, void* out, int32_t K, int3
     return MVAE_OK;
 }
 
+extern "C" int mvae_signature_head_fwd(const float* zh, int32_t ldz, int32_t off, int32_t SD, int32_t B, const float* target,
+                                       const float* row_weight, float* out, float* scalars, void* stream) {
+    if (!zh || !out || SD <= 0 || B <= 0 || off < 0 || ldz < off + SD) return MVAE_E_ARG;
+    hipLaunchKernelGGL(sig_head_fwd_k, dim3(nblocks(B, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), zh, ldz, off, SD, B,
+                       target, row_weight, out, scalars);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_signature_head_bwd(float* dz, int32_t lddz, int32_t off, int32_t SD, int32_t B, const float* out, const float* target,
+                                       const float* row_weight, float weight, void* stream) {
+    if (!dz || !out || !target || !row_weight || SD <= 0 || B <= 0 || off < 0 || lddz < off + SD) return MVAE_E_ARG;
+    hipLaunchKernelGGL(sig_head_bwd_k, dim3(nblocks((size_t)B * SD)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dz, lddz,
+                       off, SD, B, out, target, row_weight, weight);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_softmax_bwd_add(const float* probs, const float* dprobs, void* dlogits, int32_t kind, int32_t R, int32_t N,
+                                    int32_t NP, void* stream) {
+    if (!probs || !dprobs || !dlogits || R <= 0 || N <= 0 || NP < N) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(softmax_bwd_add_k<float>, dim3(nblocks(R)), dim3(256), 0, s, probs, dprobs, (float*)dlogits, R, N, NP);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(softmax_bwd_add_k<bf16_t>, dim3(nblocks(R)), dim3(256), 0, s, probs, dprobs, (bf16_t*)dlogits, R, N, NP);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 extern "C" int mvae_scalars_accumulate(float* acc, const float* x, int32_t n, float alpha, uint32_t plain_mask, void* stream) {
     if (!acc || !x || n < 0 || n > 32) return MVAE_E_ARG;
     if (n) hipLaunchKernelGGL(scalars_accumulate_k, dim3(1), dim3(32), 0, reinterpret_cast<hipStream_t>(stream), acc, x, n, alpha,

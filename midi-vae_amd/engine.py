@@ -27,8 +27,10 @@ from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
 
 # slots of the scalar accumulator
 S_NOTES_LOSS, S_NOTES_HITS, S_INSTR_LOSS, S_INSTR_HITS, S_VEL_LOSS, S_VEL_HITS, S_KL, S_STYLE_LOSS, S_STYLE_HITS = range(9)
-S_HELD_LOSS, S_HELD_HITS, S_NEXT_LOSS, S_NEXT_HITS = 10, 11, 12, 13          # (slot 9: third word of the latent kernels' block)
-N_SCALARS = 16
+S_HELD_LOSS, S_HELD_HITS, S_NEXT_LOSS, S_NEXT_HITS = 10, 11, 12, 13
+S_SIG_LOSS, S_SIG_HITS, S_CNOTES_LOSS, S_CNOTES_HITS, S_CINSTR_LOSS, S_CINSTR_HITS = 14, 15, 16, 17, 18, 19
+N_SCALARS = 32
+X_EXT = 100     # (host-side only) a recurrent layer whose x*W + b is written by the caller: classifiers on the decoder's OUTPUTS
 
 
 class _NullCtx(object):
@@ -58,6 +60,16 @@ class _Head(object):
         self.out = "dec.%s.out" % name
         self.stream = stream              # None = the critical stream (the notes stack)
         self.NP = None
+
+
+class _Aux(object):
+    """A style classifier hung on a decoder head's softmax output (reference vae_definition.py:747-761): Keras RNN over the
+    (T, B, N) probabilities -> Dense(C, softmax) on the last state."""
+
+    def __init__(self, key, src, rec, weight, slot):
+        self.key, self.src, self.rec, self.weight, self.slot = key, src, rec, weight, slot
+        self.head = _Head(key, [rec], 0, 0, weight, slot, "in.c_idx")
+        self.head.T, self.head.out = 1, key + ".out"
 
 
 class Engine(object):
@@ -320,7 +332,18 @@ class Engine(object):
         if s.meta_next:
             self.heads.append(_Head("next", self.dec_next, 0, s.Dout, s.w_next, S_NEXT_LOSS, "in.n_idx", self.s_next))
         self.head = {h.name: h for h in self.heads}
-        self.all_rec = (self.enc_notes + [m[0] for m in self.enc_meta] + [r for h in self.heads for r in h.layers])
+        self.aux = []
+        for key, src, flag, w, slot in (("cnotes", "notes", s.comp_notes, s.w_cnotes, S_CNOTES_LOSS),
+                                        ("cinstr", "instr", s.comp_instr, s.w_cinstr, S_CINSTR_LOSS)):
+            if flag:
+                hsrc = self.head[src]
+                a = _Aux(key, src, _Rec(key + ".rnn", hsrc.T, X_EXT, hsrc.N), w, slot)
+                a.head.N = s.C
+                self.aux.append(a)
+        self.dec_heads = list(self.heads)          # the decoder's own heads (self.heads also lists the classifiers' Dense heads)
+        self.heads = self.heads + [a.head for a in self.aux]
+        self.all_rec = (self.enc_notes + [m[0] for m in self.enc_meta] + [r for h in self.dec_heads for r in h.layers] +
+                        [a.rec for a in self.aux])
         self.ncat = s.ncat
         self.has_pack = s.has_pack
 
@@ -370,6 +393,12 @@ class Engine(object):
                 buf(p + ".xp0", B * GH, **esz)
                 if self.training:
                     buf(p + ".dxp0", B * GH, **f32)
+            elif r.xmode == X_EXT:
+                buf(p + ".xp", r.T * B * GH, **esz)
+        for a in getattr(self, "aux", ()):
+            if self.training:
+                buf(a.key + ".dp", a.rec.T * B * a.rec.K, **f32)    # gradient w.r.t. the source head's probabilities
+                buf(a.key + ".dh", B * H, **f32)                    # ... w.r.t. the classifier RNN's last state
         # heads
         for h in self.heads:
             h.NP = ops.head_np(h.N)
@@ -420,6 +449,13 @@ class Engine(object):
         if s.meta_next:
             regions += [("in.n_idx", T * B, torch.uint8), ("in.rw_next", T * B, torch.float32),
                         ("in.start_next", B * s.Dout, torch.float32)]
+        if s.add_dim:
+            regions += [("in.add", B * s.add_dim, torch.float32)]
+        if s.signature:
+            regions += [("in.sig", B * s.SD, torch.float32), ("in.rw_sig", B, torch.float32)]
+            buf("sig.out", B * s.SD, **f32)
+        for a in self.aux:
+            regions += [("in.rw_" + a.key, B, torch.float32)]
         self._in_regions, off = {}, 0
         for name, n, tdt in regions:
             nbytes = int(n) * (1 if tdt == torch.uint8 else 4)
@@ -484,7 +520,7 @@ class Engine(object):
         return B
 
     def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None, start_held=None,
-                             start_next=None):
+                             start_next=None, add=None):
         s = self.spec
         Bp = self.pad16(B)
         zh = self._v("zh", Bp, s.zin)
@@ -496,6 +532,12 @@ class Engine(object):
                 zh[:B, s.Z:].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
         if z is not None:
             zh[:B, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
+        if s.add_dim:           # the decoder's additional input (reference vae_definition.py:553-556): behind [z | history]
+            a0 = s.zin - s.add_dim
+            if add is None:
+                zh[:, a0:].zero_()
+            else:
+                zh[:B, a0:].copy_(torch.from_numpy(np.ascontiguousarray(add, np.float32).reshape(B, s.add_dim)).to(self.device))
         for name, val, width in (("in.start_notes", start_notes, s.Dout), ("in.start_instr", start_instr, s.ID),
                                  ("in.start_vel", start_vel, 1), ("in.start_held", start_held, 2),
                                  ("in.start_next", start_next, s.Dout)):
@@ -504,7 +546,7 @@ class Engine(object):
             self._up_rows(name, np.zeros((B, width), np.float32) if val is None else np.asarray(val, np.float32), width)
 
     def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None, n_idx=None,
-                      w_held=None, w_next=None):
+                      w_held=None, w_next=None, sig=None, w_sig=None, w_cnotes=None, w_cinstr=None):
         """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
         (score*w / mean(w != 0), then the mean over the axes) into one factor per row; padding
         rows get target 255 ("no target") and weight 0."""
@@ -536,7 +578,15 @@ class Engine(object):
         if s.style:
             ws = np.ones((B,)) if w_style is None else w_style
             self._up("in.rw_style", norm(ws, 1), torch.float32)
-            self._up("in.c_idx", np.asarray(c_idx, np.uint8), torch.uint8)
+        if s.style or self.aux:
+            c = np.full((self.pad16(B),), 255, np.uint8)       # (padding rows: "no target")
+            c[:B] = np.asarray(c_idx, np.uint8)
+            self._up("in.c_idx", c, torch.uint8)
+        if s.signature:
+            self._up_rows("in.sig", np.asarray(sig, np.float32), s.SD)
+            self._up_rows("in.rw_sig", norm(np.ones((B,)) if w_sig is None else w_sig, 1), 1)
+        for a, w in zip(self.aux, [w_cnotes if a.key == "cnotes" else w_cinstr for a in self.aux]):
+            self._up_rows("in.rw_" + a.key, norm(np.ones((B,)) if w is None else w, 1), 1)
 
     # ------------------------------------------------------------------------------------------------------
     # weight preparation: packed / transposed / converted copies the kernels consume (once per optimizer step)
@@ -611,6 +661,8 @@ class Engine(object):
             kw.update(xp=xp)
         elif r.xmode == hl.X_SCALAR:
             kw.update(xs=xs[t0:t0 + Tc], w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
+        elif r.xmode == X_EXT:
+            kw.update(xp=self._v(p + ".xp", T, B, GH)[t0:t0 + Tc])
         elif r.xmode == hl.X_CONST:
             xp0 = self._v(p + ".xp0", B, GH)
             if k == 0:
@@ -752,6 +804,7 @@ class Engine(object):
         self._mark("  encoder recurrences")
         self._S_done = False
         if self.fused_latent and (self.has_pack or self.ncat == 1) and self._latent_chain_forward(Breal, B, with_init):
+            self._signature_forward(Breal, B)
             return
         h = cat
         if self.has_pack:
@@ -774,6 +827,17 @@ class Engine(object):
                        style_target=self._v("in.c_idx", Breal) if (s.style and self._have_targets) else None,
                        style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
                        style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
+        self._signature_forward(Breal, B)
+
+    def _signature_forward(self, Breal, B):
+        """signature head (reference vae_definition.py:737-745): tanh of the latent columns behind the style classifier's"""
+        s = self.spec
+        if not s.signature:
+            return
+        tg = self._have_targets
+        ops.signature_head_fwd(self._v("zh", B, s.zin), s.sig_off, s.SD, Breal, self._v("sig.out", B, s.SD),
+                               target=self._v("in.sig", B, s.SD) if tg else None,
+                               row_weight=self._v("in.rw_sig", B) if tg else None, scalars=self.scal[S_SIG_LOSS:S_SIG_LOSS + 2])
 
     def _latent_chain_forward(self, Breal, B, with_init):
         """Encoder tail Denses, latent block and the decoder's initial-state Denses as ONE launch (csrc/latent.hip): six
@@ -821,15 +885,56 @@ class Engine(object):
 
         self._mark("  decoder initial states")
         tg = self._have_targets
-        side = [h for h in self.heads if h.stream is not None]
+        side = [h for h in self.dec_heads if h.stream is not None]
+        aux_src = {a.src for a in self.aux}
         self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
         for h in side:
             with self._on(h.stream):
-                self._head_forward(h, B, Breal, states, tg, want_probs, slot=None)
-        self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs, slot=1)
+                self._head_forward(h, B, Breal, states, tg, want_probs or h.name in aux_src, slot=None)
+        self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
         self._prefork = None
-        if not self._branches_stay_forked:
+        if not self._branches_stay_forked or self.aux:
             self._join(*[h.stream for h in side])
+        for a in self.aux:
+            self._aux_forward(a, B, Breal, tg, want_probs)
+
+    def _aux_forward(self, a, B, Breal, tg, want_probs):
+        """style classifier on a decoder head's OUTPUT (reference vae_definition.py:747-761): x*W + b from the (T*B, N) probabilities,
+        the recurrence, Dense softmax + loss on the last state"""
+        s, P = self.spec, self.P
+        r, h, H = a.rec, a.head, s.H
+        R = r.T * B
+        probs = self._v("out.%s_p" % a.src, R, r.K)
+        ops.gemm(probs, P[r.prefix + ".W"], self._v(r.prefix + ".xp", R, s.GH), R, s.GH, r.K, bias=P[r.prefix + ".b"], c_layout=self.lay)
+        self._rec_forward(r, B)
+        top = self._v(r.prefix + ".hs", r.T + 1, B, H)[r.T]
+        ops.head(0, self.kind, B, H, s.C, top, self._v(a.key + ".wt", h.NP, H), P[h.out + ".b"],
+                 target_idx=self._v("in.c_idx", B) if tg else None, row_weight=self._v("in.rw_" + a.key, B) if tg else None,
+                 grad_scale=a.weight, probs=self._v("out.%s_p" % a.key, B, s.C) if want_probs else None,
+                 argmax=self._v(a.key + ".argmax", B), dlogits=self._v(a.key + ".dl", B, h.NP) if (self.training and tg) else None,
+                 scalars=self.scal[a.slot:a.slot + 2], b_stride=B, b_valid=Breal)
+
+    def _aux_backward(self, a, B):
+        """... and back: Dense, BPTT, the classifier's parameters, then its gradient w.r.t. the source head's PROBABILITIES folded
+        into that head's d(logits) (softmax Jacobian) - before the head's own backward pass runs"""
+        s, P, G = self.spec, self.P, self.G
+        r, h, H = a.rec, a.head, s.H
+        R = r.T * B
+        dl = self._v(a.key + ".dl", B, h.NP)
+        top = self._v(r.prefix + ".hs", r.T + 1, B, H)[r.T]
+        dh = self._v(a.key + ".dh", B, H)
+        ops.gemm(dl, self._v(a.key + ".wt", h.NP, H), dh, B, H, h.NP)
+        self._side(lambda: (ops.gemm(top, dl, G[h.out + ".W"], H, s.C, B, trans_a=True, ldb=h.NP, accumulate=True),
+                            ops.colsum(dl, B, s.C, G[h.out + ".b"], ldx=h.NP)))
+        self._stack_backward([r], B, dh_last=dh, dh_last_ld=H)
+        da = self._v(r.prefix + ".da", R, s.GH)
+        probs = self._v("out.%s_p" % a.src, R, r.K)
+        self._side(lambda: ops.gemm(probs, da, G[r.prefix + ".W"], r.K, s.GH, R, trans_a=True, accumulate=True,
+                                    split_k=self._split_k(R)))
+        dp = self._v(a.key + ".dp", R, r.K)
+        ops.gemm(da, P[r.prefix + ".W"], dp, R, r.K, s.GH, trans_b=True)
+        src = self.head[a.src]
+        ops.softmax_bwd_add(probs, dp, self._v(a.src + ".dl", R, src.NP), R, src.N, src.NP)
 
     def _head_forward(self, h, B, Breal, states, tg, want_probs, slot):
         """cell stack + output Dense / activation / loss / accuracy / argmax of one decoder head (B = padded batch)"""
@@ -939,7 +1044,9 @@ class Engine(object):
             else:
                 if not fuse_b:
                     ops.colsum(da2, R, GH, G[p + ".b"])
-                if r.xmode == hl.X_INDEX:
+                if r.xmode == X_EXT:
+                    pass                                # (input-kernel gradient by the caller: _aux_backward)
+                elif r.xmode == hl.X_INDEX:
                     ops.gemm(idx[t0:t0 + Tc].reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
                              accumulate=True, split_k=sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
@@ -1028,6 +1135,8 @@ class Engine(object):
         """extra arguments of ops.head: the gradient w.r.t. the top cell's h sequence comes out of the head launch itself"""
         if not (self.training and tg and self.fuse_head_bwd and self.lay == hl.TILE16 and self.spec.H <= 256):
             return {}
+        if any(a.src == name or a.key == name for a in self.aux):     # (d(logits) of that head changes after its launch)
+            return {}
         return dict(wc=self.store[name + ".wc"], dhs=self.store[name + ".dhs"])
 
     def _head_stack_backward(self, h, B, dstates, slot):
@@ -1081,7 +1190,9 @@ class Engine(object):
         # encoder BPTT kernels are resident; it then runs beside them as before.
         self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
         # (one event for the three branches, the notes head's gradient GEMM and the notes stack's lower layers)
-        side = [h for h in self.heads if h.stream is not None]
+        for a in self.aux:
+            self._aux_backward(a, B)
+        side = [h for h in self.dec_heads if h.stream is not None]
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
             self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
         else:
@@ -1094,7 +1205,9 @@ class Engine(object):
         self._join(*[h.stream for h in side])
         self._mark("  decoder BPTT")
         deferred, self._deferred = self._deferred, None
-        dcat = self._latent_chain_backward(Breal, B) if (self.fused_latent and (self.has_pack or self.ncat == 1)) else None
+        # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
+        dcat = (self._latent_chain_backward(Breal, B)
+                if (self.fused_latent and (self.has_pack or self.ncat == 1) and not s.signature) else None)
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
         ldc = self.ncat * H
@@ -1143,6 +1256,9 @@ class Engine(object):
                             ops.colsum(dS, B, ldS, G["dec.init.b"])))
         dzh = self._v("dzh", B, s.zin)
         ops.gemm(dS, P["dec.init.W"], dzh, B, s.zin, ldS, trans_b=True)
+        if s.signature:
+            ops.signature_head_bwd(dzh, s.sig_off, s.SD, Breal, self._v("sig.out", B, s.SD), self._v("in.sig", B, s.SD),
+                                   self._v("in.rw_sig", B), s.w_sig)
         # ---- latent ------------------------------------------------------------------------------------
         mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
         dmu, dlv = self._v("dmu", B, Z), self._v("dlv", B, Z)
@@ -1302,7 +1418,7 @@ class Engine(object):
         # The velocity / instrument branches' backward depends on nothing the notes branch does in between: no join at
         # the end of the decoder forward pass and no fork at the start of the backward pass (two packets less on the
         # critical queue); they are joined where the decoder BPTT ends.
-        self._branches_stay_forked = self.lean_sync and self.multi_stream
+        self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
             self.decoder_forward(B)
             self._mark("decoder forward + heads")
@@ -1367,7 +1483,7 @@ class Engine(object):
 
     # hit-count slots of the scalar block (accumulated as counts; everything else as batch-size weighted means)
     HIT_MASK = ((1 << S_NOTES_HITS) | (1 << S_INSTR_HITS) | (1 << S_VEL_HITS) | (1 << S_STYLE_HITS) | (1 << S_HELD_HITS) |
-                (1 << S_NEXT_HITS))
+                (1 << S_NEXT_HITS) | (1 << S_SIG_HITS) | (1 << S_CNOTES_HITS) | (1 << S_CINSTR_HITS))
 
     def reset_accumulated(self):
         self.acc.zero_()
@@ -1505,6 +1621,12 @@ class Engine(object):
         if s.style:
             m["style_loss"], m["style_acc"] = v[S_STYLE_LOSS], v[S_STYLE_HITS] / B
             total += s.w_style * m["style_loss"]
+        if s.signature:
+            m["sig_loss"], m["sig_acc"] = v[S_SIG_LOSS], v[S_SIG_HITS] / B
+            total += s.w_sig * m["sig_loss"]
+        for a in self.aux:
+            m[a.key + "_loss"], m[a.key + "_acc"] = v[a.slot], v[a.slot + 1] / B
+            total += a.weight * m[a.key + "_loss"]
         m["loss"] = total
         return m
 
@@ -1513,10 +1635,14 @@ class Engine(object):
         s = self.spec
         Bp = self.pad16(B)
         out = OrderedDict()
-        for h in self.heads:
+        for h in self.dec_heads:
             out[h.name] = self._v("out.%s_p" % h.name, h.T, Bp, h.N)[:, :B].permute(1, 0, 2).cpu().numpy()
         if s.style:
             out["style"] = self._v("style_p", Bp, s.C)[:B].cpu().numpy()
+        if s.signature:
+            out["sig"] = self._v("sig.out", Bp, s.SD)[:B].cpu().numpy()
+        for a in self.aux:
+            out[a.key] = self._v("out.%s_p" % a.key, Bp, s.C)[:B].cpu().numpy()
         return out
 
     def note_indices(self, B):

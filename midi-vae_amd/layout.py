@@ -56,6 +56,15 @@ class ModelSpec:
     w_held: float = 1.0
     meta_next: bool = False
     w_next: float = 1.0
+    # the optional heads of reference vae_definition.py:737-761 and the decoder's additional input (:553-556), all off by default
+    signature: bool = False          # tanh(z[:, off:off+SD]) against the song's signature vector, mse
+    SD: int = 15
+    w_sig: float = 1.0
+    comp_notes: bool = False         # a Keras RNN + Dense softmax style classifier on the decoder's notes OUTPUT
+    w_cnotes: float = 1.0
+    comp_instr: bool = False         # ... on its instrument OUTPUT
+    w_cinstr: float = 1.0
+    add_dim: int = 0                 # width of decoder_additional_input (composer one-hot and / or signature vector)
 
     def oracle_cfg(self):
         """dict accepted by oracle.vae_oracle.make_cfg (tests only)."""
@@ -77,7 +86,12 @@ class ModelSpec:
 
     @property
     def zin(self):
-        return 2 * self.Z if self.history else self.Z
+        return (2 * self.Z if self.history else self.Z) + self.add_dim
+
+    @property
+    def sig_off(self):
+        """the signature head reads z behind the style classifier's columns (reference vae_definition.py:739-743)"""
+        return self.C if self.style else 0
 
     @property
     def ncat(self):
@@ -96,9 +110,7 @@ class ModelSpec:
 
 
 _UNSUPPORTED_SWITCHES = (
-    ("use_embedding", False), ("bidirectional", False), ("decoder_additional_input", False),
-    ("signature_decoder", False), ("composer_decoder_at_notes_output", False),
-    ("composer_decoder_at_instrument_output", False),
+    ("use_embedding", False), ("bidirectional", False),
 )
 
 
@@ -113,7 +125,9 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
     for name, want in (("lstm_activation", "tanh"), ("lstm_state_activation", "tanh"),
                        ("activation_before_splitting", "tanh"), ("activation", "softmax"),
                        ("meta_instrument_activation", "softmax"), ("meta_velocity_activation", "sigmoid"),
-                       ("vae_loss", "categorical_crossentropy")):
+                       ("vae_loss", "categorical_crossentropy"), ("signature_activation", "tanh"),
+                       ("composer_decoder_at_notes_activation", "softmax"),
+                       ("composer_decoder_at_instrument_activation", "softmax")):
         if g(name, want) != want:
             raise NotImplementedError("VAE.create(%s=%r): only %r is implemented" % (name, g(name), want))
     if g("epsilon_factor", 0.0) != 0.0:
@@ -138,7 +152,12 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         prior_mean=float(g("prior_mean", 0.0)), prior_std=float(g("prior_std", 1.0)),
         epsilon_std=float(g("epsilon_std", 1.0)), lr=float(g("learning_rate", 0.001)), optimizer=opt,
         meta_held=bool(g("meta_held_notes", False)), w_held=float(g("meta_held_notes_weight", 1.0)),
-        meta_next=bool(g("meta_next_notes", False)), w_next=float(g("meta_next_notes_weight", 1.0)))
+        meta_next=bool(g("meta_next_notes", False)), w_next=float(g("meta_next_notes_weight", 1.0)),
+        signature=bool(g("signature_decoder", False)), SD=int(g("signature_dim", 15) or 15), w_sig=float(g("signature_weight", 1.0)),
+        comp_notes=bool(g("composer_decoder_at_notes_output", False)), w_cnotes=float(g("composer_decoder_at_notes_weight", 1.0)),
+        comp_instr=bool(g("composer_decoder_at_instrument_output", False)),
+        w_cinstr=float(g("composer_decoder_at_instrument_weight", 1.0)),
+        add_dim=int(g("decoder_additional_input_dim", 0)) if g("decoder_additional_input", False) else 0)
     # the asserts of reference vae_definition.py:177-208
     assert s.Le > 0 and s.Ld > 0 and s.T > 0 and s.H > 0 and s.Z > 0 and s.beta > 0
     assert int(g("input_length", s.T)) > 0
@@ -167,6 +186,14 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
             raise NotImplementedError("meta_next_notes_output_length != output_length")
     # (teacher forcing - teacher_force / meta_next_notes_teacher_force - only changes what the unused readout state holds,
     #  the cell graph never reads it, so the switch is accepted and has no effect, as in the reference)
+    if s.signature:
+        assert s.w_sig > 0 and s.SD > 0
+        if s.sig_off + s.SD > s.Z:
+            raise ValueError("signature_dim does not fit the latent behind the style columns")
+    if s.comp_notes or s.comp_instr:
+        assert 0 < s.C
+        if s.comp_instr and not s.meta_instrument:
+            raise ValueError("composer_decoder_at_instrument_output needs meta_instrument")
     if s.style:
         assert 0 < s.C <= min(s.Z, 64)
     if s.H % 64 or s.H > 256:
@@ -280,6 +307,11 @@ class ParamLayout:
                 rnn("dec.next.%d" % l, spec.Dout if l == 0 else H, "dec")
             add("dec.next.out.W", (H, spec.Dout), "dec")
             add("dec.next.out.b", (spec.Dout,), "dec")
+        for key, flag, k in (("cnotes", spec.comp_notes, spec.Dout), ("cinstr", spec.comp_instr, spec.ID)):
+            if flag:
+                rnn(key + ".rnn", k, "dec")
+                add(key + ".out.W", (H, spec.C), "dec")
+                add(key + ".out.b", (spec.C,), "dec")
         L.total = cur
         return L
 
@@ -409,7 +441,7 @@ def init_params(spec: ModelSpec, seed: int = 0) -> "OrderedDict[str, np.ndarray]
             out[n] = _glorot_uniform(rng, shape)
         else:
             out[n] = np.zeros(shape)
-            if spec.cell == "LSTM" and n.startswith("enc.") and (n[:-2] + ".U") in L.entries:
+            if spec.cell == "LSTM" and n.startswith(("enc.", "cnotes.", "cinstr.")) and (n[:-2] + ".U") in L.entries:
                 out[n][H:2 * H] = 1.0
         out[n] = out[n].astype(np.float32)
     return out

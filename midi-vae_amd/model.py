@@ -108,6 +108,14 @@ class _Shared(object):
     def epsilon(self, n):
         return (self.rng.standard_normal((n, self.spec.Z)) * self.spec.epsilon_std).astype(np.float32)
 
+    def z_heads(self):
+        """(Keras output name, metric prefix) of the outputs behind the decoder's, in the reference's order (vae_definition.py:
+        392-432): style classifier on z, signature head, classifiers on the notes / instrument outputs"""
+        sp = self.spec
+        return ([("composer_decoder", "style")] if sp.style else []) + ([("signature_decoder", "sig")] if sp.signature else []) + \
+               ([("composer_decoder_at_notes", "cnotes")] if sp.comp_notes else []) + \
+               ([("composer_decoder_at_instruments", "cinstr")] if sp.comp_instr else [])
+
     def head_names(self):
         """decoder outputs in the reference's order (vae_definition.py:341-351): notes, instrument, velocity, held, next"""
         sp = self.spec
@@ -223,6 +231,9 @@ class Decoder(_ModelView):
         hist = x[i] if sp.history else None
         i += int(sp.history)
         res = dict(start_notes=start, z=z, hist=hist)
+        if sp.add_dim:
+            res["add"] = x[i]
+            i += 1
         for flag, key in ((sp.meta_instrument, "start_instr"), (sp.meta_velocity, "start_vel"), (sp.meta_held, "start_held"),
                           (sp.meta_next, "start_next")):
             if flag:
@@ -273,19 +284,18 @@ class Autoencoder(_ModelView):
     def metrics_names(self):
         """Keras 2.0.8 naming: repeated 'decoder_loss' / 'decoder_acc' per decoder output; the reference
         de-duplicates them itself (vae_training.py:172-187)."""
-        sp = self._s.spec
         k = len(self._decoder_outputs())
-        single = k == 1 and not sp.style
-        if single:
+        zh = self._s.z_heads()
+        if k == 1 and not zh:
             return ["loss", "acc"]
-        names = ["loss"] + ["decoder_loss"] * k + (["composer_decoder_loss"] if sp.style else [])
-        names += ["decoder_acc"] * k + (["composer_decoder_acc"] if sp.style else [])
+        names = ["loss"] + ["decoder_loss"] * k + [n + "_loss" for n, _ in zh]
+        names += ["decoder_acc"] * k + [n + "_acc" for n, _ in zh]
         return names
 
     def _history_keys(self):
-        sp = self._s.spec
         outs = self._decoder_outputs()
-        if len(outs) == 1 and not sp.style:
+        zh = self._s.z_heads()
+        if len(outs) == 1 and not zh:
             return [("loss", "loss"), ("acc", "notes_acc")]
         keys = [("loss", "loss")]
         if len(outs) == 1:
@@ -293,8 +303,8 @@ class Autoencoder(_ModelView):
         else:
             for i, o in enumerate(outs, 1):
                 keys += [("decoder_loss_%d" % i, o + "_loss"), ("decoder_acc_%d" % i, o + "_acc")]
-        if sp.style:
-            keys += [("composer_decoder_loss", "style_loss"), ("composer_decoder_acc", "style_acc")]
+        for n, m in zh:
+            keys += [(n + "_loss", m + "_loss"), (n + "_acc", m + "_acc")]
         return keys
 
     # ---- list unpacking (orders of reference vae_definition.py:924-1040) -------------------------------------
@@ -307,6 +317,9 @@ class Autoencoder(_ModelView):
         i = 2 + int(bool(self._s.teacher_force))
         a["hist"] = x[i] if sp.history else None
         i += int(sp.history)
+        if sp.add_dim:
+            a["Add"] = x[i]
+            i += 1
         for flag, k_start, k_in in ((sp.meta_instrument, "start_instr", "I"), (sp.meta_velocity, "start_vel", "Vel"),
                                     (sp.meta_held, "start_held", "Held")):
             if flag:
@@ -326,8 +339,9 @@ class Autoencoder(_ModelView):
         if sp.meta_next:
             t["Next"] = y[i]
             i += 1
-        if sp.style:
-            t["C_"] = y[i]
+        for _, m in self._s.z_heads():                       # [C, S, C, C]
+            t["S" if m == "sig" else "C_"] = y[i]
+            i += 1
         return t
 
     def _unpack_w(self, w, n):
@@ -339,7 +353,7 @@ class Autoencoder(_ModelView):
         if w is None:
             return {}
         w = list(w) if isinstance(w, (list, tuple)) else [w]
-        outs = self._s.head_names() + (["style"] if sp.style else [])
+        outs = self._s.head_names() + [m for _, m in self._s.z_heads()]
         if len(w) != len(outs):
             raise ValueError("sample_weight has %d entries for the %d outputs %s" % (len(w), len(outs), outs))
         res = {}
@@ -454,7 +468,7 @@ class Autoencoder(_ModelView):
     def predict(self, x, batch_size=32, verbose=0):
         sp = self._s.spec
         _, outs, _ = self._forward_all(x, None, batch_size, want_probs=True)
-        res = [np.concatenate([o[h] for o in outs], 0) for h in self._s.head_names() + (["style"] if sp.style else [])]
+        res = [np.concatenate([o[h] for o in outs], 0) for h in self._s.head_names() + [m for _, m in self._s.z_heads()]]
         return res if len(res) > 1 else res[0]
 
 

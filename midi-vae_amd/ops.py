@@ -276,6 +276,21 @@ def scalars_accumulate(acc, x, alpha, plain_mask=0):
              "mvae_scalars_accumulate")
 
 
+def signature_head_fwd(zh, off, SD, B, out, target=None, row_weight=None, scalars=None):
+    hl.check(hl.load().mvae_signature_head_fwd(_pv(zh), zh.stride(0), int(off), int(SD), int(B), _p(target), _p(row_weight), _p(out),
+                                               _p(scalars), _stream()), "mvae_signature_head_fwd")
+
+
+def signature_head_bwd(dz, off, SD, B, out, target, row_weight, weight):
+    hl.check(hl.load().mvae_signature_head_bwd(_pv(dz), dz.stride(0), int(off), int(SD), int(B), _p(out), _p(target), _p(row_weight),
+                                               float(weight), _stream()), "mvae_signature_head_bwd")
+
+
+def softmax_bwd_add(probs, dprobs, dlogits, R, N, NP):
+    hl.check(hl.load().mvae_softmax_bwd_add(_p(probs), _p(dprobs), _p(dlogits), kind_of(dlogits), int(R), int(N), int(NP), _stream()),
+             "mvae_softmax_bwd_add")
+
+
 def copy2d(dst, src, rows, cols, src_row0=0, zero_rows=0):
     """dst[:rows, :cols] = src[src_row0 : src_row0 + rows, :cols] (f32, row strides from the views); the first ``zero_rows`` rows
     of dst are zeroed instead"""

@@ -30,13 +30,18 @@ class Norm(object):
     """Normalisers of one GLOBAL minibatch (Keras weighted objectives, SURVEY Appendix A.7: score*w / mean(w != 0), then
     the mean over the remaining axes): B windows, and the number of non-zero sample weights per output."""
 
-    def __init__(self, B, nz_notes, nz_instr, nz_vel, nz_style, nz_held=None, nz_next=None):
+    def __init__(self, B, nz_notes, nz_instr, nz_vel, nz_style, nz_held=None, nz_next=None, nz_sig=None, nz_cnotes=None,
+                 nz_cinstr=None):
         self.B, self.nz_notes, self.nz_instr, self.nz_vel, self.nz_style = int(B), nz_notes, nz_instr, nz_vel, nz_style
         self.nz_held = int(B) if nz_held is None else nz_held
         self.nz_next = int(B) if nz_next is None else nz_next
+        self.nz_sig = int(B) if nz_sig is None else nz_sig
+        self.nz_cnotes = int(B) if nz_cnotes is None else nz_cnotes
+        self.nz_cinstr = int(B) if nz_cinstr is None else nz_cinstr
 
     @staticmethod
-    def of(lo, hi, T, w_notes=None, w_instr=None, w_vel=None, w_style=None, w_held=None, w_next=None):
+    def of(lo, hi, T, w_notes=None, w_instr=None, w_vel=None, w_style=None, w_held=None, w_next=None, w_sig=None, w_cnotes=None,
+           w_cinstr=None):
         B = hi - lo
 
         def nz(w, full):
@@ -45,7 +50,8 @@ class Norm(object):
             c = int(np.count_nonzero(np.asarray(w)[lo:hi]))
             return max(c, 1)
 
-        return Norm(B, nz(w_notes, B * T), nz(w_instr, B), nz(w_vel, B), nz(w_style, B), nz(w_held, B), nz(w_next, B))
+        return Norm(B, nz(w_notes, B * T), nz(w_instr, B), nz(w_vel, B), nz(w_style, B), nz(w_held, B), nz(w_next, B),
+                    nz(w_sig, B), nz(w_cnotes, B), nz(w_cinstr, B))
 
 
 def _host_kind(a):
@@ -155,7 +161,8 @@ class Stager(object):
     # ---- one minibatch ------------------------------------------------------------------------------------------
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
-              norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None):
+              norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None,
+              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
@@ -193,9 +200,12 @@ class Stager(object):
             self._rows_bm(k, "in.hist", hist, lo, hi, s.Z, Bp)
         if z is not None:
             self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
+        if s.add_dim:
+            self._rows_bm(k, "in.add", Add, lo, hi, s.add_dim, Bp)
         have_targets = Y is not None
         if have_targets:
-            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next)
+            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next, w_sig, w_cnotes,
+                                                       w_cinstr)
             self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
             if w_notes is None:
                 out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
@@ -214,7 +224,15 @@ class Stager(object):
                 self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
             if s.style:
                 self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
-                self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 0, "style target")
+            if s.style or s.comp_notes or s.comp_instr:
+                self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 255, "style target")
+            if s.signature:
+                self._rows_bm(k, "in.sig", S, lo, hi, s.SD, Bp)
+                self._per_window(k, "in.rw_sig", w_sig, lo, hi, 1, Bp, 1.0 / nm.nz_sig)
+            if s.comp_notes:
+                self._per_window(k, "in.rw_cnotes", w_cnotes, lo, hi, 1, Bp, 1.0 / nm.nz_cnotes)
+            if s.comp_instr:
+                self._per_window(k, "in.rw_cinstr", w_cinstr, lo, hi, 1, Bp, 1.0 / nm.nz_cinstr)
             eng.norm_B = float(nm.B)
         else:
             eng.norm_B = float(B)
@@ -237,5 +255,7 @@ class Stager(object):
                 ops.copy2d(zh[:, s.Z:], eng._v("in.hist", Bp, s.Z), Bp, s.Z)
         if z is not None:
             ops.copy2d(zh[:, :s.Z], eng._v("in.z", Bp, s.Z), Bp, s.Z)
+        if s.add_dim:
+            ops.copy2d(zh[:, s.zin - s.add_dim:], eng._v("in.add", Bp, s.add_dim), Bp, s.add_dim)
         eng._have_staged_targets = have_targets
         return B

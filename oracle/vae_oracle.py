@@ -46,6 +46,9 @@ DEFAULT_CFG = dict(
     style=True, w_instr=0.1, w_vel=1.0, w_style=0.1, beta=0.1, prior_mean=0.0, prior_std=1.0,
     lr=2e-4, optimizer="Adam",
     meta_held=False, w_held=1.0, meta_next=False, w_next=1.0,      # reference settings.py:217,227 (off by default)
+    signature=False, SD=15, w_sig=1.0,                             # reference settings.py:189-192
+    comp_notes=False, w_cnotes=1.0, comp_instr=False, w_cinstr=1.0,   # reference settings.py:195-200
+    add_dim=0,                                                      # decoder_additional_input_dim, settings.py:167-177
 )
 
 
@@ -92,7 +95,7 @@ def param_shapes(cfg):
     h2 = H - H // 2 if cfg["split"] else H
     P["enc.zmean.W"], P["enc.zmean.b"] = (h1, Z), (Z,)
     P["enc.zlogvar.W"], P["enc.zlogvar.b"] = (h2, Z), (Z,)
-    zin = 2 * Z if cfg["history"] else Z
+    zin = (2 * Z if cfg["history"] else Z) + cfg["add_dim"]
 
     def init(prefix):
         for s in range(ns):
@@ -121,6 +124,12 @@ def param_shapes(cfg):
         for l in range(cfg["Ld"]):
             rnn("dec.next.%d" % l, cfg["Dout"] if l == 0 else H)
         P["dec.next.out.W"], P["dec.next.out.b"] = (H, cfg["Dout"]), (cfg["Dout"],)
+    if cfg["comp_notes"]:                                   # reference :747-753: Keras RNN over the notes OUTPUT -> Dense(C)
+        rnn("cnotes.rnn", cfg["Dout"])
+        P["cnotes.out.W"], P["cnotes.out.b"] = (H, cfg["C"]), (cfg["C"],)
+    if cfg["comp_instr"]:                                   # reference :755-761: the same over the instrument OUTPUT
+        rnn("cinstr.rnn", cfg["ID"])
+        P["cinstr.out.W"], P["cinstr.out.b"] = (H, cfg["C"]), (cfg["C"],)
     return P
 
 
@@ -340,12 +349,15 @@ class OracleVAE(object):
         cache[key] = layers
         return x_seq @ p[outprefix + ".W"] + p[outprefix + ".b"]           # (steps,B,out) logits
 
-    def decode(self, p, z, hist, starts, cache=None):
-        """z (B,Z), hist (B,Z) or None, starts = dict(notes (B,Dout), instr (B,ID), vel (B,)).
-        Returns dict of batch-major outputs: notes (B,T,Dout) probs, instr (B,V,ID) probs, vel (B,T,1)."""
+    def decode(self, p, z, hist, starts, cache=None, add=None):
+        """z (B,Z), hist (B,Z) or None, starts = dict(notes (B,Dout), instr (B,ID), vel (B,)), add (B,add_dim) = the decoder's
+        additional input (reference :553-556).  Returns dict of batch-major outputs: notes (B,T,Dout) probs, instr (B,V,ID)
+        probs, vel (B,T,1)."""
         cfg, dt = self.cfg, self.dtype
         c = {} if cache is None else cache
         zh = np.concatenate([z, np.asarray(hist, dt)], axis=1) if cfg["history"] else z
+        if cfg["add_dim"]:
+            zh = np.concatenate([zh, np.asarray(add, dt)], axis=1)
         c["zh"] = zh
         out = {}
         Ld = cfg["Ld"]
@@ -386,7 +398,7 @@ class OracleVAE(object):
                       held=batch.get("start_held", np.zeros((B, 2))),
                       next=batch.get("start_next", np.zeros((B, cfg["Dout"]))))
         c["starts"] = starts
-        out = self.decode(p, z, batch.get("Hist", np.zeros((B, cfg["Z"]))), starts, c)
+        out = self.decode(p, z, batch.get("Hist", np.zeros((B, cfg["Z"]))), starts, c, add=batch.get("Add"))
         c["out"] = out
         m = OrderedDict()
         ones = np.ones((B,), dt)
@@ -444,6 +456,28 @@ class OracleVAE(object):
             m["style_acc"] = np.mean(np.argmax(ps_, -1) == np.argmax(Ct, -1))
             total = total + cfg["w_style"] * m["style_loss"]
             out["style"] = ps_
+        if cfg["signature"]:                                 # reference :737-745: tanh(z[:, off:off+SD]) vs the signature vector, mse
+            off = cfg["C"] if cfg["style"] else 0
+            St = np.asarray(batch["S"], dt)
+            wg = np.asarray(batch.get("w_sig", ones), dt)
+            sig = np.tanh(z[:, off:off + cfg["SD"]])
+            c["sig"] = sig
+            m["sig_loss"], c["g_sig"] = _weighted_mean(np.mean((sig - St) ** 2, axis=1), wg)
+            m["sig_acc"] = np.mean(np.argmax(sig, -1) == np.argmax(St, -1))
+            total = total + cfg["w_sig"] * m["sig_loss"]
+            out["sig"] = sig
+        for key, src, flag, w in (("cnotes", "notes", "comp_notes", "w_cnotes"), ("cinstr", "instr", "comp_instr", "w_cinstr")):
+            if cfg[flag]:                                    # reference :747-761: Keras RNN over a decoder OUTPUT -> Dense softmax
+                Ct = np.asarray(batch["C"], dt)
+                x_tm = out[src].transpose(1, 0, 2)
+                hs, cs, acts = self._enc_rnn(p, key + ".rnn", x_tm)
+                pc = softmax(hs[-1] @ p[key + ".out.W"] + p[key + ".out.b"])
+                c[key] = (x_tm, hs, cs, acts, pc)
+                wq = np.asarray(batch.get("w_" + key, ones), dt)
+                m[key + "_loss"], c["g_" + key] = _weighted_mean(_cce(pc, Ct), wq)
+                m[key + "_acc"] = np.mean(np.argmax(pc, -1) == np.argmax(Ct, -1))
+                total = total + cfg[w] * m[key + "_loss"]
+                out[key] = pc
         m["loss"] = total
         c["batch"] = batch
         return m, c
@@ -492,13 +526,28 @@ class OracleVAE(object):
         B = c["mu"].shape[0]
         self._zh = c["zh"]
         dzh = np.zeros_like(c["zh"])
+        # classifiers on the decoder's outputs: their gradient arrives at the softmax PROBABILITIES of the notes / instrument heads
+        dprob = {}
+        for key, src, flag, w in (("cnotes", "notes", "comp_notes", "w_cnotes"), ("cinstr", "instr", "comp_instr", "w_cinstr")):
+            if cfg[flag]:
+                x_tm, hs, cs, acts, pc = c[key]
+                Ct = np.asarray(b["C"], dt)
+                dlc = _cce_grad_logits(pc, Ct) * (cfg[w] * c["g_" + key])[:, None]
+                g[key + ".out.W"], g[key + ".out.b"] = hs[-1].T @ dlc, dlc.sum(0)
+                dx = self._enc_rnn_backward(p, g, key + ".rnn", (x_tm, hs, cs, acts), None, dlc @ p[key + ".out.W"].T, True)
+                pr = out[src].transpose(1, 0, 2)
+                dprob[src] = pr * (dx - np.sum(pr * dx, axis=-1, keepdims=True))       # softmax Jacobian -> d(logits), time-major
         # heads
         Y = np.asarray(b["Y"], dt)
         dl = (_cce_grad_logits(out["notes"], Y) * c["g_notes"][..., None]).transpose(1, 0, 2)
+        if "notes" in dprob:
+            dl = dl + dprob["notes"]
         self._dec_head_backward(p, g, c["dec_notes"], dl, "dec.notes.out", np.asarray(c["starts"]["notes"], dt), dzh)
         if cfg["meta_instrument"]:
             It = np.asarray(b["I"], dt)
             dl = (_cce_grad_logits(out["instr"], It) * (cfg["w_instr"] * c["g_instr"])[..., None]).transpose(1, 0, 2)
+            if "instr" in dprob:
+                dl = dl + dprob["instr"]
             self._dec_head_backward(p, g, c["dec_instr"], dl, "dec.instr.out",
                                     np.asarray(c["starts"]["instr"], dt), dzh)
         if cfg["meta_velocity"]:
@@ -519,6 +568,10 @@ class OracleVAE(object):
         if cfg["style"]:
             Ct = np.asarray(b["C"], dt)
             dz[:, :cfg["C"]] += _cce_grad_logits(c["p_style"], Ct) * (cfg["w_style"] * c["g_style"])[:, None]
+        if cfg["signature"]:
+            off = cfg["C"] if cfg["style"] else 0
+            St, sig = np.asarray(b["S"], dt), c["sig"]
+            dz[:, off:off + cfg["SD"]] += (cfg["w_sig"] * c["g_sig"])[:, None] * 2.0 * (sig - St) / cfg["SD"] * (1.0 - sig ** 2)
         # latent
         mu, lv, eps = c["mu"], c["lv"], c["eps"]
         pvar = cfg["prior_std"] ** 2

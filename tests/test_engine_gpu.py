@@ -39,17 +39,20 @@ def _problem(cell, B, seed=0, H=64, Z=32, T=12, V=4, C=2, **kw):
     w_notes = np.where(x_idx == spec.Dout - 1, 0.5, 1.0)
     d_idx = (rng.random((B, T)) < 0.4).astype(np.uint8)                   # held-notes roll (reference import_midi.py:267-286)
     n_idx = rng.integers(0, spec.Dout, (B, T)).astype(np.uint8)          # the next window's notes
+    sig = (rng.standard_normal((B, spec.SD)) * 0.5).astype(np.float32)        # signature vectors (reference data_class.py:96-221)
+    add = rng.standard_normal((B, max(spec.add_dim, 1))).astype(np.float32)[:, :spec.add_dim]
     batch = dict(X=_onehot(x_idx, spec.Din), I=_onehot(i_idx, spec.ID), Vel=vel[..., None].astype(np.float64),
                  Hist=hist.astype(np.float64), Y=_onehot(x_idx, spec.Dout), C=_onehot(c_idx, C), w_notes=w_notes,
-                 Held=_onehot(d_idx, 2), Next=_onehot(n_idx, spec.Dout))
-    raw = dict(x_idx=x_idx, i_idx=i_idx, vel=vel, hist=hist, eps=eps, c_idx=c_idx, w_notes=w_notes, d_idx=d_idx, n_idx=n_idx)
+                 Held=_onehot(d_idx, 2), Next=_onehot(n_idx, spec.Dout), S=sig.astype(np.float64), Add=add.astype(np.float64))
+    raw = dict(x_idx=x_idx, i_idx=i_idx, vel=vel, hist=hist, eps=eps, c_idx=c_idx, w_notes=w_notes, d_idx=d_idx, n_idx=n_idx,
+               sig=sig, add=add)
     return spec, params, batch, raw
 
 
 def _stage(eng, raw, B):
     eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"], d_idx=raw["d_idx"])
-    eng.stage_decoder_inputs(B, hist=raw["hist"])
-    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"])
+    eng.stage_decoder_inputs(B, hist=raw["hist"], add=raw["add"])
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"], sig=raw["sig"])
 
 
 def _rel_l2(a, b):
@@ -390,14 +393,20 @@ def test_baseline_config0_elbo_within_1e3_of_oracle(cell):
                                 dict(style=False), dict(extra_layer=False, split=False, meta_instrument=False),
                                 dict(meta_held=True, w_held=0.7), dict(meta_next=True, w_next=0.3),
                                 dict(meta_held=True, meta_next=True, Ld=1, C=3),
-                                dict(meta_held=True, meta_instrument=False, meta_velocity=False)])
+                                dict(meta_held=True, meta_instrument=False, meta_velocity=False),
+                                dict(signature=True, SD=5, w_sig=0.6), dict(signature=True, style=False), dict(add_dim=3),
+                                dict(comp_notes=True, w_cnotes=0.7), dict(comp_instr=True, w_cinstr=0.4),
+                                dict(comp_notes=True, comp_instr=True, signature=True, SD=7, add_dim=2, meta_held=True,
+                                     meta_next=True, C=3)])
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 def test_model_switches_match_oracle(cell, kw):
     """The settings.py switches that change the graph around the latent and the stacks (no meta encoders / decoders and so no
     pack Dense, un-split or missing extra Dense, no history input, 4 styles, no style head, 1- and 3-layer stacks; the held-notes
     roll + head and the next-notes head of reference vae_definition.py:476-480,648-726, alone - where the reference's pack-Dense
-    condition does not fire and the extra Dense takes the 2H concatenation - and together): losses and every gradient of one
-    forward + backward pass against the oracle in f32 - also the fused latent chain's variants."""
+    condition does not fire and the extra Dense takes the 2H concatenation - and together; the signature head, the decoder's
+    additional input and the style classifiers on the decoder's notes / instrument OUTPUTS of :737-761, whose gradient re-enters
+    the decoder through the softmax of the head they read): losses and every gradient of one forward + backward pass against the
+    oracle in f32 - also the fused latent chain's variants."""
     B = 8
     spec, params, batch, raw = _problem(cell, B, seed=3, H=64, Z=16, T=8, **kw)
     if not spec.history:
@@ -409,8 +418,8 @@ def test_model_switches_match_oracle(cell, kw):
     eng = Engine(spec, max_batch=B, dtype="f32", seed=0)
     eng.set_params(params)
     eng.stage_encoder_inputs(raw["x_idx"], raw["i_idx"], raw["vel"], raw["eps"], d_idx=raw["d_idx"])
-    eng.stage_decoder_inputs(B, hist=raw["hist"] if spec.history else None)
-    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"])
+    eng.stage_decoder_inputs(B, hist=raw["hist"] if spec.history else None, add=raw["add"])
+    eng.stage_targets(B, raw["x_idx"], raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"], sig=raw["sig"])
     eng.forward_backward(B)
     m, g = eng.metrics(B), eng.get_grads()
     for k in m_o:
@@ -444,3 +453,28 @@ def test_three_layer_stacks_pipelined_h256_bf16(cell):
     for k, g0 in out[False][1].items():
         if np.linalg.norm(g0) > 1e-9:
             assert _rel_l2(out[True][1][k], g0) < 1e-4, (k, _rel_l2(out[True][1][k], g0))
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_optional_heads_on_the_resident_bf16_path(cell):
+    """H=256 bf16 with every optional head on (held / next notes, signature, additional decoder input, classifiers on the notes
+    and instrument outputs): loss parts and every gradient against the oracle at the bf16 tolerances."""
+    B = 16
+    spec, params, batch, raw = _problem(cell, B, seed=19, H=256, Z=32, T=32, meta_held=True, meta_next=True, signature=True, SD=6,
+                                        add_dim=4, comp_notes=True, comp_instr=True)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    eng = Engine(spec, max_batch=B, dtype="bf16")
+    eng.set_params(params)
+    _stage(eng, raw, B)
+    eng.forward_backward(B)
+    eng.check_pipeline()
+    m, g = eng.metrics(B), eng.get_grads()
+    for k in m_o:
+        if not k.endswith("_acc"):
+            assert abs(m[k] - m_o[k]) <= 3e-2 * (1 + abs(m_o[k])), (k, m[k], m_o[k])
+    for k in g_o:
+        if np.linalg.norm(g_o[k]) > 1e-9:
+            assert _rel_l2(g[k], g_o[k]) < 8e-2, (k, _rel_l2(g[k], g_o[k]))

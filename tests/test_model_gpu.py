@@ -146,3 +146,50 @@ def test_held_and_next_heads_through_the_reference_lists(cell):
     dec_in = pk.prepare_decoder_input(s, z, C, S, None)
     d_out = m.decoder.predict(dec_in, batch_size=s["batch_size"])
     assert [o.shape for o in d_out] == [(n, 16, 61), (n, 4, 16), (n, 16, 1), (n, 16, 2), (n, 16, 61)]
+
+
+def test_signature_and_output_classifier_heads_through_the_reference_lists():
+    """signature_decoder, composer_decoder_at_notes_output / _at_instrument_output and the decoder's additional input
+    (append_signature_vector_to_latent + decoder_input_composer) through the reference's list layout (vae_definition.py:880-1045):
+    evaluate equals the oracle's forward pass, fit reports the reference's history keys (vae_training.py:817-864), predict returns
+    the outputs in the reference's order."""
+    s = build_settings(cell_type="GRU", lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=8,
+                       learning_rate=1e-3, signature_decoder=True, composer_decoder_at_notes_output=True,
+                       composer_decoder_at_instrument_output=True, append_signature_vector_to_latent=True,
+                       decoder_input_composer=True, epsilon_std=0.0)
+    m = VAE().create(compute_dtype="f32", seed=2, **create_kwargs(s))
+    n = 11
+    w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=8)
+    X, Y, C, I, V, D = to_reference_format(w)
+    rng = np.random.default_rng(3)
+    Hh = rng.standard_normal((n, s["latent_dim"])) * 0.1
+    S = rng.standard_normal((n, s["signature_vector_length"])) * 0.4
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, Hh, return_sample_weight=True)
+    assert len(x) == 8 and len(y) == 7 and len(sw) == 7 and x[3].shape == (n, 17)
+    names = m.autoencoder.metrics_names
+    assert names[4:8] == ["composer_decoder_loss", "signature_decoder_loss", "composer_decoder_at_notes_loss",
+                          "composer_decoder_at_instruments_loss"]
+    res = dict(zip(["loss", "l1", "l2", "l3", "ls", "lsig", "lcn", "lci", "a1", "a2", "a3", "as", "asig", "acn", "aci"],
+                   m.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)))
+    spec = m.spec
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    from midi_vae_amd.layout import init_params
+    p = {k: v.astype(np.float64) for k, v in init_params(spec, 2).items()}
+    tot = {}
+    for lo in range(0, n, s["batch_size"]):
+        hi = min(n, lo + s["batch_size"])
+        b = dict(X=x[0][lo:hi], Hist=x[2][lo:hi], Add=x[3][lo:hi], I=x[5][lo:hi], Vel=x[7][lo:hi], Y=y[0][lo:hi], C=y[3][lo:hi],
+                 S=y[4][lo:hi])
+        mo, _ = orc.forward(p, b, np.zeros((hi - lo, spec.Z)))
+        for k, v in mo.items():
+            tot[k] = tot.get(k, 0.0) + v * (hi - lo) / n
+    for got, want in (("loss", "loss"), ("l1", "notes_loss"), ("ls", "style_loss"), ("lsig", "sig_loss"), ("lcn", "cnotes_loss"),
+                      ("lci", "cinstr_loss"), ("asig", "sig_acc"), ("acn", "cnotes_acc"), ("aci", "cinstr_acc")):
+        assert abs(res[got] - tot[want]) <= 2e-4 * (1 + abs(tot[want])), (got, res[got], tot[want])
+    hist = m.autoencoder.fit(x, y, epochs=2, batch_size=s["batch_size"], shuffle=False, sample_weight=sw, verbose=False)
+    for k in ("signature_decoder_loss", "signature_decoder_acc", "composer_decoder_at_notes_loss", "composer_decoder_at_notes_acc",
+              "composer_decoder_at_instruments_loss", "composer_decoder_at_instruments_acc"):
+        assert len(hist.history[k]) == 2
+    assert hist.history["loss"][1] < hist.history["loss"][0]
+    outs = m.autoencoder.predict(x, batch_size=s["batch_size"])
+    assert [o.shape for o in outs] == [(n, 16, 61), (n, 4, 16), (n, 16, 1), (n, 2), (n, 15), (n, 2), (n, 2)]
