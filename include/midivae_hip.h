@@ -386,6 +386,15 @@ int mvae_signature_head_bwd(float* dz, int32_t lddz, int32_t off, int32_t SD, in
 int mvae_softmax_bwd_add(const float* probs, const float* dprobs, void* dlogits, int32_t kind, int32_t R, int32_t N, int32_t NP,
                          void* stream);
 
+/* Bidirectional encoder layers (keras.layers.Bidirectional(..., merge_mode='concat'), reference vae_definition.py:445-453): the
+ * backward layer runs on the time-reversed sequence.  f, r: the (T, B, H) output sequences of the forward layer and of the
+ * backward layer (in ITS time order), row-major, of `kind`; cat (T, B, 2H) = [f[t] | r[T-1-t]] - the time-aligned concatenation the
+ * next layer reads - and cat_rev (optional) the same reversed in time (what the next BACKWARD layer reads).  H*elemsize % 16 == 0. */
+int mvae_bi_concat(const void* f, const void* r, void* cat, void* cat_rev, int32_t kind, int32_t T, int32_t B, int32_t H, void* stream);
+/* dst[t] = (a ? a[t] : 0) + b[T-1-t] for T contiguous slabs of `slab` elements (% 4 == 0) of `kind`: gradients that cross between
+ * the two time directions.  A time step of a (T*B, H) sequence is one slab in row-major AND in MVAE_TILE16 layout (B % 16 == 0). */
+int mvae_add_time_reversed(void* dst, const void* a, const void* b, int32_t kind, int32_t T, size_t slab, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * HOST-side packers (csrc/hostpack.cpp): every pointer below is a HOST pointer, nothing touches the device.
  * The reference hands the Keras Models float64 NumPy windows - one-hot rows (n, T, K) (reference import_midi.py:245-286,

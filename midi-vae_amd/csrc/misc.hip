@@ -368,6 +368,36 @@ __global__ void softmax_bwd_add_k(const float* __restrict__ p, const float* __re
     }
 }
 
+// ---- bidirectional encoder layers (Keras Bidirectional(..., merge_mode='concat')) -----------------------------------------
+// cat[t, b, :H] = f[t, b, :], cat[t, b, H:] = r[T-1-t, b, :]  and  cat_rev[k] = cat[T-1-k]  (16-byte chunks; rows of H elements)
+__global__ void bi_concat_k(const uint4* __restrict__ f, const uint4* __restrict__ r, uint4* __restrict__ cat, uint4* __restrict__ cat_rev,
+                            int T, int B, int hc /* 16-byte chunks per H row */) {
+    const size_t n = (size_t)T * B * hc;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % hc);
+        const size_t row = e / hc;
+        const int b = (int)(row % B), t = (int)(row / B);
+        const uint4 vf = f[e];
+        const uint4 vr = r[((size_t)(T - 1 - t) * B + b) * hc + c];
+        const size_t o = ((size_t)t * B + b) * 2 * hc, orv = ((size_t)(T - 1 - t) * B + b) * 2 * hc;
+        cat[o + c] = vf;
+        cat[o + hc + c] = vr;
+        if (cat_rev) { cat_rev[orv + c] = vf; cat_rev[orv + hc + c] = vr; }
+    }
+}
+// dst[t] = (a ? a[t] : 0) + b[T-1-t] over T contiguous slabs of `slab` elements (row-major and TILE16 alike: a time step of a
+// (T*B, H) sequence is one contiguous slab in both layouts when B is a multiple of 16)
+template <typename WT>
+__global__ void add_time_reversed_k(WT* __restrict__ dst, const WT* __restrict__ a, const WT* __restrict__ b, int T, size_t slab) {
+    const size_t n = (size_t)T * slab;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += (size_t)gridDim.x * blockDim.x * 4) {
+        const size_t t = e / slab, w = e % slab;
+        f32x4 v = st<WT>::load4(b + (size_t)(T - 1 - t) * slab + w);
+        if (a) { const f32x4 u = st<WT>::load4(a + e); v = v + u; }
+        st<WT>::store4(dst + e, v);
+    }
+}
+
 inline int nblocks(size_t n, int per = 256, int cap = 2048) {
     size_t b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -648,6 +678,30 @@ extern "C" int mvae_softmax_bwd_add(const float* probs, const float* dprobs, voi
         hipLaunchKernelGGL(softmax_bwd_add_k<float>, dim3(nblocks(R)), dim3(256), 0, s, probs, dprobs, (float*)dlogits, R, N, NP);
     else if (kind == MVAE_BF16)
         hipLaunchKernelGGL(softmax_bwd_add_k<bf16_t>, dim3(nblocks(R)), dim3(256), 0, s, probs, dprobs, (bf16_t*)dlogits, R, N, NP);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_bi_concat(const void* f, const void* r, void* cat, void* cat_rev, int32_t kind, int32_t T, int32_t B, int32_t H,
+                              void* stream) {
+    const int esz = kind == MVAE_BF16 ? 2 : 4;
+    if (!f || !r || !cat || T <= 0 || B <= 0 || H <= 0 || (H * esz) % 16 || (kind != MVAE_BF16 && kind != MVAE_F32)) return MVAE_E_ARG;
+    const int hc = H * esz / 16;
+    hipLaunchKernelGGL(bi_concat_k, dim3(nblocks((size_t)T * B * hc)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (const uint4*)f, (const uint4*)r, (uint4*)cat, (uint4*)cat_rev, T, B, hc);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_add_time_reversed(void* dst, const void* a, const void* b, int32_t kind, int32_t T, size_t slab, void* stream) {
+    if (!dst || !b || T <= 0 || slab == 0 || (slab % 4)) return MVAE_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nb = nblocks((size_t)T * slab / 4);
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(add_time_reversed_k<float>, dim3(nb), dim3(256), 0, s, (float*)dst, (const float*)a, (const float*)b, T, slab);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(add_time_reversed_k<bf16_t>, dim3(nb), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)a, (const bf16_t*)b, T,
+                           slab);
     else
         return MVAE_E_ARG;
     MVAE_CHECK_LAUNCH();

@@ -292,10 +292,17 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------------
     def _build_graph_description(self):
         s = self.spec
-        self.enc_notes = []
-        for l in range(s.Le):
-            self.enc_notes.append(_Rec("enc.notes.%d" % l, s.T, hl.X_INDEX if l == 0 else hl.X_DENSE,
-                                       s.Din if l == 0 else s.H, lower=self.enc_notes[-1] if l else None))
+        self.enc_notes, self.enc_bi = [], []
+        layers = s.enc_layers()
+        if len(layers) > 1 and len(layers[0]) > 1:
+            # bidirectional stack: every layer a [forward, backward] pair of records, ONE plain layer on top (_enc_bi_forward)
+            for li, layer in enumerate(layers):
+                self.enc_bi.append([_Rec(prefix, s.T, hl.X_INDEX if li == 0 else X_EXT, k) for prefix, _, k in layer])
+            self.enc_notes = [self.enc_bi[-1][0]]
+        else:           # (bidirectional with Le = 2 builds no Bidirectional layer at all: one plain layer - as written)
+            for l, layer in enumerate(layers):
+                self.enc_notes.append(_Rec(layer[0][0], s.T, hl.X_INDEX if l == 0 else hl.X_DENSE, layer[0][2],
+                                           lower=self.enc_notes[-1] if l else None))
         self.enc_instr = _Rec("enc.instr", s.V, hl.X_INDEX, s.ID) if s.meta_instrument else None
         self.enc_vel = _Rec("enc.vel", s.T, hl.X_SCALAR, 1) if s.meta_velocity else None
         self.enc_held = _Rec("enc.held", s.T, hl.X_INDEX, 2) if s.meta_held else None
@@ -342,7 +349,8 @@ class Engine(object):
                 self.aux.append(a)
         self.dec_heads = list(self.heads)          # the decoder's own heads (self.heads also lists the classifiers' Dense heads)
         self.heads = self.heads + [a.head for a in self.aux]
-        self.all_rec = (self.enc_notes + [m[0] for m in self.enc_meta] + [r for h in self.dec_heads for r in h.layers] +
+        enc_recs = [r for layer in self.enc_bi for r in layer] if self.enc_bi else self.enc_notes
+        self.all_rec = (enc_recs + [m[0] for m in self.enc_meta] + [r for h in self.dec_heads for r in h.layers] +
                         [a.rec for a in self.aux])
         self.ncat = s.ncat
         self.has_pack = s.has_pack
@@ -395,6 +403,22 @@ class Engine(object):
                     buf(p + ".dxp0", B * GH, **f32)
             elif r.xmode == X_EXT:
                 buf(p + ".xp", r.T * B * GH, **esz)
+        for li, layer in enumerate(getattr(self, "enc_bi", ())):
+            if li == 0:
+                continue
+            T = layer[0].T
+            buf("enc.bi.%d.cat" % li, T * B * 2 * H, **esz)              # [forward | backward] outputs of the layer below, time-aligned
+            if len(layer) > 1:
+                buf("enc.bi.%d.cat_rev" % li, T * B * 2 * H, **esz)      # ... reversed in time: what this layer's backward RNN reads
+            for r in layer:
+                buf(r.prefix + ".wt2", GH * 2 * H, **esz)                # W^T (GH, 2H)
+                if self.training:
+                    buf(r.prefix + ".wc2", 2 * H * GH, **esz)            # W (2H, GH) in the compute dtype
+                    buf(r.prefix + ".g1", T * B * H, **esz)              # d(input)[:, :H] and [:, H:] of this record
+                    buf(r.prefix + ".g2", T * B * H, **esz)
+            if self.training:
+                buf("enc.bi.%d.dext_f" % li, T * B * H, **esz)           # gradient arriving at the forward / backward layer below
+                buf("enc.bi.%d.dext_r" % li, T * B * H, **esz)
         for a in getattr(self, "aux", ()):
             if self.training:
                 buf(a.key + ".dp", a.rec.T * B * a.rec.K, **f32)    # gradient w.r.t. the source head's probabilities
@@ -449,6 +473,8 @@ class Engine(object):
         if s.meta_next:
             regions += [("in.n_idx", T * B, torch.uint8), ("in.rw_next", T * B, torch.float32),
                         ("in.start_next", B * s.Dout, torch.float32)]
+        if self.enc_bi:
+            regions += [("in.x_idx_rev", T * B, torch.uint8)]
         if s.add_dim:
             regions += [("in.add", B * s.add_dim, torch.float32)]
         if s.signature:
@@ -509,6 +535,8 @@ class Engine(object):
         B = x_idx.shape[0]
         self.norm_B = float(B)
         self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
+        if self.enc_bi:
+            self._up_tm("in.x_idx_rev", np.asarray(x_idx, np.uint8)[:, ::-1], torch.uint8)
         if self.spec.meta_instrument:
             self._up_tm("in.i_idx", np.asarray(i_idx, np.uint8), torch.uint8)
         if self.spec.meta_velocity:
@@ -608,6 +636,10 @@ class Engine(object):
                         pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
                     elif r.xmode == hl.X_DENSE:
                         pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
+                    if (p + ".wt2") in self.store:
+                        pb.transpose_convert(P[p + ".W"], self._v(p + ".wt2", s.GH, 2 * s.H))
+                        if self.training:
+                            pb.convert(P[p + ".W"], self._v(p + ".wc2", 2 * s.H, s.GH))
                     if self.training:
                         pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
                         if r.xmode == hl.X_DENSE:
@@ -704,6 +736,8 @@ class Engine(object):
         """ONE launch per layer for the whole sequence; layer l+1 follows layer l at a distance of ``pipe_chunk`` time
         steps, released chunk by chunk through device-side counters (include/midivae_hip.h, 'time-pipelined stacks')
         instead of one launch per (layer, chunk)."""
+        if len(layers) < 2:
+            return False
         T = layers[0].T
         return (self.pipeline and self.multi_stream and not self.use_graphs and len(layers) > 1 and
                 len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 64 and
@@ -798,7 +832,10 @@ class Engine(object):
             with self._on(st):
                 inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
                 self._rec_forward(r, B, h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc, **inp)
-        self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
+        if self.enc_bi:
+            self._enc_bi_forward(B, cat[:, 0:H], ldc)
+        else:
+            self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._prefork = None
         self._join(*[st for _, st, _ in self.enc_meta])
         self._mark("  encoder recurrences")
@@ -828,6 +865,69 @@ class Engine(object):
                        style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
                        style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
         self._signature_forward(Breal, B)
+
+    # ---- bidirectional encoder stack (reference vae_definition.py:445-453) --------------------------------------------------
+    def _enc_bi_forward(self, B, h_last, ldc):
+        """Le-2 Bidirectional(concat) layers and one plain layer on top.  The backward RNN of a pair runs the same kernels on
+        the time-reversed input (reversed index roll for the one-hot layer, ``cat_rev`` above it); layer l+1 reads the
+        time-aligned concatenation [forward | backward] of layer l (mvae_bi_concat), projected by ONE GEMM with K = 2H."""
+        s, P = self.spec, self.P
+        H, GH, T = s.H, s.GH, s.T
+        R = T * B
+        for li, layer in enumerate(self.enc_bi):
+            top = li == len(self.enc_bi) - 1
+            if li > 0:
+                lo = self.enc_bi[li - 1]
+                catb = self._v("enc.bi.%d.cat" % li, R, 2 * H)
+                rev = self._v("enc.bi.%d.cat_rev" % li, R, 2 * H) if len(layer) > 1 else None
+                ops.bi_concat(self._v(lo[0].prefix + ".hs", T + 1, B, H)[1:], self._v(lo[1].prefix + ".hs", T + 1, B, H)[1:], catb, rev,
+                              T, B, H)
+            for j, r in enumerate(layer):
+                if li == 0:
+                    self._rec_forward(r, B, idx=self._v("in.x_idx_rev" if j else "in.x_idx", T, B))
+                else:
+                    src = rev if j else catb
+                    ops.gemm(src, self._v(r.prefix + ".wt2", GH, 2 * H), self._v(r.prefix + ".xp", R, GH), R, GH, 2 * H, trans_b=True,
+                             bias=P[r.prefix + ".b"], c_layout=self.lay)
+                    self._rec_forward(r, B, h_last=h_last if top else None, h_last_ld=ldc if top else 0)
+
+    def _enc_bi_backward(self, B, dh_last, ldc):
+        s, P, G = self.spec, self.P, self.G
+        H, GH, T = s.H, s.GH, s.T
+        R = T * B
+        for li in range(len(self.enc_bi) - 1, -1, -1):
+            layer = self.enc_bi[li]
+            top = li == len(self.enc_bi) - 1
+            for j, r in enumerate(layer):
+                dext = None
+                if not top:
+                    dext = self._v("enc.bi.%d.dext_%s" % (li + 1, "r" if j else "f"), T, B, H)
+                idx = self._v("in.x_idx_rev" if j else "in.x_idx", T, B) if li == 0 else None
+                self._rec_bptt(r, B, dhs_ext=dext, dh_last=dh_last if top else None, dh_last_ld=ldc if top else 0)
+                self._rec_param_grads(r, B, idx=idx)
+                if li > 0:
+                    da = self._v(r.prefix + ".da", R, GH)
+                    src = self._v("enc.bi.%d.cat%s" % (li, "_rev" if j else ""), R, 2 * H)
+                    self._side(lambda src=src, da=da, r=r: ops.gemm(src, da, G[r.prefix + ".W"], 2 * H, GH, R, trans_a=True,
+                                                                    accumulate=True, split_k=self._split_k(R)))
+                    wc = self._v(r.prefix + ".wc2", 2 * H, GH)
+                    for half, name in ((0, ".g1"), (1, ".g2")):       # d(input)[:, :H] -> forward layer below, [:, H:] -> backward
+                        ops.gemm(da, wc[half * H:(half + 1) * H], self._v(r.prefix + name, R, H), R, H, GH, trans_b=True,
+                                 c_layout=self.lay)
+            if li > 0:
+                # the layer below: its forward RNN lives in natural time, its backward RNN in reversed time; gradients computed by
+                # this layer's forward record are in natural time, by its backward record in reversed time
+                f = layer[0].prefix
+                g1f, g2f = self._v(f + ".g1", R, H), self._v(f + ".g2", R, H)
+                df, dr = self._v("enc.bi.%d.dext_f" % li, R, H), self._v("enc.bi.%d.dext_r" % li, R, H)
+                if len(layer) > 1:
+                    b = layer[1].prefix
+                    g1b, g2b = self._v(b + ".g1", R, H), self._v(b + ".g2", R, H)
+                    ops.add_time_reversed(df, g1f, g1b, T, B * H)       # d f(t) = G1_fwd(t) + G1_bwd(T-1-t)
+                    ops.add_time_reversed(dr, g2b, g2f, T, B * H)       # d b(k) = G2_bwd(k) + G2_fwd(T-1-k)
+                else:
+                    df.copy_(g1f)
+                    ops.add_time_reversed(dr, None, g2f, T, B * H)
 
     def _signature_forward(self, Breal, B):
         """signature head (reference vae_definition.py:737-745): tanh of the latent columns behind the style classifier's"""
@@ -1228,7 +1328,10 @@ class Engine(object):
             with self._on(st):
                 inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
                 self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc, **inp)
-        self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+        if self.enc_bi:
+            self._enc_bi_backward(B, dcat[:, 0:H], ldc)
+        else:
+            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
         self._prefork = None
         if deferred:
             word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da

@@ -136,6 +136,8 @@ SIGNATURES = {
     "mvae_signature_head_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mvae_signature_head_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp]),
     "mvae_softmax_bwd_add": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_bi_concat": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_add_time_reversed": (_i32, [_vp, _vp, _vp, _i32, _i32, _sz, _vp]),
     "mvae_host_threads": (_i32, [_i32]),
     "mvae_host_onehot_to_index_tm": (_i32, [_vp, _i32, _i64, _i32, _i32, _i64, _i64, _vp, _i32, C.c_uint8, C.POINTER(_i64)]),
     "mvae_host_index_to_tm": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _i32, C.c_uint8]),

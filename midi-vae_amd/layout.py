@@ -65,6 +65,7 @@ class ModelSpec:
     comp_instr: bool = False         # ... on its instrument OUTPUT
     w_cinstr: float = 1.0
     add_dim: int = 0                 # width of decoder_additional_input (composer one-hot and / or signature vector)
+    bidirectional: bool = False      # reference vae_definition.py:445-453 (Le-2 Bidirectional layers + one on top, as written)
 
     def oracle_cfg(self):
         """dict accepted by oracle.vae_oracle.make_cfg (tests only)."""
@@ -88,6 +89,19 @@ class ModelSpec:
     def zin(self):
         return (2 * self.Z if self.history else self.Z) + self.add_dim
 
+    def enc_layers(self):
+        """[[(prefix, reversed?, input width)]] of the encoder's notes stack, bottom to top (oracle.vae_oracle.enc_notes_layers):
+        the reference's bidirectional loop is ``range(1, Le-1)`` - Le-2 Bidirectional(concat) layers and ONE plain layer on top."""
+        if not self.bidirectional:
+            return [[("enc.notes.%d" % l, False, self.Din if l == 0 else self.H)] for l in range(self.Le)]
+        nbi = max(self.Le - 2, 0)
+        out = []
+        for l in range(nbi):
+            k = self.Din if l == 0 else 2 * self.H
+            out.append([("enc.notes.%d" % l, False, k), ("enc.notes.%d.rev" % l, True, k)])
+        out.append([("enc.notes.%d" % nbi, False, self.Din if nbi == 0 else 2 * self.H)])
+        return out
+
     @property
     def sig_off(self):
         """the signature head reads z behind the style classifier's columns (reference vae_definition.py:739-743)"""
@@ -110,7 +124,7 @@ class ModelSpec:
 
 
 _UNSUPPORTED_SWITCHES = (
-    ("use_embedding", False), ("bidirectional", False),
+    ("use_embedding", False),
 )
 
 
@@ -157,7 +171,8 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         comp_notes=bool(g("composer_decoder_at_notes_output", False)), w_cnotes=float(g("composer_decoder_at_notes_weight", 1.0)),
         comp_instr=bool(g("composer_decoder_at_instrument_output", False)),
         w_cinstr=float(g("composer_decoder_at_instrument_weight", 1.0)),
-        add_dim=int(g("decoder_additional_input_dim", 0)) if g("decoder_additional_input", False) else 0)
+        add_dim=int(g("decoder_additional_input_dim", 0)) if g("decoder_additional_input", False) else 0,
+        bidirectional=bool(g("bidirectional", False)))
     # the asserts of reference vae_definition.py:177-208
     assert s.Le > 0 and s.Ld > 0 and s.T > 0 and s.H > 0 and s.Z > 0 and s.beta > 0
     assert int(g("input_length", s.T)) > 0
@@ -253,8 +268,9 @@ class ParamLayout:
             add(prefix + ".U", (H, GH), group)
             add(prefix + ".b", (GH,), group)
 
-        for l in range(spec.Le):
-            rnn("enc.notes.%d" % l, spec.Din if l == 0 else H, "enc")
+        for layer in spec.enc_layers():
+            for prefix, _, k in layer:
+                rnn(prefix, k, "enc")
         ncat = 1
         if spec.meta_instrument:
             rnn("enc.instr", spec.ID, "enc")

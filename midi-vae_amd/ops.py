@@ -291,6 +291,18 @@ def softmax_bwd_add(probs, dprobs, dlogits, R, N, NP):
              "mvae_softmax_bwd_add")
 
 
+def bi_concat(f, r, cat, cat_rev, T, B, H):
+    """cat (T,B,2H) = [f[t] | r[T-1-t]], cat_rev = cat reversed in time (or None)"""
+    hl.check(hl.load().mvae_bi_concat(_p(f), _p(r), _p(cat), _p(cat_rev), kind_of(cat), int(T), int(B), int(H), _stream()),
+             "mvae_bi_concat")
+
+
+def add_time_reversed(dst, a, b, T, slab):
+    """dst[t] = (a[t] if a is not None else 0) + b[T-1-t] over T slabs of ``slab`` elements"""
+    hl.check(hl.load().mvae_add_time_reversed(_p(dst), _p(a), _p(b), kind_of(dst), int(T), int(slab), _stream()),
+             "mvae_add_time_reversed")
+
+
 def copy2d(dst, src, rows, cols, src_row0=0, zero_rows=0):
     """dst[:rows, :cols] = src[src_row0 : src_row0 + rows, :cols] (f32, row strides from the views); the first ``zero_rows`` rows
     of dst are zeroed instead"""

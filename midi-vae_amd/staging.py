@@ -181,6 +181,8 @@ class Stager(object):
         if self.done[k] is not None:
             self.done[k].synchronize()              # the upload that last read this mirror has completed
         self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
+        if eng.enc_bi:          # the backward RNNs of a bidirectional encoder read the roll reversed in time
+            self._view(k, "in.x_idx_rev", np.uint8, T * Bp).reshape(T, Bp)[:] = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)[::-1]
         if s.meta_instrument:
             self._rows_u8(k, "in.i_idx", I, lo, hi, V, s.ID, Bp, 0, "instrument input")
         if s.meta_velocity:

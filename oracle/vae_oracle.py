@@ -49,7 +49,25 @@ DEFAULT_CFG = dict(
     signature=False, SD=15, w_sig=1.0,                             # reference settings.py:189-192
     comp_notes=False, w_cnotes=1.0, comp_instr=False, w_cinstr=1.0,   # reference settings.py:195-200
     add_dim=0,                                                      # decoder_additional_input_dim, settings.py:167-177
+    bidirectional=False,                                            # settings.py:159
 )
+
+
+def enc_notes_layers(cfg):
+    """[(prefix, reversed?, input width)] of the encoder's notes stack, bottom to top.  Unidirectional: Le layers.  Bidirectional
+    (reference vae_definition.py:445-453, as written): ``range(1, Le-1)`` builds Le-2 Bidirectional(..., merge_mode='concat')
+    layers - each a forward and a backward RNN whose outputs are concatenated per time step - and ONE unidirectional layer on top;
+    with the default Le=2 that is no bidirectional layer at all."""
+    H = cfg["H"]
+    if not cfg["bidirectional"]:
+        return [[("enc.notes.%d" % l, False, cfg["Din"] if l == 0 else H)] for l in range(cfg["Le"])]
+    nbi = max(cfg["Le"] - 2, 0)
+    out = []
+    for l in range(nbi):
+        k = cfg["Din"] if l == 0 else 2 * H
+        out.append([("enc.notes.%d" % l, False, k), ("enc.notes.%d.rev" % l, True, k)])
+    out.append([("enc.notes.%d" % nbi, False, cfg["Din"] if nbi == 0 else 2 * H)])
+    return out
 
 
 def make_cfg(**kw):
@@ -74,8 +92,9 @@ def param_shapes(cfg):
         P[prefix + ".U"] = (H, GH)
         P[prefix + ".b"] = (GH,)
 
-    for l in range(cfg["Le"]):
-        rnn("enc.notes.%d" % l, cfg["Din"] if l == 0 else H)
+    for layer in enc_notes_layers(cfg):
+        for prefix, _, k in layer:
+            rnn(prefix, k)
     ncat = 1
     if cfg["meta_instrument"]:
         rnn("enc.instr", cfg["ID"])
@@ -288,12 +307,16 @@ class OracleVAE(object):
         c = {} if cache is None else cache
         x = np.asarray(X, dt).transpose(1, 0, 2)
         seqs = []
-        for l in range(cfg["Le"]):
-            hs, cs, acts = self._enc_rnn(p, "enc.notes.%d" % l, x)
-            seqs.append((x, hs, cs, acts))
-            x = hs[1:]
+        for layer in enc_notes_layers(cfg):
+            outs = []
+            for prefix, rev, _ in layer:
+                xin = x[::-1] if rev else x              # Keras Bidirectional: the backward layer reads the sequence reversed ...
+                hs, cs, acts = self._enc_rnn(p, prefix, xin)
+                seqs.append((prefix, rev, xin, hs, cs, acts))
+                outs.append(hs[1:][::-1] if rev else hs[1:])     # ... and its outputs are put back in time order
+            x = outs[0] if len(outs) == 1 else np.concatenate(outs, axis=-1)
         c["enc_notes"] = seqs
-        feats = [seqs[-1][1][-1]]
+        feats = [seqs[-1][3][-1]]
         if cfg["meta_instrument"]:
             xi = np.asarray(I, dt).transpose(1, 0, 2)
             hs, cs, acts = self._enc_rnn(p, "enc.instr", xi)
@@ -601,10 +624,22 @@ class OracleVAE(object):
         if cfg["meta_held"]:
             self._enc_rnn_backward(p, g, "enc.held", c["enc_held"], None, dh[:, k:k + H], False)
             k += H
-        dext, dlast = None, d_notes
-        for l in range(cfg["Le"] - 1, -1, -1):
-            dext = self._enc_rnn_backward(p, g, "enc.notes.%d" % l, c["enc_notes"][l], dext, dlast, l > 0)
-            dlast = None
+        layers = enc_notes_layers(cfg)
+        recs = {r[0]: r for r in c["enc_notes"]}
+        dx, dlast = None, d_notes                 # dx: gradient w.r.t. the (time-ordered) input sequence of the layer above
+        for li in range(len(layers) - 1, -1, -1):
+            acc = None
+            for j, (prefix, rev, _) in enumerate(layers[li]):
+                dext = None
+                if dx is not None:
+                    dext = dx[..., j * H:(j + 1) * H] if len(layers[li]) > 1 else dx
+                    dext = dext[::-1] if rev else dext
+                _, _, xin, hs, cs, acts = recs[prefix]
+                d_in = self._enc_rnn_backward(p, g, prefix, (xin, hs, cs, acts), dext, dlast, li > 0)
+                if d_in is not None:
+                    d_in = d_in[::-1] if rev else d_in
+                    acc = d_in if acc is None else acc + d_in
+            dx, dlast = acc, None
         return g
 
     # ---- optimizer ------------------------------------------------------------------------------

@@ -397,7 +397,8 @@ def test_baseline_config0_elbo_within_1e3_of_oracle(cell):
                                 dict(signature=True, SD=5, w_sig=0.6), dict(signature=True, style=False), dict(add_dim=3),
                                 dict(comp_notes=True, w_cnotes=0.7), dict(comp_instr=True, w_cinstr=0.4),
                                 dict(comp_notes=True, comp_instr=True, signature=True, SD=7, add_dim=2, meta_held=True,
-                                     meta_next=True, C=3)])
+                                     meta_next=True, C=3),
+                                dict(bidirectional=True), dict(bidirectional=True, Le=3), dict(bidirectional=True, Le=4, Ld=1)])
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 def test_model_switches_match_oracle(cell, kw):
     """The settings.py switches that change the graph around the latent and the stacks (no meta encoders / decoders and so no
@@ -405,7 +406,8 @@ def test_model_switches_match_oracle(cell, kw):
     roll + head and the next-notes head of reference vae_definition.py:476-480,648-726, alone - where the reference's pack-Dense
     condition does not fire and the extra Dense takes the 2H concatenation - and together; the signature head, the decoder's
     additional input and the style classifiers on the decoder's notes / instrument OUTPUTS of :737-761, whose gradient re-enters
-    the decoder through the softmax of the head they read): losses and every gradient of one forward + backward pass against the
+    the decoder through the softmax of the head they read; the bidirectional encoder of :445-453 - Le-2 Bidirectional(concat)
+    layers and one plain layer on top, as written, so Le=2 builds a single plain layer): losses and every gradient of one forward + backward pass against the
     oracle in f32 - also the fused latent chain's variants."""
     B = 8
     spec, params, batch, raw = _problem(cell, B, seed=3, H=64, Z=16, T=8, **kw)
@@ -456,12 +458,14 @@ def test_three_layer_stacks_pipelined_h256_bf16(cell):
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-def test_optional_heads_on_the_resident_bf16_path(cell):
+@pytest.mark.parametrize("bi", [False, True])
+def test_optional_heads_on_the_resident_bf16_path(cell, bi):
     """H=256 bf16 with every optional head on (held / next notes, signature, additional decoder input, classifiers on the notes
-    and instrument outputs): loss parts and every gradient against the oracle at the bf16 tolerances."""
+    and instrument outputs), with a plain and with a bidirectional (Le=3) encoder: loss parts and every gradient against the
+    oracle at the bf16 tolerances."""
     B = 16
     spec, params, batch, raw = _problem(cell, B, seed=19, H=256, Z=32, T=32, meta_held=True, meta_next=True, signature=True, SD=6,
-                                        add_dim=4, comp_notes=True, comp_instr=True)
+                                        add_dim=4, comp_notes=True, comp_instr=True, bidirectional=bi, Le=3 if bi else 2)
     orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
     p64 = {k: v.astype(np.float64) for k, v in params.items()}
     m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))

@@ -38,7 +38,7 @@ def test_history_keys_are_the_ones_the_training_script_reads():
     assert m2.autoencoder.metrics_names == ["loss", "acc"]
 
 
-@pytest.mark.parametrize("switch", ["bidirectional", "use_embedding"])
+@pytest.mark.parametrize("switch", ["use_embedding"])
 def test_unimplemented_switches_fail_loudly(switch):
     kw = _kw()
     kw[switch] = True
