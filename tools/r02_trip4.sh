@@ -1,10 +1,10 @@
 # round 2, fourth GPU trip: whole -m gpu suite, e2e fit with host-time breakdown, bench (+cpu baseline), kernel trace + timeline, PMC traffic
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02d
+O=$R/gpurun_out/r02e
 mkdir -p $O
 cd $R
-timeout 1800 python -m pytest tests -m gpu -q --durations=8 > $O/gpu_tests.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -q --durations=8 --timeout 400 --maxfail 12 > $O/gpu_tests.log 2>&1
 echo "pytest rc=$?" >> $O/gpu_tests.log
 tail -25 $O/gpu_tests.log
 timeout 600 python tools/fit_e2e_bench.py > $O/fit_e2e.txt 2>&1
