@@ -139,6 +139,7 @@ class Engine(object):
         self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
+        self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "1") == "1"   # last layer's gradient GEMMs on the critical queue
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
         self._build_graph_description()
@@ -840,7 +841,7 @@ class Engine(object):
         self._join(*[st for _, st, _ in self.enc_meta])
         self._mark("  encoder recurrences")
         self._S_done = False
-        if self.fused_latent and (self.has_pack or self.ncat == 1) and self._latent_chain_forward(Breal, B, with_init):
+        if self.fused_latent and self._chain_ok() and self._latent_chain_forward(Breal, B, with_init):
             self._signature_forward(Breal, B)
             return
         h = cat
@@ -928,6 +929,11 @@ class Engine(object):
                 else:
                     df.copy_(g1f)
                     ops.add_time_reversed(dr, None, g2f, T, B * H)
+
+    def _chain_ok(self):
+        """shapes the fused latent chain (csrc/latent.hip) takes: a pack Dense whenever rolls are concatenated, 16-byte rows"""
+        s = self.spec
+        return (self.has_pack or self.ncat == 1) and s.zin % 4 == 0 and s.Z % 4 == 0
 
     def _signature_forward(self, Breal, B):
         """signature head (reference vae_definition.py:737-745): tanh of the latent columns behind the style classifier's"""
@@ -1099,7 +1105,7 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True):
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
@@ -1118,12 +1124,15 @@ class Engine(object):
         da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
         sk = self._split_k(R)
         mb = self.grad_gemm_blocks
+        if on_main:         # the LAST layer of the backward pass: on the critical queue itself - the optimizer follows it there
+            fork = False    # without a cross-queue hop (two barrier packets that resolve late cost 100+ us at the end of a step)
+        g1 = g2 = (_NullCtx() if on_main else None)
         if fork:
             self._fork(self.s_grad, self.s_grad2)
         # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
         fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
         gb = G[p + ".b"]
-        with self._on(self.s_grad):
+        with (g1 or self._on(self.s_grad)):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
@@ -1134,7 +1143,7 @@ class Engine(object):
             else:
                 ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb,
                          colsum_b=gb if fuse_b else None)
-        with self._on(self.s_grad2):
+        with (g2 or self._on(self.s_grad2)):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
                 ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1) or self._dxp0_clean)
@@ -1156,7 +1165,7 @@ class Engine(object):
                     ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
 
     def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
-                             xs=None, start=None):
+                             xs=None, start=None, tail_on_main=False):
         cs = self.pipe_chunk
         T = layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
@@ -1180,7 +1189,8 @@ class Engine(object):
                 ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
                 self._rec_bptt(r, B, 0, 1, dhs_ext=ext, dh_last=dh_last if top else None,
                                dh_last_ld=dh_last_ld if top else 0, pipe=pipe, **ds)
-                self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
+                if not (tail_on_main and li == L - 1):
+                    self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
             if top:
                 run()
             else:
@@ -1192,13 +1202,16 @@ class Engine(object):
                                  chunk_wait=sync[li, 0], chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)
         # chained join: the latest finisher (the bottom layer) last - ahead of the dX GEMMs it would put two hops in series
         self._join(*gemm_streams, *lower_streams)
+        if tail_on_main:        # the bottom layer finishes last: its parameter gradients right here, the optimizer behind them
+            self._rec_param_grads(order[-1], B, 0, 1, idx=idx, xs=xs, start=start, on_main=True)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
-                        start=None, slot=0):
+                        start=None, slot=0, tail_on_main=False):
         """BPTT through a stack (top layer first), pipelined over time chunks in reverse order."""
         if self._pipelined(layers):
             return self._stack_backward_pipe(layers, B, slot, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
-                                             dstates=dstates, idx=idx, xs=xs, start=start)
+                                             dstates=dstates, idx=idx, xs=xs, start=start,
+                                             tail_on_main=tail_on_main and self._deferred is None)
         nch = self._nchunks(layers)
         order = list(reversed(layers))               # order[0] = top layer
         streams = [None] + self.s_layer[:len(layers) - 1]
@@ -1307,7 +1320,7 @@ class Engine(object):
         deferred, self._deferred = self._deferred, None
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
         dcat = (self._latent_chain_backward(Breal, B)
-                if (self.fused_latent and (self.has_pack or self.ncat == 1) and not s.signature) else None)
+                if (self.fused_latent and self._chain_ok() and not s.signature) else None)
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
         ldc = self.ncat * H
@@ -1331,7 +1344,8 @@ class Engine(object):
         if self.enc_bi:
             self._enc_bi_backward(B, dcat[:, 0:H], ldc)
         else:
-            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3,
+                                 tail_on_main=self.tail_on_main)
         self._prefork = None
         if deferred:
             word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da

@@ -133,8 +133,8 @@ def prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_
     w_list = None
     if return_sample_weight:
         w_notes = np.ones((n, T))
-        if _g(s, "include_silent_note"):
-            w_notes[np.where(Y[:, :, -1] == 1)] = _g(s, "silent_weight")
+        if _g(s, "include_silent_note") and _g(s, "silent_weight") != 1.0:     # (weight 1.0 - the default - leaves the ones as they
+            w_notes[Y[:, :, -1] == 1] = _g(s, "silent_weight")                 #  are: no strided pass over the window tensor)
         w_list = [w_notes]
         for flag in ("include_composer_decoder", "signature_decoder", "composer_decoder_at_notes_output",
                      "composer_decoder_at_instrument_output"):

@@ -14,28 +14,42 @@ ap.add_argument("--config", type=int, default=5)
 ap.add_argument("--cell", default="LSTM")
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--gemm-blocks", type=int, default=0, help="persistent grid of the projection GEMM between pipelined layers (0 = default)")
+ap.add_argument("--split", type=int, default=1, help="decode the batch as this many consecutive sub-batches")
 a = ap.parse_args()
 seq, V, Z, B = {5: (512, 8, 128, 1024), 2: (128, 4, 64, 256)}[a.config]      # per-GPU share of BASELINE configs[4] / [1]
 B = a.batch or B
 T = seq * V
 spec = ModelSpec(cell=a.cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
-eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1234, training=False)
+Bs = B // a.split
+eng = Engine(spec, max_batch=Bs, dtype="bf16", device="cuda:0", seed=1234, training=False)
 if T // eng.pipe_chunk > 64:
     eng.pipe_chunk = T // 64
+if a.gemm_blocks:
+    eng.pipe_gemm_blocks = a.gemm_blocks
 rng = np.random.default_rng(1234)
 z = rng.standard_normal((B, Z)).astype(np.float32)
 hist = np.concatenate([np.zeros((1, Z), np.float32), z[:-1]])             # history = z shifted by one window
-eng.stage_decoder_inputs(B, hist=hist, z=z)
+def run():
+    for k in range(a.split):
+        if a.split > 1 or first[0]:
+            eng.stage_decoder_inputs(Bs, hist=hist[k * Bs:(k + 1) * Bs], z=z[k * Bs:(k + 1) * Bs])
+        eng.decode(Bs, want_probs=False)
+
+
+first = [True]
 for _ in range(2):
-    eng.decode(B, want_probs=False)
+    run()
+first[0] = False
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.reps):
-    eng.decode(B, want_probs=False)
+    run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
-idx = eng.note_indices(B)
-print("decode config %d (%s): T=%d V=%d z=%d batch=%d: %.2f ms per batch = %.0f windows/s (%.2f us per decoder time step); "
-      "argmax indices %s, %d distinct" % (a.config, a.cell, T, V, Z, B, dt * 1e3, B / dt, dt * 1e6 / T, tuple(idx.shape),
+eng.check_pipeline()
+idx = eng.note_indices(Bs)
+print("decode config %d (%s) gemm-blocks %d split %d: T=%d V=%d z=%d batch=%d: %.2f ms per batch = %.0f windows/s (%.2f us per decoder time step); "
+      "argmax indices %s, %d distinct" % (a.config, a.cell, eng.pipe_gemm_blocks, a.split, T, V, Z, B, dt * 1e3, B / dt, dt * 1e6 / T, tuple(idx.shape),
                                            len(np.unique(idx))))
 print("device memory resident: %.1f GB" % (eng.bytes_resident() / 1e9))
