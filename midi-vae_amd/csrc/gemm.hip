@@ -325,12 +325,23 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     // A and B panels, so they go to ONE XCD (workgroup b runs on XCD b % 8) - spread over all eight, every XCD's L2 fetches
     // every panel of A (2.4x the unique bytes from HBM for a 256 x 1024 output).
     const bool xcd_split = splits >= 8 && !a.chunk_rows && (gridDim.x % 8) == 0;
+    // Persistent chunked mode (the projection / dX GEMM between two time-pipelined layers): the tiles_n column tiles of one row
+    // block read the same 128 x K panel of A.  Dealt out round-robin they land on eight different XCDs and every XCD's L2 fetches
+    // the panel from the fabric; with the row blocks of residue x (mod 8) given to the workgroups of XCD x the panel is fetched
+    // once and its other tiles_n - 1 readers hit that L2 (the weight panels, 64 KB each, stay resident in every L2).
+    const bool xcd_rows = a.chunk_rows && splits == 1 && (gridDim.x % 8) == 0 && (tiles_mc % 8) == 0;
     const int total_tiles = tiles_n * tiles_mc * (xcd_split ? (splits + 7) / 8 * 8 : splits);
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
     if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
+        if (xcd_rows) {
+            const int x = tile & 7, i = tile >> 3;          // the i-th tile of XCD x's share of this chunk
+            bx = i % tiles_n;
+            by = chunk * tiles_mc + x + 8 * (i / tiles_n);
+            bz = 0;
+        }
         if (xcd_split) {
             const int x = tile & 7, i = tile >> 3, per_k = tiles_n * tiles_mc, within = i % per_k;
             bz = (i / per_k) * 8 + x;

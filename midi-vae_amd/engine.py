@@ -139,7 +139,7 @@ class Engine(object):
         self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
-        self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "1") == "1"   # last layer's gradient GEMMs on the critical queue
+        self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
         self._build_graph_description()
@@ -556,9 +556,9 @@ class Engine(object):
         zh[B:].zero_()
         if s.history:
             if hist is None:
-                zh[:, s.Z:].zero_()
+                zh[:, s.Z:2 * s.Z].zero_()
             else:
-                zh[:B, s.Z:].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
+                zh[:B, s.Z:2 * s.Z].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
         if z is not None:
             zh[:B, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
         if s.add_dim:           # the decoder's additional input (reference vae_definition.py:553-556): behind [z | history]
