@@ -193,3 +193,39 @@ def test_signature_and_output_classifier_heads_through_the_reference_lists():
     assert hist.history["loss"][1] < hist.history["loss"][0]
     outs = m.autoencoder.predict(x, batch_size=s["batch_size"])
     assert [o.shape for o in outs] == [(n, 16, 61), (n, 4, 16), (n, 16, 1), (n, 2), (n, 15), (n, 2), (n, 2)]
+
+
+def test_device_history_equals_host_history():
+    """f-1: the history pre-pass kept in HBM.  ``encoder.predict(device=True)`` returns a DeviceLatent; in the history slot of the
+    fit / evaluate lists it stands for the rolled array the reference builds on the host (vae_training.py:795-798: H[1:] = z[:-1],
+    H[0] = 0).  Same epsilon stream on both sides -> same z, same history, same losses after a fit call (ragged minibatches:
+    the roll crosses minibatch boundaries) and the same parameters."""
+    from midi_vae_amd.model import DeviceLatent
+    res = {}
+    for on_device in (True, False):
+        s, m, (X, Y, C, I, V, D) = _setup("GRU", n=21, seed=4)
+        n = X.shape[0]
+        S = np.zeros((n, s["signature_vector_length"]))
+        m._shared.rng = np.random.default_rng(7)
+        enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+        z = m.encoder.predict(enc_in, batch_size=s["batch_size"], verbose=False, device=on_device)
+        if on_device:
+            assert isinstance(z, DeviceLatent) and z.shape == (n, s["latent_dim"])
+            H = z
+            res["z"] = z.latent()
+            np.testing.assert_array_equal(z.numpy()[1:], res["z"][:-1])
+            assert not z.numpy()[0].any()
+        else:
+            np.testing.assert_allclose(z, res["z"], rtol=0, atol=1e-6)
+            H = history_from_z(z)
+        x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+        ev = m.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)
+        hist = m.autoencoder.fit(x, y, epochs=1, batch_size=s["batch_size"], shuffle=False, sample_weight=sw, verbose=False)
+        res[on_device] = (ev, {k: v[0] for k, v in hist.history.items()}, m.autoencoder.get_weights())
+    (e1, h1, w1), (e0, h0, w0) = res[True], res[False]
+    # (evaluate / fit draw their own epsilon: the same stream on both sides because both sides made the same calls before)
+    np.testing.assert_allclose(e1, e0, rtol=1e-5, atol=1e-6)
+    for k in h0:
+        assert abs(h1[k] - h0[k]) <= 1e-5 * (1 + abs(h0[k])), (k, h1[k], h0[k])
+    for a, b in zip(w1, w0):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
