@@ -487,8 +487,15 @@ class Engine(object):
             buf("sig.out", B * s.SD, **f32)
         for a in self.aux:
             regions += [("in.rw_" + a.key, B, torch.float32)]
+        # the targets / row weights only the decoder heads read go LAST: staging can upload them in a second copy, converted on
+        # the host while the encoder recurrences already run (Stager.stage(defer_targets=True))
+        late = ("in.y_idx", "in.n_idx", "in.rw_notes", "in.rw_instr", "in.rw_vel", "in.rw_held", "in.rw_next")
+        regions = [r for r in regions if r[0] not in late] + [r for r in regions if r[0] in late]
         self._in_regions, off = {}, 0
+        self._in_late_off = None
         for name, n, tdt in regions:
+            if name in late and self._in_late_off is None:
+                self._in_late_off = off
             nbytes = int(n) * (1 if tdt == torch.uint8 else 4)
             self._in_regions[name] = (off, nbytes, tdt)
             off += (nbytes + 255) // 256 * 256
@@ -1565,6 +1572,37 @@ class Engine(object):
             self.pipeline = False
             self._dxp0_clean = False
             redo()
+
+    def train_step_begin(self, B):
+        """First part of a train step - weight preparation and the encoder up to the sampled z - for callers that stage the
+        decoder heads' targets while it runs (Stager.stage(defer_targets=True) ... Stager.finish_targets()); the rest:
+        train_step_finish."""
+        assert self.training and not self.use_graphs
+        self._have_targets = True
+        if self._weights_dirty:
+            self.prepare_weights()
+            self._dxp0_clean = True
+        else:
+            self.scal.zero_()
+            self._dxp0_clean = False
+        if not self._grads_clean:
+            self.grads.zero_()
+        self._grads_clean = False
+        self.encoder_forward(B, with_init=True)
+
+    def train_step_finish(self, B, allreduce=None):
+        self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
+        self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
+        try:
+            self.decoder_forward(B)
+            self.backward(B)
+        finally:
+            self._branches_stay_forked = False
+            self._bucket_hook = None
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
+                                       self.backward(B)))
+        gs = allreduce(self.grads) if allreduce is not None else 1.0
+        self.optimizer_step(gs if gs is not None else 1.0)
 
     def train_step(self, B, allreduce=None):
         """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.

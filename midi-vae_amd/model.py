@@ -413,8 +413,11 @@ class Autoencoder(_ModelView):
                 a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
                 if b0 > a0:
                     norm = Norm.of(lo, hi, sp.T, **ws)
-                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, **a)
-                    eng.train_step(B, allreduce=dp.allreduce_grads if dp is not None else allreduce)
+                    # the encoder's inputs first; the heads' targets are converted while the encoder already runs on the device
+                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, defer_targets=True, **a)
+                    eng.train_step_begin(B)
+                    st.finish_targets()
+                    eng.train_step_finish(B, allreduce=dp.allreduce_grads if dp is not None else allreduce)
                     eng.accumulate_metrics(hi - lo)
                 else:
                     eng.train_step_empty(dp.allreduce_grads)

@@ -99,6 +99,7 @@ class Stager(object):
             h[:] = 0
         self.done = [None, None]                     # event after the last upload from each mirror
         self.k = 0
+        self._late = None
 
     def _view(self, k, name, dtype, n):
         off, length, _ = self.regions[name]
@@ -162,12 +163,16 @@ class Stager(object):
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
               norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None,
-              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None):
+              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
         a DEVICE tensor (n, Z) of sampled z whose row i-1 is the history of window i (zeros for window 0) - the fused history
-        pre-pass; neither: zeros.  Returns the number of windows staged."""
+        pre-pass; neither: zeros.  Returns the number of windows staged.
+
+        ``defer_targets``: convert and upload everything the ENCODER needs now and leave the decoder heads' targets and row weights
+        (the second 64 MB float64 tensor of a minibatch) to ``finish_targets()`` - called after the encoder's launches are
+        enqueued, so that conversion runs on the host while the encoder recurrences run on the device."""
         eng, s = self.eng, self.eng.spec
         if batch_local:
             lo, hi = 0, hi - lo
@@ -178,6 +183,7 @@ class Stager(object):
         T, V = s.T, s.V
         k = self.k
         self.k ^= 1
+        self._late = None
         if self.done[k] is not None:
             self.done[k].synchronize()              # the upload that last read this mirror has completed
         self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
@@ -208,22 +214,27 @@ class Stager(object):
         if have_targets:
             nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next, w_sig, w_cnotes,
                                                        w_cinstr)
-            self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
-            if w_notes is None:
-                out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
-                out[:, :B] = 1.0 / nm.nz_notes
-                out[:, B:] = 0.0
-            else:
-                self._rows_f32(k, "in.rw_notes", w_notes, lo, hi, T, Bp, scale=1.0 / nm.nz_notes)
-            if s.meta_instrument:
-                self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
-            if s.meta_velocity:
-                self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
-            if s.meta_held:
-                self._per_window(k, "in.rw_held", w_held, lo, hi, T, Bp, 1.0 / (nm.nz_held * T))
-            if s.meta_next:
-                self._per_window(k, "in.rw_next", w_next, lo, hi, T, Bp, 1.0 / (nm.nz_next * T))
-                self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
+            def late():
+                self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
+                if w_notes is None:
+                    out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
+                    out[:, :B] = 1.0 / nm.nz_notes
+                    out[:, B:] = 0.0
+                else:
+                    self._rows_f32(k, "in.rw_notes", w_notes, lo, hi, T, Bp, scale=1.0 / nm.nz_notes)
+                if s.meta_instrument:
+                    self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
+                if s.meta_velocity:
+                    self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
+                if s.meta_held:
+                    self._per_window(k, "in.rw_held", w_held, lo, hi, T, Bp, 1.0 / (nm.nz_held * T))
+                if s.meta_next:
+                    self._per_window(k, "in.rw_next", w_next, lo, hi, T, Bp, 1.0 / (nm.nz_next * T))
+                    self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
+
+            self._late = (k, late) if defer_targets else None
+            if not defer_targets:
+                late()
             if s.style:
                 self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
             if s.style or s.comp_notes or s.comp_instr:
@@ -239,7 +250,12 @@ class Stager(object):
         else:
             eng.norm_B = float(B)
         # ---- ONE upload, ordered on the current stream behind whatever still reads the block -------------------------------
-        eng._in_block.copy_(self.host[k], non_blocking=True)
+        cut = eng._in_late_off if (have_targets and defer_targets) else None
+        if cut is None:
+            self._late = None
+            eng._in_block.copy_(self.host[k], non_blocking=True)
+        else:
+            eng._in_block[:cut].copy_(self.host[k][:cut], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.done[k] = ev
@@ -261,3 +277,17 @@ class Stager(object):
             ops.copy2d(zh[:, s.zin - s.add_dim:], eng._v("in.add", Bp, s.add_dim), Bp, s.add_dim)
         eng._have_staged_targets = have_targets
         return B
+
+    def finish_targets(self):
+        """second half of ``stage(defer_targets=True)``: the decoder heads' targets and row weights, converted now (the encoder is
+        already enqueued) and uploaded behind it on the same stream"""
+        if self._late is None:
+            return
+        k, late = self._late
+        self._late = None
+        late()
+        cut = self.eng._in_late_off
+        self.eng._in_block[cut:].copy_(self.host[k][cut:], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.done[k] = ev

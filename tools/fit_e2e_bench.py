@@ -36,7 +36,7 @@ print("host packer threads: %d; one song = %d windows = %.0f MB of float64 one-h
 
 # host-side wall time inside fit, by part (the device runs asynchronously beside all of it)
 from midi_vae_amd import staging as _st, engine as _en
-HOST = {"stage": 0.0, "train_step enqueue": 0.0, "read-back": 0.0}
+HOST = {"stage": 0.0, "stage targets": 0.0, "train_step enqueue": 0.0, "read-back": 0.0}
 
 
 def _timed(cls, name, key):
@@ -52,7 +52,9 @@ def _timed(cls, name, key):
 
 
 _timed(_st.Stager, "stage", "stage")
-_timed(_en.Engine, "train_step", "train_step enqueue")
+_timed(_st.Stager, "finish_targets", "stage targets")
+_timed(_en.Engine, "train_step_begin", "train_step enqueue")
+_timed(_en.Engine, "train_step_finish", "train_step enqueue")
 _timed(_en.Engine, "read_accumulated", "read-back")
 
 
