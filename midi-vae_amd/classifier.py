@@ -20,7 +20,7 @@ import torch
 
 from . import hiplib as hl
 from . import ops
-from .engine import Engine, N_SCALARS, _Head, _Rec
+from .engine import Engine, _Head, _Rec
 from .layout import ClassifierSpec, classifier_layout, init_classifier_params
 from .model import History
 from .staging import host_onehot_to_index

@@ -128,8 +128,8 @@ class Engine(object):
         self.pipe_gemm_blocks = 64       # persistent grid of the projection / dX GEMM between two pipelined layers
         if not training and self.maxB >= 512:
             # decoder inference at large batches is bound by THAT GEMM (time per step proportional to 1 / its grid: 15.2 / 10.6 / 8.2
-            # / 7.1 us at 32 / 48 / 64 / 96 workgroups, 1024 windows), not by the recurrences
-            self.pipe_gemm_blocks = 96
+            # / 7.1 / 6.2 us at 32 / 48 / 64 / 96 / 128 workgroups, 1024 windows), not by the recurrences
+            self.pipe_gemm_blocks = 128
         # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
         # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
         # Parameter-gradient GEMMs once per layer (after its last BPTT chunk), NOT per time chunk: throughput GEMMs running
