@@ -201,18 +201,23 @@ class StyleClassifier(object):
         n, T = x.shape
         c = self._targets(Y, n)
         eng = self._engine(T, batch_size)
-        h = History()
+        pending = []
         for e in range(epochs):
-            eng.reset_accumulated()
+            pending.append(eng.reset_accumulated())
             for lo in range(0, n, batch_size):
                 hi = min(n, lo + batch_size)
                 B = eng.stage(x[lo:hi], c[lo:hi])
                 eng.train_step(B)
                 eng.accumulate_metrics(hi - lo)
-            m = eng.read_accumulated(n)
-            for k in ("loss", "acc"):
-                h.history.setdefault(k, []).append(m[k])
-            h.epoch.append(e)
+
+        def resolve(out):
+            for acc in pending:
+                m = eng.read_accumulated(n, acc=acc)
+                for k in ("loss", "acc"):
+                    out.setdefault(k, []).append(m[k])
+
+        h = History(resolve)
+        h.epoch = list(range(epochs))
         return h
 
     def evaluate(self, X, Y, batch_size=32, verbose=0):

@@ -1645,18 +1645,21 @@ class Engine(object):
                 (1 << S_NEXT_HITS) | (1 << S_SIG_HITS) | (1 << S_CNOTES_HITS) | (1 << S_CINSTR_HITS))
 
     def reset_accumulated(self):
-        self.acc.zero_()
+        """start a fresh set of epoch accumulators (a NEW device buffer: a History that has not been read yet keeps its own)"""
+        self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)
+        return self.acc
 
     def accumulate_metrics(self, B_global):
         """acc += B_global * (loss slots), += (hit slots) of the step just enqueued - Keras' BaseLogger on the device, no read"""
         ops.scalars_accumulate(self.acc, self.scal, float(B_global), self.HIT_MASK)
 
-    def read_accumulated(self, n_windows, allreduce_sum=None):
-        """means over ``n_windows`` windows of everything accumulated since reset_accumulated (ONE device->host read; with
-        ``allreduce_sum`` the per-rank shares are summed first)"""
+    def read_accumulated(self, n_windows, allreduce_sum=None, acc=None):
+        """means over ``n_windows`` windows of everything accumulated into ``acc`` (default: since the last reset_accumulated): ONE
+        device->host read; with ``allreduce_sum`` the per-rank shares are summed first"""
+        acc = self.acc if acc is None else acc
         if allreduce_sum is not None:
-            allreduce_sum(self.acc)
-        v = self.acc.cpu().numpy().astype(np.float64)
+            allreduce_sum(acc)
+        v = acc.cpu().numpy().astype(np.float64)
         self.check_pipeline()
         n = max(float(n_windows), 1.0)
         hit = np.array([(self.HIT_MASK >> i) & 1 for i in range(N_SCALARS)], bool)

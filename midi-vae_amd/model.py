@@ -31,9 +31,22 @@ from .layout import ModelSpec, ParamLayout, init_params, spec_from_create_kwargs
 
 
 class History(object):
-    def __init__(self):
-        self.history = OrderedDict()
+    """What ``fit`` returns.  ``history`` (Keras: key -> list of per-epoch values) is filled on FIRST ACCESS: the losses and metrics
+    of a fit call are accumulated on the device, and reading them is the only point at which the host waits for the device.  The
+    reference reads ``hist.history[...]`` right after every ``fit`` (vae_training.py:817-864) and gets Keras' behaviour; a caller
+    that keeps the History objects of several songs and reads them later (this repo's vae_training.py: at the end of the epoch)
+    lets the next song's host work overlap the device's work on this one."""
+
+    def __init__(self, resolve=None):
+        self._resolve, self._history = resolve, OrderedDict()
         self.epoch = []
+
+    @property
+    def history(self):
+        if self._resolve is not None:
+            resolve, self._resolve = self._resolve, None
+            resolve(self._history)
+        return self._history
 
 
 class DeviceLatent(object):
@@ -403,10 +416,10 @@ class Autoencoder(_ModelView):
         eng = self._s.get_engine(batch_size, training=True)
         st = eng.stager()
         a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
-        history = History()
         keys = self._history_keys()
+        pending = []
         for e in range(epochs):
-            eng.reset_accumulated()
+            acc = eng.reset_accumulated()
             for lo in range(0, n, batch_size):
                 hi = min(n, lo + batch_size)
                 eps = self._s.epsilon(hi - lo)               # one draw per GLOBAL minibatch: every rank holds the same stream
@@ -421,10 +434,18 @@ class Autoencoder(_ModelView):
                     eng.accumulate_metrics(hi - lo)
                 else:
                     eng.train_step_empty(dp.allreduce_grads)
-            m = eng.read_accumulated(n, allreduce_sum=dp.allreduce_sum if dp is not None else None)
-            for k, src in keys:
-                history.history.setdefault(k, []).append(m[src])
-            history.epoch.append(e)
+            if dp is not None:          # every rank, every fit call, here - not when (and if) a rank reads the History
+                dp.allreduce_sum(acc)
+            pending.append(acc)
+
+        def resolve(out):
+            for acc_e in pending:
+                m = eng.read_accumulated(n, acc=acc_e)
+                for k, src in keys:
+                    out.setdefault(k, []).append(m[src])
+
+        history = History(resolve)
+        history.epoch = list(range(epochs))
         return history
 
     def _forward_all(self, x, y, batch_size, want_probs):

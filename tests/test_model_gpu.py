@@ -229,3 +229,32 @@ def test_device_history_equals_host_history():
         assert abs(h1[k] - h0[k]) <= 1e-5 * (1 + abs(h0[k])), (k, h1[k], h0[k])
     for a, b in zip(w1, w0):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+
+
+def test_history_is_filled_on_first_access_and_survives_later_fit_calls():
+    """History.history is read from the device on first access (model.History): histories of several fit calls read AFTER the
+    last call hold the same values as histories read immediately after each call."""
+    vals = {}
+    for lazy in (False, True):
+        s, m, (X, Y, C, I, V, D) = _setup("GRU", n=19, seed=6)
+        n = X.shape[0]
+        S, H = np.zeros((n, s["signature_vector_length"])), np.zeros((n, s["latent_dim"]))
+        x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+        hs, got = [], []
+        for _ in range(3):
+            h = m.autoencoder.fit(x, y, epochs=2, batch_size=s["batch_size"], shuffle=False, sample_weight=sw, verbose=False)
+            assert h.epoch == [0, 1]
+            if lazy:
+                hs.append(h)
+                assert h._resolve is not None
+            else:
+                got.append({k: list(v) for k, v in h.history.items()})
+        if lazy:
+            got = [{k: list(v) for k, v in h.history.items()} for h in hs]
+            assert all(h._resolve is None for h in hs)
+        vals[lazy] = got
+    for a, b in zip(vals[True], vals[False]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert len(a[k]) == 2 and np.allclose(a[k], b[k], rtol=1e-6, atol=1e-7), (k, a[k], b[k])
+    assert vals[False][2]["loss"][1] < vals[False][0]["loss"][0]

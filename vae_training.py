@@ -60,7 +60,7 @@ def run_epoch(model, songs, s, epoch, train):
     for n in names:                                            # reference vae_training.py:172-187
         seen[n] = seen.get(n, 0) + 1
         enum.append("%s_%d" % (n, seen[n]) if total[n] > 1 else n)
-    agg = {}
+    agg, pending = {}, []
     for song in songs:
         H = history_for(model, song, s, use_encoder=(epoch > 0 or not train))
         if train:
@@ -70,13 +70,17 @@ def run_epoch(model, songs, s, epoch, train):
                                          verbose=False)
             if s["reset_states"]:
                 model.autoencoder.reset_states()
-            vals = {k: float(np.mean(v)) for k, v in hist.history.items()}
+            pending.append(hist)        # (read after the last song: History is filled on first access - reading it here, as the
+            continue                    #  reference does, would make the host wait for the device once per song)
         else:
             x, y = vae_definition.prepare_autoencoder_input_and_output_list(
                 song["X"], song["Y"], song["C"], song["I"], song["V"], song["D"], song["S"], H)
             vals = dict(zip(enum, model.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)))
         for k, v in vals.items():
             agg[k] = agg.get(k, 0.0) + v
+    for hist in pending:
+        for k, v in hist.history.items():
+            agg[k] = agg.get(k, 0.0) + float(np.mean(v))
     out = {k: v / max(len(songs), 1) for k, v in agg.items()}
     weighted = out.get("decoder_loss_1", out.get("decoder_loss", 0.0))
     if s["meta_instrument"]:
