@@ -143,6 +143,7 @@ class Engine(object):
         self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
+        self.onehot_split_factor = int(os.environ.get("MVAE_ONEHOT_SPLIT", "2"))
         self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
@@ -1167,8 +1168,9 @@ class Engine(object):
                 if r.xmode == X_EXT:
                     pass                                # (input-kernel gradient by the caller: _aux_backward)
                 elif r.xmode == hl.X_INDEX:
+                    # (M = 61 is ONE row of tiles: 8 column tiles x 16 splits fill half the chip - the one-hot splits go twice as wide)
                     ops.gemm(idx[t0:t0 + Tc].reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
-                             accumulate=True, split_k=sk)
+                             accumulate=True, split_k=sk * self.onehot_split_factor if sk >= 8 else sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
                     ops.colsum_weighted(da2, xs[t0:t0 + Tc].reshape(-1), R, GH, G[p + ".W"])
                 else:
