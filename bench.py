@@ -64,6 +64,8 @@ def cpu_baseline(spec, B, budget_s=15.0, hard_limit_s=150.0):
             tried.append((n, rec["value"]))
             if best is None or rec["value"] > best["value"]:
                 best = rec
+            else:
+                break                                  # slower with more threads: even more will not be faster
         except (subprocess.TimeoutExpired, ValueError, IndexError):
             tried.append((n, None))
             break                                      # more threads will not finish either
