@@ -143,7 +143,7 @@ class Engine(object):
         self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
-        self.onehot_split_factor = int(os.environ.get("MVAE_ONEHOT_SPLIT", "2"))
+        self.onehot_split_factor = int(os.environ.get("MVAE_ONEHOT_SPLIT", "1"))   # (2 and 4 measured neutral: DESIGN.md section 6)
         self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
