@@ -38,6 +38,19 @@ def synthetic_songs(n_songs, s, seed):
     return songs
 
 
+def songs_from_pickle_cache(path, s):
+    """(train, test) song dicts from the reference's dataset cache (import_midi.load_pickle_cache; reference vae_training.py:142)"""
+    import import_midi
+    (V_tr, V_te, D_tr, D_te, _, _, I_tr, I_te, Y_tr, Y_te, X_tr, X_te, c_tr, c_te, _, _) = import_midi.load_pickle_cache(path)
+
+    def songs(X, Y, C, I, V, D):
+        return [dict(X=np.asarray(x), Y=np.asarray(y), C=int(c), I=np.asarray(i), V=np.asarray(v), D=np.asarray(d),
+                     S=np.zeros((np.asarray(x).shape[0], s["signature_vector_length"])))
+                for x, y, c, i, v, d in zip(X, Y, C, I, V, D)]
+
+    return songs(X_tr, Y_tr, c_tr, I_tr, V_tr, D_tr), songs(X_te, Y_te, c_te, I_te, V_te, D_te)
+
+
 def history_for(model, song, s, use_encoder, on_device=True):
     """reference vae_training.py:788-798 - zeros in epoch 0, else the previous window's SAMPLED z (a fresh epsilon: one
     extra encoder forward per song).  ``on_device``: the z of the pre-pass stays in HBM (model.DeviceLatent) and the roll
@@ -101,6 +114,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model-path", default="models/autoencode/vae/")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend when WORLD_SIZE > 1")
+    ap.add_argument("--pickle-dir", default="", help="a dataset cache written by the reference (import_midi.py:548-571: V_train.pickle ... "
+                    "test_paths.pickle) instead of synthetic songs")
     args = ap.parse_args()
     s = vars(settings)
 
@@ -126,8 +141,11 @@ def main():
     if s["load_previous_checkpoint"]:
         for view, name in ((model.autoencoder, "autoencoder"), (model.encoder, "encoder"), (model.decoder, "decoder")):
             view.load_weights(s["previous_checkpoint_path"] + name + "Epoch" + str(s["previous_epoch"]) + ".pickle", by_name=False)
-    train = synthetic_songs(args.songs, s, seed=1)             # the SAME songs on every rank (sharded inside fit)
-    test = synthetic_songs(args.test_songs, s, seed=999)
+    if args.pickle_dir:
+        train, test = songs_from_pickle_cache(args.pickle_dir, s)
+    else:
+        train = synthetic_songs(args.songs, s, seed=1)         # the SAME songs on every rank (sharded inside fit)
+        test = synthetic_songs(args.test_songs, s, seed=999)
     order_rng = np.random.default_rng(4321)                     # ... in the SAME order (the reference's shuffle is unseeded)
     path = os.path.join(args.model_path, "%s-_ls_inlen_%d_outlen_%d_beta_%s_lr_%s_lstmsize_%d_latent_%d" % (
         s["t"], s["input_length"], s["output_length"], s["beta"], s["learning_rate"], s["lstm_size"], s["latent_dim"]))
