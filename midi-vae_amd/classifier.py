@@ -178,6 +178,8 @@ class StyleClassifier(object):
 
     def _inputs(self, X):
         X = np.asarray(X)
+        if X.ndim == 2 and X.dtype == np.uint8 and self.xmode == "index":
+            return X                                   # already note / instrument indices (e.g. the decoder's fused argmax)
         if X.ndim != 3:
             raise ValueError("expected (n, T, input_dim) rolls, got %s" % (X.shape,))
         if self.xmode == "scalar":
