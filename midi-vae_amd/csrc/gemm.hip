@@ -531,6 +531,125 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     if (a.sys_release) __threadfence_system();
 }
 
+// ===========================================================================================================
+// Weights-stationary persistent projection (round 2): x*W + b of a stacked layer behind a time-pipelined lower layer, K = H = 256.
+// In the fast kernel above a 128x128 tile with K = 256 is four k-iterations: prologue latency, the reload of the same 64 KB weight
+// panel for every tile and the epilogue dominate (~8 us per tile, 10 % of a CU's MFMA rate) - decoder inference at 1024 windows
+// per GPU was bound by THIS GEMM, not by the recurrences.  Here a workgroup owns ONE column tile for the
+// whole launch: its weight panel (128 x 256 bf16, four k-tile images) is staged in LDS once; per row block only the A tile
+// (128 x 256) moves - requested into registers while the previous tile's MFMAs run, so its latency hides behind them - and the
+// main loop touches no global memory.  Row blocks of residue x (mod 8) belong to the workgroups of XCD x (as xcd_rows above).
+// Same MFMA order over k as the fast kernel: bit-identical results.  LDS: 8 images x 18 KB = 144 KB, one workgroup per CU.
+// ===========================================================================================================
+constexpr int WS_KT = 4;                 // k-tiles of 64: K = 256
+__global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IMG = f_img<false>();
+    bf16_t* Bs = reinterpret_cast<bf16_t*>(smem);                  // [WS_KT][IMG]   the weight panel, resident
+    bf16_t* As = Bs + WS_KT * IMG;                                 // [WS_KT][IMG]   the current A tile
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    const int wm = w >> 1, wn = w & 1;
+    const int N = a.N;
+    const int tiles_n = N / FBN, tiles_m = a.M / FBM;
+    const int tiles_mc = a.chunk_rows / FBM, nchunks = tiles_m / tiles_mc;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;             // XCD, index within the XCD's workgroups
+    const int bx = j % tiles_n, g = j / tiles_n, G = (gridDim.x >> 3) / tiles_n;
+    const int n0 = bx * FBN;
+    {   // the weight panel: rows n0 .. n0+127 of B (N, K) k-contiguous
+        f_stage<false, false> sb;
+#pragma unroll
+        for (int kt = 0; kt < WS_KT; ++kt) {
+            sb.load(a.B, a.ldb, n0, kt * FBK, tid);
+            sb.store(Bs + kt * IMG, tid);
+        }
+    }
+    f32x4 bias[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+        bias[jj] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + jj * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f_stage<false, false> sa[WS_KT];
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
+        if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
+        const int nloc = tiles_mc >> 3;                            // row blocks of this chunk on this XCD
+        if (g < nloc) {
+#pragma unroll
+            for (int kt = 0; kt < WS_KT; ++kt) sa[kt].load(a.A, a.lda, (chunk * tiles_mc + x + 8 * g) * FBM, kt * FBK, tid);
+        }
+        for (int bl = g; bl < nloc; bl += G) {
+            const int m0 = (chunk * tiles_mc + x + 8 * bl) * FBM;
+            __syncthreads();                                       // the previous tile's fragment reads of As are done
+#pragma unroll
+            for (int kt = 0; kt < WS_KT; ++kt) sa[kt].store(As + kt * IMG, tid);
+            __syncthreads();
+            if (bl + G < nloc) {                                   // the next tile's A: in flight while this tile multiplies
+#pragma unroll
+                for (int kt = 0; kt < WS_KT; ++kt) sa[kt].load(a.A, a.lda, (chunk * tiles_mc + x + 8 * (bl + G)) * FBM, kt * FBK, tid);
+            }
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < WS_KT; ++kt) {
+#pragma unroll
+                for (int kg = 0; kg < FBK / 32; ++kg) {
+                    u16x8 fa[4], fb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i] = f_frag<false>(As + kt * IMG, wm * 64 + i * 16, kg, q, r);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) fb[jj] = f_frag<false>(Bs + kt * IMG, wn * 64 + jj * 16, kg, q, r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_bf16(fb[jj], fa[i], acc[i][jj]);   // rows: n, cols: m
+                }
+            }
+            // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + r;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int n = n0 + wn * 64 + jj * 16 + q * 4;
+                    const f32x4 v = acc[i][jj] * a.alpha + bias[jj];
+                    if (a.c_layout == MVAE_TILE16) {
+                        const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
+                        st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
+                    } else {
+                        st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, v);
+                    }
+                }
+            }
+        }
+        if (a.chunk_done) wave_signal_done(a.chunk_done + chunk);
+    }
+    if (a.sys_release) __threadfence_system();
+}
+// the problems proj_ws_k takes: the forward projection of a pipelined stack (A (M,256) and B (N,256) k-contiguous bf16, bf16 output)
+bool ws_ok(const mvae_gemm_args& a) {
+    static const bool off = getenv("MVAE_NO_WS_GEMM") != nullptr;
+    if (off || !a.chunk_rows || a.trans_a || !a.trans_b || a.K != WS_KT * FBK || a.c_kind != MVAE_BF16 || a.accumulate ||
+        a.act != MVAE_ACT_NONE || a.split_k > 1)
+        return false;
+    const int tiles_n = a.N / FBN, tiles_mc = a.chunk_rows / FBM;
+    return a.max_blocks >= 8 * tiles_n && (a.max_blocks % (8 * tiles_n)) == 0 && (tiles_mc % 8) == 0;
+}
+int launch_ws(const mvae_gemm_args& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * WS_KT * f_img<false>() * sizeof(bf16_t);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL(proj_ws_k, dim3((unsigned)a.max_blocks), dim3(256), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 template <bool A_RC, bool B_RC, bool ONEHOT, bool CS = false>
 int launch_fast(const mvae_gemm_args& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (f_img<A_RC>() + f_img<B_RC>()) * sizeof(bf16_t);
@@ -624,6 +743,7 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     }
     if (a->colsum_b && !(fast_ok(*a) && a->trans_a && !a->trans_b && a->accumulate && a->a_kind == MVAE_BF16 && !(a->N % FBN)))
         return MVAE_E_UNSUPPORTED;
+    if (fast_ok(*a) && ws_ok(*a)) return launch_ws(*a, s);
     if (fast_ok(*a)) return dispatch_fast(*a, s);
     // A handful of output tiles with a long K (the Dense layers around the latent: M = batch, K up to nInit*H = 2304) is
     // a few workgroups marching through K for 100+ us on an otherwise idle chip: zero C and split K over atomics.
