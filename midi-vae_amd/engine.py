@@ -125,11 +125,12 @@ class Engine(object):
         # every pipe_chunk time steps (no relaunch, no weight reload, layers 32 steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
         self.pipe_chunk = 32
-        self.pipe_gemm_blocks = 64       # persistent grid of the projection / dX GEMM between two pipelined layers
-        if not training and self.maxB >= 512:
-            # decoder inference at large batches is bound by THAT GEMM (time per step proportional to 1 / its grid: 15.2 / 10.6 / 8.2
-            # / 7.1 / 6.2 us at 32 / 48 / 64 / 96 / 128 workgroups, 1024 windows), not by the recurrences
-            self.pipe_gemm_blocks = 128
+        self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
+        # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
+        # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:
+        # 64 for LSTM, 48 for GRU.  (Round 1's kernel reloaded the panel per tile; decoder inference at 1024 windows was bound by it:
+        # 8.2 us per decoder step at 64 workgroups, 6.2 at 128 - 4.1 now at 64)
+        self.pipe_proj_blocks = 8 * max(spec.GH // 128, 1)
         # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
         # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
         # Parameter-gradient GEMMs once per layer (after its last BPTT chunk), NOT per time chunk: throughput GEMMs running
@@ -774,7 +775,7 @@ class Engine(object):
     def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None):
         cs = self.pipe_chunk
         T = layers[0].T
-        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
+        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
         L = len(layers)
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
@@ -798,7 +799,7 @@ class Engine(object):
                 with torch.cuda.stream(lower_streams[li]):
                     run()
                 with torch.cuda.stream(gemm_streams[li]):     # projection for the layer above: one persistent launch
-                    self._rec_xp(layers[li + 1], B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B,
+                    self._rec_xp(layers[li + 1], B, 0, 1, max_blocks=self.pipe_proj_blocks, chunk_rows=cs * B,
                                  chunk_wait=sync[li, 0], chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status)
         self._join(*lower_streams, *gemm_streams)
 

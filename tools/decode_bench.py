@@ -26,7 +26,7 @@ eng = Engine(spec, max_batch=Bs, dtype="bf16", device="cuda:0", seed=1234, train
 if T // eng.pipe_chunk > 64:
     eng.pipe_chunk = T // 64
 if a.gemm_blocks:
-    eng.pipe_gemm_blocks = a.gemm_blocks
+    eng.pipe_proj_blocks = a.gemm_blocks
 rng = np.random.default_rng(1234)
 z = rng.standard_normal((B, Z)).astype(np.float32)
 hist = np.concatenate([np.zeros((1, Z), np.float32), z[:-1]])             # history = z shifted by one window
@@ -50,6 +50,6 @@ dt = (time.perf_counter() - t0) / a.reps
 eng.check_pipeline()
 idx = eng.note_indices(Bs)
 print("decode config %d (%s) gemm-blocks %d split %d: T=%d V=%d z=%d batch=%d: %.2f ms per batch = %.0f windows/s (%.2f us per decoder time step); "
-      "argmax indices %s, %d distinct" % (a.config, a.cell, eng.pipe_gemm_blocks, a.split, T, V, Z, B, dt * 1e3, B / dt, dt * 1e6 / T, tuple(idx.shape),
+      "argmax indices %s, %d distinct" % (a.config, a.cell, eng.pipe_proj_blocks, a.split, T, V, Z, B, dt * 1e3, B / dt, dt * 1e6 / T, tuple(idx.shape),
                                            len(np.unique(idx))))
 print("device memory resident: %.1f GB" % (eng.bytes_resident() / 1e9))

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02l
+O=$R/gpurun_out/r02m
 mkdir -p $O
 cd $R
 timeout 1800 python -m pytest tests/test_engine_gpu.py tests/test_baseline_configs_gpu.py tests/test_classifier_gpu.py tests/test_ops_gpu.py -m gpu -q --timeout 400 --maxfail 8 > $O/gpu_tests.log 2>&1
@@ -13,9 +13,9 @@ done
 unset MVAE_NO_WS_GEMM
 timeout 600 python bench.py --no-cpu-baseline --cell GRU 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('GRU', d['ms_per_step'], d['median_ms_per_step'])" >> $O/bench.txt
 cat $O/bench.txt
-for args in "--config 5 --gemm-blocks 64" "--config 5 --gemm-blocks 128" "--config 5 --gemm-blocks 64 --cell GRU" "--config 5 --batch 512 --gemm-blocks 64" "--config 2"; do
+for args in "--config 5" "--config 5 --cell GRU" "--config 5 --cell GRU --gemm-blocks 96" "--config 5 --batch 512" "--config 2" "--config 2 --cell GRU"; do
   timeout 300 python tools/decode_bench.py $args 2>&1 | grep -v amdgpu | head -1 >> $O/decode.txt
 done
 MVAE_NO_WS_GEMM=1 timeout 300 python tools/decode_bench.py --config 5 2>&1 | grep -v amdgpu | head -1 >> $O/decode.txt
 cat $O/decode.txt
-python tools/large_shape_check.py LSTM 2>&1 | grep -v amdgpu | tail -1
+python tools/large_shape_check.py 2>&1 | grep -v amdgpu | tail -2
