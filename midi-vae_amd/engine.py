@@ -124,7 +124,7 @@ class Engine(object):
         # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
         # every pipe_chunk time steps (no relaunch, no weight reload, layers 32 steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
-        self.pipe_chunk = 32
+        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "32"))
         self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
         # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:
