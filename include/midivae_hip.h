@@ -97,7 +97,9 @@ typedef struct {
      * chunk_* fields): layer l publishes chunk k (chunk_steps time steps) of hs in a counter, the GEMM waits for it,
      * projects the chunk and publishes xp, layer l+1 waits for that.  All device-side (system-scope loads / atomics,
      * ~microseconds per hand-over; stream-level wait/write values cost 50-100 us each).  Counters are plain 32-bit
-     * words in device memory, zeroed by the caller before the launches. */
+     * words in device memory, zeroed by the caller before the launches.  Every producer stores the data it hands over
+     * WRITE-THROUGH (sc1) and publishes behind a drained vmcnt - no L2 write-back: a buffer_wbl2 per hand-over writes back
+     * the whole XCD's L2 and stalls the recurrent workgroups that share it (7.5 % of a training step). */
     int32_t chunk_steps;         /* time steps per pipeline chunk; chunk k = steps [k*chunk_steps, (k+1)*chunk_steps)    */
     const uint32_t* wait_ready;  /* [chunks] chunk k of xp may be read once wait_ready[k] >= wait_value (kernel polls)    */
     uint32_t wait_value;         /* 0 = 1                                                                                 */

@@ -200,45 +200,77 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         : "memory", "scc");
     if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// This wave's global stores so far are written back to memory, then ONE increment (by its first lane) of the counter.
+// wave_signal_done<WB>: this wave's global stores so far are complete, then ONE increment (by its first lane) of the counter.
+// WB = true: the wave's data left through PLAIN stores - dirty lines of this XCD's L2 are written back first (buffer_wbl2; it
+// writes back EVERY dirty line of that L2, also the other workgroups': measured 7 % of a train step when the recurrent
+// kernels published each 32-step chunk that way).  WB = false: the producer stored the handed-over data WRITE-THROUGH
+// (store16_wt below) - nothing of it is left in L2, the drained vmcnt is the release.
+#define MVAE_SIGNAL_ASM(PRE, WB_INSN, POST)                                                                          \
+    PRE "s_waitcnt vmcnt(0)\n\t" WB_INSN "s_waitcnt vmcnt(0)\n\t"                                                    \
+        "s_mov_b64 %2, exec\n\t"                                                                                     \
+        "s_mov_b64 exec, 1\n\t"                                                                                      \
+        "v_mov_b32 %0, 0\n\t"                                                                                        \
+        "v_mov_b32 %1, 1\n\t" POST
+template <bool WB = true>
 __device__ __forceinline__ void wave_signal_done(uint32_t* counter) {
     unsigned t0, t1;
     unsigned long long save;
-    asm volatile(
-        "s_waitcnt vmcnt(0)\n\t"
-        "buffer_wbl2 sc0 sc1\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 %2, exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "v_mov_b32 %0, 0\n\t"
-        "v_mov_b32 %1, 1\n\t"
-        "global_atomic_add %0, %1, %3 sc1\n\t"
-        "s_mov_b64 exec, %2\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(t0), "=&v"(t1), "=&s"(save)
-        : "s"(counter)
-        : "memory");
+    if (WB)
+        asm volatile(MVAE_SIGNAL_ASM("", "buffer_wbl2 sc0 sc1\n\t", "global_atomic_add %0, %1, %3 sc1\n\t"
+                                                                     "s_mov_b64 exec, %2\n\t"
+                                                                     "s_waitcnt vmcnt(0)")
+                     : "=&v"(t0), "=&v"(t1), "=&s"(save)
+                     : "s"(counter)
+                     : "memory");
+    else
+        asm volatile(MVAE_SIGNAL_ASM("", "", "global_atomic_add %0, %1, %3 sc1\n\t"
+                                             "s_mov_b64 exec, %2\n\t"
+                                             "s_waitcnt vmcnt(0)")
+                     : "=&v"(t0), "=&v"(t1), "=&s"(save)
+                     : "s"(counter)
+                     : "memory");
 }
+template <bool WB = true>
 __device__ __forceinline__ void wave_signal_done_if(int t, int bound, uint32_t* counter) {
     unsigned t0, t1;
     unsigned long long save;
-    asm volatile(
-        "s_cmp_lg_u32 %3, %4\n\t"
-        "s_cbranch_scc1 L_skip_%=\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "buffer_wbl2 sc0 sc1\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 %2, exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "v_mov_b32 %0, 0\n\t"
-        "v_mov_b32 %1, 1\n\t"
-        "global_atomic_add %0, %1, %5 sc1\n\t"
-        "s_mov_b64 exec, %2\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        "L_skip_%=:"
-        : "=&v"(t0), "=&v"(t1), "=&s"(save)
-        : "s"(t), "s"(bound), "s"(counter)
-        : "memory", "scc");
+    if (WB)
+        asm volatile(MVAE_SIGNAL_ASM("s_cmp_lg_u32 %3, %4\n\t"
+                                     "s_cbranch_scc1 L_skip_%=\n\t",
+                                     "buffer_wbl2 sc0 sc1\n\t",
+                                     "global_atomic_add %0, %1, %5 sc1\n\t"
+                                     "s_mov_b64 exec, %2\n\t"
+                                     "s_waitcnt vmcnt(0)\n"
+                                     "L_skip_%=:")
+                     : "=&v"(t0), "=&v"(t1), "=&s"(save)
+                     : "s"(t), "s"(bound), "s"(counter)
+                     : "memory", "scc");
+    else
+        asm volatile(MVAE_SIGNAL_ASM("s_cmp_lg_u32 %3, %4\n\t"
+                                     "s_cbranch_scc1 L_skip_%=\n\t",
+                                     "",
+                                     "global_atomic_add %0, %1, %5 sc1\n\t"
+                                     "s_mov_b64 exec, %2\n\t"
+                                     "s_waitcnt vmcnt(0)\n"
+                                     "L_skip_%=:")
+                     : "=&v"(t0), "=&v"(t1), "=&s"(save)
+                     : "s"(t), "s"(bound), "s"(counter)
+                     : "memory", "scc");
+}
+// 16-byte write-through store (buffer_store_dwordx4 ... sc1) to uniform base + per-lane byte offset: the bytes go to memory
+// and are dropped from this XCD's L2, so a consumer on any XCD reads them after the producer's vmcnt has drained - the
+// hand-over needs no L2 write-back.  A compiler-known instruction (waitcnt and hazard bookkeeping stay correct).
+typedef unsigned int mvae_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mvae_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16_wt(const void* uniform_base, unsigned lane_off, u16x8 v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mvae_u32x4, v), r, (int)lane_off, 0, 16 /* sc1 */);
+}
+// the same for 4 bf16 of a GEMM epilogue (f32 accumulators rounded like st<bf16_t>::store4)
+__device__ __forceinline__ void store4_bf16_wt(const void* uniform_base, unsigned lane_off, f32x4 v) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(mvae_u32x2, __builtin_convertvector(v, bf16x4)), r, (int)lane_off, 0, 16);
 }
 
 // ---- weight preparation bodies (shared by the single kernels and the batched mvae_prepare_batch launch) -----------

@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     // once and its other tiles_n - 1 readers hit that L2 (the weight panels, 64 KB each, stay resident in every L2).
     const bool xcd_rows = a.chunk_rows && splits == 1 && (gridDim.x % 8) == 0 && (tiles_mc % 8) == 0;
     const int total_tiles = tiles_n * tiles_mc * (xcd_split ? (splits + 7) / 8 * 8 : splits);
+    // The output chunk a RUNNING consumer picks up (chunk_done) is stored write-through: no L2 write-back before the counter
+    // (csrc/common.h wave_signal_done) - the write-back of an XCD's L2 also stalled the recurrent workgroups on that XCD.
+    const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16 && a.c_kind != MVAE_F32 && !a.accumulate && (N % FBN) == 0;
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
     if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
@@ -511,7 +514,10 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                 }
                 if (a.c_layout == MVAE_TILE16) {
                     const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
-                    if (a.c_kind == MVAE_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + off) = v;
+                    if (wt) {       // handed over to a running kernel: write-through, relative to this tile's (uniform) origin
+                        const size_t off0 = (((size_t)(m0 >> 4) * (N >> 4) + (n0 >> 4)) * 64) * 4;
+                        store4_bf16_wt(reinterpret_cast<bf16_t*>(a.C) + off0, (unsigned)(off - off0) * 2u, v);
+                    } else if (a.c_kind == MVAE_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + off) = v;
                     else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
                 } else if (a.accumulate) {
                     float* cp = reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n;
@@ -526,7 +532,10 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
             }
         }
     }
-    if (a.chunk_done) wave_signal_done(a.chunk_done + chunk);
+    if (a.chunk_done) {
+        if (wt) wave_signal_done<false>(a.chunk_done + chunk);
+        else wave_signal_done<true>(a.chunk_done + chunk);
+    }
     }   // chunk loop
     if (a.sys_release) __threadfence_system();
 }
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     for (int jj = 0; jj < 4; ++jj)
         bias[jj] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + jj * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     f_stage<false, false> sa[WS_KT];
+    const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16;        // (see gemm_fast_k)
     for (int ci = 0; ci < nchunks; ++ci) {
         const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
         if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
@@ -616,14 +626,20 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
                     const f32x4 v = acc[i][jj] * a.alpha + bias[jj];
                     if (a.c_layout == MVAE_TILE16) {
                         const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
-                        st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
+                        if (wt) {
+                            const size_t off0 = (((size_t)(m0 >> 4) * (N >> 4) + (n0 >> 4)) * 64) * 4;
+                            store4_bf16_wt(reinterpret_cast<bf16_t*>(a.C) + off0, (unsigned)(off - off0) * 2u, v);
+                        } else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
                     } else {
                         st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, v);
                     }
                 }
             }
         }
-        if (a.chunk_done) wave_signal_done(a.chunk_done + chunk);
+        if (a.chunk_done) {
+            if (wt) wave_signal_done<false>(a.chunk_done + chunk);
+            else wave_signal_done<true>(a.chunk_done + chunk);
+        }
     }
     if (a.sys_release) __threadfence_system();
 }

@@ -573,6 +573,10 @@ typedef __attribute__((address_space(1))) u16x4 g_u16x4;
 typedef __attribute__((address_space(1))) u16x8 g_u16x8;
 __device__ __forceinline__ gbyte* to_global(const void* p) { return (gbyte*)(const_cast<void*>(p)); }
 __device__ __forceinline__ void pins(gbyte*& p) { asm volatile("" : "+s"(p)); }
+// the data a pipelined stack hands over (saved h rows forward, gate gradients backward) leaves WRITE-THROUGH (common.h)
+__device__ __forceinline__ void store16_wt(gbyte* uniform_base, unsigned lane_off, u16x8 v) {
+    ::store16_wt((const void*)uniform_base, lane_off, v);
+}
 
 // Residency class of the 32 fragment groups of a step (group = the 4 gate fragments of one k-group of one unit tile, in
 // order of use).  CLS_T: group 7 (tile 0's last).  With the NLG groups that live in LDS all at the end of the step (F0 = 32 -
@@ -860,8 +864,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
                         pinv(accB[0]); pinv(accB[1]); pinv(accB[2]); pinv(accB[3]);
                         if (SAVE >= SAVE_HS && !ABL_NOTRG) {
                             pinu(tg0);
-                            *reinterpret_cast<g_u16x8*>(hs_p + tg0) = lt[0];
-                            *reinterpret_cast<g_u16x8*>(hs_p + 1024 + tg0) = lt[1];
+                            store16_wt(hs_p, tg0, lt[0]);
+                            store16_wt(hs_p, tg0 + 1024u, lt[1]);
                         }
                     }
                     if constexpr (g == 0 && gi + 2 < NGRP && !ABL_NOB)
@@ -906,15 +910,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         STAMP(7);
         // pipelined stack: hs slot t (= h_{t-1}) left this step, so the chunk ending at step t-1 is complete
         if (cs_steps && t == phi) {
-            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(a.signal_done + pk);
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done<false>(a.signal_done + pk);
             ++pk;
             phi += cs_steps;
         }
     }
     if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
-        *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
-        *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
-        if (cs_steps && a.signal_done) wave_signal_done(a.signal_done + pk);
+        store16_wt(hs_p, tg0, *reinterpret_cast<const u16x8*>(hbuf + tl0));
+        store16_wt(hs_p, tg0 + 1024u, *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u)));
+        if (cs_steps && a.signal_done) wave_signal_done<false>(a.signal_done + pk);
     }
     vm_drain();
 }
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
                 if constexpr (sl == 20 || sl == 24) {
                     if (SAVE >= SAVE_HS) {
                         pinu(tg0);
-                        *reinterpret_cast<g_u16x8*>(hs_p + (sl == 24 ? 1024 : 0) + tg0) = cp[sl == 24 ? 1 : 0];
+                        store16_wt(hs_p, tg0 + (sl == 24 ? 1024u : 0u), cp[sl == 24 ? 1 : 0]);
                     }
                 }
             } else {
@@ -1219,7 +1223,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         tl0 ^= 8192u;
         res_barrier();
         if (cs_steps && t == phi) {
-            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done(uniform_ptr(a.signal_done + pk));
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
             ++pk;
             phi += cs_steps;
         }
@@ -1235,9 +1239,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         *reinterpret_cast<g_u16x8*>(hh_prev_p + 1024 + lane16) = hh_pk[1];
     }
     if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
-        *reinterpret_cast<g_u16x8*>(hs_p + tg0) = *reinterpret_cast<const u16x8*>(hbuf + tl0);
-        *reinterpret_cast<g_u16x8*>(hs_p + tg0 + 1024) = *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u));
-        if (cs_steps && a.signal_done) wave_signal_done(uniform_ptr(a.signal_done + pk));
+        store16_wt(hs_p, tg0, *reinterpret_cast<const u16x8*>(hbuf + tl0));
+        store16_wt(hs_p, tg0 + 1024u, *reinterpret_cast<const u16x8*>(hbuf + (tl0 ^ 1056u)));
+        if (cs_steps && a.signal_done) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
     }
     vm_drain();
 }
@@ -1635,7 +1639,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
                 if constexpr (j >= 2) {
                     constexpr int js = j - 2;
                     pinu(lane16);
-                    *reinterpret_cast<g_u16x8*>(da_p + (js >> 1) * 2048 + (js & 1) * 1024 + lane16) = lt[js & 3];
+                    store16_wt(da_p, lane16 + (unsigned)((js >> 1) * 2048 + (js & 1) * 1024), lt[js & 3]);
                 }
                 if constexpr (j < 8)
                     lt[j & 3] = *reinterpret_cast<const frag*>(dabuf + (tc0 ^ ((j >> 1) << 4)) + (j >> 1) * 2048 + (j & 1) * 1024);
@@ -1654,7 +1658,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         res_barrier();
         STAMP(8);
         // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
-        wave_signal_done_if(t, psig, a.signal_done + pk);
+        wave_signal_done_if<false>(t, psig, a.signal_done + pk);
         {   // scalar bookkeeping (s_cselect, no branch): next chunk once its first step has been processed
             const bool adv = cs_steps && t == plo;
             pk -= adv ? 1 : 0;
@@ -1808,7 +1812,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         const unsigned ch = j < 4 ? (unsigned)l : 64u + ((unsigned)l & 31u);
         unsigned go = row * (GH * 2) + ch * 16u;
         pinu(go);
-        *reinterpret_cast<g_u16x8*>(da_p + go) = v;
+        store16_wt(da_p, go, v);
     };
 
     frag bq[3], lt[4], cp[4];
@@ -1981,7 +1985,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         if (a.rh) rh_p -= hs_step;
         res_barrier();
         // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
-        wave_signal_done_if(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
+        wave_signal_done_if<false>(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
         {
             const bool adv = cs_steps && t == plo;
             pk -= adv ? 1 : 0;

@@ -122,9 +122,9 @@ class Engine(object):
         # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
         self.time_chunks = 4
         # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
-        # every pipe_chunk time steps (no relaunch, no weight reload, layers 32 steps apart instead of T/4)
+        # every pipe_chunk time steps (no relaunch, no weight reload, layers pipe_chunk steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
-        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "32"))
+        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "16"))   # (A/B r02: 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms)
         self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
         # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:
@@ -754,7 +754,7 @@ class Engine(object):
             return False
         T = layers[0].T
         return (self.pipeline and self.multi_stream and not self.use_graphs and len(layers) > 1 and
-                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 64 and
+                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 128 and
                 all(self._seq_layout(r) == hl.TILE16P for r in layers))
 
     def _sync_region(self, slot, n_if, nchp, nwaves, pwaves):

@@ -206,6 +206,38 @@ def test_time_pipelined_stacks_match_chunked_launches(cell):
     assert abs(res[True][0][0]["loss"] - m_o["loss"]) <= 3e-2 * (1 + abs(m_o["loss"]))
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+@pytest.mark.parametrize("B,T,chunk", [(32, 64, 8), (64, 128, 16), (256, 64, 32)])
+def test_pipelined_hand_over_never_serves_the_previous_step(cell, B, T, chunk):
+    """The hand-over buffers (saved h rows, projected inputs, gate gradients, dX) are REWRITTEN every step at the same addresses,
+    and the producers store them write-through with no L2 write-back before the counter (csrc/common.h store16_wt): a consumer
+    that hit a stale cache line would read the PREVIOUS step's values.  Two unrelated batches with unrelated weights alternate
+    on one engine (sizes that stay L2-resident between steps included); every step must equal the same step of the
+    chunk-per-launch schedule, which has a kernel boundary at every hand-over."""
+    probs = [_problem(cell, B, seed=s, H=256, Z=64, T=T) for s in (41, 42)]
+    res = {}
+    for pipe in (True, False):
+        eng = Engine(probs[0][0], max_batch=B, dtype="bf16")
+        eng.pipeline, eng.pipe_chunk = pipe, chunk
+        assert eng._pipelined(eng.enc_notes) == pipe and eng._pipelined(eng.dec_notes) == pipe
+        out = []
+        for it in range(6):
+            spec, params, batch, raw = probs[it & 1]
+            eng.set_params(params)
+            _stage(eng, raw, B)
+            eng.forward_backward(B)
+            out.append((eng.metrics(B), eng.get_grads()))
+        eng.check_pipeline()
+        res[pipe] = out
+    for it, ((m1, g1), (m0, g0)) in enumerate(zip(res[True], res[False])):
+        assert abs(m1["loss"] - m0["loss"]) <= 1e-5 * (1 + abs(m0["loss"])), it
+        for k in g0:
+            if np.linalg.norm(g0[k]) > 1e-9:
+                assert _rel_l2(g1[k], g0[k]) < 1e-4, (it, k, _rel_l2(g1[k], g0[k]))
+    # the two batches really differ (a stale read could not hide)
+    assert abs(res[False][0][0]["loss"] - res[False][1][0]["loss"]) > 1e-3
+
+
 @pytest.mark.parametrize("cell,kw", [("LSTM", {}), ("GRU", dict(H=64, Z=8, T=8)), ("LSTM", dict(H=64, Z=16, T=8))])
 def test_fused_latent_chain_matches_separate_launches(cell, kw):
     """The Dense chain around the latent as one launch each way (csrc/latent.hip, f32 FMAs) against the same chain as
