@@ -152,6 +152,11 @@ __device__ __forceinline__ void lds_barrier() {
 //
 // wave_wait_ge: until *flag >= value (system-scope loads), then drop this XCD's possibly stale cache lines of the data the
 // flag guards.  Bounded (~0.5 s): then *status = 1 and the kernel carries on - it never hangs.
+#ifdef MVAE_EXP_AGENT_INV
+#define MVAE_ACQ_INV "buffer_inv sc1"
+#else
+#define MVAE_ACQ_INV "buffer_inv sc0 sc1"
+#endif
 __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status) {
     unsigned tmp, spins, val;
     asm volatile(
@@ -168,7 +173,7 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         "s_cmp_lt_u32 %1, 0x80000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
-        "buffer_inv sc0 sc1"
+        MVAE_ACQ_INV
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(flag), "s"(value)
         : "memory", "scc");
@@ -193,7 +198,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         "s_cmp_lt_u32 %1, 0x80000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
-        "buffer_inv sc0 sc1\n"
+        MVAE_ACQ_INV "\n"
         "L_skip_%=:"
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(t), "s"(bound), "s"(flag), "s"(value)
