@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 2
+#define MVAE_ABI_VERSION 3
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -184,6 +184,16 @@ typedef struct {
     float* colsum_b;              /* (N) f32 or NULL: += column sums of B over K (the bias gradient beside a weight-gradient
                                      GEMM C = A^T B, whose B tiles pass through the CU anyway: no second pass over B).
                                      Fast bf16 path with trans_a = 1, trans_b = 0 and accumulate only (else MVAE_E_UNSUPPORTED) */
+    /* K-streaming (fast bf16 path, trans_a = 1, accumulate = 1, row-major C): a weight-gradient GEMM C += A^T B that FOLLOWS the
+     * running BPTT kernel producing B (= da).  The K rows come in chunks of k_chunk_rows; chunk c may be read once
+     * k_wait[c] >= k_wait_value (the counters a pipelined layer publishes, mvae_rnn_bwd_args.signal_done).  split_k = P
+     * partitions: workgroup (tile, p) takes rows [c*k_chunk_rows + p*k_chunk_rows/P, ... + k_chunk_rows/P) of every chunk,
+     * keeps its 128 x 128 accumulator in registers across ALL chunks and adds it to C once at the end - one workgroup per
+     * (tile, partition), all resident for the whole launch (max_blocks must be 0).  k_reverse: last chunk first (BPTT order).
+     * What is left when the producer ends is one chunk's share, not the whole GEMM.  chunk_status reports a timed-out wait. */
+    const uint32_t* k_wait;
+    uint32_t k_wait_value;
+    int32_t k_chunk_rows, k_reverse;
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
 

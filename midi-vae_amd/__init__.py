@@ -19,6 +19,6 @@ import os as _os
 # pipelined layers / gradient GEMMs).  ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
 # with more streams than queues, unrelated streams share a queue and serialise (seen in profiles/r01_b: the
 # gradient GEMMs delayed the lower layer's BPTT by milliseconds).  Must be set before the HIP runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 __version__ = "0.1.0"

@@ -157,6 +157,7 @@ __device__ __forceinline__ void lds_barrier() {
 #else
 #define MVAE_ACQ_INV "buffer_inv sc0 sc1"
 #endif
+template <int SLEEP = 8>        // (64: a throughput consumer that polls for most of its producer's run time)
 __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status) {
     unsigned tmp, spins, val;
     asm volatile(
@@ -168,14 +169,14 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         "v_readfirstlane_b32 %2, %0\n\t"
         "s_cmp_ge_u32 %2, %4\n\t"
         "s_cbranch_scc1 L_ready_%=\n\t"
-        "s_sleep 8\n\t"
+        "s_sleep %5\n\t"
         "s_add_u32 %1, %1, 1\n\t"
         "s_cmp_lt_u32 %1, 0x80000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         MVAE_ACQ_INV
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
-        : "s"(flag), "s"(value)
+        : "s"(flag), "s"(value), "n"(SLEEP)
         : "memory", "scc");
     if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

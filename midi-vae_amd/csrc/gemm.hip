@@ -354,12 +354,15 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
         }
         const int m0 = by * FBM, n0 = bx * FBN;
         int kbeg = 0, kend = K;
-        if (splits > 1) {
+        if (splits > 1 && !a.k_wait) {
             const int per = ((K + splits - 1) / splits + FBK - 1) / FBK * FBK;
             kbeg = bz * per;
             kend = min(K, kbeg + per);
             if (kbeg >= kend) continue;
         }
+        // K-streaming (mvae_gemm_args.k_wait): the K range arrives chunk by chunk from a running producer; this workgroup takes
+        // partition bz of every chunk and keeps accumulating in registers
+        const int nseg = a.k_wait ? K / a.k_chunk_rows : 1;
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -384,6 +387,14 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
         //     k-group 0's MFMAs carry the global loads and k-group 1's LDS reads, k-group 1's MFMAs the LDS writes.
         f_stage<A_RC, ONEHOT> sa0, sa1;
         f_stage<B_RC, false> sb0, sb1;
+        for (int seg = 0; seg < nseg; ++seg) {
+        if (a.k_wait) {
+            const int c = a.k_reverse ? nseg - 1 - seg : seg, part = a.k_chunk_rows / splits;
+            if (w == 0) wave_wait_ge<64>(a.k_wait + c, a.k_wait_value, a.chunk_status);     // one polling wave per workgroup
+            __syncthreads();
+            kbeg = c * a.k_chunk_rows + bz * part;
+            kend = kbeg + part;
+        }
         const int ntiles = (kend - kbeg + FBK - 1) / FBK, klast = kbeg + (ntiles - 1) * FBK;
         sa0.load(a.A, a.lda, m0, kbeg, tid);
         sb0.load(a.B, a.ldb, n0, kbeg, tid, nlim);
@@ -394,6 +405,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
         sb0.store(Bs, tid);
         __syncthreads();
         int cur = 0;
+        (void)seg;
         auto frags = [&](int buf, int kg, u16x8 (&fa)[4], u16x8 (&fb)[4]) __attribute__((always_inline)) {
             const bf16_t* Ai = As + buf * IA;
             const bf16_t* Bi = Bs + buf * IB;
@@ -461,6 +473,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
                 mfmas(fa, fb);
             }
         }
+        }   // K segments
         __syncthreads();                       // every wave is done with the images: the epilogue / the next prologue reuse them
         if (CS && want_cs && r == 0) {     // lane (q, r = 0) holds the sums of columns .. + q*4 + 0..3
 #pragma unroll
@@ -755,6 +768,15 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
         if (a->chunk_rows <= 0 || (a->chunk_rows % FBM) || (a->M % a->chunk_rows) || a->split_k > 1 || a->max_blocks <= 0 ||
             a->max_blocks > 256 || a->accumulate)
             return MVAE_E_ARG;
+        if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
+    }
+    if (a->k_wait) {                                            // K-streaming behind a running producer: fast path only
+        const int sk = a->split_k > 1 ? a->split_k : 1;
+        if (!a->trans_a || !a->accumulate || a->c_layout != MVAE_ROWMAJOR || a->k_chunk_rows <= 0 || (a->K % a->k_chunk_rows) ||
+            a->max_blocks != 0 || a->chunk_rows || (a->k_chunk_rows % sk) || ((a->k_chunk_rows / sk) % FBK))
+            return MVAE_E_ARG;
+        // every workgroup must be resident at once (each one waits for every chunk)
+        if ((long long)((a->N + FBN - 1) / FBN) * ((a->M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk) > 256) return MVAE_E_ARG;
         if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
     }
     if (a->colsum_b && !(fast_ok(*a) && a->trans_a && !a->trans_b && a->accumulate && a->a_kind == MVAE_BF16 && !(a->N % FBN)))

@@ -112,6 +112,7 @@ class Engine(object):
             self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
+            self.s_kgrad = [torch.cuda.Stream() for _ in range(3 * spec.Le)]     # K-streaming weight-gradient GEMMs of the encoder stack
         self.multi_stream = True
         self._prefork = None
         self._branches_stay_forked = False
@@ -146,6 +147,12 @@ class Engine(object):
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
         self.onehot_split_factor = int(os.environ.get("MVAE_ONEHOT_SPLIT", "1"))   # (2 and 4 measured neutral: DESIGN.md section 6)
         self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
+        # Encoder stack (the LAST recurrence phase of a step): its weight-gradient GEMMs FOLLOW the running BPTT kernels chunk by chunk
+        # (mvae_gemm k_wait: one resident workgroup per (output tile, K partition) accumulates in registers over all chunks) - what
+        # is left when the recurrence ends is one chunk's share instead of four whole GEMMs (0.55 ms of the 0.77 ms tail).
+        # kstream_wgs workgroups per GEMM: 4-6 such GEMMs wait beside three recurrences that need 16 EMPTY CUs each.
+        self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "0") == "1"
+        self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "32"))
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
         self._build_graph_description()
@@ -233,7 +240,7 @@ class Engine(object):
     def _join_into(self, stream):
         """``stream`` waits for everything enqueued so far on the current stream and on every side stream"""
         stream.wait_stream(torch.cuda.current_stream())
-        for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
+        for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj, *self.s_kgrad):
             stream.wait_stream(st)
 
     def _side_streams(self):
@@ -754,7 +761,7 @@ class Engine(object):
             return False
         T = layers[0].T
         return (self.pipeline and self.multi_stream and not self.use_graphs and len(layers) > 1 and
-                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and T // self.pipe_chunk <= 128 and
+                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and len(layers) * 2 * (T // self.pipe_chunk) <= 1024 and
                 all(self._seq_layout(r) == hl.TILE16P for r in layers))
 
     def _sync_region(self, slot, n_if, nchp, nwaves, pwaves):
@@ -1082,7 +1089,7 @@ class Engine(object):
     def _split_k(self, K):
         # weight-gradient GEMMs have a tiny output (H x G*H = 16 tiles of 128x128) and K = T*B: split K so that
         # tiles x splits ~ the CU count; more splits only add atomic traffic (212 vs 367 TFLOP/s at 64 vs 16)
-        return int(min(16, max(1, K // 8192)))
+        return int(min(16, max(1, K // int(os.environ.get("MVAE_SPLIT_ROWS", "8192")))))
 
     def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0,
                   pipe=None):
@@ -1118,7 +1125,7 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False):
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False, kstream=None):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
@@ -1137,6 +1144,8 @@ class Engine(object):
         da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
         sk = self._split_k(R)
         mb = self.grad_gemm_blocks
+        if kstream is not None:
+            return self._rec_param_grads_kstream(r, B, hprev, da2, idx, kstream)
         if on_main:         # the LAST layer of the backward pass: on the critical queue itself - the optimizer follows it there
             fork = False    # without a cross-queue hop (two barrier packets that resolve late cost 100+ us at the end of a step)
         g1 = g2 = (_NullCtx() if on_main else None)
@@ -1178,6 +1187,57 @@ class Engine(object):
                     lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc].reshape(R, H)
                     ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
 
+    def _kstream_ok(self, layers, B):
+        """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
+        or dense input, bias gradient fused), and the waiting workgroups must leave the recurrences their empty CUs."""
+        s = self.spec
+        per_layer = 3 if s.cell == "GRU" else 2
+        return (self.kstream_grads and self._deferred is None and self.fuse_bias_grad and self.tile16 and
+                per_layer * len(layers) <= len(self.s_kgrad) and B <= 256 and
+                all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
+
+    def _rec_param_grads_kstream(self, r, B, hprev, da2, idx, ks):
+        """the layer's weight-gradient GEMMs as K-streaming launches (one stream each: they all run for the whole BPTT)"""
+        s, G, p = self.spec, self.G, r.prefix
+        H, GH, T = s.H, s.GH, r.T
+        R = T * B
+        streams, kw = ks["streams"], dict(k_wait=ks["counters"], k_wait_value=ks["target"], k_chunk_rows=ks["rows"], k_reverse=True,
+                                          chunk_status=ks["status"])
+        def parts(M, N):        # K partitions per chunk: kstream_wgs workgroups per GEMM, whole 64-row k tiles each
+            tiles = -(-M // 128) * -(-N // 128)
+            P = 1
+            while P * 2 * tiles <= self.kstream_wgs and ks["rows"] % (P * 2 * 64) == 0:
+                P *= 2
+            return P
+        gb = G[p + ".b"]
+        jobs = []
+        if s.cell == "GRU":
+            rh = self._v(p + ".rh", T, B, H)
+            jobs.append(lambda: ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True,
+                                         split_k=parts(H, 2 * H), colsum_b=gb[:2 * H], **kw))
+            jobs.append(lambda: ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
+                                         accumulate=True, split_k=parts(H, H), colsum_b=gb[2 * H:], **kw))
+        else:
+            jobs.append(lambda: ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=parts(H, GH),
+                                         colsum_b=gb, **kw))
+        if r.xmode == hl.X_INDEX:
+            jobs.append(lambda: ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
+                                         accumulate=True, split_k=parts(r.K, GH), **kw))
+        else:
+            lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:1 + T].reshape(R, H)
+            jobs.append(lambda: ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=parts(H, GH), **kw))
+        for st, job in zip(streams, jobs):
+            with torch.cuda.stream(st):
+                job()
+        return len(jobs)
+
+    def _join_kgrad(self):
+        """the current stream waits for the K-streaming gradient GEMMs: chained, the bottom layer's queues (the latest) last"""
+        n = getattr(self, "_kgrad_used", 0)
+        if n:
+            self._join(*self.s_kgrad[:n])
+            self._kgrad_used = 0
+
     def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
                              xs=None, start=None, tail_on_main=False):
         cs = self.pipe_chunk
@@ -1185,7 +1245,11 @@ class Engine(object):
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
         order = list(reversed(layers))               # order[0] = top layer: runs on this stream, publishes da
         L = len(order)
-        sync, da_target, dx_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
+        kstream = self._kstream_ok(layers, B)
+        if kstream:
+            tail_on_main = False
+            before = torch.cuda.current_stream().record_event()      # the layers' saved inputs and the zeroed gradient buffers
+        sync, da_target, dx_target = self._sync_region(slot, L, nchp, nwaves, pwaves)     # (row L-1: the bottom layer's da)
         self._pipe_started = (sync[0, 0][nchp - 1:nchp], da_target)      # reached when the top layer's first chunk is out
         status = self.store["pipe_status"]
         lower_streams = self.s_layer[:L - 1]         # order[li], li >= 1, on lower_streams[li - 1]
@@ -1197,13 +1261,13 @@ class Engine(object):
             pipe = dict(chunk_steps=cs, status=status)
             if li > 0:
                 pipe.update(wait_ready=sync[li - 1, 1], wait_value=dx_target)
-            if li < L - 1:
+            if li < L - 1 or kstream:
                 pipe["signal_done"] = sync[li, 0]
             def run():
                 ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
                 self._rec_bptt(r, B, 0, 1, dhs_ext=ext, dh_last=dh_last if top else None,
                                dh_last_ld=dh_last_ld if top else 0, pipe=pipe, **ds)
-                if not (tail_on_main and li == L - 1):
+                if not kstream and not (tail_on_main and li == L - 1):
                     self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
             if top:
                 run()
@@ -1215,6 +1279,16 @@ class Engine(object):
                     self._rec_dx(r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True,
                                  chunk_wait=sync[li, 0], chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)
         # chained join: the latest finisher (the bottom layer) last - ahead of the dX GEMMs it would put two hops in series
+        if kstream:     # behind every kernel of the stack in host order: the recurrences are dispatched first
+            used = 0
+            per_layer = 3 if self.spec.cell == "GRU" else 2
+            for li, r in enumerate(order):
+                sts = self.s_kgrad[used:used + per_layer]
+                for q in sts:
+                    q.wait_event(before)
+                used += self._rec_param_grads(r, B, 0, 1, idx=idx, kstream=dict(
+                    streams=sts, counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
+            self._kgrad_used = used
         self._join(*gemm_streams, *lower_streams)
         if tail_on_main:        # the bottom layer finishes last: its parameter gradients right here, the optimizer behind them
             self._rec_param_grads(order[-1], B, 0, 1, idx=idx, xs=xs, start=start, on_main=True)
@@ -1373,6 +1447,7 @@ class Engine(object):
         # early finishers are chained into one of them, the other is waited for directly
         self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
         self._join(self.s_grad2)
+        self._join_kgrad()
 
     def _latent_backward_unfused(self, Breal, B):
         """initial-state Denses, latent block and encoder tail Denses backward, one launch per operation; returns d(cat)"""

@@ -23,7 +23,7 @@ CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -53,7 +53,8 @@ class GemmArgs(C.Structure):
                 ("accumulate", _i32), ("act", _i32), ("split_k", _i32), ("alpha", _f32),
                 ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("c_layout", _i32), ("max_blocks", _i32),
                 ("sys_release", _i32), ("chunk_rows", _i32), ("chunk_reverse", _i32), ("chunk_wait", _vp),
-                ("chunk_wait_value", C.c_uint32), ("chunk_done", _vp), ("chunk_status", _vp), ("colsum_b", _vp)]
+                ("chunk_wait_value", C.c_uint32), ("chunk_done", _vp), ("chunk_status", _vp), ("colsum_b", _vp),
+                ("k_wait", _vp), ("k_wait_value", C.c_uint32), ("k_chunk_rows", C.c_int32), ("k_reverse", C.c_int32)]
 
 
 class PrepJob(C.Structure):

@@ -77,9 +77,11 @@ def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh
 
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
          accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0, sys_release=False, chunk_rows=0,
-         chunk_reverse=False, chunk_wait=None, chunk_wait_value=0, chunk_done=None, chunk_status=None, colsum_b=None):
+         chunk_reverse=False, chunk_wait=None, chunk_wait_value=0, chunk_done=None, chunk_status=None, colsum_b=None,
+         k_wait=None, k_wait_value=0, k_chunk_rows=0, k_reverse=False):
     """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths.
-    ``colsum_b`` (N,) f32 += column sums of B (weight-gradient GEMMs: the bias gradient from the same pass over B)."""
+    ``colsum_b`` (N,) f32 += column sums of B (weight-gradient GEMMs: the bias gradient from the same pass over B).
+    ``k_wait`` ...: K-streaming behind a running producer of B (include/midivae_hip.h)."""
     a_kind = kind_of(A) if a_kind is None else a_kind
     if lda is None:
         lda = (M if trans_a else K)
@@ -90,7 +92,7 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
     g = hl.GemmArgs(M, N, K, int(trans_a), int(trans_b), a_kind, kind_of(B), kind_of(C), lda, ldb, ldc,
                     int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks,
                     int(sys_release), int(chunk_rows), int(chunk_reverse), _pv(chunk_wait), int(chunk_wait_value), _pv(chunk_done),
-                    _pv(chunk_status), _pv(colsum_b))
+                    _pv(chunk_status), _pv(colsum_b), _pv(k_wait), int(k_wait_value), int(k_chunk_rows), int(k_reverse))
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
 
 

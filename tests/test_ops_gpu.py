@@ -611,6 +611,61 @@ def test_gemm_weight_gradient_with_fused_column_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("onehot", [False, True])
+@pytest.mark.parametrize("live", [False, True])
+def test_gemm_k_streaming_follows_a_producer(onehot, live):
+    """mvae_gemm k_wait: C += A^T B with the K rows arriving in chunks (last chunk first), P partitions per chunk, the accumulator
+    kept in registers over all chunks.  ``live``: the GEMM is launched FIRST and waits; a second stream then writes B chunk by
+    chunk (NaN before) and publishes each chunk's counter - a chunk read early would poison C.  Against float64 on the bf16-rounded
+    operands, with the fused column sums (bias gradient) and the one-hot left operand (table gradient)."""
+    rng = np.random.default_rng(11 + onehot)
+    M, N, rows, nch, P = (61 if onehot else 256), 512, 1024, 8, 2
+    K = rows * nch
+    if onehot:
+        idx = torch.tensor(rng.integers(0, M, (K,)), dtype=torch.uint8, device=DEV)
+        A = idx
+        A64 = np.zeros((K, M))
+        A64[np.arange(K), idx.cpu().numpy()] = 1.0
+    else:
+        A = torch.tensor(rng.standard_normal((K, M)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+        A64 = A.double().cpu().numpy()
+    Btrue = torch.tensor(rng.standard_normal((K, N)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+    Bf = torch.full_like(Btrue, float("nan")) if live else Btrue.clone()
+    C = torch.full((M, N), 0.5, device=DEV)
+    cs = torch.full((N,), 0.25, device=DEV)
+    target = 7
+    counters = torch.zeros(nch, dtype=torch.int32, device=DEV) if live else torch.full((nch,), target + 3, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        ops.gemm(A, Bf, C, M, N, K, trans_a=True, accumulate=True, split_k=P, a_kind=hl.ONEHOT if onehot else None,
+                 colsum_b=None if onehot else cs, k_wait=counters, k_wait_value=target, k_chunk_rows=rows, k_reverse=True,
+                 chunk_status=status)
+    if live:
+        with torch.cuda.stream(s2):
+            for c in range(nch - 1, -1, -1):
+                Bf[c * rows:(c + 1) * rows].copy_(Btrue[c * rows:(c + 1) * rows])
+                ops.stream_write_value32(counters[c:c + 1], target, stream=s2)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    B64 = Btrue.double().cpu().numpy()
+    np.testing.assert_allclose(C.cpu().numpy(), 0.5 + A64.T @ B64, rtol=2e-3, atol=2e-3 * np.sqrt(K))
+    if not onehot:
+        np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + B64.sum(0), rtol=2e-3, atol=2e-3 * np.sqrt(K))
+    # argument checks: partitions must be whole 64-row k tiles, the grid must be resident, store mode is refused
+    lib = hl.load()
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, Bf, C, M, N, K, trans_a=True, accumulate=True, split_k=3, a_kind=hl.ONEHOT if onehot else None,
+                 k_wait=counters, k_wait_value=target, k_chunk_rows=rows)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A, Bf, C, M, N, K, trans_a=True, accumulate=True, split_k=P, max_blocks=8, a_kind=hl.ONEHOT if onehot else None,
+                 k_wait=counters, k_wait_value=target, k_chunk_rows=rows)
+    torch.cuda.synchronize()
+    assert lib is not None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
 @pytest.mark.parametrize("kind,N", [(0, 61), (0, 16), (1, 1)])
 def test_head_fused_input_gradient(dtype, tol, kind, N):
