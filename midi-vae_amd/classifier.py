@@ -122,7 +122,6 @@ class ClassifierEngine(Engine):
         self._prefork = None
         self._join(self.s_grad)
         self._join(self.s_grad2)
-        self._join_kgrad()
 
     def train_step(self, B, allreduce=None):
         assert self.training

@@ -11,6 +11,7 @@
 // f32 operands use v_mfma_f32_16x16x4_f32 (exact f32, parity mode), bf16 operands v_mfma_f32_16x16x32_bf16.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -306,9 +307,9 @@ struct f_stage {
     }
 };
 
+// (the body is a device function of a VIRTUAL grid - block vb of nvb: gemm_kstream_multi_k runs several problems in one launch)
 template <bool A_RC, bool B_RC, bool ONEHOT, bool CS = false>      // CS: also the column sums of B (mvae_gemm_args.colsum_b)
-__global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_fast_body(const mvae_gemm_args a, const int vb, const int nvb, unsigned char* smem) {
     constexpr int IA = f_img<A_RC>(), IB = f_img<B_RC>();
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);                  // [2][IA]
     bf16_t* Bs = As + 2 * IA;                                      // [2][IB]
@@ -324,12 +325,12 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     // Split-K with >= 8 splits (the weight-gradient GEMMs: 16 output tiles, K = T*B): the tiles of one k-range share their
     // A and B panels, so they go to ONE XCD (workgroup b runs on XCD b % 8) - spread over all eight, every XCD's L2 fetches
     // every panel of A (2.4x the unique bytes from HBM for a 256 x 1024 output).
-    const bool xcd_split = splits >= 8 && !a.chunk_rows && (gridDim.x % 8) == 0;
+    const bool xcd_split = splits >= 8 && !a.chunk_rows && (nvb % 8) == 0;
     // Persistent chunked mode (the projection / dX GEMM between two time-pipelined layers): the tiles_n column tiles of one row
     // block read the same 128 x K panel of A.  Dealt out round-robin they land on eight different XCDs and every XCD's L2 fetches
     // the panel from the fabric; with the row blocks of residue x (mod 8) given to the workgroups of XCD x the panel is fetched
     // once and its other tiles_n - 1 readers hit that L2 (the weight panels, 64 KB each, stay resident in every L2).
-    const bool xcd_rows = a.chunk_rows && splits == 1 && (gridDim.x % 8) == 0 && (tiles_mc % 8) == 0;
+    const bool xcd_rows = a.chunk_rows && splits == 1 && (nvb % 8) == 0 && (tiles_mc % 8) == 0;
     const int total_tiles = tiles_n * tiles_mc * (xcd_split ? (splits + 7) / 8 * 8 : splits);
     // The output chunk a RUNNING consumer picks up (chunk_done) is stored write-through: no L2 write-back before the counter
     // (csrc/common.h wave_signal_done) - the write-back of an XCD's L2 also stalled the recurrent workgroups on that XCD.
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
     if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    for (int tile = vb; tile < total_tiles; tile += nvb) {
         int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
         if (xcd_rows) {
             const int x = tile & 7, i = tile >> 3;          // the i-th tile of XCD x's share of this chunk
@@ -552,6 +553,30 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
     }   // chunk loop
     if (a.sys_release) __threadfence_system();
 }
+template <bool A_RC, bool B_RC, bool ONEHOT, bool CS = false>
+__global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_fast_body<A_RC, B_RC, ONEHOT, CS>(a, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+// Several K-streaming weight-gradient GEMMs (mvae_gemm_args.k_wait) behind ONE pipelined stack as ONE launch on ONE queue: every
+// such GEMM runs for the whole BPTT, so each needs its own queue otherwise - and every additional busy queue costs the step
+// 0.14 ms of command-processor time (profiles/r02_n_ab_kstream_gradients.txt).  Workgroups [base[i], base[i+1]) run problem i.
+constexpr int KS_MAX = 6;
+struct kstream_multi {
+    mvae_gemm_args p[KS_MAX];
+    int32_t base[KS_MAX + 1];
+    int32_t variant[KS_MAX];     // 0: dense A, 1: dense A + column sums of B, 2: one-hot A
+    int32_t n;
+};
+__global__ __launch_bounds__(256) void gemm_kstream_multi_k(const kstream_multi m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.base[i + 1]) ++i;
+    const int vb = (int)blockIdx.x - m.base[i], nvb = m.base[i + 1] - m.base[i];
+    if (m.variant[i] == 1) gemm_fast_body<true, true, false, true>(m.p[i], vb, nvb, smem);
+    else if (m.variant[i] == 2) gemm_fast_body<true, true, true, false>(m.p[i], vb, nvb, smem);
+    else gemm_fast_body<true, true, false, false>(m.p[i], vb, nvb, smem);
+}
 
 // ===========================================================================================================
 // Weights-stationary persistent projection (round 2): x*W + b of a stacked layer behind a time-pipelined lower layer, K = H = 256.
@@ -755,7 +780,58 @@ int by_trans(const mvae_gemm_args& a, hipStream_t s) {
     return a.trans_b ? launch<OT, AKIND, BKIND, false, true>(a, s) : launch<OT, AKIND, BKIND, false, false>(a, s);
 }
 
+
+// the argument checks of a K-streaming problem (shared by mvae_gemm and mvae_gemm_kstream_multi); workgroups it needs in *wgs
+int kstream_check(const mvae_gemm_args* a, long long* wgs) {
+    const int sk = a->split_k > 1 ? a->split_k : 1;
+    if (!a->k_wait || !a->trans_a || !a->accumulate || a->c_kind != MVAE_F32 || a->c_layout != MVAE_ROWMAJOR || a->k_chunk_rows <= 0 ||
+        (a->K % a->k_chunk_rows) || a->max_blocks != 0 || a->chunk_rows || (a->k_chunk_rows % sk) || ((a->k_chunk_rows / sk) % FBK))
+        return MVAE_E_ARG;
+    // every workgroup must be resident at once (each one waits for every chunk)
+    *wgs = (long long)((a->N + FBN - 1) / FBN) * ((a->M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk);
+    if (*wgs > 256) return MVAE_E_ARG;
+    if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
+    return MVAE_OK;
+}
+
 }  // namespace
+
+extern "C" int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n, void* stream) {
+    if (!problems || n <= 0 || n > KS_MAX) return MVAE_E_ARG;
+    kstream_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const mvae_gemm_args* a = problems + i;
+        if (!a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->trans_b || a->bias || a->act != MVAE_ACT_NONE)
+            return MVAE_E_ARG;
+        long long wgs = 0;
+        const int rc = kstream_check(a, &wgs);
+        if (rc != MVAE_OK) return rc;
+        if (a->a_kind == MVAE_A_ONEHOT) m.variant[i] = 2;
+        else if (a->colsum_b) {
+            if (a->N % FBN) return MVAE_E_UNSUPPORTED;
+            m.variant[i] = 1;
+        } else m.variant[i] = 0;
+        m.p[i] = *a;
+        m.base[i] = (int32_t)total;
+        total += wgs;
+    }
+    m.base[n] = (int32_t)total;
+    if (total > 256) return MVAE_E_ARG;         // all of them wait for the producers: they must fit beside them
+    const size_t lds = (size_t)2 * (f_img<true>() + f_img<true>()) * sizeof(bf16_t);
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kstream_multi_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL(gemm_kstream_multi_k, dim3((unsigned)total), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 
 extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MVAE_E_ARG;
@@ -771,13 +847,9 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
         if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
     }
     if (a->k_wait) {                                            // K-streaming behind a running producer: fast path only
-        const int sk = a->split_k > 1 ? a->split_k : 1;
-        if (!a->trans_a || !a->accumulate || a->c_layout != MVAE_ROWMAJOR || a->k_chunk_rows <= 0 || (a->K % a->k_chunk_rows) ||
-            a->max_blocks != 0 || a->chunk_rows || (a->k_chunk_rows % sk) || ((a->k_chunk_rows / sk) % FBK))
-            return MVAE_E_ARG;
-        // every workgroup must be resident at once (each one waits for every chunk)
-        if ((long long)((a->N + FBN - 1) / FBN) * ((a->M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk) > 256) return MVAE_E_ARG;
-        if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
+        long long wgs = 0;
+        const int rc = kstream_check(a, &wgs);
+        if (rc != MVAE_OK) return rc;
     }
     if (a->colsum_b && !(fast_ok(*a) && a->trans_a && !a->trans_b && a->accumulate && a->a_kind == MVAE_BF16 && !(a->N % FBN)))
         return MVAE_E_UNSUPPORTED;

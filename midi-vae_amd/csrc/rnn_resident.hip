@@ -1964,7 +1964,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
             if constexpr (sl == 26 || sl == 31) {
                 if (a.rh) {
                     pinu(tg0);
-                    *reinterpret_cast<g_u16x8*>(rh_p + (sl == 31 ? 1024 : 0) + tg0) = cp[sl == 31 ? 1 : 0];
+                    store16_wt(rh_p, tg0 + (sl == 31 ? 1024u : 0u), cp[sl == 31 ? 1 : 0]);    // (read by the K-streaming dU GEMM while this kernel runs)
                 }
             }
             if constexpr (!GB_NOCOPY && sl >= 36 && (sl - 36) % 5 == 0 && sl < 36 + 20)

@@ -112,7 +112,6 @@ class Engine(object):
             self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
             self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
             self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
-            self.s_kgrad = [torch.cuda.Stream() for _ in range(3 * spec.Le)]     # K-streaming weight-gradient GEMMs of the encoder stack
         self.multi_stream = True
         self._prefork = None
         self._branches_stay_forked = False
@@ -149,10 +148,13 @@ class Engine(object):
         self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
         # Encoder stack (the LAST recurrence phase of a step): its weight-gradient GEMMs FOLLOW the running BPTT kernels chunk by chunk
         # (mvae_gemm k_wait: one resident workgroup per (output tile, K partition) accumulates in registers over all chunks) - what
-        # is left when the recurrence ends is one chunk's share instead of four whole GEMMs (0.55 ms of the 0.77 ms tail).
-        # kstream_wgs workgroups per GEMM: 4-6 such GEMMs wait beside three recurrences that need 16 EMPTY CUs each.
-        self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "0") == "1"
+        # is left when the recurrence ends is one chunk's share instead of four whole GEMMs (0.55 ms of the 0.77 ms tail).  All of
+        # them are ONE launch (mvae_gemm_kstream_multi) on the second gradient queue - a queue each cost more than the tail saved -
+        # and the other gradient work of that phase (velocity / instrument encoders) goes to the first one.
+        # kstream_wgs workgroups per GEMM: they wait beside three recurrences that need 16 EMPTY CUs each.
+        self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "32"))
+        self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
         self._build_graph_description()
@@ -240,7 +242,7 @@ class Engine(object):
     def _join_into(self, stream):
         """``stream`` waits for everything enqueued so far on the current stream and on every side stream"""
         stream.wait_stream(torch.cuda.current_stream())
-        for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj, *self.s_kgrad):
+        for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
             stream.wait_stream(st)
 
     def _side_streams(self):
@@ -1125,7 +1127,7 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False, kstream=None):
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
@@ -1144,17 +1146,16 @@ class Engine(object):
         da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
         sk = self._split_k(R)
         mb = self.grad_gemm_blocks
-        if kstream is not None:
-            return self._rec_param_grads_kstream(r, B, hprev, da2, idx, kstream)
         if on_main:         # the LAST layer of the backward pass: on the critical queue itself - the optimizer follows it there
             fork = False    # without a cross-queue hop (two barrier packets that resolve late cost 100+ us at the end of a step)
         g1 = g2 = (_NullCtx() if on_main else None)
+        sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
         if fork:
-            self._fork(self.s_grad, self.s_grad2)
+            self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
         # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
         fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
         gb = G[p + ".b"]
-        with (g1 or self._on(self.s_grad)):
+        with (g1 or self._on(sg1)):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
@@ -1165,7 +1166,7 @@ class Engine(object):
             else:
                 ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb,
                          colsum_b=gb if fuse_b else None)
-        with (g2 or self._on(self.s_grad2)):
+        with (g2 or self._on(sg2)):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
                 ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1) or self._dxp0_clean)
@@ -1189,20 +1190,22 @@ class Engine(object):
 
     def _kstream_ok(self, layers, B):
         """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
-        or dense input, bias gradient fused), and the waiting workgroups must leave the recurrences their empty CUs."""
+        or dense input, bias gradient fused), at most 6 of them, and the waiting workgroups must leave the recurrences their empty CUs."""
         s = self.spec
         per_layer = 3 if s.cell == "GRU" else 2
-        return (self.kstream_grads and self._deferred is None and self.fuse_bias_grad and self.tile16 and
-                per_layer * len(layers) <= len(self.s_kgrad) and B <= 256 and
+        return (self.kstream_grads and self.multi_stream and self._deferred is None and self.fuse_bias_grad and self.tile16 and
+                per_layer * len(layers) <= 6 and B <= 256 and self._pipelined(layers) and
                 all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
 
-    def _rec_param_grads_kstream(self, r, B, hprev, da2, idx, ks):
-        """the layer's weight-gradient GEMMs as K-streaming launches (one stream each: they all run for the whole BPTT)"""
+    def _kstream_problems(self, r, B, idx, ks):
+        """the layer's weight-gradient GEMMs as K-streaming problems (mvae_gemm_args, not launched)"""
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
         R = T * B
-        streams, kw = ks["streams"], dict(k_wait=ks["counters"], k_wait_value=ks["target"], k_chunk_rows=ks["rows"], k_reverse=True,
-                                          chunk_status=ks["status"])
+        hprev = self._v(p + ".hs", T + 1, B, H)[:T].reshape(R, H)
+        da2 = self._v(p + ".da", T, B, GH).view(R, GH)
+        kw = dict(k_wait=ks["counters"], k_wait_value=ks["target"], k_chunk_rows=ks["rows"], k_reverse=True, chunk_status=ks["status"],
+                  trans_a=True, accumulate=True, build_only=True)
         def parts(M, N):        # K partitions per chunk: kstream_wgs workgroups per GEMM, whole 64-row k tiles each
             tiles = -(-M // 128) * -(-N // 128)
             P = 1
@@ -1210,33 +1213,20 @@ class Engine(object):
                 P *= 2
             return P
         gb = G[p + ".b"]
-        jobs = []
+        out = []
         if s.cell == "GRU":
             rh = self._v(p + ".rh", T, B, H)
-            jobs.append(lambda: ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True,
-                                         split_k=parts(H, 2 * H), colsum_b=gb[:2 * H], **kw))
-            jobs.append(lambda: ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                                         accumulate=True, split_k=parts(H, H), colsum_b=gb[2 * H:], **kw))
+            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=parts(H, 2 * H), colsum_b=gb[:2 * H], **kw))
+            out.append(ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, ldb=GH, ldc=GH, split_k=parts(H, H),
+                                colsum_b=gb[2 * H:], **kw))
         else:
-            jobs.append(lambda: ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=parts(H, GH),
-                                         colsum_b=gb, **kw))
+            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, split_k=parts(H, GH), colsum_b=gb, **kw))
         if r.xmode == hl.X_INDEX:
-            jobs.append(lambda: ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
-                                         accumulate=True, split_k=parts(r.K, GH), **kw))
+            out.append(ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, a_kind=hl.ONEHOT, split_k=parts(r.K, GH), **kw))
         else:
             lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:1 + T].reshape(R, H)
-            jobs.append(lambda: ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=parts(H, GH), **kw))
-        for st, job in zip(streams, jobs):
-            with torch.cuda.stream(st):
-                job()
-        return len(jobs)
-
-    def _join_kgrad(self):
-        """the current stream waits for the K-streaming gradient GEMMs: chained, the bottom layer's queues (the latest) last"""
-        n = getattr(self, "_kgrad_used", 0)
-        if n:
-            self._join(*self.s_kgrad[:n])
-            self._kgrad_used = 0
+            out.append(ops.gemm(lower, da2, G[p + ".W"], H, GH, R, split_k=parts(H, GH), **kw))
+        return out
 
     def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
                              xs=None, start=None, tail_on_main=False):
@@ -1280,15 +1270,12 @@ class Engine(object):
                                  chunk_wait=sync[li, 0], chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)
         # chained join: the latest finisher (the bottom layer) last - ahead of the dX GEMMs it would put two hops in series
         if kstream:     # behind every kernel of the stack in host order: the recurrences are dispatched first
-            used = 0
-            per_layer = 3 if self.spec.cell == "GRU" else 2
+            problems = []
             for li, r in enumerate(order):
-                sts = self.s_kgrad[used:used + per_layer]
-                for q in sts:
-                    q.wait_event(before)
-                used += self._rec_param_grads(r, B, 0, 1, idx=idx, kstream=dict(
-                    streams=sts, counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
-            self._kgrad_used = used
+                problems += self._kstream_problems(r, B, idx, dict(counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
+            self.s_grad2.wait_event(before)
+            with torch.cuda.stream(self.s_grad2):
+                ops.gemm_kstream_multi(problems)
         self._join(*gemm_streams, *lower_streams)
         if tail_on_main:        # the bottom layer finishes last: its parameter gradients right here, the optimizer behind them
             self._rec_param_grads(order[-1], B, 0, 1, idx=idx, xs=xs, start=start, on_main=True)
@@ -1424,6 +1411,8 @@ class Engine(object):
             with torch.cuda.stream(self.s_comm):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: three independent branches -------------------------------------------------
+        if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
+            self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
         self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
         for k, (r, st, src) in enumerate(self.enc_meta, 1):
             with self._on(st):
@@ -1435,6 +1424,7 @@ class Engine(object):
             self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3,
                                  tail_on_main=self.tail_on_main)
         self._prefork = None
+        self._grad_streams = None
         if deferred:
             word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da
             for st in (self.s_grad, self.s_grad2):
@@ -1447,7 +1437,6 @@ class Engine(object):
         # early finishers are chained into one of them, the other is waited for directly
         self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
         self._join(self.s_grad2)
-        self._join_kgrad()
 
     def _latent_backward_unfused(self, Breal, B):
         """initial-state Denses, latent block and encoder tail Denses backward, one launch per operation; returns d(cat)"""

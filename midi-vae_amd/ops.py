@@ -78,7 +78,7 @@ def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
          accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0, sys_release=False, chunk_rows=0,
          chunk_reverse=False, chunk_wait=None, chunk_wait_value=0, chunk_done=None, chunk_status=None, colsum_b=None,
-         k_wait=None, k_wait_value=0, k_chunk_rows=0, k_reverse=False):
+         k_wait=None, k_wait_value=0, k_chunk_rows=0, k_reverse=False, build_only=False):
     """C (M,N) = alpha * opA(A) opB(B) (+bias)(tanh).  Leading dimensions default to the packed row lengths.
     ``colsum_b`` (N,) f32 += column sums of B (weight-gradient GEMMs: the bias gradient from the same pass over B).
     ``k_wait`` ...: K-streaming behind a running producer of B (include/midivae_hip.h)."""
@@ -93,7 +93,15 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
                     int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks,
                     int(sys_release), int(chunk_rows), int(chunk_reverse), _pv(chunk_wait), int(chunk_wait_value), _pv(chunk_done),
                     _pv(chunk_status), _pv(colsum_b), _pv(k_wait), int(k_wait_value), int(k_chunk_rows), int(k_reverse))
+    if build_only:          # (for gemm_kstream_multi; the tensors must stay alive until that launch)
+        return g
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
+
+
+def gemm_kstream_multi(problems):
+    """several K-streaming GEMMs (``gemm(..., k_wait=..., build_only=True)``) as ONE launch on the current stream"""
+    arr = (hl.GemmArgs * len(problems))(*problems)
+    hl.check(hl.load().mvae_gemm_kstream_multi(arr, len(problems), _stream()), "mvae_gemm_kstream_multi")
 
 
 def stream_wait_value32(word, value, stream=None):

@@ -666,6 +666,47 @@ def test_gemm_k_streaming_follows_a_producer(onehot, live):
 
 
 @pytest.mark.gpu
+def test_gemm_k_streaming_multi_launch():
+    """mvae_gemm_kstream_multi: three K-streaming problems of different kinds (dense + fused column sums, dense, one-hot) and
+    different partition counts as ONE launch, released chunk by chunk by a second stream (B is NaN before its chunk is written)."""
+    rng = np.random.default_rng(23)
+    rows, nch, N = 1024, 6, 512
+    K = rows * nch
+    A1 = torch.tensor(rng.standard_normal((K, 256)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+    A2 = torch.tensor(rng.standard_normal((K, 128)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+    idx = torch.tensor(rng.integers(0, 61, (K,)), dtype=torch.uint8, device=DEV)
+    Btrue = torch.tensor(rng.standard_normal((K, N)) * 0.5, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+    Bf = torch.full_like(Btrue, float("nan"))
+    C1, C2, C3 = (torch.zeros((m, N), device=DEV) for m in (256, 128, 61))
+    cs = torch.zeros((N,), device=DEV)
+    counters = torch.zeros(nch, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    kw = dict(trans_a=True, accumulate=True, k_wait=counters, k_wait_value=3, k_chunk_rows=rows, k_reverse=True, chunk_status=status,
+              build_only=True)
+    problems = [ops.gemm(A1, Bf, C1, 256, N, K, split_k=4, colsum_b=cs, **kw), ops.gemm(A2, Bf, C2, 128, N, K, split_k=2, **kw),
+                ops.gemm(idx, Bf, C3, 61, N, K, split_k=8, a_kind=hl.ONEHOT, **kw)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        ops.gemm_kstream_multi(problems)
+    with torch.cuda.stream(s2):
+        for c in range(nch - 1, -1, -1):
+            Bf[c * rows:(c + 1) * rows].copy_(Btrue[c * rows:(c + 1) * rows])
+            ops.stream_write_value32(counters[c:c + 1], 3, stream=s2)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    B64 = Btrue.double().cpu().numpy()
+    A3 = np.zeros((K, 61))
+    A3[np.arange(K), idx.cpu().numpy()] = 1.0
+    for C, A64 in ((C1, A1.double().cpu().numpy()), (C2, A2.double().cpu().numpy()), (C3, A3)):
+        np.testing.assert_allclose(C.cpu().numpy(), A64.T @ B64, rtol=2e-3, atol=2e-3 * np.sqrt(K))
+    np.testing.assert_allclose(cs.cpu().numpy(), B64.sum(0), rtol=2e-3, atol=2e-3 * np.sqrt(K))
+    with pytest.raises(RuntimeError):       # more than 256 waiting workgroups in all
+        ops.gemm_kstream_multi([ops.gemm(A1, Bf, C1, 256, N, K, split_k=16, **kw)] * 3)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
 @pytest.mark.parametrize("kind,N", [(0, 61), (0, 16), (1, 1)])
 def test_head_fused_input_gradient(dtype, tol, kind, N):
