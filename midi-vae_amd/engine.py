@@ -1192,9 +1192,9 @@ class Engine(object):
         """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
         or dense input, bias gradient fused), at most 6 of them, and the waiting workgroups must leave the recurrences their empty CUs."""
         s = self.spec
-        per_layer = 3 if s.cell == "GRU" else 2
+        count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
         return (self.kstream_grads and self.multi_stream and self._deferred is None and self.fuse_bias_grad and self.tile16 and
-                per_layer * len(layers) <= 6 and B <= 256 and self._pipelined(layers) and
+                count <= 6 and B <= 256 and self._pipelined(layers) and
                 all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
 
     def _kstream_problems(self, r, B, idx, ks):
@@ -1216,7 +1216,8 @@ class Engine(object):
         out = []
         if s.cell == "GRU":
             rh = self._v(p + ".rh", T, B, H)
-            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=parts(H, 2 * H), colsum_b=gb[:2 * H], **kw))
+            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=parts(H, 2 * H),
+                                colsum_b=gb[:2 * H], **kw))
             out.append(ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, ldb=GH, ldc=GH, split_k=parts(H, H),
                                 colsum_b=gb[2 * H:], **kw))
         else:
@@ -1274,6 +1275,10 @@ class Engine(object):
             for li, r in enumerate(order):
                 problems += self._kstream_problems(r, B, idx, dict(counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
             self.s_grad2.wait_event(before)
+            # Its workgroups wait, resident, for the whole BPTT: they may only take CUs once EVERY kernel they wait for is running
+            # (a recurrent workgroup needs a whole empty CU) - the queue holds the launch back until the BOTTOM layer has
+            # published its first chunk, which it can only do with the layers above it and the dX GEMMs running too.
+            ops.stream_wait_value32(sync[L - 1, 0][nchp - 1:nchp], da_target, stream=self.s_grad2)
             with torch.cuda.stream(self.s_grad2):
                 ops.gemm_kstream_multi(problems)
         self._join(*gemm_streams, *lower_streams)
