@@ -18,6 +18,8 @@ ap.add_argument("--T", type=int, default=512)
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-major sequences)")
+ap.add_argument("--signal", type=int, default=0, help="publish every N steps in a counter like a pipelined producer (nobody waits)")
+ap.add_argument("--concurrent", type=int, default=1, help="run k copies of every launch on k streams (own buffers): contention")
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
@@ -56,16 +58,41 @@ def timeit(fn):
     return e0.elapsed_time(e1) / a.reps
 
 
+counters = torch.zeros(1024, dtype=torch.int32, device=dev)
+status = torch.zeros(1, dtype=torch.int32, device=dev)
+sig = dict(chunk_steps=a.signal, signal_done=counters, status=status) if a.signal else {}
+streams = [torch.cuda.Stream() for _ in range(a.concurrent)]
+copies = [dict(hs=torch.zeros_like(hs), cs=None if cs is None else torch.zeros_like(cs), acts=torch.zeros_like(acts),
+               da=torch.zeros_like(da), rh=torch.zeros_like(rh)) for _ in range(a.concurrent - 1)]
+
+
+def conc(fn):
+    """fn(buffers) on every stream at once (copy 0 uses the shared buffers)"""
+    def run():
+        if a.concurrent == 1:
+            return fn(None)
+        ev = torch.cuda.current_stream().record_event()
+        for i, st in enumerate(streams):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                fn(None if i == 0 else copies[i - 1])
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    return run
+
+
 modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": dict(xs=xs, w_row=w_row, bias=bias),
          "const": dict(xp0=xp0)}
 flop = 2.0 * B * H * GH * T
 for name, kw in modes.items():
     lay = hl.TILE16 if (name == "scalar" and LAY == hl.TILE16P) else LAY
-    ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=lay, **kw))
+    ms = timeit(conc(lambda c: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=c["hs"] if c else hs, cs=c["cs"] if c else cs,
+                                           acts=c["acts"] if c else acts, h_last=hl_, seq_layout=lay,
+                                           **(sig if lay == hl.TILE16P else {}), **kw)))
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
 ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
 for ext in (True, False):
-    ms = timeit(lambda: ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, da, dhs_ext=dext if ext else None, rh=rh,
-                                    dh0=hl_, seq_layout=LAY))
+    ms = timeit(conc(lambda c: ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, c["da"] if c else da, dhs_ext=dext if ext else None,
+                                           rh=c["rh"] if c else rh, dh0=hl_, seq_layout=LAY, **(sig if LAY == hl.TILE16P else {}))))
     print("bwd ext=%d  %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (ext, ms, ms * 1e3 / T, flop / ms / 1e9))
