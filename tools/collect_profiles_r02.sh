@@ -1,7 +1,7 @@
-# Round 2: the exact command list behind profiles/r02_h_* (run on the GPU box: gpurun -- 'bash tools/collect_profiles_r02.sh')
+# Round 2: the exact command list behind profiles/r02_p_* (run on the GPU box: gpurun -- 'bash tools/collect_profiles_r02.sh')
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02h
+O=$R/gpurun_out/r02p
 mkdir -p $O
 # 1. the bench line (CPU baseline first, then the GPU phase), LSTM and GRU; f32 "parity mode" beside them
 python $R/bench.py > $O/bench_lstm.json 2> $O/bench_lstm.err

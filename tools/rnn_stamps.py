@@ -8,6 +8,7 @@ import midi_vae_amd  # noqa
 from midi_vae_amd import hiplib as hl, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--cell", default="GRU"); ap.add_argument("--which", default="fwd"); ap.add_argument("--mode", default="dense")
+ap.add_argument("--concurrent", type=int, default=1, help="k-1 more copies of the launch on other streams (own output buffers)")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]; G, H, T, B = hl.GATES[cell], 256, 512, 256; GH = G * H
 dev = "cuda:0"; bf = torch.bfloat16
@@ -20,11 +21,18 @@ acts = torch.zeros((T, B, GH), dtype=bf, device=dev); da = torch.zeros((T, B, GH
 rh = torch.zeros((T, B, H), dtype=bf, device=dev); dext = (torch.randn((T, B, H), device=dev) * 0.01).to(bf)
 hl_ = torch.zeros((B, H), device=dev)
 kw = dict(xp=xp) if a.mode == "dense" else dict(xp0=xp0)
+streams = [torch.cuda.Stream() for _ in range(a.concurrent)]
+bufs = [dict(hs=torch.zeros_like(hs), cs=None if cs is None else torch.zeros_like(cs), acts=torch.zeros_like(acts), da=torch.zeros_like(da),
+             rh=torch.zeros_like(rh)) for _ in range(a.concurrent)]
 for _ in range(2):
-    if a.which == "fwd":
-        ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=hs, cs=cs, acts=acts, h_last=hl_, seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1), **kw)
-    else:
-        ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, da, dhs_ext=dext, rh=rh, dh0=hl_, seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1))
+    for st, c in zip(streams, bufs):
+        with torch.cuda.stream(st):
+            if a.which == "fwd":
+                ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=c["hs"], cs=c["cs"], acts=c["acts"], h_last=hl_,
+                            seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1), **kw)
+            else:
+                ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, c["da"], dhs_ext=dext, rh=c["rh"], dh0=hl_,
+                            seq_layout=(2 if a.cell in ("LSTM", "GRU") else 1))
     torch.cuda.synchronize()
 lib = hl.load()
 buf = (ctypes.c_ulonglong * 128)()
