@@ -206,6 +206,12 @@ int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n, void* str
  * memory): `stream` proceeds once *addr >= value / writes value to *addr after everything enqueued before it on `stream`. */
 int mvae_stream_wait_value32(void* stream, const uint32_t* addr, uint32_t value);
 int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value);
+/* Device-side join (the engine's fork / join of its queues, reference: the implicit data dependencies of the Keras graph,
+ * vae_definition.py:443-767): mvae_flag_set ends a side queue's work with a one-thread kernel storing `value` to *flag;
+ * mvae_flags_wait runs a one-wave kernel on the joining queue that returns once flags[0..n) >= value (bounded: *status = 1
+ * after ~0.5 s).  What follows it on that queue sees everything the side queues wrote before their flags. */
+int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream);
+int mvae_flags_wait(const uint32_t* flags, int32_t n, uint32_t value, uint32_t* status, void* stream);
 
 /* out[n] (+)= sum_r X[r, n]  for X (R, N) of `kind`; ldx elements between rows; atomic f32 accumulate */
 int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream);

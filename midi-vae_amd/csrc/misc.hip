@@ -535,6 +535,28 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
     return hipStreamWriteValue32(reinterpret_cast<hipStream_t>(stream), addr, value, 0) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
 }
 
+// ---- device-side join of queues ------------------------------------------------------------------------------------
+// A cross-queue wait at the level of the command processors (an AQL barrier packet on the completion signal of another queue's last
+// kernel) takes 100-200 us to resolve when that kernel ends late - at the end of the training step it is 0.16 ms in front of the
+// optimizer.  Instead: the side queue ends with a one-thread kernel that stores a sequence number, and the joining queue runs a
+// one-wave kernel that polls for it (bounded, like every device-side wait here); kernels follow each other within a queue in ~8 us.
+__global__ void flag_set_k(uint32_t* flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void flags_wait_k(const uint32_t* flags, int n, uint32_t value, uint32_t* status) {
+    for (int i = 0; i < n; ++i) wave_wait_ge(flags + i, value, status);
+}
+extern "C" int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream) {
+    if (!flag) return MVAE_E_ARG;
+    hipLaunchKernelGGL(flag_set_k, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag, value);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+extern "C" int mvae_flags_wait(const uint32_t* flags, int32_t n, uint32_t value, uint32_t* status, void* stream) {
+    if (!flags || n <= 0 || n > 64) return MVAE_E_ARG;
+    hipLaunchKernelGGL(flags_wait_k, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), flags, n, value, status);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
 constexpr int PREP_MAX_JOBS = 64, PREP_BLOCKS_PER_JOB = 64;      // (64 x 48-byte jobs = 3 KiB of kernel arguments; the limit is 4 KiB)
 struct prep_batch {

@@ -116,6 +116,9 @@ class Engine(object):
         self._prefork = None
         self._branches_stay_forked = False
         self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
+        self.device_join = os.environ.get("MVAE_DEVICE_JOIN", "1") == "1"   # joins by flag kernels instead of barrier packets (_join)
+        self._join_flags = torch.zeros(64 * 8, dtype=torch.int32, device=dev)
+        self._join_seq = 0
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
@@ -229,6 +232,21 @@ class Engine(object):
 
     def _join(self, *streams):
         cur = torch.cuda.current_stream()
+        if self.device_join and self.multi_stream and streams and not self.use_graphs:
+            # device-side: every side queue ends with a flag kernel, this queue polls them with a one-wave kernel (csrc/misc.hip) -
+            # kernels follow each other within a queue in ~8 us, a command-processor barrier that resolves late costs 100-200
+            self._join_seq += 1
+            slot = (self._join_seq % 64) * 8
+            n = 0
+            for st in dict.fromkeys(streams):           # (a stream may be listed twice)
+                if st is cur:
+                    continue
+                ops.flag_set(self._join_flags[slot + n:slot + n + 1], self._join_seq, st)
+                n += 1
+                assert n <= 8
+            if n:
+                ops.flags_wait(self._join_flags[slot:slot + n], n, self._join_seq, self.store["pipe_status"])
+            return
         if self.lean_sync and len(streams) > 1:
             # chained: every side queue takes its barrier packet when ITS work ends; the joining queue (the critical one)
             # processes one barrier packet instead of len(streams)
@@ -1633,15 +1651,16 @@ class Engine(object):
         """First use of time-pipelined stacks: make sure no kernel gave up waiting for its producer (that can only happen if
         two of the engine's streams share a hardware queue, e.g. GPU_MAX_HW_QUEUES was overridden).  If one did, fall back
         to one launch per chunk and redo the work."""
-        if not self.pipeline or self._pipe_verified:
+        if not (self.pipeline or self.device_join) or self._pipe_verified:
             return
         self._pipe_verified = True
         if int(self.store["pipe_status"].item()) != 0:
             import warnings
-            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers; falling back to chunked "
-                          "launches (Engine.pipeline = False)")
+            warnings.warn("time-pipelined recurrent kernels / device-side joins timed out waiting for their producers; falling "
+                          "back to chunked launches and stream-level joins (Engine.pipeline = device_join = False)")
             self.store["pipe_status"].zero_()
             self.pipeline = False
+            self.device_join = False         # (kernels that run one at a time - counter collection - cannot wait for each other)
             self._dxp0_clean = False
             redo()
 

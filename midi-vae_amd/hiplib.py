@@ -115,6 +115,8 @@ SIGNATURES = {
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mvae_stream_wait_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_stream_write_value32": (_i32, [_vp, _vp, C.c_uint32]),
+    "mvae_flag_set": (_i32, [_vp, C.c_uint32, _vp]),
+    "mvae_flags_wait": (_i32, [_vp, _i32, C.c_uint32, _vp, _vp]),
     "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -116,6 +116,16 @@ def stream_write_value32(word, value, stream=None):
              "mvae_stream_write_value32")
 
 
+def flag_set(word, value, stream):
+    """``stream`` ends its work so far with a one-thread kernel that stores ``value`` to the 32-bit device word"""
+    hl.check(hl.load().mvae_flag_set(_p(word), int(value), stream.cuda_stream), "mvae_flag_set")
+
+
+def flags_wait(words, n, value, status=None):
+    """a one-wave kernel on the current stream that returns once words[0..n) >= value (device-side join)"""
+    hl.check(hl.load().mvae_flags_wait(_p(words), int(n), int(value), _pv(status), _stream()), "mvae_flags_wait")
+
+
 def colsum(X, R, N, out, ldx=None):
     hl.check(hl.load().mvae_colsum(X.data_ptr(), kind_of(X), R, N, N if ldx is None else ldx, _p(out), _stream()),
              "mvae_colsum")
