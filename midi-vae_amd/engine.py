@@ -157,6 +157,8 @@ class Engine(object):
         # kstream_wgs workgroups per GEMM: they wait beside three recurrences that need 16 EMPTY CUs each.
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "32"))
+        self.kstream_singles = os.environ.get("MVAE_KSTREAM_SINGLES", "1") == "1"   # ... and the dU GEMM of a full-length single-layer encoder branch
+        self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
         self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
         self.set_params(self._initial_params(seed))
@@ -405,7 +407,7 @@ class Engine(object):
 
         esz = dict(dtype=dt, device=dev)
         # time-pipelined stacks: progress counters / ready flags (4 stack slots x 1024 words) and the time-out status word
-        st["sync"] = torch.zeros(4 * 1024, dtype=torch.int32, device=dev)
+        st["sync"] = torch.zeros(5 * 1024, dtype=torch.int32, device=dev)     # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch
         st["pipe_status"] = torch.zeros(1, dtype=torch.int32, device=dev)
         for r in self.all_rec:
             p = r.prefix
@@ -1145,7 +1147,7 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False):
+    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False, skip_dU=False):
         """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
         into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
         is done - only the last chunk's share is left when the recurrence finishes."""
@@ -1175,7 +1177,9 @@ class Engine(object):
         gb = G[p + ".b"]
         with (g1 or self._on(sg1)):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
-            if s.cell == "GRU":
+            if skip_dU:             # (with its bias gradient in a K-streaming launch)
+                pass
+            elif s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
                 ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=mb,
                          colsum_b=gb[:2 * H] if fuse_b else None)
@@ -1215,7 +1219,7 @@ class Engine(object):
                 count <= 6 and B <= 256 and self._pipelined(layers) and
                 all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
 
-    def _kstream_problems(self, r, B, idx, ks):
+    def _kstream_problems(self, r, B, idx, ks, only_dU=False):
         """the layer's weight-gradient GEMMs as K-streaming problems (mvae_gemm_args, not launched)"""
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
@@ -1240,6 +1244,8 @@ class Engine(object):
                                 colsum_b=gb[2 * H:], **kw))
         else:
             out.append(ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, split_k=parts(H, GH), colsum_b=gb, **kw))
+        if only_dU:
+            return out
         if r.xmode == hl.X_INDEX:
             out.append(ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, a_kind=hl.ONEHOT, split_k=parts(r.K, GH), **kw))
         else:
@@ -1292,7 +1298,15 @@ class Engine(object):
             problems = []
             for li, r in enumerate(order):
                 problems += self._kstream_problems(r, B, idx, dict(counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
+            gates = []
+            for extra, word, value in (self._kstream_extra or ()):       # single-layer branches launched before this stack (backward)
+                if len(problems) + len(extra) <= 6:
+                    problems += extra
+                    gates.append((word, value))
+            self._kstream_extra = None
             self.s_grad2.wait_event(before)
+            for word, value in gates:
+                ops.stream_wait_value32(word, value, stream=self.s_grad2)
             # Its workgroups wait, resident, for the whole BPTT: they may only take CUs once EVERY kernel they wait for is running
             # (a recurrent workgroup needs a whole empty CU) - the queue holds the launch back until the BOTTOM layer has
             # published its first chunk, which it can only do with the layers above it and the dX GEMMs running too.
@@ -1304,7 +1318,7 @@ class Engine(object):
             self._rec_param_grads(order[-1], B, 0, 1, idx=idx, xs=xs, start=start, on_main=True)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
-                        start=None, slot=0, tail_on_main=False):
+                        start=None, slot=0, tail_on_main=False, kstream_extra=None):
         """BPTT through a stack (top layer first), pipelined over time chunks in reverse order."""
         if self._pipelined(layers):
             return self._stack_backward_pipe(layers, B, slot, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
@@ -1312,6 +1326,18 @@ class Engine(object):
                                              tail_on_main=tail_on_main and self._deferred is None)
         nch = self._nchunks(layers)
         order = list(reversed(layers))               # order[0] = top layer
+        if kstream_extra is not None and len(layers) == 1 and nch == 1:
+            # a single-layer branch beside a K-streaming stack: ONE launch that publishes its da chunk by chunk (nobody waits inside
+            # the stack), its dU GEMM joins the stack's K-streaming launch, the rest of its gradients follows its end as usual
+            r, cs = layers[0], self.pipe_chunk
+            sync, target, _ = self._sync_region(4, 1, r.T // cs, 4 * (B // 16), 0)
+            self._rec_bptt(r, B, 0, 1, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
+                           pipe=dict(chunk_steps=cs, status=self.store["pipe_status"], signal_done=sync[0, 0]),
+                           **(dstates(r) if dstates else {}))
+            ks = dict(counters=sync[0, 0], target=target, rows=cs * B, status=self.store["pipe_status"])
+            kstream_extra.append((self._kstream_problems(r, B, idx, ks, only_dU=True), sync[0, 0][r.T // cs - 1:r.T // cs], target))
+            self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start, skip_dU=True)
+            return
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[torch.cuda.Event() for _ in range(nch)] for _ in order]
         if nch > 1:
@@ -1434,13 +1460,18 @@ class Engine(object):
             with torch.cuda.stream(self.s_comm):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: three independent branches -------------------------------------------------
+        ks_extra = None
         if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
             self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
+            ks_extra = self._kstream_extra = []
         self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
         for k, (r, st, src) in enumerate(self.enc_meta, 1):
             with self._on(st):
                 inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
-                self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc, **inp)
+                follow = (ks_extra is not None and not ks_extra and self.kstream_singles and r.T == T and self._seq_layout(r) == hl.TILE16P and
+                          r.xmode != hl.X_CONST and (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 6)
+                self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                     kstream_extra=ks_extra if follow else None, **inp)
         if self.enc_bi:
             self._enc_bi_backward(B, dcat[:, 0:H], ldc)
         else:
