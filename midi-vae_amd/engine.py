@@ -116,7 +116,9 @@ class Engine(object):
         self._prefork = None
         self._branches_stay_forked = False
         self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
-        self.device_join = os.environ.get("MVAE_DEVICE_JOIN", "1") == "1"   # joins by flag kernels instead of barrier packets (_join)
+        # joins by flag kernels instead of barrier packets (_join): -1.2 % on the training step, but decoder inference runs 5-10x slower
+        # in most processes with it (cause not found: DESIGN.md section 6) - off
+        self.device_join = os.environ.get("MVAE_DEVICE_JOIN", "0") == "1"
         self._join_flags = torch.zeros(64 * 8, dtype=torch.int32, device=dev)
         self._join_seq = 0
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
