@@ -104,7 +104,7 @@ typedef struct {
     const uint32_t* wait_ready;  /* [chunks] chunk k of xp may be read once wait_ready[k] >= wait_value (kernel polls)    */
     uint32_t wait_value;         /* 0 = 1                                                                                 */
     uint32_t* signal_done;       /* [chunks] += 1 per WAVE (4 * B/16 of them) once chunk k of hs is complete and visible  */
-    uint32_t* status;            /* [1] set non-zero if a wait timed out (~0.5 s): results are invalid                      */
+    uint32_t* status;            /* [1] set non-zero if a wait timed out (~2-4 s): results are invalid                    */
     int32_t seq_layout;    /* layout of xp, acts and cs (hs is always row-major): MVAE_ROWMAJOR, MVAE_TILE16 or
                               MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
                               (H=256, bf16): TILE16 the phased ones, TILE16P the slot-interleaved ones (LSTM, GRU; not
@@ -209,7 +209,7 @@ int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value);
 /* Device-side join (the engine's fork / join of its queues, reference: the implicit data dependencies of the Keras graph,
  * vae_definition.py:443-767): mvae_flag_set ends a side queue's work with a one-thread kernel storing `value` to *flag;
  * mvae_flags_wait runs a one-wave kernel on the joining queue that returns once flags[0..n) >= value (bounded: *status = 1
- * after ~0.5 s).  What follows it on that queue sees everything the side queues wrote before their flags. */
+ * after ~2-4 s).  What follows it on that queue sees everything the side queues wrote before their flags. */
 int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream);
 int mvae_flags_wait(const uint32_t* flags, int32_t n, uint32_t value, uint32_t* status, void* stream);
 

@@ -151,7 +151,7 @@ __device__ __forceinline__ void lds_barrier() {
 // increment per producer wave.
 //
 // wave_wait_ge: until *flag >= value (system-scope loads), then drop this XCD's possibly stale cache lines of the data the
-// flag guards.  Bounded (~0.5 s): then *status = 1 and the kernel carries on - it never hangs.
+// flag guards.  Bounded (~2-4 s: a host that stalls in the middle of enqueuing a step must not look like a dead producer): then *status = 1 and the kernel carries on - it never hangs.
 #ifdef MVAE_EXP_AGENT_INV
 #define MVAE_ACQ_INV "buffer_inv sc1"
 #else
@@ -171,14 +171,14 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         "s_cbranch_scc1 L_ready_%=\n\t"
         "s_sleep %5\n\t"
         "s_add_u32 %1, %1, 1\n\t"
-        "s_cmp_lt_u32 %1, 0x80000\n\t"
+        "s_cmp_lt_u32 %1, 0x200000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         MVAE_ACQ_INV
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(flag), "s"(value), "n"(SLEEP)
         : "memory", "scc");
-    if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x200000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the same under a scalar condition evaluated inside the block: if (t == bound) wait
 __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         "s_cbranch_scc1 L_ready_%=\n\t"
         "s_sleep 8\n\t"
         "s_add_u32 %1, %1, 1\n\t"
-        "s_cmp_lt_u32 %1, 0x80000\n\t"
+        "s_cmp_lt_u32 %1, 0x200000\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         MVAE_ACQ_INV "\n"
@@ -204,7 +204,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(t), "s"(bound), "s"(flag), "s"(value)
         : "memory", "scc");
-    if (spins >= 0x80000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x200000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // wave_signal_done<WB>: this wave's global stores so far are complete, then ONE increment (by its first lane) of the counter.
 // WB = true: the wave's data left through PLAIN stores - dirty lines of this XCD's L2 are written back first (buffer_wbl2; it
