@@ -151,14 +151,14 @@ __device__ __forceinline__ void lds_barrier() {
 // increment per producer wave.
 //
 // wave_wait_ge: until *flag >= value (system-scope loads), then drop this XCD's possibly stale cache lines of the data the
-// flag guards.  Bounded (~2-4 s: a host that stalls in the middle of enqueuing a step must not look like a dead producer): then *status = 1 and the kernel carries on - it never hangs.
+// flag guards.  Bounded (~2-4 s: a host that stalls in the middle of enqueuing a step must not look like a dead producer): then *status = code (which kind of wait: 1 recurrent forward, 2 BPTT, 3 chunked GEMM, 4 K-streaming GEMM, 5 join) and the kernel carries on - it never hangs.
 #ifdef MVAE_EXP_AGENT_INV
 #define MVAE_ACQ_INV "buffer_inv sc1"
 #else
 #define MVAE_ACQ_INV "buffer_inv sc0 sc1"
 #endif
 template <int SLEEP = 8>        // (64: a throughput consumer that polls for most of its producer's run time)
-__device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status) {
+__device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status, uint32_t code = 1u) {
     unsigned tmp, spins, val;
     asm volatile(
         "s_mov_b32 %1, 0\n"
@@ -178,10 +178,10 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(flag), "s"(value), "n"(SLEEP)
         : "memory", "scc");
-    if (spins >= 0x200000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x200000u && status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the same under a scalar condition evaluated inside the block: if (t == bound) wait
-__device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status) {
+__device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status, uint32_t code = 1u) {
     unsigned tmp, spins, val;
     asm volatile(
         "s_mov_b32 %1, 0\n\t"
@@ -204,7 +204,7 @@ __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
         : "s"(t), "s"(bound), "s"(flag), "s"(value)
         : "memory", "scc");
-    if (spins >= 0x200000u && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= 0x200000u && status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // wave_signal_done<WB>: this wave's global stores so far are complete, then ONE increment (by its first lane) of the counter.
 // WB = true: the wave's data left through PLAIN stores - dirty lines of this XCD's L2 are written back first (buffer_wbl2; it

@@ -337,7 +337,7 @@ __device__ __forceinline__ void gemm_fast_body(const mvae_gemm_args a, const int
     const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16 && a.c_kind != MVAE_F32 && !a.accumulate && (N % FBN) == 0;
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
-    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
+    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
     for (int tile = vb; tile < total_tiles; tile += nvb) {
         int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
         if (xcd_rows) {
@@ -391,7 +391,7 @@ __device__ __forceinline__ void gemm_fast_body(const mvae_gemm_args a, const int
         for (int seg = 0; seg < nseg; ++seg) {
         if (a.k_wait) {
             const int c = a.k_reverse ? nseg - 1 - seg : seg, part = a.k_chunk_rows / splits;
-            if (w == 0) wave_wait_ge<64>(a.k_wait + c, a.k_wait_value, a.chunk_status);     // one polling wave per workgroup
+            if (w == 0) wave_wait_ge<64>(a.k_wait + c, a.k_wait_value, a.chunk_status, 4u);     // one polling wave per workgroup
             __syncthreads();
             kbeg = c * a.k_chunk_rows + bz * part;
             kend = kbeg + part;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16;        // (see gemm_fast_k)
     for (int ci = 0; ci < nchunks; ++ci) {
         const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
-        if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status);
+        if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
         const int nloc = tiles_mc >> 3;                            // row blocks of this chunk on this XCD
         if (g < nloc) {
 #pragma unroll

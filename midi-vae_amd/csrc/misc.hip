@@ -542,7 +542,7 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
 // one-wave kernel that polls for it (bounded, like every device-side wait here); kernels follow each other within a queue in ~8 us.
 __global__ void flag_set_k(uint32_t* flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __global__ void flags_wait_k(const uint32_t* flags, int n, uint32_t value, uint32_t* status) {
-    for (int i = 0; i < n; ++i) wave_wait_ge(flags + i, value, status);
+    for (int i = 0; i < n; ++i) wave_wait_ge(flags + i, value, status, 5u);
 }
 extern "C" int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream) {
     if (!flag) return MVAE_E_ARG;

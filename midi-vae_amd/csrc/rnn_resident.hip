@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const int cs_steps = a.chunk_steps;
     const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
     int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;   // (the division runs on the VALU)
-    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status);
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status, 2u);
     int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;      // step at whose start chunk pk-1 must be ready (-1: never)
     int psig = (cs_steps && a.signal_done) ? plo : -1;                 // step after which chunk pk is published
     // saved forward values of the step about to be processed; acts / cs are TILE16P: element 0..3 of a 16-byte lane
@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
         pinu(da0); pinu(tc0); pinu(bb0);
         STAMP(0);
         // pipelined stack: the upstream gradient of step t-1 is requested during this step's M phase
-        if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status);
+        if (HAS_EXT) wave_wait_ge_if(t, pwait, a.wait_ready + (pk - 1), wait_value, a.status, 2u);
         // ---- E: everything requested during the previous M phase has had that whole phase to arrive (the compiler's
         // counted waits for the loads; no drain: the da stores issued at the end of that phase may still be in flight)
         if (GB_DRAIN) vm_drain();
@@ -1759,7 +1759,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
     const int cs_steps = a.chunk_steps;
     const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
     int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;
-    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status);
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status, 2u);
     int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;      // step at whose start chunk pk-1 must be ready (-1: never)
     int psig = (cs_steps && a.signal_done) ? plo : -1;                 // step after which chunk pk is published
 
@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         if (a.rh) pins(rh_p);
         STAMP(0);
         // pipelined stack: the upstream gradient of step t-1 is requested during this step's MFMA phases
-        if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status);
+        if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status, 2u);
         if (GB_DRAIN) vm_drain();       // (else the compiler's counted waits: the copy stores of M2 may still be in flight)
         STAMP(1);
         pinq(qr[0]); pinq(qr[1]);

@@ -172,7 +172,7 @@ class Engine(object):
         self._count_only = None
         self._count_pending = False
         self._sync_cum = {}
-        self._pipe_verified = False
+        self._pipe_verified = set()
         self._dxp0_clean = False
         self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
         self._have_staged_targets = False
@@ -1680,13 +1680,22 @@ class Engine(object):
         self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
                                        self.backward(B)))
 
-    def _verify_pipeline(self, redo):
-        """First use of time-pipelined stacks: make sure no kernel gave up waiting for its producer (that can only happen if
-        two of the engine's streams share a hardware queue, e.g. GPU_MAX_HW_QUEUES was overridden).  If one did, fall back
-        to one launch per chunk and redo the work."""
-        if not (self.pipeline or self.device_join) or self._pipe_verified:
+    def _verify_pipeline(self, redo, key="train"):
+        """First use of time-pipelined stacks by each kind of call (train step / encode / decode / predict): make sure no kernel
+        gave up waiting for its producer.  A first use can stall for seconds for reasons that do not repeat - first launches of the
+        kind's kernels, and memory-management calls of the runtime (first pinned / device allocations of the caller's staging beside
+        it) that hold new dispatches back while a WAITING kernel is resident: seen as one 'chunked GEMM' time-out in ~30 first train
+        steps behind an encoder pre-pass - so the work is first redone as it is; if a kernel gives up again (two of the engine's
+        streams share a hardware queue, or kernels run one at a time under counter collection) the engine falls back to one launch per
+        chunk and stream-level joins for good and redoes it once more."""
+        if not (self.pipeline or self.device_join) or key in self._pipe_verified:
             return
-        self._pipe_verified = True
+        self._pipe_verified.add(key)
+        if int(self.store["pipe_status"].item()) == 0:
+            return
+        self.store["pipe_status"].zero_()
+        self._dxp0_clean = False
+        redo()
         if int(self.store["pipe_status"].item()) != 0:
             import warnings
             warnings.warn("time-pipelined recurrent kernels / device-side joins timed out waiting for their producers; falling "
@@ -1844,7 +1853,7 @@ class Engine(object):
         self.encoder_forward(B, with_init=True)
         self.decoder_forward(B, want_probs=want_probs)
         self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B, with_init=True),
-                                       self.decoder_forward(B, want_probs=want_probs)))
+                                       self.decoder_forward(B, want_probs=want_probs)), key="predict")
 
     def encode(self, B):
         """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
@@ -1853,7 +1862,7 @@ class Engine(object):
         if self._weights_dirty:
             self.prepare_weights()
         self.encoder_forward(B)
-        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B)))
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B)), key="encode")
         return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
 
     def decode(self, B, want_probs=True):
@@ -1864,17 +1873,19 @@ class Engine(object):
         if self._weights_dirty:
             self.prepare_weights()
         self.decoder_forward(B, want_probs=want_probs)
-        self._verify_pipeline(lambda: (self.scal.zero_(), self.decoder_forward(B, want_probs=want_probs)))
+        self._verify_pipeline(lambda: (self.scal.zero_(), self.decoder_forward(B, want_probs=want_probs)), key="decode")
 
     # ------------------------------------------------------------------------------------------------------
     # results
     # ------------------------------------------------------------------------------------------------------
     def check_pipeline(self):
         """Raises if a kernel of a time-pipelined stack gave up waiting for its input (results of that step are invalid)."""
-        if int(self.store["pipe_status"].item()) != 0:
+        code = int(self.store["pipe_status"].item())
+        if code != 0:
             self.store["pipe_status"].zero_()
-            raise RuntimeError("a time-pipelined recurrent kernel timed out waiting for its producer (stream / hardware "
-                               "queue aliasing?); set Engine.pipeline = False")
+            kind = {1: "recurrent forward kernel", 2: "BPTT kernel", 3: "chunked GEMM", 4: "K-streaming GEMM", 5: "join"}.get(code, "kernel")
+            raise RuntimeError("a device-side wait timed out (%s waiting for its producer: stream / hardware queue aliasing?); "
+                               "set Engine.pipeline = False" % kind)
 
     def metrics(self, B) -> "OrderedDict[str, float]":
         """Losses / accuracies of the last step with the oracle's key names (one device->host copy)."""
