@@ -1,4 +1,4 @@
-bash tools/r02_trip53.sh
+bash tools/trips/r02_trip53.sh
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r02q
 echo "prepass stress failures: $(wc -l < $O/stress4.txt)"
