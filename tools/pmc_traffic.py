@@ -7,6 +7,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies the 128
 64 bytes - doubled here; WRITE_SIZE counted 64-byte write requests exactly in the calibration below.
 Calibration on this kernel (profiles/r02_pmc_counters.txt): TCC_EA0_RDREQ_sum x 128 B = 2 x FETCH_SIZE and TCC_EA0_WRREQ_sum x 64 B
 = WRITE_SIZE, and both equal the algorithmic bytes of a launch to 1-2 %."""
+import statistics
 import argparse, collections, csv, json, os, re
 
 ap = argparse.ArgumentParser()
@@ -22,8 +23,15 @@ pat = "lstm_bwd_il_k" if a.cell == "LSTM" else "gru_bwd_il_k"
 
 
 def per_launch(path, counter):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if pat in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    first = open(path).readline()
+    if "Counter_Name" in first:     # rocprofv3's counter_collection.csv
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if pat in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    else:                           # the kernel's rows as committed under profiles/ (no header): the value follows the counter's name
+        vals = []
+        for row in csv.reader(open(path)):
+            if counter in row and any(pat in c for c in row):
+                vals.append(float(row[row.index(counter) + 1]))
     srt = sorted(vals)
     # Launch sizes seen under the profiler: the 4-step instrument layers (100x smaller), 128-step chunks (counter collection runs
     # one kernel at a time, so the time-pipelined stacks - whose kernels wait for producers running BESIDE them - fall back to one
@@ -33,7 +41,10 @@ def per_launch(path, counter):
     big = [v for v in vals if v > 0.93 * top]
     print("%s %s: %d launches; deciles %s; %d whole-sequence launches averaged" % (
         pat, counter, len(vals), ["%.3g" % srt[int(q * (len(srt) - 1) / 10)] for q in range(11)], len(big)))
-    return sum(big) / len(big), len(big), len(vals)
+    # MEDIAN of the class: the launches of the first step WAIT for producers that cannot run beside them under counter collection
+    # (before the engine falls back, twice since the first use is retried once) and their polling loads count as fetches
+    # (2.3x the bytes of an ordinary launch)
+    return statistics.median(big), len(big), len(vals)
 
 
 f, nf, tf = per_launch(a.fetch, "FETCH_SIZE")
@@ -45,7 +56,7 @@ rec = {"kernel": pat, "T": a.T, "B": a.B, "read_bytes_per_launch": rd, "write_by
        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg, "launches_averaged": [nf, nw],
        "launches_seen": [tf, tw],
        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py "
-                 "--no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0`; 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, mean over the "
+                 "--no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0`; 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, median over the "
                  "whole-sequence (T-step) launches of the kernel that read an upstream-gradient sequence - under counter collection "
                  "kernels run one at a time, so the stacked layers run as 128-step chunk launches (same bytes per time step) and the "
                  "T-step launches are those of the velocity decoder layer: same kernel, same shape as a stacked decoder layer "
