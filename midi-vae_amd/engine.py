@@ -129,7 +129,12 @@ class Engine(object):
         # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
         # every pipe_chunk time steps (no relaunch, no weight reload, layers pipe_chunk steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
-        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "16"))   # (A/B r02: 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms)
+        # time steps per hand-over: a hand-over costs every workgroup a drained vmcnt and a counter, the persistent GEMM a wait - the
+        # bigger the batch, the more rows a chunk should carry (A/B r02: 256 windows 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms;
+        # 512 windows, T=2048: 35.7 / 34.5 / 35.4 at 16 / 32 / 64; decode of 1024 windows: 57.0 / 58.9 / 60.1 / 59.9 k at 16 / 32 / 64 / 128)
+        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "0")) or (16 if self.maxB <= 256 else 32 if self.maxB <= 512 else 64)
+        while self.pipe_chunk > 16 and spec.T % self.pipe_chunk:
+            self.pipe_chunk //= 2
         self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
         # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:

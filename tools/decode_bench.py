@@ -23,8 +23,8 @@ T = seq * V
 spec = ModelSpec(cell=a.cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
 Bs = B // a.split
 eng = Engine(spec, max_batch=Bs, dtype="bf16", device="cuda:0", seed=1234, training=False)
-if T // eng.pipe_chunk > 64:
-    eng.pipe_chunk = T // 64
+while 2 * 2 * (T // eng.pipe_chunk) > 1024:      # (the engine's counter region holds layers x 2 x chunks words: Engine._pipelined)
+    eng.pipe_chunk *= 2
 if a.gemm_blocks:
     eng.pipe_proj_blocks = a.gemm_blocks
 rng = np.random.default_rng(1234)
