@@ -196,7 +196,7 @@ typedef struct {
     int32_t k_chunk_rows, k_reverse;
 } mvae_gemm_args;
 int mvae_gemm(const mvae_gemm_args* a, void* stream);
-/* n <= 6 K-streaming problems (k_wait set, trans_a = 1, trans_b = 0, accumulate, no bias) behind the kernels of ONE pipelined stack
+/* n <= 8 K-streaming problems (k_wait set, trans_a = 1, trans_b = 0, accumulate, no bias) behind the kernels of ONE pipelined stack
  * as ONE launch on ONE queue (each would otherwise hold a queue of its own for the whole BPTT); at most 256 workgroups in all
  * (MVAE_E_ARG beyond) - they all wait, resident, for their producers.  Replaces the reference's implicit "gradients of every
  * weight of the encoder stack" inside K.gradients (vae_definition.py:1016-1045 via Keras' train_function). */

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void gemm_fast_k(const mvae_gemm_args a) {
 // Several K-streaming weight-gradient GEMMs (mvae_gemm_args.k_wait) behind ONE pipelined stack as ONE launch on ONE queue: every
 // such GEMM runs for the whole BPTT, so each needs its own queue otherwise - and every additional busy queue costs the step
 // 0.14 ms of command-processor time (profiles/r02_n_ab_kstream_gradients.txt).  Workgroups [base[i], base[i+1]) run problem i.
-constexpr int KS_MAX = 6;
+constexpr int KS_MAX = 8;
 struct kstream_multi {
     mvae_gemm_args p[KS_MAX];
     int32_t base[KS_MAX + 1];

@@ -163,7 +163,7 @@ class Engine(object):
         # and the other gradient work of that phase (velocity / instrument encoders) goes to the first one.
         # kstream_wgs workgroups per GEMM: they wait beside three recurrences that need 16 EMPTY CUs each.
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
-        self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "32"))
+        self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "0")) or (24 if spec.cell == "GRU" else 32)   # (GRU: 3 GEMMs per layer)
         self.kstream_singles = os.environ.get("MVAE_KSTREAM_SINGLES", "1") == "1"   # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
@@ -1219,11 +1219,11 @@ class Engine(object):
 
     def _kstream_ok(self, layers, B):
         """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
-        or dense input, bias gradient fused), at most 6 of them, and the waiting workgroups must leave the recurrences their empty CUs."""
+        or dense input, bias gradient fused), at most 8 of them, and the waiting workgroups must leave the recurrences their empty CUs."""
         s = self.spec
         count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
         return (self.kstream_grads and self.multi_stream and self._deferred is None and self.fuse_bias_grad and self.tile16 and
-                count <= 6 and B <= 256 and self._pipelined(layers) and
+                count <= 8 and B <= 256 and self._pipelined(layers) and
                 all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
 
     def _kstream_problems(self, r, B, idx, ks, only_dU=False):
@@ -1307,7 +1307,7 @@ class Engine(object):
                 problems += self._kstream_problems(r, B, idx, dict(counters=sync[li, 0], target=da_target, rows=cs * B, status=status))
             gates = []
             for extra, word, value in (self._kstream_extra or ()):       # single-layer branches launched before this stack (backward)
-                if len(problems) + len(extra) <= 6:
+                if len(problems) + len(extra) <= 8:
                     problems += extra
                     gates.append((word, value))
             self._kstream_extra = None
@@ -1476,7 +1476,7 @@ class Engine(object):
             with self._on(st):
                 inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
                 follow = (ks_extra is not None and not ks_extra and self.kstream_singles and r.T == T and self._seq_layout(r) == hl.TILE16P and
-                          r.xmode != hl.X_CONST and (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 6)
+                          r.xmode != hl.X_CONST and (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 8)
                 self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                      kstream_extra=ks_extra if follow else None, **inp)
         if self.enc_bi:
