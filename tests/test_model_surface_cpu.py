@@ -130,3 +130,38 @@ def test_engine_refuses_to_run_without_gpu():
     from midi_vae_amd.engine import Engine
     with pytest.raises(RuntimeError):
         Engine(ModelSpec(H=64, Z=32), max_batch=16)
+
+
+def test_first_use_verification_retries_once_then_falls_back():
+    """Engine._verify_pipeline (host logic only): a timed-out first use of a kind of call is redone once as it is; only a second
+    time-out switches the engine to chunked launches and stream-level joins; every kind of call is verified separately."""
+    import types
+    import warnings
+    import torch
+    from midi_vae_amd.engine import Engine
+
+    def fake(status_after_redo):
+        calls = []
+        eng = types.SimpleNamespace(pipeline=True, device_join=False, _pipe_verified=set(), _dxp0_clean=True,
+                                    store={"pipe_status": torch.tensor([3], dtype=torch.int32)})
+
+        def redo():
+            calls.append(1)
+            eng.store["pipe_status"].fill_(status_after_redo[min(len(calls), len(status_after_redo)) - 1])
+        return eng, redo, calls
+
+    eng, redo, calls = fake([0])                     # transient: the retry succeeds
+    Engine._verify_pipeline(eng, redo, key="train")
+    assert calls == [1] and eng.pipeline and "train" in eng._pipe_verified and int(eng.store["pipe_status"]) == 0
+    Engine._verify_pipeline(eng, redo, key="train")  # verified once per kind
+    assert calls == [1]
+    eng.store["pipe_status"].fill_(2)
+    Engine._verify_pipeline(eng, redo, key="decode")  # another kind of call is checked on ITS first use
+    assert calls == [1, 1] and eng.pipeline
+
+    eng, redo, calls = fake([4, 0])                  # persistent: falls back, redoes once more
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Engine._verify_pipeline(eng, redo, key="train")
+    assert calls == [1, 1] and not eng.pipeline and not eng.device_join and len(w) == 1
+    assert int(eng.store["pipe_status"]) == 0 and eng._dxp0_clean is False
