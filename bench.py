@@ -105,7 +105,6 @@ def main():
     ap.add_argument("--prewarm-min", type=float, default=1.0, help="seconds of untimed passes before the warmup steps, at least")
     ap.add_argument("--prewarm-max", type=float, default=8.0, help="... at most (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--dp-overlap", type=int, default=0,
                     help="N>1: 1 = reduce the decoder gradient bucket beside the encoder BPTT (dp.BucketedAllReduce)")
     ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
@@ -138,7 +137,7 @@ def main():
     # the CPU baseline FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
     # process sees the GPU busy at the end of the run rather than idle
     cpu = cpu_baseline(spec, B) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
-    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234, use_graphs=args.graphs)
+    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234)
     if args.chunks:
         eng.time_chunks = args.chunks
     w = make_windows(B, T, 61, args.voices, 16, 2, args.latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
@@ -178,7 +177,7 @@ def main():
     # of 9.1 ms per step over 10 timed steps when the brackets first appeared inside the timed region).
     KINDS = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1")}
     eng.prof_kinds = KINDS
-    if not args.graphs and args.warmup:
+    if args.warmup:
         eng.prof = {}
     for _ in range(args.warmup):
         step()
@@ -192,8 +191,7 @@ def main():
     # critical-path figure): every event pair costs launch slots - all 26 BPTT launches bracketed slow the step by 0.5 ms.
     # One more event per step boundary on the critical stream gives the per-step times (median).
     eng.prof_kinds = KINDS
-    if not args.graphs:
-        eng.prof = {}           # HIP events on the launch streams; with graph replay: timed in a second pass
+    eng.prof = {}               # HIP events on the launch streams
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
@@ -214,11 +212,6 @@ def main():
         tt = torch.tensor([elapsed, median_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
-    if args.graphs:
-        # same process, same inputs, same K steps, launched eagerly so individual launches can be bracketed with events
-        eng.prof = {}
-        for _ in range(args.steps):
-            step()
     prof = eng.prof_summary()
     eng.prof = None
     m = eng.metrics(B)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 3
+#define MVAE_ABI_VERSION 4
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -206,12 +206,13 @@ int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n, void* str
  * memory): `stream` proceeds once *addr >= value / writes value to *addr after everything enqueued before it on `stream`. */
 int mvae_stream_wait_value32(void* stream, const uint32_t* addr, uint32_t value);
 int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value);
-/* Device-side join (the engine's fork / join of its queues, reference: the implicit data dependencies of the Keras graph,
- * vae_definition.py:443-767): mvae_flag_set ends a side queue's work with a one-thread kernel storing `value` to *flag;
- * mvae_flags_wait runs a one-wave kernel on the joining queue that returns once flags[0..n) >= value (bounded: *status = 1
- * after ~2-4 s).  What follows it on that queue sees everything the side queues wrote before their flags. */
-int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream);
-int mvae_flags_wait(const uint32_t* flags, int32_t n, uint32_t value, uint32_t* status, void* stream);
+/* Workgroups per CU of the library's RESIDENT kernels as the loaded code object and the device report it
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor with the launch's dynamic LDS size): which = 0 the persistent dX GEMM between two
+ * pipelined layers (mvae_gemm chunk_*, NT), 1 the weights-stationary forward projection, 2 a K-streaming workgroup
+ * (mvae_gemm_kstream_multi); the recurrent kernels are one workgroup per CU by construction (__launch_bounds__(256, 1)).
+ * The host decides from these whether the kernels of a time-pipelined stack can all be resident at once (engine.py
+ * _resident_cus) - the reference has no counterpart: Keras runs one op at a time.  < 0: error code. */
+int mvae_occupancy(int32_t which);
 
 /* out[n] (+)= sum_r X[r, n]  for X (R, N) of `kind`; ldx elements between rows; atomic f32 accumulate */
 int mvae_colsum(const void* X, int32_t kind, int32_t R, int32_t N, int32_t ldx, float* out, void* stream);
@@ -339,7 +340,9 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *                              (the step's loss / metric accumulators: one fill launch less)
  *   MVAE_PREP_CONVERT_PAD      src (a, b) f32, c = padded row length >= b     -> dst (a, c) kind, columns b..c-1 zero
  *   MVAE_PREP_ADD_I32          src = NULL or a guard word (uint32)            -> *(int32_t*)dst += a unless *src != 0 (the
- *                              optimizer's step count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own) */
+ *                              optimizer's step count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own);
+ *                              src2 = NULL or a latch word (uint32): a non-zero *src is then moved there (max) and CLEARED -
+ *                              the status word of the time-pipelined stacks lives for one step, the latch until the host reads it */
 enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
        MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5, MVAE_PREP_ADD_I32 = 6 };
 typedef struct {
@@ -397,6 +400,15 @@ int mvae_scalars_accumulate(float* acc, const float* x, int32_t n, float alpha, 
 int mvae_copy2d_f32(float* dst, int32_t ldd, const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_row0,
                     int32_t zero_rows, void* stream);
 
+/* The history pre-pass FUSED into the first train step of a song (reference vae_training.py:788-798: z' = encoder.predict(song) with
+ * a fresh draw, H[1:] = z'[:-1], H[0] = 0; then fit on the same weights, :804-809): from the mu / logvar (B, Z) the step's own
+ * encoder forward produced and the pre-pass's draw eps2 (B, Z; already scaled by epsilon_std):
+ *   z_out[b] = mu[b] + exp(logvar[b] / 2) * eps2[b]          (rows of stride ldo; may be NULL)
+ *   hist[b]  = b == 0 ? (prev ? prev : 0) : z'[b-1]          (rows of stride ldh: the history columns of [z | history]), b < B
+ *   hist[b]  = 0 for B <= b < B_pad */
+int mvae_history_from_latent(const float* mu, const float* logvar, const float* eps2, int32_t B, int32_t B_pad, int32_t Z,
+                             float* hist, int32_t ldh, const float* prev, float* z_out, int32_t ldo, void* stream);
+
 /* Signature head (reference vae_definition.py:737-745, loss :409-416; off by default): out (B,SD) = tanh(zh[:, off:off+SD]);
  * with a target (B,SD): scalars[0] += sum_b row_weight[b] * mean_j (out - target)^2, scalars[1] += rows whose argmax matches the
  * target's (Keras 'accuracy' on this output).  bwd: dz[b, off+j] += weight * row_weight[b] * 2 (out - target) / SD * (1 - out^2). */
@@ -429,7 +441,8 @@ enum { MVAE_HOST_F64 = 0, MVAE_HOST_F32 = 1, MVAE_HOST_U8 = 2 };
 /* size of the worker pool: n > 0 sets it, 0 restores the default (min(16, cores)), < 0 only queries; returns the size */
 int mvae_host_threads(int32_t n);
 /* windows [lo, hi) of x (n, T, K) one-hot rows of xkind -> out (T, Bp) uint8: out[t*Bp + (b-lo)] = position of the 1;
- * columns hi-lo .. Bp-1 = fill.  A row that is not exactly one 1 among zeros: MVAE_E_FORMAT, *bad_row = its flat row. */
+ * columns hi-lo .. Bp-1 = fill.  A row that is not exactly one 1 among zeros: MVAE_E_FORMAT, *bad_row = the LOWEST such flat row.
+ * The host packers are serialised internally: concurrent callers (threads) are safe, they take turns. */
 int mvae_host_onehot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_t T, int32_t K, int64_t lo, int64_t hi,
                                  uint8_t* out, int32_t Bp, uint8_t fill, int64_t* bad_row);
 /* the same for rows that already are indices: idx (n, T) uint8 */

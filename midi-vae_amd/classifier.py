@@ -86,8 +86,11 @@ class ClassifierEngine(Engine):
         return B
 
     # ---- forward / backward ------------------------------------------------------------------------------------
-    def forward(self, B, want_probs=False):
+    def forward(self, B, want_probs=False, verify=None):
+        """``verify``: check the first time-pipelined use of a forward-only call (evaluate / predict) as Engine.encode does; a
+        train step verifies once, after its backward pass"""
         s, P = self.spec, self.P
+        Breal0 = B
         Breal, B = B, self.pad16(B)
         if self._weights_dirty:
             self.prepare_weights()
@@ -104,6 +107,8 @@ class ClassifierEngine(Engine):
                  grad_scale=1.0, probs=self._v("out.cls_p", B, s.C) if want_probs else None, argmax=self._v("cls.argmax", B),
                  dlogits=self._v("cls.dl", B, h.NP) if (self.training and tg) else None, scalars=self.scal[S_LOSS:S_LOSS + 2],
                  b_stride=B, b_valid=Breal)
+        if verify:
+            self._verify_pipeline(lambda: (self.scal.zero_(), self.forward(Breal0, want_probs, verify=False)), key="cls_fwd")
 
     def backward(self, B):
         s, P, G = self.spec, self.P, self.G
@@ -130,6 +135,8 @@ class ClassifierEngine(Engine):
         self._grads_clean = False
         self.forward(B)
         self.backward(B)
+        self._verify_pipeline(lambda: (self.grads.zero_(), self.scal.zero_(), self.forward(B, verify=False), self.backward(B)),
+                              key="cls_train")
         gs = allreduce(self.grads) if allreduce is not None else 1.0
         self.optimizer_step(gs if gs is not None else 1.0)
 
@@ -231,7 +238,7 @@ class StyleClassifier(object):
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
             B = eng.stage(x[lo:hi], c[lo:hi])
-            eng.forward(B)
+            eng.forward(B, verify=True)
             eng.accumulate_metrics(hi - lo)
         m = eng.read_accumulated(n)
         return [m["loss"], m["acc"]]
@@ -244,7 +251,7 @@ class StyleClassifier(object):
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
             B = eng.stage(x[lo:hi], None)
-            eng.forward(B, want_probs=True)
+            eng.forward(B, want_probs=True, verify=True)
             out.append(eng.probs(B))
         eng.check_pipeline()
         return np.concatenate(out, 0) if out else np.zeros((0, self.cfg["C"]), np.float32)

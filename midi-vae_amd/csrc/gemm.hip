@@ -833,6 +833,28 @@ extern "C" int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n
     return MVAE_OK;
 }
 
+extern "C" int mvae_occupancy(int32_t which) {
+    int n = 0;
+    hipError_t e;
+    if (which == 0) {            // the dX GEMM between two pipelined layers: da (R, G*H) x W (H, G*H)^T, both k-contiguous
+        const size_t lds = (size_t)2 * (f_img<false>() + f_img<false>()) * sizeof(bf16_t);
+        const void* f = reinterpret_cast<const void*>(&gemm_fast_k<false, false, false, false>);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MVAE_E_LAUNCH;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds);
+    } else if (which == 1) {
+        const size_t lds = (size_t)2 * WS_KT * f_img<false>() * sizeof(bf16_t);
+        const void* f = reinterpret_cast<const void*>(&proj_ws_k);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MVAE_E_LAUNCH;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds);
+    } else if (which == 2) {
+        const size_t lds = (size_t)2 * (f_img<true>() + f_img<true>()) * sizeof(bf16_t);
+        const void* f = reinterpret_cast<const void*>(&gemm_kstream_multi_k);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MVAE_E_LAUNCH;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds);
+    } else return MVAE_E_ARG;
+    return e == hipSuccess ? n : MVAE_E_LAUNCH;
+}
+
 extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MVAE_E_ARG;
     if (a->accumulate && a->c_kind != MVAE_F32) return MVAE_E_ARG;

@@ -90,6 +90,10 @@ private:
 };
 
 std::mutex g_pool_mutex;
+// One packer call at a time: ctypes releases the GIL around these calls, so two Python threads (two models, two Stagers) can arrive
+// together - Pool::parallel holds ONE job (fn_, parts_, pending_), and mvae_host_threads may replace the pool.  Every entry point
+// takes this lock for its whole duration; a second caller waits (the conversion is memory-bound: it would not run faster beside the first).
+std::mutex g_call_mutex;
 Pool* g_pool = nullptr;
 int g_threads = 0;          // 0 = default
 
@@ -147,9 +151,10 @@ int onehot_to_index_tm(const T* x, int64_t n, int T_, int K, int64_t lo, int64_t
         for (int64_t b = b0; b < b1; ++b) {
             // window b: rows (lo+b)*T .. +T of x -> column b of the (T, Bp) output
             const int64_t r = onehot_rows<T>(x + (lo + b) * (int64_t)T_ * K, T_, K, out + b, Bp);
-            if (r >= 0) {
-                int64_t want = -1, mine = (lo + b) * (int64_t)T_ + r;
-                bad.compare_exchange_strong(want, mine);
+            if (r >= 0) {       // the LOWEST offending row over all parts (each part meets its own lowest first)
+                const int64_t mine = (lo + b) * (int64_t)T_ + r;
+                int64_t cur = bad.load();
+                while ((cur < 0 || mine < cur) && !bad.compare_exchange_weak(cur, mine)) {}
                 return;
             }
         }
@@ -182,6 +187,7 @@ void rows_to_tm(const T* v, int T_, int64_t lo, int64_t hi, float scale, float* 
 }  // namespace
 
 extern "C" int mvae_host_threads(int32_t n) {
+    std::lock_guard<std::mutex> call(g_call_mutex);
     {
         std::lock_guard<std::mutex> g(g_pool_mutex);
         if (n >= 0) g_threads = n;
@@ -192,6 +198,7 @@ extern "C" int mvae_host_threads(int32_t n) {
 extern "C" int mvae_host_onehot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_t T, int32_t K, int64_t lo, int64_t hi,
                                             uint8_t* out, int32_t Bp, uint8_t fill, int64_t* bad_row) {
     if (!x || !out || n < 0 || T <= 0 || K <= 0 || K > 255 || lo < 0 || hi < lo || hi > n || Bp < hi - lo) return MVAE_E_ARG;
+    std::lock_guard<std::mutex> call(g_call_mutex);
     switch (xkind) {
         case MVAE_HOST_F64: return onehot_to_index_tm<double>(static_cast<const double*>(x), n, T, K, lo, hi, out, Bp, fill, bad_row);
         case MVAE_HOST_F32: return onehot_to_index_tm<float>(static_cast<const float*>(x), n, T, K, lo, hi, out, Bp, fill, bad_row);
@@ -216,6 +223,7 @@ extern "C" int mvae_host_index_to_tm(const uint8_t* idx, int64_t n, int32_t T, i
 extern "C" int mvae_host_rows_to_tm_f32(const void* v, int32_t vkind, int64_t n, int32_t T, int64_t lo, int64_t hi, float scale,
                                         float* out, int32_t Bp) {
     if (!v || !out || n < 0 || T <= 0 || lo < 0 || hi < lo || hi > n || Bp < hi - lo) return MVAE_E_ARG;
+    std::lock_guard<std::mutex> call(g_call_mutex);
     switch (vkind) {
         case MVAE_HOST_F64: rows_to_tm<double>(static_cast<const double*>(v), T, lo, hi, scale, out, Bp); return MVAE_OK;
         case MVAE_HOST_F32: rows_to_tm<float>(static_cast<const float*>(v), T, lo, hi, scale, out, Bp); return MVAE_OK;

@@ -535,28 +535,6 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
     return hipStreamWriteValue32(reinterpret_cast<hipStream_t>(stream), addr, value, 0) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
 }
 
-// ---- device-side join of queues ------------------------------------------------------------------------------------
-// A cross-queue wait at the level of the command processors (an AQL barrier packet on the completion signal of another queue's last
-// kernel) takes 100-200 us to resolve when that kernel ends late - at the end of the training step it is 0.16 ms in front of the
-// optimizer.  Instead: the side queue ends with a one-thread kernel that stores a sequence number, and the joining queue runs a
-// one-wave kernel that polls for it (bounded, like every device-side wait here); kernels follow each other within a queue in ~8 us.
-__global__ void flag_set_k(uint32_t* flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__global__ void flags_wait_k(const uint32_t* flags, int n, uint32_t value, uint32_t* status) {
-    for (int i = 0; i < n; ++i) wave_wait_ge(flags + i, value, status, 5u);
-}
-extern "C" int mvae_flag_set(uint32_t* flag, uint32_t value, void* stream) {
-    if (!flag) return MVAE_E_ARG;
-    hipLaunchKernelGGL(flag_set_k, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag, value);
-    MVAE_CHECK_LAUNCH();
-    return MVAE_OK;
-}
-extern "C" int mvae_flags_wait(const uint32_t* flags, int32_t n, uint32_t value, uint32_t* status, void* stream) {
-    if (!flags || n <= 0 || n > 64) return MVAE_E_ARG;
-    hipLaunchKernelGGL(flags_wait_k, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), flags, n, value, status);
-    MVAE_CHECK_LAUNCH();
-    return MVAE_OK;
-}
-
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
 constexpr int PREP_MAX_JOBS = 64, PREP_BLOCKS_PER_JOB = 64;      // (64 x 48-byte jobs = 3 KiB of kernel arguments; the limit is 4 KiB)
 struct prep_batch {
@@ -595,9 +573,17 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             }
             break;
         }
-        case MVAE_PREP_ADD_I32:        // (src = optional guard word: no increment while it is non-zero - the update was skipped too)
-            if (bid == 0 && threadIdx.x == 0 && !(job.src && *reinterpret_cast<const uint32_t*>(job.src) != 0u))
-                *reinterpret_cast<int32_t*>(job.dst) += job.a;
+        case MVAE_PREP_ADD_I32:        // (src = optional guard word: no increment while it is non-zero - the update was skipped too;
+            if (bid == 0 && threadIdx.x == 0) {         //  src2 = optional latch word: the guard word is moved there and cleared)
+                uint32_t* g = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(job.src));
+                const uint32_t st = g ? *g : 0u;
+                if (st == 0u) *reinterpret_cast<int32_t*>(job.dst) += job.a;
+                else if (job.src2) {
+                    uint32_t* l = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(job.src2));
+                    if (st > *l) *l = st;
+                    *g = 0u;
+                }
+            }
             break;
         case MVAE_PREP_ZERO: {
             const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
@@ -616,6 +602,7 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
         for (int j = 0; j < pb.n; ++j) {
             const mvae_prep_job& job = jobs[j0 + j];
             if ((!job.src && job.op != MVAE_PREP_ZERO && job.op != MVAE_PREP_ADD_I32) || !job.dst || job.op < 0 ||
+                (job.op == MVAE_PREP_ADD_I32 && job.src2 && !job.src) ||
                 job.op > MVAE_PREP_ADD_I32 ||
                 (job.op == MVAE_PREP_CONVERT_PAD && job.c < job.b) ||
                 (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
@@ -743,6 +730,30 @@ extern "C" int mvae_copy2d_f32(float* dst, int32_t ldd, const float* src, int32_
     if (rows && cols)
         hipLaunchKernelGGL(copy2d_f32_k, dim3(nblocks((size_t)rows * cols)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst,
                            ldd, src, lds, rows, cols, src_row0, zero_rows);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+// the fused history pre-pass (include/midivae_hip.h): z' = mu + exp(lv / 2) * eps2 - the expression of the latent kernels, so a
+// pre-pass run on its own gives the same bits - stored and rolled by one window into the history columns
+__global__ void history_from_latent_k(const float* mu, const float* lv, const float* eps2, int B, int Bp, int Z, float* hist, int ldh,
+                                      const float* prev, float* z_out, int ldo) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)Bp * Z; e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / Z), j = (int)(e % Z);
+        if (b < B && z_out) z_out[(size_t)b * ldo + j] = mu[e] + expf(0.5f * lv[e]) * eps2[e];
+        float h = 0.0f;
+        if (b == 0) h = prev ? prev[j] : 0.0f;
+        else if (b < B) {
+            const size_t q = e - Z;
+            h = mu[q] + expf(0.5f * lv[q]) * eps2[q];
+        }
+        hist[(size_t)b * ldh + j] = h;
+    }
+}
+extern "C" int mvae_history_from_latent(const float* mu, const float* logvar, const float* eps2, int32_t B, int32_t B_pad, int32_t Z,
+                                        float* hist, int32_t ldh, const float* prev, float* z_out, int32_t ldo, void* stream) {
+    if (!mu || !logvar || !eps2 || !hist || B <= 0 || B_pad < B || Z <= 0 || ldh < Z || (z_out && ldo < Z)) return MVAE_E_ARG;
+    hipLaunchKernelGGL(history_from_latent_k, dim3(nblocks((size_t)B_pad * Z)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mu,
+                       logvar, eps2, B, B_pad, Z, hist, ldh, prev, z_out, ldo);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }

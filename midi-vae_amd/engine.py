@@ -74,7 +74,11 @@ class _Aux(object):
 
 class Engine(object):
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
-                 training: bool = True, use_graphs: bool = False):
+                 training: bool = True, share: "Engine | None" = None):
+        """``share``: another Engine of the same spec on the same device whose PARAMETERS (the flat f32 buffer itself) and HIP
+        streams this one uses - the forward-only engine model.py keeps beside the training engine for chip-filling inference
+        batches (encoder.predict / evaluate / decoder.predict, DESIGN.md section 3.4).  Its derived weight copies are its own;
+        which of the two engines last prepared them for the current parameters is tracked by a shared version counter."""
         hl.load()          # raises HipLibraryMissing - no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("the MIDI-VAE engine needs an MI355X (torch.cuda.is_available() is False)")
@@ -88,46 +92,55 @@ class Engine(object):
         self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR          # what the GEMM epilogues write (xp, dX)
         self.maxB = (int(max_batch) + 15) // 16 * 16
         self.layout = self._make_layout()
-        self.use_graphs = use_graphs
-        self._graphs = {}
         self.prof = None       # dict -> per-kernel HIP-event pairs are recorded on the launch stream (bench.py)
         self.prof_kinds = None # None = every timed launch, else a set of kinds ("rnn_fwd", "rnn_bwd")
         L, dev = self.layout, self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.params = torch.zeros(L.total, **f32)
-        self.grads = torch.zeros(L.total, **f32)
-        self.opt_m = torch.zeros(L.total, **f32)
-        self.opt_v = torch.zeros(L.total, **f32)
+        if share is not None:
+            assert not training and share.layout.total == L.total and share.device == self.device
+            self.params, self._pver = share.params, share._pver
+        else:
+            self.params, self._pver = torch.zeros(L.total, **f32), [0]
+        self._prepared_ver = -1
+        n_opt = L.total if training else 0              # a forward-only engine holds no gradients / optimizer state
+        self.grads = torch.zeros(n_opt, **f32)
+        self.opt_m = torch.zeros(n_opt, **f32)
+        self.opt_v = torch.zeros(n_opt, **f32)
         self.t_done = torch.zeros(1, dtype=torch.int32, device=dev)
         self.P = {n: L.view(self.params, n) for n in L.entries}
-        self.G = {n: L.view(self.grads, n) for n in L.entries}
+        self.G = {n: L.view(self.grads, n) for n in L.entries} if training else {}
         self.scal = torch.zeros(N_SCALARS, **f32)
         # Each recurrent kernel occupies B/16 CUs of 256, so the independent branches of the graph (notes stack /
         # velocity / instrument, forward and backward) run on their own HIP streams, and parameter-gradient GEMMs
-        # (needed only by the optimizer) go to a fourth stream off the critical path.  Fork / join is event based.
-        with torch.cuda.device(self.device):
-            self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
-            self.s_held = torch.cuda.Stream() if spec.meta_held else None
-            self.s_next = torch.cuda.Stream() if spec.meta_next else None
-            self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
-            self.s_layer = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]
-            self.s_proj = [torch.cuda.Stream() for _ in range(max(spec.Le, spec.Ld) - 1)]     # x*W / dX of pipelined stacks
+        # (needed only by the optimizer) go to two more streams off the critical path.  Fork / join is event based.
+        # A forward-only engine beside a training engine uses THAT engine's streams: a second set would alias onto the same
+        # hardware queues, and two streams of one pipelined stack on one queue is the one thing the schedule cannot take.
+        nl = max(spec.Le, spec.Ld) - 1
+        if share is not None:
+            self.s_vel, self.s_instr, self.s_grad, self.s_grad2 = share.s_vel, share.s_instr, share.s_grad, share.s_grad2
+            self.s_held, self.s_next = share.s_held, share.s_next
+            self.s_layer, self.s_proj = share.s_layer, share.s_proj
+        else:
+            with torch.cuda.device(self.device):
+                self.s_vel, self.s_instr, self.s_grad = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+                self.s_held = torch.cuda.Stream() if spec.meta_held else None
+                self.s_next = torch.cuda.Stream() if spec.meta_next else None
+                self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
+                self.s_layer = [torch.cuda.Stream() for _ in range(nl)]
+                self.s_proj = [torch.cuda.Stream() for _ in range(nl)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
         self._prefork = None
         self._branches_stay_forked = False
         self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
-        # joins by flag kernels instead of barrier packets (_join): -1.2 % on the training step, but decoder inference runs 5-10x slower
-        # in most processes with it (cause not found: DESIGN.md section 6) - off
-        self.device_join = os.environ.get("MVAE_DEVICE_JOIN", "0") == "1"
-        self._join_flags = torch.zeros(64 * 8, dtype=torch.int32, device=dev)
-        self._join_seq = 0
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
+        self.status_allreduce = None     # data parallel: MAX of the pipeline status word over the ranks (dp.DataParallel)
         # Stacked layers are pipelined over TIME CHUNKS: layer l runs chunk k (on its own stream) as soon as layer l-1
         # has produced it, instead of waiting for the whole sequence.  The f32 state is carried across launches.
         self.time_chunks = 4
-        # ... and where the slot-interleaved LSTM kernels apply, as ONE launch per layer with device-side hand-over
-        # every pipe_chunk time steps (no relaunch, no weight reload, layers pipe_chunk steps apart instead of T/4)
+        # ... and where the slot-interleaved LSTM / GRU kernels apply AND the stack's kernels fit on the chip together
+        # (_pipelined), as ONE launch per layer with device-side hand-over every pipe_chunk time steps (no relaunch, no weight
+        # reload, layers pipe_chunk steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
         # time steps per hand-over: a hand-over costs every workgroup a drained vmcnt and a counter, the persistent GEMM a wait - the
         # bigger the batch, the more rows a chunk should carry (A/B r02: 256 windows 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms;
@@ -141,34 +154,30 @@ class Engine(object):
         # 64 for LSTM, 48 for GRU.  (Round 1's kernel reloaded the panel per tile; decoder inference at 1024 windows was bound by it:
         # 8.2 us per decoder step at 64 workgroups, 6.2 at 128 - 4.1 now at 64)
         self.pipe_proj_blocks = 8 * max(spec.GH // 128, 1)
-        # workgroup budget of the off-critical-path gradient GEMMs: a recurrent workgroup needs a WHOLE idle CU
-        # (160 KiB LDS / 512 registers); unbounded GEMM grids starve it for milliseconds (profiles/r01_b timeline)
-        # Parameter-gradient GEMMs once per layer (after its last BPTT chunk), NOT per time chunk: throughput GEMMs running
-        # beside the latency-bound recurrences slow those down by more than the ~1 ms tail they would save (measured:
-        # 14.1 ms per step with per-chunk gradients, 13.0 ms without; bounding their grids is worse still).
-        self.grad_per_chunk = False
-        self._deferred = None
-        self.zero_grads_in_optimizer = True
+        # Parameter-gradient GEMMs once per layer (after its BPTT), NOT per time chunk: throughput GEMMs running beside the
+        # latency-bound recurrences slow those down by more than the tail they would save.
         self._grads_clean = False
-        self.defer_decoder_grads = False # decoder parameter-gradient work released once the encoder BPTT is resident (see backward)
         self.fuse_head_bwd = True        # d(h sequence) of the output Denses from the head launch (mvae_head wc / dhs)
         self.fuse_bias_grad = True       # bias gradients from the recurrent-kernel gradient GEMM's pass over da (mvae_gemm colsum_b)
         self.fused_latent = True         # Dense chain around the latent as one launch each way (csrc/latent.hip)
-        self.onehot_split_factor = int(os.environ.get("MVAE_ONEHOT_SPLIT", "1"))   # (2 and 4 measured neutral: DESIGN.md section 6)
-        self.tail_on_main = os.environ.get("MVAE_TAIL_ON_MAIN", "0") == "1"   # last layer's gradient GEMMs on the critical queue (measured neutral: DESIGN.md section 6)
         # Encoder stack (the LAST recurrence phase of a step): its weight-gradient GEMMs FOLLOW the running BPTT kernels chunk by chunk
         # (mvae_gemm k_wait: one resident workgroup per (output tile, K partition) accumulates in registers over all chunks) - what
         # is left when the recurrence ends is one chunk's share instead of four whole GEMMs (0.55 ms of the 0.77 ms tail).  All of
         # them are ONE launch (mvae_gemm_kstream_multi) on the second gradient queue - a queue each cost more than the tail saved -
         # and the other gradient work of that phase (velocity / instrument encoders) goes to the first one.
-        # kstream_wgs workgroups per GEMM: they wait beside three recurrences that need 16 EMPTY CUs each.
+        # kstream_wgs workgroups per GEMM: they wait beside the recurrences, one per CU (_kstream_ok: residency).
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "0")) or (24 if spec.cell == "GRU" else 32)   # (GRU: 3 GEMMs per layer)
         self.kstream_singles = os.environ.get("MVAE_KSTREAM_SINGLES", "1") == "1"   # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
-        self.grad_gemm_blocks = 0        # 0 = unbounded; bounding only pays once the GEMM itself is fast
-        self.set_params(self._initial_params(seed))
+        self._n_side = 0                 # recurrences running beside the stack being scheduled (residency, _pipelined)
+        self._cur_B = self.maxB          # padded batch of the call being scheduled
+        self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self._occ = {k: max(1, hl.load().mvae_occupancy(i)) for i, k in enumerate(("dx", "proj", "kstream"))}
+        self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
+        if share is None:
+            self.set_params(self._initial_params(seed))
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
@@ -178,10 +187,24 @@ class Engine(object):
         self._count_pending = False
         self._sync_cum = {}
         self._pipe_verified = set()
+        self._pipe_used = False          # a time-pipelined stack has been launched since the engine was built
         self._dxp0_clean = False
         self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
         self._have_staged_targets = False
         self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)     # epoch accumulators (accumulate_metrics)
+
+    @property
+    def _weights_dirty(self):
+        """the derived weight copies of THIS engine are older than the parameters (shared version counter: an optimizer step or
+        set_params on the training engine also invalidates the copies of the forward-only engine that shares its parameters)"""
+        return self._prepared_ver != self._pver[0]
+
+    @_weights_dirty.setter
+    def _weights_dirty(self, dirty):
+        if dirty:
+            self._pver[0] += 1
+        else:
+            self._prepared_ver = self._pver[0]
 
     # (hooks of the style-classifier engine, classifier.py: the same recurrent / head / optimizer machinery on another graph)
     def _make_layout(self):
@@ -241,21 +264,6 @@ class Engine(object):
 
     def _join(self, *streams):
         cur = torch.cuda.current_stream()
-        if self.device_join and self.multi_stream and streams and not self.use_graphs:
-            # device-side: every side queue ends with a flag kernel, this queue polls them with a one-wave kernel (csrc/misc.hip) -
-            # kernels follow each other within a queue in ~8 us, a command-processor barrier that resolves late costs 100-200
-            self._join_seq += 1
-            slot = (self._join_seq % 64) * 8
-            n = 0
-            for st in dict.fromkeys(streams):           # (a stream may be listed twice)
-                if st is cur:
-                    continue
-                ops.flag_set(self._join_flags[slot + n:slot + n + 1], self._join_seq, st)
-                n += 1
-                assert n <= 8
-            if n:
-                ops.flags_wait(self._join_flags[slot:slot + n], n, self._join_seq, self.store["pipe_status"])
-            return
         if self.lean_sync and len(streams) > 1:
             # chained: every side queue takes its barrier packet when ITS work ends; the joining queue (the critical one)
             # processes one barrier packet instead of len(streams)
@@ -279,7 +287,7 @@ class Engine(object):
     def _side(self, fn):
         """Run ``fn`` (parameter-gradient work nobody waits for before the optimizer) on the second gradient stream,
         ordered after everything enqueued so far on the current stream."""
-        if not self.multi_stream or not getattr(self, "side_grads", True):
+        if not self.multi_stream:
             fn()
             return
         self.s_grad2.wait_stream(torch.cuda.current_stream())
@@ -415,7 +423,8 @@ class Engine(object):
         esz = dict(dtype=dt, device=dev)
         # time-pipelined stacks: progress counters / ready flags (4 stack slots x 1024 words) and the time-out status word
         st["sync"] = torch.zeros(5 * 1024, dtype=torch.int32, device=dev)     # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch
-        st["pipe_status"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        words = torch.zeros(2, dtype=torch.int32, device=dev)     # [live status of the running step, latched status since the last check]
+        st["pipe_words"], st["pipe_status"], st["pipe_latched"] = words, words[0:1], words[1:2]
         for r in self.all_rec:
             p = r.prefix
             buf(p + ".u_pack", GH * H, **esz)
@@ -423,7 +432,7 @@ class Engine(object):
             buf(p + ".sh", B * H, **f32)                 # carried f32 state between time chunks (h, c, dh, dc)
             buf(p + ".sc", B * H, **f32)
             buf(p + ".hs", (r.T + 1) * B * H, **esz)
-            if s.cell == "LSTM":
+            if s.cell == "LSTM" and self.training:       # (cell states are saved for the backward pass only)
                 buf(p + ".cs", (r.T + 1) * B * H, **esz)
             if self.training:
                 buf(p + ".acts", r.T * B * GH, **esz)
@@ -510,7 +519,8 @@ class Engine(object):
                    ("in.rw_notes", T * B, torch.float32), ("in.rw_instr", V * B, torch.float32),
                    ("in.rw_vel", T * B, torch.float32), ("in.rw_style", B, torch.float32),
                    ("in.start_notes", B * s.Dout, torch.float32), ("in.start_instr", B * s.ID, torch.float32),
-                   ("in.start_vel", B, torch.float32), ("in.hist", B * Z, torch.float32), ("in.z", B * Z, torch.float32)]
+                   ("in.start_vel", B, torch.float32), ("in.hist", B * Z, torch.float32), ("in.z", B * Z, torch.float32),
+                   ("in.eps2", B * Z, torch.float32)]
         if s.meta_held:
             regions += [("in.d_idx", T * B, torch.uint8), ("in.rw_held", T * B, torch.float32), ("in.start_held", B * 2, torch.float32)]
         if s.meta_next:
@@ -541,6 +551,18 @@ class Engine(object):
         for name, (o, nbytes, tdt) in self._in_regions.items():
             st[name] = self._in_block[o:o + nbytes].view(tdt)
         self._stager = None
+
+    @staticmethod
+    def forward_bytes_per_window(spec, kind):
+        """HBM a forward-only engine holds per window of its batch (sizing of model._Shared.get_infer): the h sequences of every
+        recurrent layer, x*W + b of the stacked / 1-feature layers, the heads' probabilities on request, inputs"""
+        e = 2 if kind == hl.BF16 else 4
+        T, V, H, GH = spec.T, spec.V, spec.H, spec.GH
+        n_T = spec.Le + spec.Ld + 2 * int(spec.meta_velocity) + 2 * int(spec.meta_held) + spec.Ld * int(spec.meta_next)
+        n_xp = (spec.Le - 1) + (spec.Ld - 1) + int(spec.meta_velocity) + (spec.Ld - 1) * int(spec.meta_next)
+        per = n_T * (T + 1) * H * e + 2 * int(spec.meta_instrument) * (V + 1) * H * e + n_xp * T * GH * e
+        per += T * (spec.Dout * 4 + 64) + 4096
+        return int(per * 1.25)
 
     def bytes_resident(self):
         return (sum(t.numel() * t.element_size() for t in self.store.values()) +
@@ -677,7 +699,11 @@ class Engine(object):
 
         if self._prep is None:          # built once: every source / destination is a fixed view
             self._prep, self._prep_count = ops.PrepBatch(), ops.PrepBatch()
-            self._prep_count.add_i32(self.t_done, guard=self._guard())   # ... the optimizer's step count rides along after an eager step
+            # the optimizer's step count rides along after a step (not while the status word of that step is set: its update was
+            # skipped too); either way the status word is moved to the latched word and cleared for the step that starts here
+            latch = dict(guard=self.store["pipe_status"], latch=self.store["pipe_latched"])
+            self._prep.add_i32(self.t_done, 0, **latch)
+            self._prep_count.add_i32(self.t_done, 1, **latch)
             for pb in (self._prep, self._prep_count):
                 for r in self.all_rec:
                     p = r.prefix
@@ -782,16 +808,30 @@ class Engine(object):
                  **chunked)
 
     # ---- time-pipelined stacks (slot-interleaved LSTM kernels) ---------------------------------------------------
+    def _resident_cus(self, layers, B, backward=None):
+        """CUs the kernels of a time-pipelined stack over ``layers`` occupy AT THE SAME TIME at a padded batch of B windows,
+        with the ``_n_side`` single-layer recurrences of the phase running beside it.  A recurrent workgroup (16 windows) owns a
+        whole CU (__launch_bounds__(256, 1): 512 registers per lane, up to 160 KiB of LDS); the persistent projection / dX GEMM
+        between two layers holds ceil(grid / workgroups per CU) more (occupancy from the library: mvae_occupancy)."""
+        per, L = B // 16, len(layers)
+        cus = {True: -(-self.pipe_gemm_blocks // self._occ["dx"]), False: -(-self.pipe_proj_blocks // self._occ["proj"])}
+        g = max(cus.values()) if backward is None else cus[bool(backward)]
+        return L * per + (L - 1) * g + self._n_side * per
+
     def _pipelined(self, layers):
         """ONE launch per layer for the whole sequence; layer l+1 follows layer l at a distance of ``pipe_chunk`` time
         steps, released chunk by chunk through device-side counters (include/midivae_hip.h, 'time-pipelined stacks')
-        instead of one launch per (layer, chunk)."""
+        instead of one launch per (layer, chunk).  Only when every kernel of the stack - and the recurrences of the phase's
+        other branches - is RESIDENT together: a consumer that takes its CUs first and waits for a producer that no longer
+        finds a free one is the time-out the schedule must not depend on luck to avoid (chip-filling inference batches run the
+        layers as chunk launches ordered by events instead - nothing waits on the device there)."""
         if len(layers) < 2:
             return False
         T = layers[0].T
-        return (self.pipeline and self.multi_stream and not self.use_graphs and len(layers) > 1 and
-                len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and len(layers) * 2 * (T // self.pipe_chunk) <= 1024 and
-                all(self._seq_layout(r) == hl.TILE16P for r in layers))
+        return (self.pipeline and self.multi_stream and len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and
+                len(layers) * 2 * (T // self.pipe_chunk) <= 1024 and
+                all(self._seq_layout(r) == hl.TILE16P for r in layers) and
+                self._resident_cus(layers, self._cur_B) <= self.num_cus)
 
     def _sync_region(self, slot, n_if, nchp, nwaves, pwaves):
         """[n_if][2][nchp] 32-bit counters (hs / da chunks published, xp / dX chunks published) of pipelined stack number
@@ -815,6 +855,7 @@ class Engine(object):
         L = len(layers)
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
+        self._pipe_used = True
         lower_streams = self.s_layer[:L - 1]              # layer l < L-1 on lower_streams[l]; the top layer on this stream
         gemm_streams = self.s_proj[:L - 1]
         self._fork(*lower_streams, *gemm_streams)
@@ -841,6 +882,7 @@ class Engine(object):
 
     def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0, xs=None):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
+        self._cur_B = B
         if self._pipelined(layers):
             return self._stack_forward_pipe(layers, B, slot, states=states, h_last=h_last, h_last_ld=h_last_ld, idx=idx,
                                             start=start, xs=xs)
@@ -877,6 +919,7 @@ class Engine(object):
         Breal, B = B, self.pad16(B)
         cat = self._v("cat", B, self.ncat * H)
         ldc = self.ncat * H
+        self._cur_B, self._n_side = B, len(self.enc_meta)
         self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
         for k, (r, st, src) in enumerate(self.enc_meta, 1):
             with self._on(st):
@@ -887,16 +930,28 @@ class Engine(object):
         else:
             self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
         self._prefork = None
+        self._n_side = 0
         self._join(*[st for _, st, _ in self.enc_meta])
         self._mark("  encoder recurrences")
         self._S_done = False
-        if self.fused_latent and self._chain_ok() and self._latent_chain_forward(Breal, B, with_init):
-            self._signature_forward(Breal, B)
-            return
-        h = cat
+        fused_hist = self._hist_fused            # (history of this minibatch from this very forward pass: train_step_begin)
+        if not (self.fused_latent and self._chain_ok() and
+                self._latent_chain_forward(Breal, B, with_init and fused_hist is None)):
+            self._latent_forward_unfused(Breal, B)
+        if fused_hist is not None:
+            eps2, z_out = fused_hist
+            zh = self._v("zh", B, s.zin)
+            ops.history_from_latent(self._v("mu", B, Z), self._v("lv", B, Z), eps2, Breal, B, Z, zh[:, Z:2 * Z], z_out=z_out)
+        self._signature_forward(Breal, B)
+
+    def _latent_forward_unfused(self, Breal, B):
+        """encoder tail Denses, z_mean / z_log_var, KL + sampling + style softmax, one launch per operation"""
+        s, P = self.spec, self.P
+        H, Z = s.H, s.Z
+        h = self._v("cat", B, self.ncat * H)
         if self.has_pack:
             pk = self._v("pack", B, H)
-            ops.gemm(cat, P["enc.pack.W"], pk, B, H, self.ncat * H, bias=P["enc.pack.b"], act=hl.ACT_TANH)
+            ops.gemm(h, P["enc.pack.W"], pk, B, H, self.ncat * H, bias=P["enc.pack.b"], act=hl.ACT_TANH)
             h = pk
         if s.extra_layer:
             ex = self._v("extra", B, H)
@@ -914,7 +969,6 @@ class Engine(object):
                        style_target=self._v("in.c_idx", Breal) if (s.style and self._have_targets) else None,
                        style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
                        style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
-        self._signature_forward(Breal, B)
 
     # ---- bidirectional encoder stack (reference vae_definition.py:445-453) --------------------------------------------------
     def _enc_bi_forward(self, B, h_last, ldc):
@@ -1042,12 +1096,14 @@ class Engine(object):
         tg = self._have_targets
         side = [h for h in self.dec_heads if h.stream is not None]
         aux_src = {a.src for a in self.aux}
+        self._cur_B, self._n_side = B, len(side)
         self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
         for h in side:
             with self._on(h.stream):
                 self._head_forward(h, B, Breal, states, tg, want_probs or h.name in aux_src, slot=None)
         self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
         self._prefork = None
+        self._n_side = 0
         if not self._branches_stay_forked or self.aux:
             self._join(*[h.stream for h in side])
         for a in self.aux:
@@ -1118,7 +1174,7 @@ class Engine(object):
     def _split_k(self, K):
         # weight-gradient GEMMs have a tiny output (H x G*H = 16 tiles of 128x128) and K = T*B: split K so that
         # tiles x splits ~ the CU count; more splits only add atomic traffic (212 vs 367 TFLOP/s at 64 vs 16)
-        return int(min(16, max(1, K // int(os.environ.get("MVAE_SPLIT_ROWS", "8192")))))
+        return int(min(16, max(1, K // 8192)))
 
     def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0,
                   pipe=None):
@@ -1154,77 +1210,66 @@ class Engine(object):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, k=0, nch=1, *, idx=None, xs=None, start=None, fork=True, on_main=False, skip_dU=False):
-        """Parameter gradients of one layer from time chunk k of its da (chunks arrive last to first), accumulated
-        into the f32 gradient buffer: off the critical path, on the two gradient streams, as soon as the chunk's BPTT
-        is done - only the last chunk's share is left when the recurrence finishes."""
-        if self._deferred is not None:     # decoder layers: enqueued once the encoder BPTT is running (see backward)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._deferred.append((ev, lambda: self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start, fork=False)))
-            return
+    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False):
+        """Parameter gradients of one layer from its da, accumulated into the f32 gradient buffer: off the critical path, on
+        the two gradient streams, once per layer after its BPTT."""
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
-        Tc = T // nch
-        t0 = k * Tc
-        R = Tc * B
-        hs = self._v(p + ".hs", T + 1, B, H)
-        da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
-        da2, hprev = da.view(R, GH), hs[t0:t0 + Tc].reshape(R, H)
+        R = T * B
+        da = self._v(p + ".da", T, B, GH)
+        da2, hprev = da.view(R, GH), self._v(p + ".hs", T + 1, B, H)[:T].reshape(R, H)
         sk = self._split_k(R)
-        mb = self.grad_gemm_blocks
-        if on_main:         # the LAST layer of the backward pass: on the critical queue itself - the optimizer follows it there
-            fork = False    # without a cross-queue hop (two barrier packets that resolve late cost 100+ us at the end of a step)
-        g1 = g2 = (_NullCtx() if on_main else None)
         sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
-        if fork:
-            self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
+        self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
         # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
         fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
         gb = G[p + ".b"]
-        with (g1 or self._on(sg1)):
+        with self._on(sg1):
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if skip_dU:             # (with its bias gradient in a K-streaming launch)
                 pass
             elif s.cell == "GRU":
-                rh = self._v(p + ".rh", T, B, H)[t0:t0 + Tc]
-                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk, max_blocks=mb,
+                rh = self._v(p + ".rh", T, B, H)
+                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk,
                          colsum_b=gb[:2 * H] if fuse_b else None)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                         accumulate=True, split_k=sk, max_blocks=mb, colsum_b=gb[2 * H:] if fuse_b else None)
+                         accumulate=True, split_k=sk, colsum_b=gb[2 * H:] if fuse_b else None)
             else:
-                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb,
+                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk,
                          colsum_b=gb if fuse_b else None)
-        with (g2 or self._on(sg2)):
+        with self._on(sg2):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
-                ops.sum_over_time(da, Tc, B * GH, dxp0, accumulate=(k != nch - 1) or self._dxp0_clean)
-                if k == 0:
-                    ops.colsum(dxp0, B, GH, G[p + ".b"])
-                    ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True, max_blocks=mb)
+                ops.sum_over_time(da, T, B * GH, dxp0, accumulate=self._dxp0_clean)
+                ops.colsum(dxp0, B, GH, G[p + ".b"])
+                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
             else:
                 if not fuse_b:
                     ops.colsum(da2, R, GH, G[p + ".b"])
                 if r.xmode == X_EXT:
                     pass                                # (input-kernel gradient by the caller: _aux_backward)
                 elif r.xmode == hl.X_INDEX:
-                    # (M = 61 is ONE row of tiles: 8 column tiles x 16 splits fill half the chip - the one-hot splits go twice as wide)
-                    ops.gemm(idx[t0:t0 + Tc].reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT,
-                             accumulate=True, split_k=sk * self.onehot_split_factor if sk >= 8 else sk)
+                    ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
-                    ops.colsum_weighted(da2, xs[t0:t0 + Tc].reshape(-1), R, GH, G[p + ".W"])
+                    ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"])
                 else:
-                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t0:1 + t0 + Tc].reshape(R, H)
-                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk, max_blocks=mb)
+                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:1 + T].reshape(R, H)
+                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
 
     def _kstream_ok(self, layers, B):
         """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
-        or dense input, bias gradient fused), at most 8 of them, and the waiting workgroups must leave the recurrences their empty CUs."""
+        or dense input, bias gradient fused), at most 8 of them - and their workgroups, which wait RESIDENT for the whole BPTT,
+        must find their CUs beside the stack's own kernels and the phase's other recurrences: a workgroup that only gets its CU
+        when another one retires does its whole share after the recurrence, which is the tail the launch exists to remove.
+        (At 256 windows: 256 - (32 + 32 + 32) = 160 free CUs for 128 workgroups - the single-layer branch's 32 on top are the ones
+        that may start late; at 512 windows 96: ordinary GEMMs then, as measured, profiles/r02_q_pipe_chunk_by_batch.txt.)"""
         s = self.spec
         count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
-        return (self.kstream_grads and self.multi_stream and self._deferred is None and self.fuse_bias_grad and self.tile16 and
-                count <= 8 and B <= 256 and self._pipelined(layers) and
-                all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers))
+        if not (self.kstream_grads and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
+                self._pipelined(layers) and all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers)):
+            return False
+        free = (self.num_cus - self._resident_cus(layers, B, backward=True)) * self._occ["kstream"]
+        return free >= self.kstream_wgs * count
 
     def _kstream_problems(self, r, B, idx, ks, only_dU=False):
         """the layer's weight-gradient GEMMs as K-streaming problems (mvae_gemm_args, not launched)"""
@@ -1261,7 +1306,7 @@ class Engine(object):
         return out
 
     def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
-                             xs=None, start=None, tail_on_main=False):
+                             xs=None, start=None):
         cs = self.pipe_chunk
         T = layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
@@ -1269,28 +1314,28 @@ class Engine(object):
         L = len(order)
         kstream = self._kstream_ok(layers, B)
         if kstream:
-            tail_on_main = False
             before = torch.cuda.current_stream().record_event()      # the layers' saved inputs and the zeroed gradient buffers
         sync, da_target, dx_target = self._sync_region(slot, L, nchp, nwaves, pwaves)     # (row L-1: the bottom layer's da)
-        self._pipe_started = (sync[0, 0][nchp - 1:nchp], da_target)      # reached when the top layer's first chunk is out
         status = self.store["pipe_status"]
+        self._pipe_used = True
         lower_streams = self.s_layer[:L - 1]         # order[li], li >= 1, on lower_streams[li - 1]
         gemm_streams = self.s_proj[:L - 1]
         self._fork(*lower_streams, *gemm_streams)
         for li, r in enumerate(order):
             top = li == 0
             ds = dstates(r) if dstates else {}
-            pipe = dict(chunk_steps=cs, status=status)
+            # EVERY layer publishes its da chunks, the bottom one too, whether or not a K-streaming launch follows it in THIS
+            # call: the counters are cumulative over calls (_sync_region), so a row that is only advanced by some calls - the
+            # K-streaming decision depends on the call's batch - would fall behind its thresholds for good (0.03 us per step)
+            pipe = dict(chunk_steps=cs, status=status, signal_done=sync[li, 0])
             if li > 0:
                 pipe.update(wait_ready=sync[li - 1, 1], wait_value=dx_target)
-            if li < L - 1 or kstream:
-                pipe["signal_done"] = sync[li, 0]
             def run():
                 ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
                 self._rec_bptt(r, B, 0, 1, dhs_ext=ext, dh_last=dh_last if top else None,
                                dh_last_ld=dh_last_ld if top else 0, pipe=pipe, **ds)
-                if not kstream and not (tail_on_main and li == L - 1):
-                    self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
+                if not kstream:
+                    self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
             if top:
                 run()
             else:
@@ -1321,16 +1366,14 @@ class Engine(object):
             with torch.cuda.stream(self.s_grad2):
                 ops.gemm_kstream_multi(problems)
         self._join(*gemm_streams, *lower_streams)
-        if tail_on_main:        # the bottom layer finishes last: its parameter gradients right here, the optimizer behind them
-            self._rec_param_grads(order[-1], B, 0, 1, idx=idx, xs=xs, start=start, on_main=True)
 
     def _stack_backward(self, layers, B, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None, xs=None,
-                        start=None, slot=0, tail_on_main=False, kstream_extra=None):
+                        start=None, slot=0, kstream_extra=None):
         """BPTT through a stack (top layer first), pipelined over time chunks in reverse order."""
+        self._cur_B = B
         if self._pipelined(layers):
             return self._stack_backward_pipe(layers, B, slot, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
-                                             dstates=dstates, idx=idx, xs=xs, start=start,
-                                             tail_on_main=tail_on_main and self._deferred is None)
+                                             dstates=dstates, idx=idx, xs=xs, start=start)
         nch = self._nchunks(layers)
         order = list(reversed(layers))               # order[0] = top layer
         if kstream_extra is not None and len(layers) == 1 and nch == 1:
@@ -1343,7 +1386,7 @@ class Engine(object):
                            **(dstates(r) if dstates else {}))
             ks = dict(counters=sync[0, 0], target=target, rows=cs * B, status=self.store["pipe_status"])
             kstream_extra.append((self._kstream_problems(r, B, idx, ks, only_dU=True), sync[0, 0][r.T // cs - 1:r.T // cs], target))
-            self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start, skip_dU=True)
+            self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, skip_dU=True)
             return
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[torch.cuda.Event() for _ in range(nch)] for _ in order]
@@ -1363,10 +1406,8 @@ class Engine(object):
                                    dh_last_ld=dh_last_ld if top else 0, **ds)
                     if nch > 1:
                         done[li][k].record()
-                    if self.grad_per_chunk:
-                        self._rec_param_grads(r, B, k, nch, idx=idx, xs=xs, start=start)
-                    elif k == 0:
-                        self._rec_param_grads(r, B, 0, 1, idx=idx, xs=xs, start=start)
+                    if k == 0:
+                        self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
                 if li > 0 and nch > 1:
                     with torch.cuda.stream(streams[li]):
                         run()
@@ -1408,8 +1449,7 @@ class Engine(object):
             ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
         self._fork(self.s_grad)
         with self._on(self.s_grad):
-            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R),
-                     max_blocks=self.grad_gemm_blocks)
+            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
             ops.colsum(dl, R, N, G[outb], ldx=NP)
         return dhs
 
@@ -1426,17 +1466,12 @@ class Engine(object):
             return dict(dh0=dS[:, k * H:(k + 1) * H], dc0=dS[:, (k + 1) * H:(k + 2) * H] if s.cell == "LSTM" else None,
                         dh0_ld=ldS)
 
-        # ---- decoder: three independent branches ---------------------------------------------------------
-        # Their parameter-gradient GEMMs keep every CU supplied with workgroups for ~1 ms.  A resident-weights recurrent
-        # kernel needs whole EMPTY CUs (160 KiB LDS, 512 registers per lane): launched behind such GEMMs the encoder BPTT
-        # waits until they run out of workgroups (0.4 ms, measured on the kernel timeline).  So the decoder's gradient work is
-        # collected here and released - by a device-side wait on the encoder stack's first published chunk - once the
-        # encoder BPTT kernels are resident; it then runs beside them as before.
-        self._deferred = [] if (self.defer_decoder_grads and self.multi_stream and self._pipelined(self.enc_notes)) else None
-        # (one event for the three branches, the notes head's gradient GEMM and the notes stack's lower layers)
+        # ---- decoder: the notes stack and the side heads, independent branches -----------------------------------
+        # (one event for the branches, the notes head's gradient GEMM and the notes stack's lower layers)
+        side = [h for h in self.dec_heads if h.stream is not None]
+        self._cur_B, self._n_side = B, len(side)
         for a in self.aux:
             self._aux_backward(a, B)
-        side = [h for h in self.dec_heads if h.stream is not None]
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
             self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
         else:
@@ -1448,7 +1483,6 @@ class Engine(object):
         self._prefork = None
         self._join(*[h.stream for h in side])
         self._mark("  decoder BPTT")
-        deferred, self._deferred = self._deferred, None
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
         dcat = (self._latent_chain_backward(Breal, B)
                 if (self.fused_latent and self._chain_ok() and not s.signature) else None)
@@ -1457,7 +1491,7 @@ class Engine(object):
         ldc = self.ncat * H
         self._mark("  latent block backward")
         hook = self._bucket_hook
-        if hook is not None and self.multi_stream and not deferred and self.layout.dec_begin > 0:
+        if hook is not None and self.multi_stream and self.layout.dec_begin > 0:
             # data parallel: every decoder-side gradient [dec_begin, total) is queued by now - start its all-reduce on the
             # communication stream, beside the encoder BPTT (dp.BucketedAllReduce)
             if self.s_comm is None:
@@ -1466,7 +1500,8 @@ class Engine(object):
             self._join_into(self.s_comm)
             with torch.cuda.stream(self.s_comm):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
-        # ---- encoder recurrences: three independent branches -------------------------------------------------
+        # ---- encoder recurrences: the notes stack and the meta rolls, independent branches ---------------------------
+        self._cur_B, self._n_side = B, len(self.enc_meta)
         ks_extra = None
         if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
             self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
@@ -1482,18 +1517,10 @@ class Engine(object):
         if self.enc_bi:
             self._enc_bi_backward(B, dcat[:, 0:H], ldc)
         else:
-            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3,
-                                 tail_on_main=self.tail_on_main)
+            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
         self._prefork = None
         self._grad_streams = None
-        if deferred:
-            word, value = self._pipe_started         # the encoder's top layer has published its first chunk of da
-            for st in (self.s_grad, self.s_grad2):
-                for ev, _ in deferred:
-                    st.wait_event(ev)
-                ops.stream_wait_value32(word, value, stream=st)
-            for _, fn in deferred:
-                fn()
+        self._n_side = 0
         # the two gradient queues finish last and together: chained, they would put two cross-queue hops in series - the
         # early finishers are chained into one of them, the other is waited for directly
         self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
@@ -1623,7 +1650,10 @@ class Engine(object):
     def _guard(self):
         """The status word of the time-pipelined stacks as the optimizer's guard: while it is non-zero (a kernel gave up waiting
         for its producer: that step's gradients are invalid) the update and the step count are skipped ON THE DEVICE, so the
-        parameters and moments stay valid until the host notices (check_pipeline / metrics raise)."""
+        parameters and moments stay valid.  The word lives for ONE step: the weight-preparation launch of the next step moves it
+        into ``pipe_latched`` (what check_pipeline / the metric reads report) and clears it - one time-out costs one update, not
+        the rest of the epoch.  Under data parallelism the word is MAX-reduced over the ranks behind the gradient all-reduce
+        (status_allreduce), so every rank skips or applies the same updates."""
         return self.store["pipe_status"] if self.pipeline else None
 
     def get_optimizer_state(self):
@@ -1638,28 +1668,27 @@ class Engine(object):
 
     def optimizer_step(self, grad_scale=1.0):
         s = self.spec
+        if self.status_allreduce is not None and self.pipeline:
+            self.status_allreduce(self.store["pipe_status"])
         # (the gradients are zeroed as they are consumed: the next step starts without a 17 MB fill launch in front of it)
-        z = self.zero_grads_in_optimizer
         if s.optimizer == "Adam":
-            # eager: the step count is bumped by the weight-preparation launch that follows anyway (one dependent launch
-            # less between two steps); under graph capture the optimizer graph bumps it itself
-            keep = not self.use_graphs
+            # the step count is bumped by the weight-preparation launch that follows anyway (one dependent launch less
+            # between two steps)
             if self._count_pending:
                 self._flush_count()
             ops.adam_step_dev(self.params, self.grads, self.opt_m, self.opt_v, s.lr, self.t_done, grad_scale=grad_scale,
-                              zero_grad=z, keep_count=keep, guard=self._guard())
-            self._count_pending = keep
+                              zero_grad=True, keep_count=True, guard=self._guard())
+            self._count_pending = True
         else:
-            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=z, guard=self._guard())
-        self._grads_clean = z
+            ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=True, guard=self._guard())
+        self._grads_clean = True
         self._weights_dirty = True
 
-    def forward_backward(self, B):
-        """One pass of forward + losses + backward on the staged batch (gradients left in self.grads)."""
+    def _step_begin(self):
+        """weight preparation (or, with unchanged weights, the zeroing it would have done) and clean gradient buffers"""
         assert self.training
         self._have_targets = True
-        self._mark("step start")
-        if self._weights_dirty or self.use_graphs:
+        if self._weights_dirty:
             self.prepare_weights()          # (also zeroes the loss / metric accumulators and the constant-input cells' dxp0 sums)
             self._dxp0_clean = True
         else:
@@ -1668,6 +1697,18 @@ class Engine(object):
         if not self._grads_clean:
             self.grads.zero_()
         self._grads_clean = False
+
+    def _redo_step(self, B):
+        self.scal.zero_()
+        self.grads.zero_()
+        self.encoder_forward(B, with_init=True)
+        self.decoder_forward(B)
+        self.backward(B)
+
+    def forward_backward(self, B):
+        """One pass of forward + losses + backward on the staged batch (gradients left in self.grads)."""
+        self._mark("step start")
+        self._step_begin()
         self._mark("weights prepared")
         self.encoder_forward(B, with_init=True)
         self._mark("encoder forward (incl. latent)")
@@ -1682,19 +1723,17 @@ class Engine(object):
         finally:
             self._branches_stay_forked = False
         self._mark("backward")
-        self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
-                                       self.backward(B)))
+        self._verify_pipeline(lambda: self._redo_step(B))
 
     def _verify_pipeline(self, redo, key="train"):
         """First use of time-pipelined stacks by each kind of call (train step / encode / decode / predict): make sure no kernel
         gave up waiting for its producer.  A first use can stall for seconds for reasons that do not repeat - first launches of the
-        kind's kernels, and memory-management calls of the runtime (first pinned / device allocations of the caller's staging beside
-        it) that hold new dispatches back while a WAITING kernel is resident: seen as one 'chunked GEMM' time-out in ~30 first train
-        steps behind an encoder pre-pass - so the work is first redone as it is; if a kernel gives up again (two of the engine's
-        streams share a hardware queue, or kernels run one at a time under counter collection) the engine falls back to one launch per
-        chunk and stream-level joins for good and redoes it once more."""
-        if not (self.pipeline or self.device_join) or key in self._pipe_verified:
-            return
+        kind's kernels (code-object loads, hipFuncSetAttribute) and first pinned / device allocations of the caller's staging beside
+        it, all of which hold new dispatches back while a WAITING kernel is resident - so the work is first redone as it is; if a
+        kernel gives up again (two of the engine's streams share a hardware queue, or kernels run one at a time under counter
+        collection) the engine falls back to one launch per chunk for good and redoes it once more."""
+        if not self.pipeline or key in self._pipe_verified or not self._pipe_used:
+            return                     # (a call whose batch did not run any stack pipelined verifies nothing)
         self._pipe_verified.add(key)
         if int(self.store["pipe_status"].item()) == 0:
             return
@@ -1703,30 +1742,31 @@ class Engine(object):
         redo()
         if int(self.store["pipe_status"].item()) != 0:
             import warnings
-            warnings.warn("time-pipelined recurrent kernels / device-side joins timed out waiting for their producers; falling "
-                          "back to chunked launches and stream-level joins (Engine.pipeline = device_join = False)")
+            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers; falling back to chunked "
+                          "launches (Engine.pipeline = False)")
             self.store["pipe_status"].zero_()
             self.pipeline = False
-            self.device_join = False         # (kernels that run one at a time - counter collection - cannot wait for each other)
             self._dxp0_clean = False
             redo()
 
-    def train_step_begin(self, B):
+    def train_step_begin(self, B, hist_fused=None):
         """First part of a train step - weight preparation and the encoder up to the sampled z - for callers that stage the
         decoder heads' targets while it runs (Stager.stage(defer_targets=True) ... Stager.finish_targets()); the rest:
-        train_step_finish."""
-        assert self.training and not self.use_graphs
-        self._have_targets = True
-        if self._weights_dirty:
-            self.prepare_weights()
-            self._dxp0_clean = True
-        else:
-            self.scal.zero_()
-            self._dxp0_clean = False
-        if not self._grads_clean:
-            self.grads.zero_()
-        self._grads_clean = False
-        self.encoder_forward(B, with_init=True)
+        train_step_finish.
+
+        ``hist_fused`` = (eps2, z_out): the FUSED HISTORY PRE-PASS (reference vae_training.py:788-798 + :804-809 in one encoder
+        forward).  The reference runs ``encoder.predict`` over the song - with the weights this step starts from and a fresh
+        draw eps2 - to obtain the history input H[i] = z'[i-1] of ``fit``, then the step's own encoder forward with another
+        draw.  Same weights, same inputs, same mu / log sigma^2: here z' = mu + sigma * eps2 comes out of THIS step's encoder
+        forward (eps2: (Bp, Z) device view, already scaled; z_out: (>= B, Z) device rows that receive z'), is rolled into the
+        history columns of [z | history] (window 0: zeros) and the decoder's initial-state Denses follow as a separate GEMM.
+        Only for a minibatch that starts at window 0 of its song."""
+        self._step_begin()
+        self._hist_fused = hist_fused
+        try:
+            self.encoder_forward(B, with_init=True)
+        finally:
+            self._hist_fused = None
 
     def train_step_finish(self, B, allreduce=None):
         self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
@@ -1737,17 +1777,12 @@ class Engine(object):
         finally:
             self._branches_stay_forked = False
             self._bucket_hook = None
-        self._verify_pipeline(lambda: (self.scal.zero_(), self.grads.zero_(), self.encoder_forward(B), self.decoder_forward(B),
-                                       self.backward(B)))
+        self._verify_pipeline(lambda: self._redo_step(B))
         gs = allreduce(self.grads) if allreduce is not None else 1.0
         self.optimizer_step(gs if gs is not None else 1.0)
 
     def train_step(self, B, allreduce=None):
-        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.
-        With ``use_graphs`` the launch sequence (all streams, events and the ~200 kernels of a step) is captured once
-        per batch size into a hipGraph and replayed: the step is otherwise bound by host-side launch issue."""
-        if self.use_graphs and self.prof is None:
-            return self._graph_step(B, allreduce)
+        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch."""
         self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
         try:
             self.forward_backward(B)
@@ -1804,51 +1839,6 @@ class Engine(object):
         v = np.where(hit, v, v / n)
         return self._metrics_from(v, n)
 
-    def _graph_step(self, B, allreduce):
-        key = (B, allreduce is not None)
-        if key not in self._graphs:
-            world_scale = [1.0]
-            self._weights_dirty = True
-
-            def body_fb():
-                self.forward_backward(B)
-
-            def body_opt():
-                self.optimizer_step(world_scale[0])
-
-            # warm-up on a side stream (lazy module loads, hipFuncSetAttribute, allocator) - required before capture
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                snap = (self.params.clone(), self.opt_m.clone(), self.opt_v.clone(), self.t_done.clone())
-                body_fb()
-                if allreduce is not None:
-                    world_scale[0] = allreduce(self.grads) or 1.0
-                body_opt()
-                self.params.copy_(snap[0]); self.opt_m.copy_(snap[1]); self.opt_v.copy_(snap[2]); self.t_done.copy_(snap[3])
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self._weights_dirty = True
-            if allreduce is None:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    body_fb()
-                    body_opt()
-                self._graphs[key] = (g, None)
-            else:           # the collective stays outside the graphs: capture the two halves separately
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    body_fb()
-                with torch.cuda.graph(g2):
-                    body_opt()
-                self._graphs[key] = (g1, g2)
-        g1, g2 = self._graphs[key]
-        self._weights_dirty = True      # replay always re-prepares the packed weights (first kernels of the graph)
-        g1.replay()
-        if g2 is not None:
-            allreduce(self.grads)
-            g2.replay()
-
     def eval_step(self, B, want_probs=False):
         """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""
         self._have_targets = True
@@ -1884,10 +1874,11 @@ class Engine(object):
     # results
     # ------------------------------------------------------------------------------------------------------
     def check_pipeline(self):
-        """Raises if a kernel of a time-pipelined stack gave up waiting for its input (results of that step are invalid)."""
-        code = int(self.store["pipe_status"].item())
+        """Raises if a kernel of a time-pipelined stack gave up waiting for its input since the last check (the results of that
+        step are invalid; its optimizer update was skipped)."""
+        code = int(self.store["pipe_words"].max().item())
         if code != 0:
-            self.store["pipe_status"].zero_()
+            self.store["pipe_words"].zero_()
             kind = {1: "recurrent forward kernel", 2: "BPTT kernel", 3: "chunked GEMM", 4: "K-streaming GEMM", 5: "join"}.get(code, "kernel")
             raise RuntimeError("a device-side wait timed out (%s waiting for its producer: stream / hardware queue aliasing?); "
                                "set Engine.pipeline = False" % kind)

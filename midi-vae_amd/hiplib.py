@@ -23,7 +23,7 @@ CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -115,8 +115,7 @@ SIGNATURES = {
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mvae_stream_wait_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_stream_write_value32": (_i32, [_vp, _vp, C.c_uint32]),
-    "mvae_flag_set": (_i32, [_vp, C.c_uint32, _vp]),
-    "mvae_flags_wait": (_i32, [_vp, _i32, C.c_uint32, _vp, _vp]),
+    "mvae_occupancy": (_i32, [_i32]),
     "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
@@ -137,6 +136,7 @@ SIGNATURES = {
     "mvae_rmsprop_step": (_i32, [_vp, _vp, _vp, _sz, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "mvae_scalars_accumulate": (_i32, [_vp, _vp, _i32, _f32, C.c_uint32, _vp]),
     "mvae_copy2d_f32": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mvae_history_from_latent": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp]),
     "mvae_signature_head_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mvae_signature_head_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _f32, _vp]),
     "mvae_softmax_bwd_add": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -23,6 +23,7 @@ reference).
 from __future__ import annotations
 
 import json
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -53,11 +54,31 @@ class DeviceLatent(object):
     """Sampled z of every window of a song, resident in HBM - what ``encoder.predict(..., device=True)`` returns instead of a
     host array.  Passed in the history slot of the fit / evaluate input list it stands for the ROLLED history of reference
     vae_training.py:795-798 (H[1:] = z[:-1], H[0] = 0): the engine places row i-1 beside window i on the device, so the
-    history pre-pass costs no device->host->device round trip.  ``numpy()`` gives the rolled host array the reference builds."""
+    history pre-pass costs no device->host->device round trip.  ``numpy()`` gives the rolled host array the reference builds.
 
-    def __init__(self, z_dev):
-        self.z = z_dev                    # (n, Z) f32 device tensor, UNROLLED
-        self.shape = tuple(z_dev.shape)
+    The object is DEFERRED when it is created: the draw of the pre-pass (a fresh epsilon per window, taken from the model's
+    generator at the time of the ``predict`` call, so the random stream is the reference's) and the caller's arrays are kept,
+    the encoder has not run.  ``autoencoder.fit`` on the same song then takes the history of its FIRST minibatch out of that
+    minibatch's own encoder forward - same weights, same windows, same mu / log sigma^2, two draws (reference
+    vae_definition.py:498-502) - and runs the encoder once, at a chip-filling batch, over the windows of the later
+    minibatches before its first update (model.Autoencoder.fit); a song of one minibatch pays no second encoder forward at
+    all.  Any other use (evaluate, latent(), numpy(), a fit on other windows, data parallel runs) runs the pre-pass when it
+    is first needed.  Either way the weights must be those of the ``predict`` call: a model updated in between raises."""
+
+    def __init__(self, z_dev=None, shared=None, arrays=None, eps=None, parent=None, rows=None):
+        self._parent = parent
+        if parent is not None:                        # a prefix view (packers: H[:-1] with the next-notes head)
+            self.shape = (rows, parent.shape[1])
+            return
+        self._shared, self._arrays, self.eps = shared, arrays, eps
+        if z_dev is not None:
+            self._z, self._valid = z_dev, True
+        else:
+            import torch
+            self._z = torch.zeros(eps.shape, dtype=torch.float32, device=shared.engine_device())
+            self._valid = False
+            self._version = shared.param_version()
+        self.shape = tuple(self._z.shape)
 
     def __len__(self):
         return self.shape[0]
@@ -66,7 +87,44 @@ class DeviceLatent(object):
         """prefix slices only (the packers drop the last window when the next-notes head is on: H[:-1])"""
         if not (isinstance(sl, slice) and sl.start in (None, 0) and sl.step in (None, 1)):
             raise IndexError("DeviceLatent supports prefix slices only; use .numpy() for anything else")
-        return DeviceLatent(self.z[sl])
+        rows = len(range(*sl.indices(self.shape[0])))
+        return DeviceLatent(parent=self._root(), rows=rows)
+
+    def _root(self):
+        return self if self._parent is None else self._parent
+
+    @property
+    def deferred(self):
+        return not self._root()._valid
+
+    def check_version(self):
+        r = self._root()
+        if not r._valid and r._version != r._shared.param_version():
+            raise RuntimeError("the model's weights changed between encoder.predict(device=True) and the use of its result: the "
+                               "history pre-pass must see the weights fit starts from (reference vae_training.py:795-809)")
+
+    def matches(self, X, n):
+        """is ``X`` (the notes input of a fit call) the window array this latent was requested for - or a prefix of it?"""
+        r = self._root()
+        X0 = r._arrays[0]
+        return (n == self.shape[0] and isinstance(X, np.ndarray) and isinstance(X0, np.ndarray) and X.shape[1:] == X0.shape[1:] and
+                X.dtype == X0.dtype and X.__array_interface__["data"][0] == X0.__array_interface__["data"][0] and
+                X.strides == X0.strides)
+
+    def mark_valid(self):
+        r = self._root()
+        r._valid, r._arrays = True, None
+
+    @property
+    def z(self):
+        """(n, Z) f32 device tensor, UNROLLED; runs the pre-pass if it has not run yet"""
+        r = self._root()
+        if not r._valid:
+            r.check_version()
+            X, I, Vel, Held = r._arrays
+            r._shared.encode_windows(X, I, Vel, Held, r.eps, 0, r.shape[0], r._z)
+            r.mark_valid()
+        return r._z[:self.shape[0]]
 
     def latent(self):
         return self.z.cpu().numpy()
@@ -79,36 +137,71 @@ class DeviceLatent(object):
 
 
 class _Shared(object):
-    """State shared by the three model views: spec, parameters, engine."""
+    """State shared by the three model views: spec, parameters, engines."""
 
     def __init__(self, spec: ModelSpec, dtype, seed, device):
         self.spec, self.dtype, self.seed, self.device = spec, dtype, seed, device
         self.layout = ParamLayout.build(spec)
         self.params_host = init_params(spec, seed)     # authoritative copy until an engine exists
-        self.engine = None
+        self.engine = None                # the training engine (sized for the caller's batch_size); owns the parameters
+        self.infer = None                 # forward-only engine for chip-filling inference batches; shares parameters and streams
+        self.infer_cap = int(os.environ.get("MVAE_INFER_BATCH", "2048"))
+        self.pver = [0]                   # parameter version: bumped by every update / load (Engine._pver), survives engine regrowth
         self.rng = np.random.default_rng(seed + 1)
         self.teacher_force = False        # extra ground-truth inputs in the lists (no effect on the graph, SURVEY F9)
         self.next_teacher_force = False
-        self.dp = None                    # dp.DataParallel: minibatches are sharded over its ranks inside fit
+        self.dp = None                    # dp.DataParallel: minibatches are sharded over its ranks inside fit / evaluate / predict
 
-    def get_engine(self, batch, training=True):
-        """The engine, sized for ``batch`` windows on first use (callers pass their ``batch_size``, not the length of the song
-        at hand, so that songs of different lengths do not rebuild it).  A larger request rebuilds it; parameters AND
+    def get_engine(self, batch=16, training=True):
+        """The training engine, sized for ``batch`` windows on first use (callers pass their ``batch_size``, not the length of
+        the song at hand, so that songs of different lengths do not rebuild it).  A larger request rebuilds it; parameters AND
         optimizer state (Adam moments, step count) move to the new engine - Keras keeps both across fit calls."""
         from .engine import Engine                      # imported lazily: needs the HIP library and a GPU
         need = max(int(batch), 16)
-        if self.engine is None or self.engine.maxB < need or (training and not self.engine.training):
+        if self.engine is None or self.engine.maxB < need:
             old = self.engine
             params = old.get_params() if old is not None else self.params_host
-            opt = old.get_optimizer_state() if (old is not None and old.training) else None
-            self.engine = None
+            opt = old.get_optimizer_state() if old is not None else None
+            self.engine = self.infer = None             # (the forward-only engine views the old engine's parameter buffer)
             del old
             self.engine = Engine(self.spec, max_batch=need, dtype=self.dtype, device=self.device, seed=self.seed,
                                  training=True)
             self.engine.set_params(params)
+            self.engine._pver = self.pver               # (the same parameters in a bigger engine: the version does not move)
             if opt is not None:
                 self.engine.set_optimizer_state(opt)
         return self.engine
+
+    def get_infer(self, n):
+        """The forward-only engine for ``n`` windows at once (capped: MVAE_INFER_BATCH, default 2048, and a third of the free
+        HBM).  encoder.predict / autoencoder.evaluate / predict / decoder.predict* run through it at a chip-filling batch whatever
+        ``batch_size`` the caller passes: a recurrence occupies one CU per 16 windows, so the caller's 256 windows are 16 of 256
+        CUs for a pass that has no optimizer step to wait for (results are per window: identical either way)."""
+        import torch
+        from .engine import Engine
+        base = self.get_engine()
+        want = min(Engine.pad16(max(int(n), 16)), max(self.infer_cap, 16))
+        if self.infer is None or self.infer.maxB < want:
+            have = self.infer.maxB if self.infer is not None else 0
+            self.infer = None
+            size = 256
+            while size < want:
+                size *= 2
+            size = min(size, max(Engine.pad16(self.infer_cap), 16))
+            free, _ = torch.cuda.mem_get_info(base.device)
+            per = Engine.forward_bytes_per_window(self.spec, base.kind)
+            size = max(16, min(size, int(free // 3 // per) // 16 * 16))
+            size = max(size, min(have, want))
+            self.infer = Engine(self.spec, max_batch=size, dtype=self.dtype, device=self.device, seed=self.seed, training=False,
+                                share=base)
+        return self.infer
+
+    def engine_device(self):
+        import torch
+        return torch.device(self.device)
+
+    def param_version(self):
+        return self.pver[0]
 
     def current_params(self):
         return self.engine.get_params() if self.engine is not None else self.params_host
@@ -117,9 +210,42 @@ class _Shared(object):
         self.params_host = OrderedDict((k, np.asarray(v, np.float32)) for k, v in named.items())
         if self.engine is not None:
             self.engine.set_params(self.params_host)
+        else:
+            self.pver[0] += 1
 
     def epsilon(self, n):
         return (self.rng.standard_normal((n, self.spec.Z)) * self.spec.epsilon_std).astype(np.float32)
+
+    def epsilon_batches(self, n, batch_size):
+        """(n, Z) draws in the order a loop over minibatches of ``batch_size`` windows takes them (Keras' predict / evaluate
+        sample once per batch): internal batching changes nothing about the random stream"""
+        if n <= 0:
+            return np.zeros((0, self.spec.Z), np.float32)
+        return np.concatenate([self.epsilon(min(n, lo + batch_size) - lo) for lo in range(0, n, batch_size)], 0)
+
+    def world(self):
+        dp = self.dp
+        return dp if (dp is not None and dp.world > 1) else None
+
+    def encode_windows(self, X, I, Vel, Held, eps, lo, hi, out):
+        """sampled z of windows [lo, hi) -> rows [lo, hi) of the device tensor ``out``, through the forward-only engine at its
+        batch; under data parallelism every rank encodes a contiguous share and the rows are exchanged (one all-reduce of a
+        buffer that is zero outside the rank's share: n x Z floats)."""
+        from .dp import shard_bounds
+        if hi <= lo:
+            return
+        dp = self.world()
+        a0, b0 = (lo, hi) if dp is None else tuple(lo + v for v in shard_bounds(hi - lo, dp.world, dp.rank))
+        eng = self.get_infer(b0 - a0)
+        st = eng.stager()
+        if dp is not None:
+            out[lo:hi].zero_()
+        for p in range(a0, b0, eng.maxB):
+            q = min(b0, p + eng.maxB)
+            B = st.stage(p, q, X=X, I=I, Vel=Vel, Held=Held, eps=eps[p:q])
+            out[p:q].copy_(eng.encode(B))
+        if dp is not None:
+            dp.allreduce_sum(out[lo:hi])
 
     def z_heads(self):
         """(Keras output name, metric prefix) of the outputs behind the decoder's, in the reference's order (vae_definition.py:
@@ -210,23 +336,23 @@ class Encoder(_ModelView):
         return X, I, V, D
 
     def predict(self, x, batch_size=32, verbose=0, device=False):
-        """Sampled z for every window (fresh epsilon per call, reference vae_definition.py:498-502).  The batches run back to
-        back on the device; z is read back once.  ``device=True``: no read-back at all - a DeviceLatent for the history slot of
-        the next fit / evaluate (the history pre-pass of reference vae_training.py:788-798, kept in HBM)."""
+        """Sampled z for every window (fresh epsilon per call, drawn per ``batch_size`` windows as Keras' predict loop does:
+        reference vae_definition.py:498-502).  The encoder itself runs at a chip-filling internal batch (_Shared.get_infer), under
+        data parallelism on this rank's share of the windows; z is read back once.  ``device=True``: no read-back and - until
+        something needs the values - no encoder pass either: a deferred DeviceLatent for the history slot of the next fit /
+        evaluate (the history pre-pass of reference vae_training.py:788-798, fused into that call)."""
         import torch
         X, I, Vel, Held = self._unpack(x)
         n = np.asarray(X).shape[0]
-        eng = self._s.get_engine(batch_size)
-        st = eng.stager()
-        out = torch.empty((n, self._s.spec.Z), dtype=torch.float32, device=eng.device)
-        for lo in range(0, n, batch_size):
-            hi = min(n, lo + batch_size)
-            B = st.stage(lo, hi, X=X, I=I, Vel=Vel, Held=Held, eps=self._s.epsilon(hi - lo))
-            out[lo:hi].copy_(eng.encode(B))
+        eps = self._s.epsilon_batches(n, batch_size)
         if device:
-            return DeviceLatent(out)
+            return DeviceLatent(shared=self._s, arrays=(X, I, Vel, Held), eps=eps)
+        eng = self._s.get_engine()
+        out = torch.zeros((n, self._s.spec.Z), dtype=torch.float32, device=eng.device)
+        self._s.encode_windows(X, I, Vel, Held, eps, 0, n, out)
         res = out.cpu().numpy()
-        eng.check_pipeline()
+        if self._s.infer is not None:
+            self._s.infer.check_pipeline()
         return res
 
 
@@ -255,20 +381,23 @@ class Decoder(_ModelView):
         return res
 
     def _run(self, x, batch_size, want_probs=True):
+        """decoder forward over all windows at the forward-only engine's batch (``batch_size`` is the caller's: results are per
+        window); every rank decodes everything it is given - decoding is pure replicas"""
         sp = self._s.spec
         a = self._unpack(x)
         z = np.asarray(a.pop("z"))
         n = z.shape[0]
-        eng = self._s.get_engine(batch_size)
+        eng = self._s.get_infer(n)
         outs, idxs = [], []
-        for lo in range(0, n, batch_size):
-            hi = min(n, lo + batch_size)
+        for lo in range(0, n, eng.maxB):
+            hi = min(n, lo + eng.maxB)
             B = hi - lo
             eng.stage_decoder_inputs(B, z=z[lo:hi], **{k: (None if v is None else np.asarray(v)[lo:hi]) for k, v in a.items()})
             eng.decode(B, want_probs=want_probs)
             if want_probs:
                 outs.append(eng.outputs(B))
             idxs.append(eng.note_indices(B))
+        eng.check_pipeline()
         return outs, np.concatenate(idxs, 0) if idxs else np.zeros((0, sp.T), np.uint8)
 
     def predict(self, x, batch_size=32, verbose=0):
@@ -387,7 +516,7 @@ class Autoencoder(_ModelView):
     @staticmethod
     def _history_source(hist):
         if isinstance(hist, DeviceLatent):
-            return None, hist.z
+            return None, hist.z             # (runs the pre-pass if it is still deferred)
         return hist, None
 
     # ---- Keras methods -----------------------------------------------------------------------------------------
@@ -396,12 +525,18 @@ class Autoencoder(_ModelView):
         values are batch-size-weighted means over the minibatches of each epoch (Keras BaseLogger semantics), accumulated on
         the device and read back ONCE per epoch.
 
+        A deferred DeviceLatent in the history slot (``encoder.predict(..., device=True)`` on the same song, reference
+        vae_training.py:788-798) is the FUSED history pre-pass: the windows of the later minibatches are encoded first - forward
+        only, at a chip-filling batch, with the weights this call starts from - and the first minibatch's history comes out of its
+        own encoder forward (Engine.train_step_begin ``hist_fused``): a song of one minibatch runs its encoder once, not twice.
+
         Data parallel (``dp``: dp.DataParallel, or VAE.set_data_parallel): every rank calls fit with the SAME arguments; each
         global minibatch is split contiguously over the ranks (dp.shard_bounds), the losses are normalised by the GLOBAL counts,
         gradients are summed by one all-reduce per step - the parameters after every step equal the single-process run's (to
         f32 summation order), ragged last minibatches and empty shards included, and every rank executes the same number of
-        collectives by construction.  ``allreduce`` (legacy hook: each rank trains on its OWN minibatches, mean of gradients)
-        is kept for bench-style callers."""
+        collectives by construction.  NOTE: the ranks SPLIT ``batch_size``; keep per-GPU work constant by growing it with the
+        world (256 windows per rank fill 16 of a GPU's 256 CUs per recurrence - fewer do not run faster).  ``allreduce``
+        (legacy hook: each rank trains on its OWN minibatches, mean of gradients) is kept for bench-style callers."""
         if shuffle:
             raise NotImplementedError("shuffle=True (the reference always passes shuffle=False)")
         from .dp import shard_bounds
@@ -414,8 +549,20 @@ class Autoencoder(_ModelView):
         a.update(ws)
         dp = self._dp(dp)
         eng = self._s.get_engine(batch_size, training=True)
+        eng.status_allreduce = dp.allreduce_max if dp is not None else None
         st = eng.stager()
-        a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
+        lat = a.get("hist") if isinstance(a.get("hist"), DeviceLatent) else None
+        fused = None
+        if lat is not None and lat.deferred:
+            lat.check_version()
+            if dp is None and epochs == 1 and n > 0 and lat.matches(a["X"], n):
+                fused = lat
+                b0 = min(n, batch_size)
+                if n > b0:      # histories of the later minibatches: before the first update, forward only, chip-filling
+                    self._s.encode_windows(a["X"], a.get("I"), a.get("Vel"), a.get("Held"), lat._root().eps, b0, n, lat._root()._z)
+                a["hist"], a["hist_dev"] = None, lat._root()._z
+        if fused is None:
+            a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
         keys = self._history_keys()
         pending = []
         for e in range(epochs):
@@ -426,14 +573,18 @@ class Autoencoder(_ModelView):
                 a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
                 if b0 > a0:
                     norm = Norm.of(lo, hi, sp.T, **ws)
+                    first = fused is not None and lo == 0
                     # the encoder's inputs first; the heads' targets are converted while the encoder already runs on the device
-                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, defer_targets=True, **a)
-                    eng.train_step_begin(B)
+                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, defer_targets=True,
+                                 eps2=fused._root().eps[:hi] if first else None, **a)
+                    eng.train_step_begin(B, hist_fused=(eng._v("in.eps2", eng.pad16(B), sp.Z), fused._root()._z[:hi]) if first else None)
                     st.finish_targets()
-                    eng.train_step_finish(B, allreduce=dp.allreduce_grads if dp is not None else allreduce)
+                    eng.train_step_finish(B, allreduce=dp.hook(eng) if dp is not None else allreduce)
                     eng.accumulate_metrics(hi - lo)
+                    if first:
+                        fused.mark_valid()
                 else:
-                    eng.train_step_empty(dp.allreduce_grads)
+                    eng.train_step_empty(dp.hook(eng))
             if dp is not None:          # every rank, every fit call, here - not when (and if) a rank reads the History
                 dp.allreduce_sum(acc)
             pending.append(acc)
@@ -449,20 +600,30 @@ class Autoencoder(_ModelView):
         return history
 
     def _forward_all(self, x, y, batch_size, want_probs):
+        """forward (+ losses) over all windows at the forward-only engine's batch; epsilon drawn per ``batch_size`` windows as
+        Keras' evaluate / predict loops draw it.  With targets and data parallelism every rank takes a contiguous share of each
+        internal batch (global normalisers, accumulators summed over the ranks: reference vae_training.py:286-300 on all GPUs)."""
+        from .dp import shard_bounds
         from .staging import Norm
         sp = self._s.spec
         a = self._unpack_x(x)
         if y is not None:
             a.update(self._unpack_y(y))
         n = np.asarray(a["X"]).shape[0]
-        eng = self._s.get_engine(batch_size)
-        st = eng.stager()
         a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
+        dp = self._s.world() if (y is not None and not want_probs) else None
+        eps = self._s.epsilon_batches(n, batch_size)
+        eng = self._s.get_infer(n if dp is None else -(-n // dp.world))
+        st = eng.stager()
         outs = []
         eng.reset_accumulated()
-        for lo in range(0, n, batch_size):
-            hi = min(n, lo + batch_size)
-            B = st.stage(lo, hi, eps=self._s.epsilon(hi - lo), norm=Norm.of(lo, hi, sp.T) if y is not None else None, **a)
+        step = eng.maxB * (dp.world if dp is not None else 1)
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
+            if b0 <= a0:
+                continue
+            B = st.stage(lo + a0, lo + b0, eps=eps[lo + a0:lo + b0], norm=Norm.of(lo, hi, sp.T) if y is not None else None, **a)
             if y is None:
                 eng._have_targets = False
                 eng.scal.zero_()
@@ -475,7 +636,11 @@ class Autoencoder(_ModelView):
                 eng.accumulate_metrics(hi - lo)
             if want_probs:
                 outs.append(eng.outputs(B))
-        tot = eng.read_accumulated(n) if y is not None else None
+        tot = None
+        if y is not None:
+            tot = eng.read_accumulated(n, allreduce_sum=dp.allreduce_sum if dp is not None else None)
+        else:
+            eng.check_pipeline()
         return tot, outs, n
 
     def evaluate(self, x, y, batch_size=32, verbose=0, sample_weight=None):

@@ -116,16 +116,6 @@ def stream_write_value32(word, value, stream=None):
              "mvae_stream_write_value32")
 
 
-def flag_set(word, value, stream):
-    """``stream`` ends its work so far with a one-thread kernel that stores ``value`` to the 32-bit device word"""
-    hl.check(hl.load().mvae_flag_set(_p(word), int(value), stream.cuda_stream), "mvae_flag_set")
-
-
-def flags_wait(words, n, value, status=None):
-    """a one-wave kernel on the current stream that returns once words[0..n) >= value (device-side join)"""
-    hl.check(hl.load().mvae_flags_wait(_p(words), int(n), int(value), _pv(status), _stream()), "mvae_flags_wait")
-
-
 def colsum(X, R, N, out, ldx=None):
     hl.check(hl.load().mvae_colsum(X.data_ptr(), kind_of(X), R, N, N if ldx is None else ldx, _p(out), _stream()),
              "mvae_colsum")
@@ -256,11 +246,12 @@ class PrepBatch:
     def zero(self, dst):
         self._add(hl.PREP_ZERO, dst, dst.numel(), 1, 0, None)
 
-    def add_i32(self, counter, value=1, guard=None):
-        """*counter (int32 device scalar) += value  (not while the device word ``guard`` is non-zero)"""
+    def add_i32(self, counter, value=1, guard=None, latch=None):
+        """*counter (int32 device scalar) += value  (not while the device word ``guard`` is non-zero); with ``latch`` a non-zero
+        guard word is then moved there (max) and cleared"""
         assert counter.dtype == torch.int32
-        self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, _p(guard), None, _p(counter)))
-        self._keep += [counter, guard]
+        self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, _p(guard), _p(latch), _p(counter)))
+        self._keep += [counter, guard, latch]
         self._arr = None
 
     def convert_pad(self, W, out, n_pad):
@@ -328,3 +319,11 @@ def copy2d(dst, src, rows, cols, src_row0=0, zero_rows=0):
     of dst are zeroed instead"""
     hl.check(hl.load().mvae_copy2d_f32(_pv(dst), dst.stride(0), _pv(src), src.stride(0), int(rows), int(cols), int(src_row0),
                                        int(zero_rows), _stream()), "mvae_copy2d_f32")
+
+
+def history_from_latent(mu, logvar, eps2, B, B_pad, Z, hist, z_out=None, prev=None):
+    """the fused history pre-pass: z' = mu + exp(logvar / 2) * eps2 -> z_out rows [0, B); hist (a column-block view of
+    [z | history]) row b = z'[b-1], row 0 = prev (or zeros), rows B.. zero"""
+    hl.check(hl.load().mvae_history_from_latent(_p(mu), _p(logvar), _pv(eps2), int(B), int(B_pad), int(Z), _pv(hist), hist.stride(0),
+                                                _pv(prev), _pv(z_out), z_out.stride(0) if z_out is not None else 0, _stream()),
+             "mvae_history_from_latent")

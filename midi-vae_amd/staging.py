@@ -163,12 +163,13 @@ class Stager(object):
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
               norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None,
-              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False):
+              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False, eps2=None):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
         a DEVICE tensor (n, Z) of sampled z whose row i-1 is the history of window i (zeros for window 0) - the fused history
-        pre-pass; neither: zeros.  Returns the number of windows staged.
+        pre-pass; neither: zeros.  ``eps2`` (B, Z): the draw of a history pre-pass FUSED into this train step (the engine then
+        writes the history columns itself: Engine.train_step_begin).  Returns the number of windows staged.
 
         ``defer_targets``: convert and upload everything the ENCODER needs now and leave the decoder heads' targets and row weights
         (the second 64 MB float64 tensor of a minibatch) to ``finish_targets()`` - called after the encoder's launches are
@@ -199,12 +200,14 @@ class Stager(object):
         if s.meta_next:
             self._rows_bm(k, "in.start_next", start_next, lo, hi, s.Dout, Bp)
         self._rows_bm(k, "in.eps", eps, 0, B, s.Z, Bp)
+        if eps2 is not None:
+            self._rows_bm(k, "in.eps2", eps2, 0, B, s.Z, Bp)
         self._rows_bm(k, "in.start_notes", start_notes, lo, hi, s.Dout, Bp)
         if s.meta_instrument:
             self._rows_bm(k, "in.start_instr", start_instr, lo, hi, s.ID, Bp)
         if s.meta_velocity:
             self._rows_bm(k, "in.start_vel", start_vel, lo, hi, 1, Bp)
-        if s.history and hist_dev is None:
+        if s.history and hist_dev is None and eps2 is None:
             self._rows_bm(k, "in.hist", hist, lo, hi, s.Z, Bp)
         if z is not None:
             self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
@@ -262,7 +265,7 @@ class Stager(object):
         # [z | history]: the decoder's initial-state Denses read one (Bp, zin) operand
         zh = eng._v("zh", Bp, s.zin)
         from . import ops
-        if s.history:
+        if s.history and eps2 is None:
             if hist_dev is not None:
                 # history of window i = sampled z of window i-1, zeros for the first window of the song
                 first = 1 if lo == 0 else 0

@@ -152,3 +152,56 @@ def test_two_rank_training_script_epoch_runs_in_step():
     for tr in (tr0, tr1):
         assert np.isfinite(tr["loss"]) and np.isfinite(tr["kl_loss"]) and tr["kl_loss"] >= 0
     assert tr1["loss"] < tr0["loss"]
+
+
+def _prepass_eval(cfg, dp):
+    """history pre-pass (encoder.predict on the device) + evaluate of two ragged songs, as vae_training.run_epoch(train=False)
+    drives them (reference vae_training.py:286-300)"""
+    s = build_settings(**cfg["settings"])
+    m = VAE().create(compute_dtype=cfg["dtype"], seed=3, **create_kwargs(s))
+    m.set_data_parallel(dp)
+    res = []
+    for i, n in enumerate(cfg["lengths"]):
+        w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=50 + i)
+        X, Y, C, I, V, D = to_reference_format(w)
+        lat = m.encoder.predict(pk.prepare_encoder_input_list(s, X, I, V, D), batch_size=s["batch_size"], device=True)
+        x, y = pk.prepare_autoencoder_input_and_output_list(s, X, Y, i % 2, I, V, D, np.zeros((n, s["signature_vector_length"])), lat)
+        ev = m.autoencoder.evaluate(x, y, batch_size=s["batch_size"], verbose=False)
+        zhost = m.encoder.predict(pk.prepare_encoder_input_list(s, X, I, V, D), batch_size=s["batch_size"])
+        res.append((lat.latent(), [float(v) for v in ev], zhost))
+    m._shared.infer.check_pipeline()
+    return res
+
+
+def _prepass_worker(rank, world, port, cfg, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), MVAE_PIPELINE="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from midi_vae_amd.dp import DataParallel
+        res = _prepass_eval(cfg, DataParallel(dist))
+        if rank == 1:                   # (the rank with the SMALLER shares: it must hold every window's z and the global metrics too)
+            out.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_two_rank_sharded_prepass_and_evaluate_equal_single_process(case):
+    """``encoder.predict`` and ``autoencoder.evaluate`` shard each song's windows over the ranks (the pre-pass
+    rows are exchanged, the metric accumulators summed): every rank ends up with the single-process z of EVERY window and the
+    single-process metrics - odd window counts (21 = 11 + 10, 17 = 9 + 8) and a song shorter than two shards of 16 included."""
+    cfg = dict(CASES[case], lengths=[21, 17, 3] if CASES[case]["dtype"] == "f32" else [40, 19])
+    got = _run_ranks(_prepass_worker, 2, cfg)
+    os.environ["MVAE_PIPELINE"] = "0"
+    try:
+        want = _prepass_eval(cfg, None)
+    finally:
+        os.environ.pop("MVAE_PIPELINE")
+    tol = 2e-5 if cfg["dtype"] == "f32" else 2e-3
+    for (z2, e2, h2), (z1, e1, h1) in zip(got, want):
+        np.testing.assert_allclose(z2, z1, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(h2, h1, rtol=0, atol=1e-5)
+        for a, b in zip(e2, e1):
+            assert abs(a - b) <= tol * (1 + abs(b)), (e2, e1)

@@ -258,3 +258,147 @@ def test_history_is_filled_on_first_access_and_survives_later_fit_calls():
         for k in a:
             assert len(a[k]) == 2 and np.allclose(a[k], b[k], rtol=1e-6, atol=1e-7), (k, a[k], b[k])
     assert vals[False][2]["loss"][1] < vals[False][0]["loss"][0]
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+@pytest.mark.parametrize("n,bs", [(7, 8), (21, 8)])
+def test_fused_history_prepass_matches_the_oracle(cell, n, bs):
+    """f-1, checked against the ORACLE (not against the host path): reference vae_training.py:788-809 runs
+    ``z' = encoder.predict(song)`` (fresh draw eps'), rolls it into the history input and then ``fit`` - both on the weights
+    the fit call starts from.  Here ``encoder.predict(device=True)`` returns a deferred DeviceLatent and ``fit`` takes the first
+    minibatch's history out of that minibatch's own encoder forward (one encoder pass for a one-minibatch song: n=7) and encodes
+    the windows of the later minibatches forward-only before its first update (n=21: 8 + 8 + 5).  The oracle does what the
+    reference does: ``encode`` with the PRE-step parameters and eps' gives z'; its train steps on H = roll(z') with the fit
+    call's draws give the history's loss, and the parameters after the call."""
+    from midi_vae_amd.layout import init_params
+    from midi_vae_amd.model import DeviceLatent
+    s = build_settings(cell_type=cell, lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=bs,
+                       learning_rate=1e-3, epsilon_std=0.7)
+    m = VAE().create(compute_dtype="f32", seed=3, **create_kwargs(s))
+    w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=15)
+    X, Y, C, I, V, D = to_reference_format(w)
+    S = np.zeros((n, s["signature_vector_length"]))
+    m._shared.rng = np.random.default_rng(11)
+    enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+    lat = m.encoder.predict(enc_in, batch_size=bs, verbose=False, device=True)
+    assert isinstance(lat, DeviceLatent) and lat.deferred and lat.shape == (n, s["latent_dim"])
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, lat, return_sample_weight=True)
+    hist = m.autoencoder.fit(x, y, epochs=1, batch_size=bs, shuffle=False, sample_weight=sw, verbose=False)
+    assert not lat.deferred
+    if n <= bs:
+        assert m._shared.infer is None, "a one-minibatch song must not run a separate encoder pass"
+    # ---- the oracle, doing what the reference does
+    spec = m.spec
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p = {k: v.astype(np.float64) for k, v in init_params(spec, 3).items()}
+    rng = np.random.default_rng(11)
+    draw = lambda k: (rng.standard_normal((k, spec.Z)) * spec.epsilon_std).astype(np.float32).astype(np.float64)
+    eps2 = np.concatenate([draw(min(n, lo + bs) - lo) for lo in range(0, n, bs)], 0)       # encoder.predict: one draw per batch
+    It = np.tile(I[None], (n, 1, 1))
+    z_pre = orc.encode(p, X, It, V[:, :, None], eps2)
+    np.testing.assert_allclose(lat.latent(), z_pre, rtol=0, atol=2e-5)
+    H = history_from_z(z_pre)
+    st = orc.new_opt_state(p)
+    Coh = np.eye(s["num_classes"])[np.full(n, C)]
+    tot = {}
+    for lo in range(0, n, bs):
+        hi = min(n, lo + bs)
+        b = dict(X=X[lo:hi], I=It[lo:hi], Vel=V[lo:hi, :, None], Hist=H[lo:hi], Y=Y[lo:hi], C=Coh[lo:hi])
+        for k, v in orc.train_step(p, st, b, draw(hi - lo)).items():
+            tot[k] = tot.get(k, 0.0) + v * (hi - lo) / n
+    h = {k: v[0] for k, v in hist.history.items()}
+    for got, want in (("loss", "loss"), ("decoder_loss_1", "notes_loss"), ("decoder_loss_2", "instr_loss"),
+                      ("decoder_loss_3", "vel_loss"), ("composer_decoder_loss", "style_loss")):
+        assert abs(h[got] - tot[want]) <= 2e-4 * (1 + abs(tot[want])), (got, h[got], tot[want])
+    for nme, a in zip(m.autoencoder._names(), m.autoencoder.get_weights()):
+        assert np.allclose(a, p[nme], rtol=2e-3, atol=3e-5), nme
+
+
+def test_deferred_latent_refuses_changed_weights():
+    """the pre-pass must see the weights fit starts from: a deferred DeviceLatent used after an update raises"""
+    s, m, (X, Y, C, I, V, D) = _setup("GRU", n=9)
+    n = X.shape[0]
+    S = np.zeros((n, s["signature_vector_length"]))
+    enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+    lat = m.encoder.predict(enc_in, batch_size=8, device=True)
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, np.zeros((n, s["latent_dim"])),
+                                                            return_sample_weight=True)
+    m.autoencoder.fit(x, y, epochs=1, batch_size=8, shuffle=False, sample_weight=sw, verbose=False)
+    with pytest.raises(RuntimeError):
+        lat.latent()
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_chip_filling_internal_batch_gives_the_callers_results_h256_bf16(cell, monkeypatch):
+    """encoder.predict / evaluate / decoder.predict_note_indices run at the forward-only engine's batch, whatever ``batch_size``
+    the caller passes (reference vae_training.py:289,300, vae_evaluation.py:2482: Keras loops over batch_size windows).  The
+    results are per window and epsilon is drawn per caller batch, so a model capped at the caller's batch (MVAE_INFER_BATCH=32:
+    time-pipelined stacks, 32 windows at a time) and one that takes all 400 windows at once (the layers as chunk launches: the
+    stack's kernels would not all be resident) must agree."""
+    n, bs = 400, 32
+    res = {}
+    for cap in (32, 2048):
+        monkeypatch.setenv("MVAE_INFER_BATCH", str(cap))
+        s = build_settings(cell_type=cell, lstm_size=256, latent_dim=64, input_length=16, output_length=16, batch_size=bs,
+                           epsilon_std=0.5)
+        m = VAE().create(compute_dtype="bf16", seed=5, **create_kwargs(s))
+        w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=21)
+        X, Y, C, I, V, D = to_reference_format(w)
+        S = np.zeros((n, s["signature_vector_length"]))
+        m._shared.rng = np.random.default_rng(2)
+        enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+        z = m.encoder.predict(enc_in, batch_size=bs)
+        eng = m._shared.infer
+        assert eng.maxB == (32 if cap == 32 else 512)
+        x, y = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, history_from_z(z))
+        ev = m.autoencoder.evaluate(x, y, batch_size=bs)
+        idx = m.decoder.predict_note_indices(pk.prepare_decoder_input(s, z, C, S, None), batch_size=bs)
+        res[cap] = (z, ev, idx)
+    (z0, e0, i0), (z1, e1, i1) = res[32], res[2048]
+    np.testing.assert_allclose(z1, z0, rtol=0, atol=1e-5)          # (same kernels, same arithmetic per window)
+    np.testing.assert_allclose(e1, e0, rtol=2e-4, atol=1e-5)       # (sums over another partition of the windows)
+    assert np.mean(i1 == i0) > 0.999
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_two_hundred_alternating_calls_never_time_out(cell):
+    """200 alternating fit / encoder.predict / evaluate / decoder.predict_note_indices calls on ONE model (H=256
+    bf16: training engine on time-pipelined stacks + K-streaming gradients, forward-only engine beside it on the same streams,
+    songs of 5 .. 70 windows so that ragged batches, fused and separate history pre-passes and both engines alternate): no
+    fallback warning, no time-out status on either engine, finite results throughout."""
+    import warnings
+    s = build_settings(cell_type=cell, lstm_size=256, latent_dim=64, input_length=16, output_length=16, batch_size=32,
+                       learning_rate=2e-4)
+    m = VAE().create(compute_dtype="bf16", seed=9, **create_kwargs(s))
+    rng = np.random.default_rng(0)
+    songs = []
+    for i, n in enumerate((5, 32, 33, 70, 17)):
+        w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=40 + i)
+        songs.append(to_reference_format(w) + (np.zeros((n, s["signature_vector_length"])),))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        calls = 0
+        while calls < 200:
+            X, Y, C, I, V, D, S = songs[int(rng.integers(len(songs)))]
+            n = X.shape[0]
+            enc_in = pk.prepare_encoder_input_list(s, X, I, V, D)
+            lat = m.encoder.predict(enc_in, batch_size=32, device=bool(calls % 3))       # deferred latent, or a host array
+            H = lat if calls % 3 else history_from_z(lat)
+            calls += 1
+            if calls % 2:
+                x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+                h = m.autoencoder.fit(x, y, epochs=1, batch_size=32, shuffle=False, sample_weight=sw, verbose=False)
+                assert np.isfinite(h.history["loss"][0])
+            else:
+                x, y = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H)
+                assert np.all(np.isfinite(m.autoencoder.evaluate(x, y, batch_size=32, verbose=False)))
+            calls += 1
+            if calls % 5 == 0:
+                z = lat.latent() if calls % 3 and hasattr(lat, "latent") else np.asarray(rng.standard_normal((n, s["latent_dim"])))
+                idx = m.decoder.predict_note_indices(pk.prepare_decoder_input(s, z, C, S, None), batch_size=32)
+                assert idx.shape == (n, 64) and idx.max() < 61
+                calls += 1
+    assert not [str(w.message) for w in rec if "timed out" in str(w.message)], [str(w.message) for w in rec]
+    for eng in (m._shared.engine, m._shared.infer):
+        eng.check_pipeline()
+        assert eng.pipeline, "the engine fell back to chunked launches"

@@ -134,7 +134,8 @@ def test_engine_refuses_to_run_without_gpu():
 
 def test_first_use_verification_retries_once_then_falls_back():
     """Engine._verify_pipeline (host logic only): a timed-out first use of a kind of call is redone once as it is; only a second
-    time-out switches the engine to chunked launches and stream-level joins; every kind of call is verified separately."""
+    time-out switches the engine to chunked launches; every kind of call is verified separately - by its first call that
+    actually ran a stack time-pipelined."""
     import types
     import warnings
     import torch
@@ -142,7 +143,7 @@ def test_first_use_verification_retries_once_then_falls_back():
 
     def fake(status_after_redo):
         calls = []
-        eng = types.SimpleNamespace(pipeline=True, device_join=False, _pipe_verified=set(), _dxp0_clean=True,
+        eng = types.SimpleNamespace(pipeline=True, _pipe_used=True, _pipe_verified=set(), _dxp0_clean=True,
                                     store={"pipe_status": torch.tensor([3], dtype=torch.int32)})
 
         def redo():
@@ -159,9 +160,14 @@ def test_first_use_verification_retries_once_then_falls_back():
     Engine._verify_pipeline(eng, redo, key="decode")  # another kind of call is checked on ITS first use
     assert calls == [1, 1] and eng.pipeline
 
+    eng, redo, calls = fake([0])                     # a call whose batch ran nothing pipelined verifies nothing
+    eng._pipe_used = False
+    Engine._verify_pipeline(eng, redo, key="train")
+    assert calls == [] and "train" not in eng._pipe_verified
+
     eng, redo, calls = fake([4, 0])                  # persistent: falls back, redoes once more
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         Engine._verify_pipeline(eng, redo, key="train")
-    assert calls == [1, 1] and not eng.pipeline and not eng.device_join and len(w) == 1
+    assert calls == [1, 1] and not eng.pipeline and len(w) == 1
     assert int(eng.store["pipe_status"]) == 0 and eng._dxp0_clean is False

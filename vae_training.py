@@ -53,8 +53,10 @@ def songs_from_pickle_cache(path, s):
 
 def history_for(model, song, s, use_encoder, on_device=True):
     """reference vae_training.py:788-798 - zeros in epoch 0, else the previous window's SAMPLED z (a fresh epsilon: one
-    extra encoder forward per song).  ``on_device``: the z of the pre-pass stays in HBM (model.DeviceLatent) and the roll
-    H[1:] = z[:-1], H[0] = 0 happens where the train step reads it; else the reference's host arrays."""
+    extra encoder forward per song in the reference).  ``on_device``: a deferred model.DeviceLatent - the draw is taken now, the
+    encoder pass is fused into the fit / evaluate call that receives it (first minibatch: out of its own encoder forward; the
+    rest: one chip-filling forward-only pass), z stays in HBM and the roll H[1:] = z[:-1], H[0] = 0 happens where the train
+    step reads it; else the reference's host arrays."""
     n = song["X"].shape[0]
     if not (s["history"] and use_encoder):
         return np.zeros((n, s["latent_dim"]))
@@ -159,10 +161,13 @@ def main():
             print("Epoch %d: train loss %.4f notes %.4f acc %.4f kl %.5f | %.0f windows/s" % (
                 e, tr["loss"], tr.get("decoder_loss_1", tr["loss"]), tr.get("decoder_acc_1", 0.0), tr["kl_loss"],
                 n_win / (time.time() - t0)))
-        if e % s["test_step"] == 0 and rank == 0:
+        if e % s["test_step"] == 0:
+            # EVERY rank: encoder.predict and evaluate shard each song over the ranks (and draw from the same generator on every
+            # rank, so the epsilon streams of the replicas stay identical) - reference vae_training.py:286-300 on all GPUs
             te = run_epoch(model, test, s, e, train=False)
-            print("         test  loss %.4f notes %.4f acc %.4f kl %.5f" % (
-                te["loss"], te.get("decoder_loss_1", te["loss"]), te.get("decoder_acc_1", 0.0), te["kl_loss"]))
+            if rank == 0:
+                print("         test  loss %.4f notes %.4f acc %.4f kl %.5f" % (
+                    te["loss"], te.get("decoder_loss_1", te["loss"]), te.get("decoder_acc_1", 0.0), te["kl_loss"]))
         if e % s["save_step"] == 0 and s["save_anything"] and rank == 0:
             os.makedirs(path, exist_ok=True)
             model.autoencoder.save_weights(os.path.join(path, "autoencoderEpoch%d.pickle" % e))
