@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py - MIDI-VAE train-step throughput on N MI355X (one process per GPU, RCCL over xGMI).
+"""bench.py - MIDI-VAE train-step (or decode) throughput on N MI355X (one process per GPU, RCCL over xGMI).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                      (BASELINE configs[1], the default)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
 
-Workload = BASELINE.json configs[1]: 2-style, seq_len=128 x voices=4 (T=512 interleaved rows), z=64, batch=256 per
-GPU, bf16 MFMA operands, LSTM cells (north_star; --cell GRU for the reference's shipped default), H=256, 2+2 layers,
-instrument + velocity + style heads.  A "step" = forward + all losses + backward + (gradient all-reduce) + Keras-Adam
-update on one minibatch of synthetic piano-roll windows already resident in HBM.  Weak scaling: 256 windows per GPU.
+Workloads = BASELINE.json ``configs`` by index (``--config``; the per-GPU share under weak scaling):
+  1  2-style, seq_len=128 x voices=4 (T=512 interleaved rows), z=64, 256 windows per GPU            train step   [default]
+  2  4-style, seq_len=256 x voices=8 (T=2048), z=128, 512 windows per GPU (1024 on 2 GPUs)          train step
+  3  the same with 4096 windows on 8 GPUs = 512 per GPU (velocity / instrument heads: on in every config here)  train step
+  4  style-transfer decode: seq_len=512 x voices=8 (T=4096), z=128, 1024 windows per GPU (8192 on 8)  decoder forward + fused argmax
+bf16 MFMA operands, LSTM cells (north_star; --cell GRU for the reference's shipped default), H=256, 2+2 layers, instrument +
+velocity + style heads.  A train "step" = forward + all losses + backward + (gradient all-reduce) + Keras-Adam update on one
+minibatch of synthetic piano-roll windows already resident in HBM; a decode "step" = one batch of latents through the decoder,
+one byte per row (the argmax note index) written.  Weak scaling: the per-GPU batch is fixed.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline     dominant kernel (the T-step recurrent kernels) measured live with HIP events on the launch stream
-  cpu_baseline the same step as float32 torch-CPU tensor operations on all host cores (oracle/torch_cpu.py), rank 0 / N=1 only,
+  cpu_baseline the same step as float32 torch-CPU tensor operations on the host cores (oracle/torch_cpu.py), rank 0 / N=1 only,
                bounded sample, timed BEFORE the GPU phase
+  elbo         (train configs, rank 0 / N=1) the ELBO after each of K_e optimizer steps with a fresh epsilon per step on the first
+               16 windows of the bench's inputs: this engine (bf16, the timed schedule) beside float64 torch-CPU arithmetic
+               (oracle/torch_cpu.py elbo_trajectory, in the CPU subprocess phase), and their largest difference
 """
 import argparse
 import json
@@ -77,6 +85,50 @@ def cpu_baseline(spec, B, budget_s=15.0, hard_limit_s=150.0):
     return best
 
 
+def cpu_elbo(spec, B, steps, limit_s=150.0):
+    """ELBO trajectory of ``steps`` real optimizer steps on the first B windows of the bench's inputs in float64 torch-CPU
+    arithmetic (oracle/torch_cpu.py elbo_trajectory) - a subprocess BEFORE the GPU phase, with a hard limit"""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "torch_cpu.py"), "--cell", spec.cell, "--T", str(spec.T), "--B", str(B),
+           "--V", str(spec.V), "--Z", str(spec.Z), "--C", str(spec.C), "--elbo-steps", str(steps), "--threads", "16"]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s, cwd=ROOT)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError, IndexError):
+        return None
+
+
+def gpu_elbo(spec, B, steps, dtype, device):
+    """the same trajectory on the engine: same windows, same initial parameters, same draws (torch_cpu.elbo_inputs / elbo_epsilon
+    are data generators shared by both sides, not arithmetic)"""
+    import torch
+    from midi_vae_amd.engine import Engine
+    from oracle.torch_cpu import elbo_epsilon, elbo_inputs
+    _, w, params = elbo_inputs(spec.cell, spec.T, B, spec.V, spec.Z, spec.C)
+    eng = Engine(spec, max_batch=B, dtype=dtype, device=device, seed=1234)
+    eng.set_params(params)
+    out = []
+    for i in range(steps):
+        eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], elbo_epsilon(i, B, spec.Z, spec.epsilon_std))
+        eng.stage_decoder_inputs(B, hist=w["hist"])
+        eng.stage_targets(B, w["x_idx"], w["c_idx"])
+        eng.train_step(B)
+        m = eng.metrics(B)
+        out.append({k: float(m[k]) for k in ("loss", "notes_loss", "instr_loss", "vel_loss", "style_loss", "kl")})
+    eng.check_pipeline()
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+CONFIGS = {     # BASELINE.json configs[i]: (seq_len, voices, latent, classes, windows per GPU, mode, global batch the config names, GPUs)
+    1: (128, 4, 64, 2, 256, "train", 256, 1),
+    2: (256, 8, 128, 4, 512, "train", 1024, 2),
+    3: (256, 8, 128, 4, 512, "train", 4096, 8),
+    4: (512, 8, 128, 4, 1024, "decode", 8192, 8),
+}
+
+
 def algorithmic_flops_per_window(spec):
     """Forward FLOPs of one window, SURVEY section 8(d) formula (mm(k,n) = 2kn; decoder input projections counted once per window:
     the decoder input is constant over the steps, F9; the one-hot x W of encoder layer 1 counted as the GEMM it replaces).
@@ -91,22 +143,33 @@ def algorithmic_flops_per_window(spec):
     return f_enc + f_dec
 
 
+def decoder_flops_per_window(spec):
+    """the decoder's share of the forward FLOPs (BASELINE configs[4]: decode only)"""
+    mm = lambda k, n: 2.0 * k * n
+    H, GH, T, V, D, ID = spec.H, spec.GH, spec.T, spec.V, spec.Dout, spec.ID
+    return ((spec.Ld + 2) * spec.nstate * mm(spec.zin, H) + (mm(D, GH) + T * mm(H, GH)) + (spec.Ld - 1) * T * 2 * mm(H, GH) +
+            T * mm(H, D) + (mm(ID, GH) + V * (mm(H, GH) + mm(H, ID))) + (mm(1, GH) + T * (mm(H, GH) + mm(H, 1))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs (module docstring)")
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
-    ap.add_argument("--seq-len", type=int, default=128)
-    ap.add_argument("--voices", type=int, default=4)
-    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (0 = the config's)")
+    ap.add_argument("--seq-len", type=int, default=0)
+    ap.add_argument("--voices", type=int, default=0)
+    ap.add_argument("--latent", type=int, default=0)
     ap.add_argument("--prewarm-min", type=float, default=1.0, help="seconds of untimed passes before the warmup steps, at least")
     ap.add_argument("--prewarm-max", type=float, default=8.0, help="... at most (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-overlap", type=int, default=0,
-                    help="N>1: 1 = reduce the decoder gradient bucket beside the encoder BPTT (dp.BucketedAllReduce)")
+    ap.add_argument("--elbo-steps", type=int, default=5, help="optimizer steps of the GPU-vs-CPU ELBO comparison (0 = none)")
+    ap.add_argument("--dp-overlap", type=int, default=-1,
+                    help="N>1: reduce the decoder gradient bucket beside the encoder BPTT (dp.BucketedAllReduce); -1 = the product "
+                         "policy (dp.DataParallel: on with RCCL and more than one rank)")
     ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
     args = ap.parse_args()
 
@@ -131,51 +194,75 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    T = args.seq_len * args.voices
-    spec = ModelSpec(cell=args.cell, H=256, Z=args.latent, Din=61, Dout=61, T=T, V=args.voices, ID=16, C=2, Le=2, Ld=2)
-    B = args.batch
-    # the CPU baseline FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
+    seq, voices, latent, C, B, mode, named_batch, named_gpus = CONFIGS[args.config]
+    seq, voices, latent, B = args.seq_len or seq, args.voices or voices, args.latent or latent, args.batch or B
+    T = seq * voices
+    decode = mode == "decode"
+    spec = ModelSpec(cell=args.cell, H=256, Z=latent, Din=61, Dout=61, T=T, V=voices, ID=16, C=C, Le=2, Ld=2)
+    device = "cuda:%d" % local
+    # the CPU legs FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
     # process sees the GPU busy at the end of the run rather than idle
-    cpu = cpu_baseline(spec, B) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
-    eng = Engine(spec, max_batch=B, dtype=args.dtype, device="cuda:%d" % local, seed=1234)
+    solo = world == 1 and rank == 0 and not args.no_cpu_baseline
+    cpu = cpu_baseline(spec, B) if (solo and not decode) else None
+    EB = 16
+    elbo_cpu = cpu_elbo(spec, EB, args.elbo_steps) if (solo and not decode and args.elbo_steps > 0) else None
+    elbo_gpu = gpu_elbo(spec, EB, args.elbo_steps, args.dtype, device) if elbo_cpu is not None else None
+    eng = Engine(spec, max_batch=B, dtype=args.dtype, device=device, seed=1234, training=not decode)
     if args.chunks:
         eng.time_chunks = args.chunks
-    w = make_windows(B, T, 61, args.voices, 16, 2, args.latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
-    eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
-    eng.stage_decoder_inputs(B, hist=w["hist"])
-    eng.stage_targets(B, w["x_idx"], w["c_idx"])
+    w = make_windows(B, T, 61, voices, 16, C, latent, seed=1234 + rank, epsilon_std=spec.epsilon_std)
+    if decode:
+        import numpy as np
+        z = np.random.default_rng(1234 + rank).standard_normal((B, latent)).astype(np.float32)
+        z[:, [0, 1]] = z[:, [1, 0]]                 # the latent swap of the style transfer (reference vae_evaluation.py:2471-2483)
+        eng.stage_decoder_inputs(B, z=z, hist=np.concatenate([np.zeros((1, latent), np.float32), z[:-1]]))
+    else:
+        eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
+        eng.stage_decoder_inputs(B, hist=w["hist"])
+        eng.stage_targets(B, w["x_idx"], w["c_idx"])
 
     allreduce = None
-    if use_dist:
+    if use_dist and not decode:
         from midi_vae_amd.dp import make_allreduce
-        allreduce = make_allreduce(eng, dist, world, overlap=args.dp_overlap)
+        overlap = (world > 1) if args.dp_overlap < 0 else bool(args.dp_overlap)
+        allreduce = make_allreduce(eng, dist, world, overlap=overlap)
 
     def step():
-        eng.train_step(B, allreduce=allreduce)
+        if decode:
+            eng.decode(B, want_probs=False)
+        else:
+            eng.train_step(B, allreduce=allreduce)
 
     # Steady state first: on a freshly started box the first GPU process runs its first second or two 10-16 % slower
     # (measured: 10.8 ms per step as the box's first process, 9.1 ms from the second process on; the recurrent kernels,
     # which live on memory latency, 5.6 instead of 3.9 us per time step) - clocks ramping up from idle.  Untimed
-    # forward+backward passes (no optimizer update, no collective: parameters and the reported ELBO trajectory unchanged)
+    # passes (no optimizer update, no collective: parameters and the reported ELBO trajectory unchanged)
     # until two consecutive blocks agree to 1 %, at least --prewarm-min and at most --prewarm-max seconds.
     if args.prewarm_max > 0:
         t_pre, prev = time.perf_counter(), None
+        nblk = 20 if T <= 512 else 4
         while True:
             t0 = time.perf_counter()
-            for _ in range(20):
-                eng.forward_backward(B)
+            for _ in range(nblk):
+                if decode:
+                    eng.decode(B, want_probs=False)
+                else:
+                    eng.forward_backward(B)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 20
+            dt = (time.perf_counter() - t0) / nblk
             el = time.perf_counter() - t_pre
             if rank == 0:
-                print("prewarm: %.2f s, %.3f ms per forward+backward" % (el, dt * 1e3), file=sys.stderr)
+                print("prewarm: %.2f s, %.3f ms per pass" % (el, dt * 1e3), file=sys.stderr)
             if el >= args.prewarm_max or (el >= args.prewarm_min and prev is not None and abs(dt - prev) <= 0.01 * prev):
                 break
             prev = dt
     # The warmup steps run exactly what the timed steps run - including the HIP-event brackets around the dominant kernel
     # (their first use costs tens of milliseconds in the first GPU process of a freshly started box: measured 12.9 instead
     # of 9.1 ms per step over 10 timed steps when the brackets first appeared inside the timed region).
-    KINDS = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1")}
+    # Bracket only the dominant kernel's launches, and of those the two stacked decoder layers (plus one forward layer for the
+    # critical-path figure): every event pair costs launch slots - all 26 BPTT launches bracketed slow the step by 0.5 ms.
+    KINDS = ({("rnn_fwd", "dec.notes.1")} if decode else
+             {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1")})
     eng.prof_kinds = KINDS
     if args.warmup:
         eng.prof = {}
@@ -185,10 +272,8 @@ def main():
     if eng.prof is not None:
         eng.prof_summary()
         eng.prof = None
-    first_loss = eng.metrics(B)["loss"] if args.warmup else float("nan")
+    first_loss = eng.metrics(B)["loss"] if (args.warmup and not decode) else float("nan")
 
-    # Bracket only the dominant kernel's launches, and of those the two stacked decoder layers (plus one forward layer for the
-    # critical-path figure): every event pair costs launch slots - all 26 BPTT launches bracketed slow the step by 0.5 ms.
     # One more event per step boundary on the critical stream gives the per-step times (median).
     eng.prof_kinds = KINDS
     eng.prof = {}               # HIP events on the launch streams
@@ -214,16 +299,16 @@ def main():
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
     prof = eng.prof_summary()
     eng.prof = None
-    m = eng.metrics(B)
+    m = eng.metrics(B) if not decode else None
     eng.check_pipeline()        # raises if a time-pipelined kernel ever gave up waiting for its producer (invalid results)
 
     if rank == 0:
         G, H = spec.G, spec.H
-        # Dominant kernel: backpropagation through time of the T-step recurrent layers (every launch of it in the timed
-        # region was bracketed with HIP events on its stream).  Algorithmic work = the recurrent GEMM only:
-        # 2 * B * H * (G*H) flop per time step (da U^T), summed over the steps each launch covers (the stacked layers
-        # run as time chunks) - SURVEY section 8d.
-        longk = {k: v for k, v in prof.items() if k[0] == "rnn_bwd"}
+        # Dominant kernel: backpropagation through time of the T-step recurrent layers (decode: their forward recurrence); every
+        # bracketed launch of it in the timed region was timed with HIP events on its stream.  Algorithmic work = the recurrent
+        # GEMM only: 2 * B * H * (G*H) flop per time step, summed over the steps each launch covers - SURVEY section 8d.
+        dom = "rnn_fwd" if decode else "rnn_bwd"
+        longk = {k: v for k, v in prof.items() if k[0] == dom}
         launches = sum(n for n, _, _ in longk.values())
         tot_ms = sum(n * ms for n, ms, _ in longk.values())
         tot_steps = sum(n * st for n, _, st in longk.values())
@@ -233,58 +318,80 @@ def main():
         achieved = flop_step * tot_steps / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         cus = Bp // 16                      # one workgroup (= one CU) per 16 batch rows
-        us_bwd = tot_ms * 1e3 / tot_steps
+        us_dom = tot_ms * 1e3 / tot_steps
         fwdk = [v for k, v in prof.items() if k[0] == "rnn_fwd"]
         us_fwd = sum(n * ms for n, ms, _ in fwdk) * 1e3 / max(sum(n * st for n, _, st in fwdk), 1) if fwdk else float("nan")
         ms_step = elapsed / args.steps * 1e3
         # HBM traffic of the dominant kernel from the PMC counters: bench.py cannot run a counter pass over itself, so the pass over
-        # THIS command (tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
+        # THIS command (tools/collect_profiles_r03.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950) is committed as profiles/<round>_bench_traffic.json and embedded
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r02_bench_traffic.json")
-        if os.path.exists(tf):
-            try:
-                rec = json.load(open(tf)).get("%s_%s" % (args.cell, args.dtype))
-                if rec and rec.get("T") == T and rec.get("B") == B:
-                    traffic, traffic_src = rec["bytes_per_launch"], rec
-            except (ValueError, OSError):
-                pass
-        step_flop = 3.0 * algorithmic_flops_per_window(spec) * B
+        for tf in ("r03_bench_traffic.json", "r02_bench_traffic.json"):
+            tf = os.path.join(ROOT, "profiles", tf)
+            if traffic is None and os.path.exists(tf) and not decode:
+                try:
+                    rec = json.load(open(tf)).get("%s_%s" % (args.cell, args.dtype))
+                    if rec and rec.get("T") == T and rec.get("B") == B:
+                        traffic, traffic_src = rec["bytes_per_launch"], rec
+                except (ValueError, OSError):
+                    pass
+        fwd_flop = algorithmic_flops_per_window(spec)
+        step_flop = (3.0 * fwd_flop if not decode else decoder_flops_per_window(spec)) * B
+        bytes_per_row = (10 if args.cell == "LSTM" else 9) if not decode else (5 if args.cell == "LSTM" else 4)
+        what = ("BASELINE configs[%d]: %d-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU (the config names %d windows on %d "
+                "GPU%s) %s H=256 2+2 layers, " % (args.config, C, seq, voices, T, latent, B, named_batch, named_gpus,
+                                                "s" if named_gpus > 1 else "", args.cell))
+        what += ("decoder forward on swapped latents + fused argmax decode (one byte per row leaves the chip)" if decode else
+                 "notes+instrument+velocity+style heads, Keras-Adam")
         out = {
-            "metric": "MIDI roll windows/sec (train step)", "value": B * world * args.steps / elapsed,
+            "metric": "MIDI roll windows/sec (%s)" % ("decode" if decode else "train step"), "value": B * world * args.steps / elapsed,
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU %s "
-                                   "H=256 2+2 layers, notes+instrument+velocity+style heads, Keras-Adam"
-                                   % (args.seq_len, args.voices, T, args.latent, B, args.cell),
-                       "global_batch": B * world, "T": T, "cell": args.cell, "parallelism": "dp%d" % world},
-            "elbo": {"loss_after_warmup": first_loss, "loss_final": m["loss"], "kl": m["kl"],
-                     "notes_loss": m["notes_loss"]},
-            "roofline": {"bound": "mfma", "kernel": "rnn_bwd (BPTT, %s %s, resident recurrent weights)" % (args.cell, args.dtype),
+            "config": {"workload": what, "baseline_config": args.config, "global_batch": B * world, "T": T, "cell": args.cell,
+                       "parallelism": ("replicas%d" if decode else "dp%d") % world},
+            "roofline": {"bound": "mfma", "kernel": "%s (%s, %s %s, resident recurrent weights)" % (
+                             dom, "forward recurrence" if decode else "BPTT", args.cell, args.dtype),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         # per time step and row: LSTM reads gates 4H + cell state H + upstream gradient H, writes da 4H;
-                         # GRU reads gates 3H + h H + upstream gradient H, writes da 3H + r*h H
-                         "algorithmic_bytes_per_launch": Bp * T * H * (10 if args.cell == "LSTM" else 9) * (2 if args.dtype == "bf16" else 4),
+                         # per time step and row: LSTM BPTT reads gates 4H + cell state H + upstream gradient H, writes da 4H;
+                         # GRU reads gates 3H + h H + upstream gradient H, writes da 3H + r*h H; the
+                         # inference forward reads x*W + b (G*H) and writes h (H)
+                         "algorithmic_bytes_per_launch": Bp * T * H * bytes_per_row * (2 if args.dtype == "bf16" else 4),
                          "avg_launch_ms": avg_ms, "launches": launches,
-                         "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": us_bwd,
+                         "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": us_dom,
                          "flop_per_time_step": flop_step,
                          # the recurrence is latency-bound by design: B/16 workgroups, one per CU, step after step
-                         "cus_occupied": cus, "frac_of_occupied_cus": achieved / (peak * cus / 256.0),
+                         "cus_occupied": cus, "frac_of_occupied_cus": achieved / (peak * min(cus, 256) / 256.0),
                          "launch_ms_per_step_by_layer": {"%s:%s" % k: n * ms / args.steps for k, (n, ms, _) in prof.items()},
                          # the two figures beside the per-kernel fraction
                          "whole_step": {"algorithmic_tflop": step_flop / 1e12, "tflops": step_flop / (ms_step * 1e-3) / 1e12,
-                                        "frac_of_peak": step_flop / (ms_step * 1e-3) / 1e12 / peak},
-                         "critical_path": {"what": "the four serial recurrence phases of a step (encoder forward, decoder forward, "
-                                                   "decoder BPTT, encoder BPTT): T x the measured time per time step of a stacked layer",
-                                           "us_per_step_fwd": us_fwd, "us_per_step_bwd": us_bwd,
-                                           "bound_ms": 2.0 * T * (us_fwd + us_bwd) * 1e-3,
-                                           "frac_of_step": 2.0 * T * (us_fwd + us_bwd) * 1e-3 / ms_step}},
+                                        "frac_of_peak": step_flop / (ms_step * 1e-3) / 1e12 / peak}},
         }
+        if not decode:
+            out["roofline"]["critical_path"] = {
+                "what": "the four serial recurrence phases of a step (encoder forward, decoder forward, decoder BPTT, encoder BPTT): "
+                        "T x the measured time per time step of a stacked layer",
+                "us_per_step_fwd": us_fwd, "us_per_step_bwd": us_dom, "bound_ms": 2.0 * T * (us_fwd + us_dom) * 1e-3,
+                "frac_of_step": 2.0 * T * (us_fwd + us_dom) * 1e-3 / ms_step}
+            out["elbo"] = {"loss_after_warmup": first_loss, "loss_final": m["loss"], "kl": m["kl"], "notes_loss": m["notes_loss"]}
+            if elbo_gpu is not None:
+                diff = max(abs(g[k] - c[k]) for g, c in zip(elbo_gpu, elbo_cpu) for k in g)
+                out["elbo"].update({
+                    "what": "ELBO (Keras total loss) and its parts after each of %d optimizer steps, fresh epsilon per step, on the "
+                            "first %d windows of this run's inputs from the same initial parameters: this engine (%s, the timed "
+                            "schedule) beside float64 torch-CPU arithmetic (oracle/torch_cpu.py, pinned to the NumPy oracle)"
+                            % (args.elbo_steps, EB, args.dtype),
+                    "windows": EB, "steps": args.elbo_steps, "elbo_gpu": [g["loss"] for g in elbo_gpu],
+                    "elbo_cpu": [c["loss"] for c in elbo_cpu], "parts_gpu_final": elbo_gpu[-1], "parts_cpu_final": elbo_cpu[-1],
+                    "max_abs_diff": diff, "within_1e-3": diff <= 1e-3})
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = out["value"] / cpu["value"] if cpu.get("value") else None
+        elif decode and solo:
+            out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed for the decode configuration: oracle/torch_cpu.py covers the train step (the "
+                                             "default --config 1 run carries the CPU baseline)"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -232,15 +232,7 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 //     staged AS IS and read with ds_read_b64_tr_b16, the LDS transpose read of gfx950 - the generic kernel
 //     transposes with eight 2-byte LDS stores per 16 bytes loaded.
 // ===========================================================================================================
-#ifndef GEMM_ABL_NOMFMA
-#define GEMM_ABL_NOMFMA 0          // development ablations: timing only, wrong results
-#endif
-#ifndef GEMM_ABL_NOLOAD
-#define GEMM_ABL_NOLOAD 0
-#endif
-#ifndef GEMM_ABL_NOATOMIC
-#define GEMM_ABL_NOATOMIC 0
-#endif
+#include "ablations.h"      // GEMM_ABL_* timing switches: all 0 in the product build
 constexpr int FBM = 128, FBN = 128, FBK = 64;
 constexpr int F_LDK = FBK + 8;        // k-contiguous image: [row][FBK + 8]  (144 B rows: conflict-free b128 reads)
 constexpr int F_LDR = 128 + 16;       // row-contiguous image: [k][128 + 16] (288 B rows = 32 mod 256: tr reads spread)

@@ -184,21 +184,6 @@ __global__ void transpose_convert_k(const float* W, D* out, int K, int N, int NP
     transpose_convert_body<D>(W, out, K, N, NPAD, blockIdx.x, gridDim.x);
 }
 
-// out (R, N) in TILE16 = xs[r] * w[n] + bias[n]: the input projection of a 1-feature layer, expanded so that the layer
-// runs on the dense-input recurrent kernels.  One thread = 4 consecutive n of one row = its 8 / 16 bytes of a tile.
-template <typename D>
-__global__ void outer_bias_tile16_k(const float* __restrict__ xs, const float* __restrict__ w, const float* __restrict__ bias,
-                                    D* __restrict__ out, int R, int N) {
-    const size_t total = (size_t)R * N / 4;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t tile = e >> 6;
-        const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
-        const float x = xs[m];
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + n), bv = *reinterpret_cast<const f32x4*>(bias + n);
-        st<D>::store4(out + e * 4, x * wv + bv);
-    }
-}
-
 template <typename D>
 __global__ void relayout_k(const D* src, D* dst, int rows, int cols, int to_tile) {
     const size_t n = (size_t)rows * cols;
@@ -536,13 +521,30 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
 }
 
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
-constexpr int PREP_MAX_JOBS = 64, PREP_BLOCKS_PER_JOB = 64;      // (64 x 48-byte jobs = 3 KiB of kernel arguments; the limit is 4 KiB)
+// Workgroups [base[j], base[j+1]) run job j: a job gets workgroups in proportion to its output (a 256 x 1024 fragment pack 64,
+// a 32-word fill one).
+constexpr int PREP_MAX_JOBS = 64;      // (64 x 48-byte jobs + 65 offsets = 3.3 KiB of kernel arguments; the limit is 4 KiB)
 struct prep_batch {
     int32_t n;
+    int32_t base[PREP_MAX_JOBS + 1];
     mvae_prep_job jobs[PREP_MAX_JOBS];
 };
+template <typename D>
+__device__ __forceinline__ void outer_bias_body(const float* __restrict__ xs, const float* __restrict__ w, const float* __restrict__ bias,
+                                                D* __restrict__ out, int R, int N, int bid, int nb) {
+    const size_t total = (size_t)R * N / 4;
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < total; e += (size_t)nb * blockDim.x) {
+        const size_t tile = e >> 6;
+        const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
+        const float x = xs[m];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + n), bv = *reinterpret_cast<const f32x4*>(bias + n);
+        st<D>::store4(out + e * 4, x * wv + bv);
+    }
+}
 __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
-    const int j = blockIdx.x / PREP_BLOCKS_PER_JOB, bid = blockIdx.x % PREP_BLOCKS_PER_JOB, nb = PREP_BLOCKS_PER_JOB;
+    int j = 0;
+    while (j + 1 < pb.n && (int)blockIdx.x >= pb.base[j + 1]) ++j;
+    const int bid = (int)blockIdx.x - pb.base[j], nb = pb.base[j + 1] - pb.base[j];
     const mvae_prep_job& job = pb.jobs[j];
     const float* src = reinterpret_cast<const float*>(job.src);
     const bool bf = job.kind == MVAE_BF16;
@@ -599,6 +601,7 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
     for (int j0 = 0; j0 < n_jobs; j0 += PREP_MAX_JOBS) {
         prep_batch pb;
         pb.n = n_jobs - j0 < PREP_MAX_JOBS ? n_jobs - j0 : PREP_MAX_JOBS;
+        int total = 0;
         for (int j = 0; j < pb.n; ++j) {
             const mvae_prep_job& job = jobs[j0 + j];
             if ((!job.src && job.op != MVAE_PREP_ZERO && job.op != MVAE_PREP_ADD_I32) || !job.dst || job.op < 0 ||
@@ -613,11 +616,27 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
                 if (job.a <= 0 || (job.a % 16) || (job.b % 16) || (K % KG)) return MVAE_E_ARG;
             }
             pb.jobs[j] = job;
+            // workgroups of the job: ~2048 output elements each, between 1 and 64
+            size_t out = (size_t)(job.a > 0 ? job.a : 1) * (size_t)(job.b > 0 ? job.b : 1);
+            if (job.op == MVAE_PREP_CONVERT_PAD) out = (size_t)job.a * job.c;
+            if (job.op == MVAE_PREP_TRANSPOSE_CONVERT) out = (size_t)job.a * (job.c > job.b ? job.c : job.b);
+            int nb = (int)((out + 2047) / 2048);
+            nb = job.op == MVAE_PREP_ADD_I32 ? 1 : (nb < 1 ? 1 : (nb > 64 ? 64 : nb));
+            pb.base[j] = total;
+            total += nb;
         }
-        hipLaunchKernelGGL(prepare_batch_k, dim3(pb.n * PREP_BLOCKS_PER_JOB), dim3(256), 0, s, pb);
+        pb.base[pb.n] = total;
+        if (total > 0) hipLaunchKernelGGL(prepare_batch_k, dim3(total), dim3(256), 0, s, pb);
         MVAE_CHECK_LAUNCH();
     }
     return MVAE_OK;
+}
+// out (R, N) in TILE16 = xs[r] * w[n] + bias[n]: the input projection of a 1-feature layer, expanded so that the layer
+// runs on the dense-input recurrent kernels.  One thread = 4 consecutive n of one row = its 8 / 16 bytes of a tile.
+template <typename D>
+__global__ void outer_bias_tile16_k(const float* __restrict__ xs, const float* __restrict__ w, const float* __restrict__ bias,
+                                    D* __restrict__ out, int R, int N) {
+    outer_bias_body<D>(xs, w, bias, out, R, N, (int)blockIdx.x, (int)gridDim.x);
 }
 extern "C" int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, void* out, int32_t out_kind, int32_t R,
                                       int32_t N, void* stream) {

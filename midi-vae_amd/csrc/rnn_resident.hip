@@ -51,33 +51,7 @@ extern "C" int mvae_debug_stamps(unsigned long long* out) {
 #define STAMP(k)
 #endif
 
-// Timing ablations (development only; results are wrong when any is set): -DABL_NOL=1 skips the LDS reads of
-// LDS-resident fragments, ABL_NOTRG the row-major write-back, ABL_NOSAVE the saved-activation stores, ABL_NOX the
-// input prefetch, ABL_NOMATH the gate arithmetic, ABL_NOBAR the barriers.
-#ifndef ABL_NOL
-#define ABL_NOL 0
-#endif
-#ifndef ABL_NOTRG
-#define ABL_NOTRG 0
-#endif
-#ifndef ABL_NOSAVE
-#define ABL_NOSAVE 0
-#endif
-#ifndef ABL_NOX
-#define ABL_NOX 0
-#endif
-#ifndef ABL_NOMATH
-#define ABL_NOMATH 0
-#endif
-#ifndef ABL_NOBAR
-#define ABL_NOBAR 0
-#endif
-#ifndef ABL_NOB
-#define ABL_NOB 0      // B fragments: no LDS reads after the first two of a step
-#endif
-#ifndef ABL_NOTRANS
-#define ABL_NOTRANS 0  // exp / rcp replaced by multiplies
-#endif
+#include "ablations.h"      // ABL_* timing switches: all 0 in the product build (variant builds only: tools/build_variants.sh)
 
 namespace {
 

@@ -25,12 +25,10 @@ from . import hiplib as hl
 from . import ops
 from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
 
-# slots of the scalar accumulator
-S_NOTES_LOSS, S_NOTES_HITS, S_INSTR_LOSS, S_INSTR_HITS, S_VEL_LOSS, S_VEL_HITS, S_KL, S_STYLE_LOSS, S_STYLE_HITS = range(9)
-S_HELD_LOSS, S_HELD_HITS, S_NEXT_LOSS, S_NEXT_HITS = 10, 11, 12, 13
-S_SIG_LOSS, S_SIG_HITS, S_CNOTES_LOSS, S_CNOTES_HITS, S_CINSTR_LOSS, S_CINSTR_HITS = 14, 15, 16, 17, 18, 19
-N_SCALARS = 32
-X_EXT = 100     # (host-side only) a recurrent layer whose x*W + b is written by the caller: classifiers on the decoder's OUTPUTS
+from .engine_io import ArrayStaging, Results
+from .engine_optional import OptionalGraph
+from .slots import *        # noqa: F401,F403  (scalar slots S_*, N_SCALARS, X_EXT)
+from .slots import N_SCALARS, X_EXT
 
 
 class _NullCtx(object):
@@ -72,7 +70,7 @@ class _Aux(object):
         self.head.T, self.head.out = 1, key + ".out"
 
 
-class Engine(object):
+class Engine(ArrayStaging, OptionalGraph, Results):
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
                  training: bool = True, share: "Engine | None" = None):
         """``share``: another Engine of the same spec on the same device whose PARAMETERS (the flat f32 buffer itself) and HIP
@@ -181,8 +179,7 @@ class Engine(object):
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
-        self._prep = None
-        self._prep_count = None
+        self._prep = None                # PrepBatch per (step count pending): prepare_weights
         self._count_only = None
         self._count_pending = False
         self._sync_cum = {}
@@ -311,13 +308,6 @@ class Engine(object):
         fn()
         e1.record()
         self.prof.setdefault(key, []).append((e0, e1, steps))
-
-    def prof_summary(self):
-        """key -> (launches, mean ms, mean time steps per launch) for the event pairs collected since
-        ``self.prof = {}`` (synchronises first)."""
-        torch.cuda.synchronize()
-        return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b, _ in v])), float(np.mean([n for _, _, n in v])))
-                for k, v in (self.prof or {}).items()}
 
     # ------------------------------------------------------------------------------------------------------
     # parameters
@@ -552,141 +542,10 @@ class Engine(object):
             st[name] = self._in_block[o:o + nbytes].view(tdt)
         self._stager = None
 
-    @staticmethod
-    def forward_bytes_per_window(spec, kind):
-        """HBM a forward-only engine holds per window of its batch (sizing of model._Shared.get_infer): the h sequences of every
-        recurrent layer, x*W + b of the stacked / 1-feature layers, the heads' probabilities on request, inputs"""
-        e = 2 if kind == hl.BF16 else 4
-        T, V, H, GH = spec.T, spec.V, spec.H, spec.GH
-        n_T = spec.Le + spec.Ld + 2 * int(spec.meta_velocity) + 2 * int(spec.meta_held) + spec.Ld * int(spec.meta_next)
-        n_xp = (spec.Le - 1) + (spec.Ld - 1) + int(spec.meta_velocity) + (spec.Ld - 1) * int(spec.meta_next)
-        per = n_T * (T + 1) * H * e + 2 * int(spec.meta_instrument) * (V + 1) * H * e + n_xp * T * GH * e
-        per += T * (spec.Dout * 4 + 64) + 4096
-        return int(per * 1.25)
-
-    def bytes_resident(self):
-        return (sum(t.numel() * t.element_size() for t in self.store.values()) +
-                4 * self.params.numel() * 4)
-
     def _v(self, name, *shape):
         """View of buffer ``name`` with the given shape (the storage is sized for max_batch)."""
         n = int(np.prod(shape))
         return self.store[name][:n].view(*shape)
-
-    # ------------------------------------------------------------------------------------------------------
-    # input staging (host NumPy -> device).  Layout conversion to time-major happens here, once, on the host.
-    # ------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def pad16(B):
-        return (int(B) + 15) // 16 * 16
-
-    def _up(self, name, arr, tdtype):
-        a = np.ascontiguousarray(arr)
-        t = torch.from_numpy(a).to(self.device, non_blocking=False).to(tdtype)
-        self.store[name][:t.numel()].copy_(t.reshape(-1))
-
-    def _up_tm(self, name, arr_bt, tdtype, fill=0):
-        """(B, L) batch-major host array -> (L, Bp) time-major device buffer, pad rows = ``fill``."""
-        arr_bt = np.asarray(arr_bt)
-        B, L = arr_bt.shape
-        out = np.full((L, self.pad16(B)), fill, dtype=arr_bt.dtype)
-        out[:, :B] = arr_bt.T
-        self._up(name, out, tdtype)
-
-    def _up_rows(self, name, arr, width, tdtype=torch.float32):
-        """(B, width) host array -> first B rows of the (Bp, width) device buffer; pad rows zeroed."""
-        arr = np.asarray(arr).reshape(-1, width)
-        B = arr.shape[0]
-        out = np.zeros((self.pad16(B), width), dtype=arr.dtype)
-        out[:B] = arr
-        self._up(name, out, tdtype)
-
-    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None, d_idx=None):
-        """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; d_idx (B,T) uint8 held-notes flag; eps (B,Z)
-        f32 ALREADY scaled by epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
-        B = x_idx.shape[0]
-        self.norm_B = float(B)
-        self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
-        if self.enc_bi:
-            self._up_tm("in.x_idx_rev", np.asarray(x_idx, np.uint8)[:, ::-1], torch.uint8)
-        if self.spec.meta_instrument:
-            self._up_tm("in.i_idx", np.asarray(i_idx, np.uint8), torch.uint8)
-        if self.spec.meta_velocity:
-            self._up_tm("in.vel", np.asarray(vel, np.float32), torch.float32)
-        if self.spec.meta_held:
-            self._up_tm("in.d_idx", np.asarray(d_idx, np.uint8), torch.uint8)
-        self._up_rows("in.eps", np.zeros((B, self.spec.Z), np.float32) if eps is None else np.asarray(eps, np.float32),
-                      self.spec.Z)
-        return B
-
-    def stage_decoder_inputs(self, B, hist=None, z=None, start_notes=None, start_instr=None, start_vel=None, start_held=None,
-                             start_next=None, add=None):
-        s = self.spec
-        Bp = self.pad16(B)
-        zh = self._v("zh", Bp, s.zin)
-        zh[B:].zero_()
-        if s.history:
-            if hist is None:
-                zh[:, s.Z:2 * s.Z].zero_()
-            else:
-                zh[:B, s.Z:2 * s.Z].copy_(torch.from_numpy(np.ascontiguousarray(hist, np.float32)).to(self.device))
-        if z is not None:
-            zh[:B, :s.Z].copy_(torch.from_numpy(np.ascontiguousarray(z, np.float32)).to(self.device))
-        if s.add_dim:           # the decoder's additional input (reference vae_definition.py:553-556): behind [z | history]
-            a0 = s.zin - s.add_dim
-            if add is None:
-                zh[:, a0:].zero_()
-            else:
-                zh[:B, a0:].copy_(torch.from_numpy(np.ascontiguousarray(add, np.float32).reshape(B, s.add_dim)).to(self.device))
-        for name, val, width in (("in.start_notes", start_notes, s.Dout), ("in.start_instr", start_instr, s.ID),
-                                 ("in.start_vel", start_vel, 1), ("in.start_held", start_held, 2),
-                                 ("in.start_next", start_next, s.Dout)):
-            if name not in self.store:
-                continue
-            self._up_rows(name, np.zeros((B, width), np.float32) if val is None else np.asarray(val, np.float32), width)
-
-    def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None, n_idx=None,
-                      w_held=None, w_next=None, sig=None, w_sig=None, w_cnotes=None, w_cinstr=None):
-        """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
-        (score*w / mean(w != 0), then the mean over the axes) into one factor per row; padding
-        rows get target 255 ("no target") and weight 0."""
-        s = self.spec
-        T, V = s.T, s.V
-        self.norm_B = float(B)
-        self._up_tm("in.y_idx", np.asarray(y_idx, np.uint8), torch.uint8, fill=255)
-
-        def norm(w, n_other):
-            w = np.asarray(w, np.float64)
-            nz = np.mean(w != 0)
-            return (w / (nz * w.size * n_other)).astype(np.float32)
-
-        wn = np.ones((B, T)) if w_notes is None else w_notes
-        self._up_tm("in.rw_notes", norm(wn, 1), torch.float32)
-        if s.meta_instrument:
-            wi = np.ones((B,)) if w_instr is None else w_instr
-            self._up_tm("in.rw_instr", np.repeat(norm(wi, V)[:, None], V, axis=1), torch.float32)
-        if s.meta_velocity:
-            wv = np.ones((B,)) if w_vel is None else w_vel
-            self._up_tm("in.rw_vel", np.repeat(norm(wv, T)[:, None], T, axis=1), torch.float32)
-        if s.meta_held:          # (the target is the held-notes roll staged with the encoder inputs)
-            wh = np.ones((B,)) if w_held is None else w_held
-            self._up_tm("in.rw_held", np.repeat(norm(wh, T)[:, None], T, axis=1), torch.float32)
-        if s.meta_next:
-            wx = np.ones((B,)) if w_next is None else w_next
-            self._up_tm("in.rw_next", np.repeat(norm(wx, T)[:, None], T, axis=1), torch.float32)
-            self._up_tm("in.n_idx", np.asarray(n_idx, np.uint8), torch.uint8, fill=255)
-        if s.style:
-            ws = np.ones((B,)) if w_style is None else w_style
-            self._up("in.rw_style", norm(ws, 1), torch.float32)
-        if s.style or self.aux:
-            c = np.full((self.pad16(B),), 255, np.uint8)       # (padding rows: "no target")
-            c[:B] = np.asarray(c_idx, np.uint8)
-            self._up("in.c_idx", c, torch.uint8)
-        if s.signature:
-            self._up_rows("in.sig", np.asarray(sig, np.float32), s.SD)
-            self._up_rows("in.rw_sig", norm(np.ones((B,)) if w_sig is None else w_sig, 1), 1)
-        for a, w in zip(self.aux, [w_cnotes if a.key == "cnotes" else w_cinstr for a in self.aux]):
-            self._up_rows("in.rw_" + a.key, norm(np.ones((B,)) if w is None else w, 1), 1)
 
     # ------------------------------------------------------------------------------------------------------
     # weight preparation: packed / transposed / converted copies the kernels consume (once per optimizer step)
@@ -694,51 +553,48 @@ class Engine(object):
     def prepare_weights(self):
         """Derived copies of the parameters the kernels consume (MFMA-fragment packed recurrent kernels, bf16 / transposed
         input kernels, one-hot lookup tables): ~25 jobs in ONE launch (mvae_prepare_batch) - as separate kernels they cost
-        0.3 ms per step, 0.8 ms with several steps queued."""
+        0.3 ms per step, 0.8 ms with several steps queued.  (Measured and dropped in round 3: also writing what depends on the
+        step's inputs here - x*W + b of the velocity roll, start*W + b of the constant-input decoder cells - lengthens the launch
+        everything waits for by more than the launches it replaces: +0.1 ms per step, profiles/r03_c_ab_prep_inputs.txt.)"""
         s, P = self.spec, self.P
-
-        if self._prep is None:          # built once: every source / destination is a fixed view
-            self._prep, self._prep_count = ops.PrepBatch(), ops.PrepBatch()
+        key = bool(self._count_pending)
+        pb = self._prep.get(key) if self._prep else None
+        if pb is None:                  # built once per (count pending): every source / destination is a fixed view
+            self._prep = self._prep or {}
+            pb = self._prep[key] = ops.PrepBatch()
             # the optimizer's step count rides along after a step (not while the status word of that step is set: its update was
             # skipped too); either way the status word is moved to the latched word and cleared for the step that starts here
-            latch = dict(guard=self.store["pipe_status"], latch=self.store["pipe_latched"])
-            self._prep.add_i32(self.t_done, 0, **latch)
-            self._prep_count.add_i32(self.t_done, 1, **latch)
-            for pb in (self._prep, self._prep_count):
-                for r in self.all_rec:
-                    p = r.prefix
-                    pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
-                    if r.xmode == hl.X_INDEX:
-                        pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
-                    elif r.xmode == hl.X_DENSE:
-                        pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
-                    if (p + ".wt2") in self.store:
-                        pb.transpose_convert(P[p + ".W"], self._v(p + ".wt2", s.GH, 2 * s.H))
-                        if self.training:
-                            pb.convert(P[p + ".W"], self._v(p + ".wc2", 2 * s.H, s.GH))
+            pb.add_i32(self.t_done, int(key), guard=self.store["pipe_status"], latch=self.store["pipe_latched"])
+            for r in self.all_rec:
+                p = r.prefix
+                pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
+                if r.xmode == hl.X_INDEX:
+                    pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+                elif r.xmode == hl.X_DENSE:
+                    pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
+                if (p + ".wt2") in self.store:
+                    pb.transpose_convert(P[p + ".W"], self._v(p + ".wt2", s.GH, 2 * s.H))
                     if self.training:
-                        pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
-                        if r.xmode == hl.X_DENSE:
-                            pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
+                        pb.convert(P[p + ".W"], self._v(p + ".wc2", 2 * s.H, s.GH))
+                if self.training:
+                    pb.pack_recurrent(P[p + ".U"], self.store[p + ".ut_pack"], 1)
+                    if r.xmode == hl.X_DENSE:
+                        pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
+            for h in self.heads:
+                pb.transpose_convert(P[h.out + ".W"], self._v(h.name + ".wt", h.NP, s.H), n_pad=h.NP)
+            pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
+            if self.training:
                 for h in self.heads:
-                    pb.transpose_convert(P[h.out + ".W"], self._v(h.name + ".wt", h.NP, s.H), n_pad=h.NP)
-                pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
-                if self.training:
-                    for h in self.heads:
-                        pb.convert_pad(P[h.out + ".W"], self.store[h.name + ".wc"], h.NP)
-                    for r in self.all_rec:      # sum over time of da of the constant-input cells: accumulated into a buffer this
-                        if r.xmode == hl.X_CONST:       # launch zeroes (a hipMemsetAsync per layer and step otherwise)
-                            pb.zero(self.store[r.prefix + ".dxp0"])
-                if self.training:
-                    for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
-                                         ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
-                        if tname in self.store:
-                            pb.transpose_convert(P[wname], self.store[tname])
-        if self._count_pending:
-            self._prep_count.run()
-            self._count_pending = False
-        else:
-            self._prep.run()
+                    pb.convert_pad(P[h.out + ".W"], self.store[h.name + ".wc"], h.NP)
+                for r in self.all_rec:      # sum over time of da of the constant-input cells: accumulated into a buffer this
+                    if r.xmode == hl.X_CONST:       # launch zeroes (a hipMemsetAsync per layer and step otherwise)
+                        pb.zero(self.store[r.prefix + ".dxp0"])
+                for wname, tname in (("dec.init.W", "lat.wt_init"), ("enc.zmean.W", "lat.wt_mu"), ("enc.zlogvar.W", "lat.wt_lv"),
+                                     ("enc.extra.W", "lat.wt_extra"), ("enc.pack.W", "lat.wt_pack")):
+                    if tname in self.store:
+                        pb.transpose_convert(P[wname], self.store[tname])
+        pb.run()
+        self._count_pending = False
         self._weights_dirty = False
 
     # ------------------------------------------------------------------------------------------------------
@@ -808,23 +664,27 @@ class Engine(object):
                  **chunked)
 
     # ---- time-pipelined stacks (slot-interleaved LSTM kernels) ---------------------------------------------------
-    def _resident_cus(self, layers, B, backward=None):
-        """CUs the kernels of a time-pipelined stack over ``layers`` occupy AT THE SAME TIME at a padded batch of B windows,
-        with the ``_n_side`` single-layer recurrences of the phase running beside it.  A recurrent workgroup (16 windows) owns a
-        whole CU (__launch_bounds__(256, 1): 512 registers per lane, up to 160 KiB of LDS); the persistent projection / dX GEMM
-        between two layers holds ceil(grid / workgroups per CU) more (occupancy from the library: mvae_occupancy)."""
+    def _resident_cus(self, layers, B, backward=None, side=False):
+        """CUs the kernels of a time-pipelined stack over ``layers`` occupy AT THE SAME TIME at a padded batch of B windows
+        (``side``: plus the ``_n_side`` single-layer recurrences of the phase running beside it).  A recurrent workgroup (16
+        windows) owns a whole CU (__launch_bounds__(256, 1): 512 registers per lane, up to 160 KiB of LDS); the persistent
+        projection / dX GEMM between two layers holds ceil(grid / workgroups per CU) more (occupancy from the library:
+        mvae_occupancy)."""
         per, L = B // 16, len(layers)
         cus = {True: -(-self.pipe_gemm_blocks // self._occ["dx"]), False: -(-self.pipe_proj_blocks // self._occ["proj"])}
         g = max(cus.values()) if backward is None else cus[bool(backward)]
-        return L * per + (L - 1) * g + self._n_side * per
+        return L * per + (L - 1) * g + (self._n_side * per if side else 0)
 
     def _pipelined(self, layers):
         """ONE launch per layer for the whole sequence; layer l+1 follows layer l at a distance of ``pipe_chunk`` time
         steps, released chunk by chunk through device-side counters (include/midivae_hip.h, 'time-pipelined stacks')
-        instead of one launch per (layer, chunk).  Only when every kernel of the stack - and the recurrences of the phase's
-        other branches - is RESIDENT together: a consumer that takes its CUs first and waits for a producer that no longer
-        finds a free one is the time-out the schedule must not depend on luck to avoid (chip-filling inference batches run the
-        layers as chunk launches ordered by events instead - nothing waits on the device there)."""
+        instead of one launch per (layer, chunk).  Only when every kernel of the stack can be RESIDENT together: the hardware
+        dispatches the engine's queues in no particular order, and a consumer (upper layer, projection GEMM) that takes its CUs
+        first and waits for a producer that no longer finds a free one is the time-out the schedule must not depend on luck to
+        avoid.  The phase's other recurrences (velocity / instrument branches) wait for nobody: beside an oversubscribed chip
+        they only delay the stack until they retire (decode at 1024 windows runs that way, by measurement the best schedule
+        there).  Chip-filling inference batches (2048 windows: 2 x 128 + 64 workgroups) run the layers as chunk launches ordered
+        by events instead - nothing waits on the device there."""
         if len(layers) < 2:
             return False
         T = layers[0].T
@@ -944,109 +804,10 @@ class Engine(object):
             ops.history_from_latent(self._v("mu", B, Z), self._v("lv", B, Z), eps2, Breal, B, Z, zh[:, Z:2 * Z], z_out=z_out)
         self._signature_forward(Breal, B)
 
-    def _latent_forward_unfused(self, Breal, B):
-        """encoder tail Denses, z_mean / z_log_var, KL + sampling + style softmax, one launch per operation"""
-        s, P = self.spec, self.P
-        H, Z = s.H, s.Z
-        h = self._v("cat", B, self.ncat * H)
-        if self.has_pack:
-            pk = self._v("pack", B, H)
-            ops.gemm(h, P["enc.pack.W"], pk, B, H, self.ncat * H, bias=P["enc.pack.b"], act=hl.ACT_TANH)
-            h = pk
-        if s.extra_layer:
-            ex = self._v("extra", B, H)
-            ops.gemm(h, P["enc.extra.W"], ex, B, H, s.tail_in, bias=P["enc.extra.b"], act=hl.ACT_TANH)
-            h = ex
-        self._tail = h
-        h1w = H // 2 if s.split else H
-        h2 = h[:, h1w:] if s.split else h
-        mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
-        ops.gemm(h, P["enc.zmean.W"], mu, B, Z, h1w, lda=H, bias=P["enc.zmean.b"])
-        ops.gemm(h2, P["enc.zlogvar.W"], lv, B, Z, H - h1w if s.split else H, lda=H, bias=P["enc.zlogvar.b"])
-        zh = self._v("zh", B, s.zin)
-        ops.latent_fwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, 1.0 / self.norm_B, mu, lv,
-                       self._v("in.eps", B, Z), zh, self.scal[S_KL:S_KL + 3],
-                       style_target=self._v("in.c_idx", Breal) if (s.style and self._have_targets) else None,
-                       style_row_weight=self._v("in.rw_style", Breal) if (s.style and self._have_targets) else None,
-                       style_probs=self._v("style_p", B, s.C) if s.style else None, ldz=s.zin)
-
-    # ---- bidirectional encoder stack (reference vae_definition.py:445-453) --------------------------------------------------
-    def _enc_bi_forward(self, B, h_last, ldc):
-        """Le-2 Bidirectional(concat) layers and one plain layer on top.  The backward RNN of a pair runs the same kernels on
-        the time-reversed input (reversed index roll for the one-hot layer, ``cat_rev`` above it); layer l+1 reads the
-        time-aligned concatenation [forward | backward] of layer l (mvae_bi_concat), projected by ONE GEMM with K = 2H."""
-        s, P = self.spec, self.P
-        H, GH, T = s.H, s.GH, s.T
-        R = T * B
-        for li, layer in enumerate(self.enc_bi):
-            top = li == len(self.enc_bi) - 1
-            if li > 0:
-                lo = self.enc_bi[li - 1]
-                catb = self._v("enc.bi.%d.cat" % li, R, 2 * H)
-                rev = self._v("enc.bi.%d.cat_rev" % li, R, 2 * H) if len(layer) > 1 else None
-                ops.bi_concat(self._v(lo[0].prefix + ".hs", T + 1, B, H)[1:], self._v(lo[1].prefix + ".hs", T + 1, B, H)[1:], catb, rev,
-                              T, B, H)
-            for j, r in enumerate(layer):
-                if li == 0:
-                    self._rec_forward(r, B, idx=self._v("in.x_idx_rev" if j else "in.x_idx", T, B))
-                else:
-                    src = rev if j else catb
-                    ops.gemm(src, self._v(r.prefix + ".wt2", GH, 2 * H), self._v(r.prefix + ".xp", R, GH), R, GH, 2 * H, trans_b=True,
-                             bias=P[r.prefix + ".b"], c_layout=self.lay)
-                    self._rec_forward(r, B, h_last=h_last if top else None, h_last_ld=ldc if top else 0)
-
-    def _enc_bi_backward(self, B, dh_last, ldc):
-        s, P, G = self.spec, self.P, self.G
-        H, GH, T = s.H, s.GH, s.T
-        R = T * B
-        for li in range(len(self.enc_bi) - 1, -1, -1):
-            layer = self.enc_bi[li]
-            top = li == len(self.enc_bi) - 1
-            for j, r in enumerate(layer):
-                dext = None
-                if not top:
-                    dext = self._v("enc.bi.%d.dext_%s" % (li + 1, "r" if j else "f"), T, B, H)
-                idx = self._v("in.x_idx_rev" if j else "in.x_idx", T, B) if li == 0 else None
-                self._rec_bptt(r, B, dhs_ext=dext, dh_last=dh_last if top else None, dh_last_ld=ldc if top else 0)
-                self._rec_param_grads(r, B, idx=idx)
-                if li > 0:
-                    da = self._v(r.prefix + ".da", R, GH)
-                    src = self._v("enc.bi.%d.cat%s" % (li, "_rev" if j else ""), R, 2 * H)
-                    self._side(lambda src=src, da=da, r=r: ops.gemm(src, da, G[r.prefix + ".W"], 2 * H, GH, R, trans_a=True,
-                                                                    accumulate=True, split_k=self._split_k(R)))
-                    wc = self._v(r.prefix + ".wc2", 2 * H, GH)
-                    for half, name in ((0, ".g1"), (1, ".g2")):       # d(input)[:, :H] -> forward layer below, [:, H:] -> backward
-                        ops.gemm(da, wc[half * H:(half + 1) * H], self._v(r.prefix + name, R, H), R, H, GH, trans_b=True,
-                                 c_layout=self.lay)
-            if li > 0:
-                # the layer below: its forward RNN lives in natural time, its backward RNN in reversed time; gradients computed by
-                # this layer's forward record are in natural time, by its backward record in reversed time
-                f = layer[0].prefix
-                g1f, g2f = self._v(f + ".g1", R, H), self._v(f + ".g2", R, H)
-                df, dr = self._v("enc.bi.%d.dext_f" % li, R, H), self._v("enc.bi.%d.dext_r" % li, R, H)
-                if len(layer) > 1:
-                    b = layer[1].prefix
-                    g1b, g2b = self._v(b + ".g1", R, H), self._v(b + ".g2", R, H)
-                    ops.add_time_reversed(df, g1f, g1b, T, B * H)       # d f(t) = G1_fwd(t) + G1_bwd(T-1-t)
-                    ops.add_time_reversed(dr, g2b, g2f, T, B * H)       # d b(k) = G2_bwd(k) + G2_fwd(T-1-k)
-                else:
-                    df.copy_(g1f)
-                    ops.add_time_reversed(dr, None, g2f, T, B * H)
-
     def _chain_ok(self):
         """shapes the fused latent chain (csrc/latent.hip) takes: a pack Dense whenever rolls are concatenated, 16-byte rows"""
         s = self.spec
         return (self.has_pack or self.ncat == 1) and s.zin % 4 == 0 and s.Z % 4 == 0
-
-    def _signature_forward(self, Breal, B):
-        """signature head (reference vae_definition.py:737-745): tanh of the latent columns behind the style classifier's"""
-        s = self.spec
-        if not s.signature:
-            return
-        tg = self._have_targets
-        ops.signature_head_fwd(self._v("zh", B, s.zin), s.sig_off, s.SD, Breal, self._v("sig.out", B, s.SD),
-                               target=self._v("in.sig", B, s.SD) if tg else None,
-                               row_weight=self._v("in.rw_sig", B) if tg else None, scalars=self.scal[S_SIG_LOSS:S_SIG_LOSS + 2])
 
     def _latent_chain_forward(self, Breal, B, with_init):
         """Encoder tail Denses, latent block and the decoder's initial-state Denses as ONE launch (csrc/latent.hip): six
@@ -1108,44 +869,6 @@ class Engine(object):
             self._join(*[h.stream for h in side])
         for a in self.aux:
             self._aux_forward(a, B, Breal, tg, want_probs)
-
-    def _aux_forward(self, a, B, Breal, tg, want_probs):
-        """style classifier on a decoder head's OUTPUT (reference vae_definition.py:747-761): x*W + b from the (T*B, N) probabilities,
-        the recurrence, Dense softmax + loss on the last state"""
-        s, P = self.spec, self.P
-        r, h, H = a.rec, a.head, s.H
-        R = r.T * B
-        probs = self._v("out.%s_p" % a.src, R, r.K)
-        ops.gemm(probs, P[r.prefix + ".W"], self._v(r.prefix + ".xp", R, s.GH), R, s.GH, r.K, bias=P[r.prefix + ".b"], c_layout=self.lay)
-        self._rec_forward(r, B)
-        top = self._v(r.prefix + ".hs", r.T + 1, B, H)[r.T]
-        ops.head(0, self.kind, B, H, s.C, top, self._v(a.key + ".wt", h.NP, H), P[h.out + ".b"],
-                 target_idx=self._v("in.c_idx", B) if tg else None, row_weight=self._v("in.rw_" + a.key, B) if tg else None,
-                 grad_scale=a.weight, probs=self._v("out.%s_p" % a.key, B, s.C) if want_probs else None,
-                 argmax=self._v(a.key + ".argmax", B), dlogits=self._v(a.key + ".dl", B, h.NP) if (self.training and tg) else None,
-                 scalars=self.scal[a.slot:a.slot + 2], b_stride=B, b_valid=Breal)
-
-    def _aux_backward(self, a, B):
-        """... and back: Dense, BPTT, the classifier's parameters, then its gradient w.r.t. the source head's PROBABILITIES folded
-        into that head's d(logits) (softmax Jacobian) - before the head's own backward pass runs"""
-        s, P, G = self.spec, self.P, self.G
-        r, h, H = a.rec, a.head, s.H
-        R = r.T * B
-        dl = self._v(a.key + ".dl", B, h.NP)
-        top = self._v(r.prefix + ".hs", r.T + 1, B, H)[r.T]
-        dh = self._v(a.key + ".dh", B, H)
-        ops.gemm(dl, self._v(a.key + ".wt", h.NP, H), dh, B, H, h.NP)
-        self._side(lambda: (ops.gemm(top, dl, G[h.out + ".W"], H, s.C, B, trans_a=True, ldb=h.NP, accumulate=True),
-                            ops.colsum(dl, B, s.C, G[h.out + ".b"], ldx=h.NP)))
-        self._stack_backward([r], B, dh_last=dh, dh_last_ld=H)
-        da = self._v(r.prefix + ".da", R, s.GH)
-        probs = self._v("out.%s_p" % a.src, R, r.K)
-        self._side(lambda: ops.gemm(probs, da, G[r.prefix + ".W"], r.K, s.GH, R, trans_a=True, accumulate=True,
-                                    split_k=self._split_k(R)))
-        dp = self._v(a.key + ".dp", R, r.K)
-        ops.gemm(da, P[r.prefix + ".W"], dp, R, r.K, s.GH, trans_b=True)
-        src = self.head[a.src]
-        ops.softmax_bwd_add(probs, dp, self._v(a.src + ".dl", R, src.NP), R, src.N, src.NP)
 
     def _head_forward(self, h, B, Breal, states, tg, want_probs, slot):
         """cell stack + output Dense / activation / loss / accuracy / argmax of one decoder head (B = padded batch)"""
@@ -1268,7 +991,7 @@ class Engine(object):
         if not (self.kstream_grads and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
                 self._pipelined(layers) and all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers)):
             return False
-        free = (self.num_cus - self._resident_cus(layers, B, backward=True)) * self._occ["kstream"]
+        free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
         return free >= self.kstream_wgs * count
 
     def _kstream_problems(self, r, B, idx, ks, only_dU=False):
@@ -1526,71 +1249,6 @@ class Engine(object):
         self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
         self._join(self.s_grad2)
 
-    def _latent_backward_unfused(self, Breal, B):
-        """initial-state Denses, latent block and encoder tail Denses backward, one launch per operation; returns d(cat)"""
-        s, P, G = self.spec, self.P, self.G
-        H, Z = s.H, s.Z
-        dS = self._v("dS", B, self.n_init * H)
-        ldS = self.n_init * H
-        # initial-state Denses: S = tanh([z|hist] Winit + b)
-        S, zh = self._v("S", B, ldS), self._v("zh", B, s.zin)
-        ops.tanh_bwd(S, dS, dS)
-        self._side(lambda: (ops.gemm(zh, dS, G["dec.init.W"], s.zin, ldS, B, trans_a=True, accumulate=True),
-                            ops.colsum(dS, B, ldS, G["dec.init.b"])))
-        dzh = self._v("dzh", B, s.zin)
-        ops.gemm(dS, P["dec.init.W"], dzh, B, s.zin, ldS, trans_b=True)
-        if s.signature:
-            ops.signature_head_bwd(dzh, s.sig_off, s.SD, Breal, self._v("sig.out", B, s.SD), self._v("in.sig", B, s.SD),
-                                   self._v("in.rw_sig", B), s.w_sig)
-        # ---- latent ------------------------------------------------------------------------------------
-        mu, lv = self._v("mu", B, Z), self._v("lv", B, Z)
-        dmu, dlv = self._v("dmu", B, Z), self._v("dlv", B, Z)
-        if B > Breal:            # padding rows carry no gradient
-            dmu[Breal:].zero_()
-            dlv[Breal:].zero_()
-        ops.latent_bwd(Breal, Z, s.C if s.style else 0, s.beta, s.prior_mean, s.prior_std, s.w_style, 1.0 / self.norm_B, mu, lv,
-                       self._v("in.eps", B, Z), dzh, dmu, dlv, style_probs=self._v("style_p", B, s.C) if s.style else None,
-                       style_target=self._v("in.c_idx", Breal) if s.style else None,
-                       style_row_weight=self._v("in.rw_style", Breal) if s.style else None, lddz=s.zin)
-        h = self._tail
-        h1w = H // 2 if s.split else H
-        h2w = H - h1w if s.split else H
-        dt = self._v("dtail", B, H)
-        self._side(lambda: (ops.gemm(h, dmu, G["enc.zmean.W"], h1w, Z, B, trans_a=True, lda=H, accumulate=True),
-                            ops.colsum(dmu, B, Z, G["enc.zmean.b"]),
-                            ops.gemm(h[:, h1w:] if s.split else h, dlv, G["enc.zlogvar.W"], h2w, Z, B, trans_a=True, lda=H,
-                                     accumulate=True),
-                            ops.colsum(dlv, B, Z, G["enc.zlogvar.b"])))
-        if s.split:
-            ops.gemm(dmu, P["enc.zmean.W"], dt, B, h1w, Z, trans_b=True, ldc=H)
-            ops.gemm(dlv, P["enc.zlogvar.W"], dt[:, h1w:], B, h2w, Z, trans_b=True, ldc=H)
-        else:
-            ops.gemm(dmu, P["enc.zmean.W"], dt, B, H, Z, trans_b=True)
-            dt2 = self._v("dtail2", B, H)
-            ops.gemm(dlv, P["enc.zlogvar.W"], dt2, B, H, Z, trans_b=True)
-            dt.add_(dt2)
-        # ---- encoder tail ------------------------------------------------------------------------------
-        if s.extra_layer:
-            ex = self._v("extra", B, H)
-            src = self._v("pack", B, H) if self.has_pack else self._v("cat", B, self.ncat * H)
-            ops.tanh_bwd(ex, dt, dt)
-            self._side(lambda dt=dt: (ops.gemm(src, dt, G["enc.extra.W"], s.tail_in, H, B, trans_a=True, accumulate=True),
-                                      ops.colsum(dt, B, H, G["enc.extra.b"])))
-            dt2 = self._v("dcat", B, s.tail_in) if not self.has_pack else self._v("dtail2", B, H)
-            ops.gemm(dt, P["enc.extra.W"], dt2, B, s.tail_in, H, trans_b=True)
-            dt = dt2
-        ldc = self.ncat * H
-        if self.has_pack:
-            pk, cat = self._v("pack", B, H), self._v("cat", B, ldc)
-            ops.tanh_bwd(pk, dt, dt)
-            self._side(lambda dt=dt: (ops.gemm(cat, dt, G["enc.pack.W"], ldc, H, B, trans_a=True, accumulate=True),
-                                      ops.colsum(dt, B, H, G["enc.pack.b"])))
-            dcat = self._v("dcat", B, ldc)
-            ops.gemm(dt, P["enc.pack.W"], dcat, B, ldc, H, trans_b=True)
-        else:
-            dcat = dt
-        return dcat
-
     def _latent_chain_backward(self, Breal, B):
         """The same as ONE launch (csrc/latent.hip) followed by the parameter-gradient GEMMs on the side streams; None if
         the library does not support the shape."""
@@ -1813,31 +1471,6 @@ class Engine(object):
             self._stager = Stager(self)
         return self._stager
 
-    # hit-count slots of the scalar block (accumulated as counts; everything else as batch-size weighted means)
-    HIT_MASK = ((1 << S_NOTES_HITS) | (1 << S_INSTR_HITS) | (1 << S_VEL_HITS) | (1 << S_STYLE_HITS) | (1 << S_HELD_HITS) |
-                (1 << S_NEXT_HITS) | (1 << S_SIG_HITS) | (1 << S_CNOTES_HITS) | (1 << S_CINSTR_HITS))
-
-    def reset_accumulated(self):
-        """start a fresh set of epoch accumulators (a NEW device buffer: a History that has not been read yet keeps its own)"""
-        self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)
-        return self.acc
-
-    def accumulate_metrics(self, B_global):
-        """acc += B_global * (loss slots), += (hit slots) of the step just enqueued - Keras' BaseLogger on the device, no read"""
-        ops.scalars_accumulate(self.acc, self.scal, float(B_global), self.HIT_MASK)
-
-    def read_accumulated(self, n_windows, allreduce_sum=None, acc=None):
-        """means over ``n_windows`` windows of everything accumulated into ``acc`` (default: since the last reset_accumulated): ONE
-        device->host read; with ``allreduce_sum`` the per-rank shares are summed first"""
-        acc = self.acc if acc is None else acc
-        if allreduce_sum is not None:
-            allreduce_sum(acc)
-        v = acc.cpu().numpy().astype(np.float64)
-        self.check_pipeline()
-        n = max(float(n_windows), 1.0)
-        hit = np.array([(self.HIT_MASK >> i) & 1 for i in range(N_SCALARS)], bool)
-        v = np.where(hit, v, v / n)
-        return self._metrics_from(v, n)
 
     def eval_step(self, B, want_probs=False):
         """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""
@@ -1869,78 +1502,3 @@ class Engine(object):
             self.prepare_weights()
         self.decoder_forward(B, want_probs=want_probs)
         self._verify_pipeline(lambda: (self.scal.zero_(), self.decoder_forward(B, want_probs=want_probs)), key="decode")
-
-    # ------------------------------------------------------------------------------------------------------
-    # results
-    # ------------------------------------------------------------------------------------------------------
-    def check_pipeline(self):
-        """Raises if a kernel of a time-pipelined stack gave up waiting for its input since the last check (the results of that
-        step are invalid; its optimizer update was skipped)."""
-        code = int(self.store["pipe_words"].max().item())
-        if code != 0:
-            self.store["pipe_words"].zero_()
-            kind = {1: "recurrent forward kernel", 2: "BPTT kernel", 3: "chunked GEMM", 4: "K-streaming GEMM", 5: "join"}.get(code, "kernel")
-            raise RuntimeError("a device-side wait timed out (%s waiting for its producer: stream / hardware queue aliasing?); "
-                               "set Engine.pipeline = False" % kind)
-
-    def metrics(self, B) -> "OrderedDict[str, float]":
-        """Losses / accuracies of the last step with the oracle's key names (one device->host copy)."""
-        s = self.spec
-        v = self.scal.cpu().numpy().astype(np.float64)
-        self.check_pipeline()
-        if B is not None and self.norm_B != B:
-            B = self.norm_B             # a shard of a global minibatch: this rank's SHARE of the global means
-        return self._metrics_from(v, B)
-
-    def _metrics_from(self, v, B):
-        """metric dict from the scalar slots: loss slots hold batch means already, hit slots counts over ``B`` windows"""
-        s = self.spec
-        m = OrderedDict()
-        m["kl"] = v[S_KL]
-        m["notes_loss"], m["notes_acc"] = v[S_NOTES_LOSS], v[S_NOTES_HITS] / (B * s.T)
-        total = m["notes_loss"] + m["kl"]
-        if s.meta_instrument:
-            m["instr_loss"], m["instr_acc"] = v[S_INSTR_LOSS], v[S_INSTR_HITS] / (B * s.V)
-            total += s.w_instr * m["instr_loss"]
-        if s.meta_velocity:
-            m["vel_loss"], m["vel_acc"] = v[S_VEL_LOSS], v[S_VEL_HITS] / (B * s.T)
-            total += s.w_vel * m["vel_loss"]
-        if s.meta_held:
-            m["held_loss"], m["held_acc"] = v[S_HELD_LOSS], v[S_HELD_HITS] / (B * s.T)
-            total += s.w_held * m["held_loss"]
-        if s.meta_next:
-            m["next_loss"], m["next_acc"] = v[S_NEXT_LOSS], v[S_NEXT_HITS] / (B * s.T)
-            total += s.w_next * m["next_loss"]
-        if s.style:
-            m["style_loss"], m["style_acc"] = v[S_STYLE_LOSS], v[S_STYLE_HITS] / B
-            total += s.w_style * m["style_loss"]
-        if s.signature:
-            m["sig_loss"], m["sig_acc"] = v[S_SIG_LOSS], v[S_SIG_HITS] / B
-            total += s.w_sig * m["sig_loss"]
-        for a in self.aux:
-            m[a.key + "_loss"], m[a.key + "_acc"] = v[a.slot], v[a.slot + 1] / B
-            total += a.weight * m[a.key + "_loss"]
-        m["loss"] = total
-        return m
-
-    def outputs(self, B):
-        """Batch-major NumPy copies of the decoder outputs of the last forward run with want_probs=True."""
-        s = self.spec
-        Bp = self.pad16(B)
-        out = OrderedDict()
-        for h in self.dec_heads:
-            out[h.name] = self._v("out.%s_p" % h.name, h.T, Bp, h.N)[:, :B].permute(1, 0, 2).cpu().numpy()
-        if s.style:
-            out["style"] = self._v("style_p", Bp, s.C)[:B].cpu().numpy()
-        if s.signature:
-            out["sig"] = self._v("sig.out", Bp, s.SD)[:B].cpu().numpy()
-        for a in self.aux:
-            out[a.key] = self._v("out.%s_p" % a.key, Bp, s.C)[:B].cpu().numpy()
-        return out
-
-    def note_indices(self, B):
-        """(B,T) uint8 argmax note index per row - the fused form of sample_vector(...,'argmax')."""
-        return self._v("notes.argmax", self.spec.T, self.pad16(B))[:, :B].t().contiguous().cpu().numpy()
-
-    def latent(self, B):
-        return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z].cpu().numpy()

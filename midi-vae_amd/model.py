@@ -227,7 +227,7 @@ class _Shared(object):
         dp = self.dp
         return dp if (dp is not None and dp.world > 1) else None
 
-    def encode_windows(self, X, I, Vel, Held, eps, lo, hi, out):
+    def encode_windows(self, X, I, Vel, Held, eps, lo, hi, out, X_tm=None):
         """sampled z of windows [lo, hi) -> rows [lo, hi) of the device tensor ``out``, through the forward-only engine at its
         batch; under data parallelism every rank encodes a contiguous share and the rows are exchanged (one all-reduce of a
         buffer that is zero outside the rank's share: n x Z floats)."""
@@ -242,7 +242,7 @@ class _Shared(object):
             out[lo:hi].zero_()
         for p in range(a0, b0, eng.maxB):
             q = min(b0, p + eng.maxB)
-            B = st.stage(p, q, X=X, I=I, Vel=Vel, Held=Held, eps=eps[p:q])
+            B = st.stage(p, q, X=X, I=I, Vel=Vel, Held=Held, eps=eps[p:q], X_tm=X_tm)
             out[p:q].copy_(eng.encode(B))
         if dp is not None:
             dp.allreduce_sum(out[lo:hi])
@@ -558,8 +558,12 @@ class Autoencoder(_ModelView):
             if dp is None and epochs == 1 and n > 0 and lat.matches(a["X"], n):
                 fused = lat
                 b0 = min(n, batch_size)
-                if n > b0:      # histories of the later minibatches: before the first update, forward only, chip-filling
-                    self._s.encode_windows(a["X"], a.get("I"), a.get("Vel"), a.get("Held"), lat._root().eps, b0, n, lat._root()._z)
+                if n > b0:      # histories of the later minibatches: before the first update, forward only, chip-filling; their
+                    from .staging import host_onehot_to_index_tm      # windows are converted once for this pass and their train steps
+                    xtm = host_onehot_to_index_tm(a["X"], b0, n)
+                    a["X_tm"] = (xtm, b0) if xtm is not None else None
+                    self._s.encode_windows(a["X"], a.get("I"), a.get("Vel"), a.get("Held"), lat._root().eps, b0, n, lat._root()._z,
+                                           X_tm=a["X_tm"])
                 a["hist"], a["hist_dev"] = None, lat._root()._z
         if fused is None:
             a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))

@@ -87,6 +87,25 @@ def host_onehot_to_index(a, what="input"):
     return np.ascontiguousarray(out[:, :n].T)
 
 
+def host_onehot_to_index_tm(a, lo, hi, what="notes input"):
+    """windows [lo, hi) of (n, T, K) one-hot rows -> (T, hi - lo) uint8 indices, TIME-MAJOR (the layout the engine stages): the
+    conversion of a song's windows done ONCE when two passes read them - the history pre-pass and the train steps of the later
+    minibatches (Stager.stage ``X_tm``).  None if ``a`` is not an array of one-hot rows (already indices)."""
+    a = _c(a)
+    if a.ndim != 3 or hi <= lo:
+        return None
+    n, T, K = a.shape
+    out = np.empty((T, hi - lo), np.uint8)
+    bad = C.c_int64(-1)
+    rc = hl.load().mvae_host_onehot_to_index_tm(a.ctypes.data, _host_kind(a), n, T, K, lo, hi, out.ctypes.data, hi - lo, 0,
+                                                C.byref(bad))
+    if rc == hl.E_FORMAT:
+        raise NotImplementedError("%s must be one-hot rows (reference layout, import_midi.py:255-262): row %d of window %d is not"
+                                  % (what, bad.value % T, bad.value // T))
+    hl.check(rc, "mvae_host_onehot_to_index_tm")
+    return out
+
+
 class Stager(object):
     def __init__(self, engine):
         self.eng = engine
@@ -163,13 +182,15 @@ class Stager(object):
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
               norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None,
-              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False, eps2=None):
+              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False, eps2=None, X_tm=None):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
         a DEVICE tensor (n, Z) of sampled z whose row i-1 is the history of window i (zeros for window 0) - the fused history
         pre-pass; neither: zeros.  ``eps2`` (B, Z): the draw of a history pre-pass FUSED into this train step (the engine then
-        writes the history columns itself: Engine.train_step_begin).  Returns the number of windows staged.
+        writes the history columns itself: Engine.train_step_begin).  ``X_tm`` = (indices (T, m) uint8, first window): the notes
+        input of windows [first, first + m) already converted (host_onehot_to_index_tm) - used instead of X where it covers
+        [lo, hi).  Returns the number of windows staged.
 
         ``defer_targets``: convert and upload everything the ENCODER needs now and leave the decoder heads' targets and row weights
         (the second 64 MB float64 tensor of a minibatch) to ``finish_targets()`` - called after the encoder's launches are
@@ -187,7 +208,12 @@ class Stager(object):
         self._late = None
         if self.done[k] is not None:
             self.done[k].synchronize()              # the upload that last read this mirror has completed
-        self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
+        if X_tm is not None and not batch_local and X_tm[1] <= lo and hi <= X_tm[1] + X_tm[0].shape[1]:
+            out = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)
+            out[:, :B] = X_tm[0][:, lo - X_tm[1]:hi - X_tm[1]]
+            out[:, B:] = 0
+        else:
+            self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
         if eng.enc_bi:          # the backward RNNs of a bidirectional encoder read the roll reversed in time
             self._view(k, "in.x_idx_rev", np.uint8, T * Bp).reshape(T, Bp)[:] = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)[::-1]
         if s.meta_instrument:

@@ -347,6 +347,47 @@ def timed_sample(cell, T, B, V, Z, C, budget_s=15.0, threads=0):
                       % (cell, B, n_thr, Ts, T, dt, step_s, t8)}
 
 
+def elbo_inputs(cell, T, B, V, Z, C, seed=1234):
+    """The first ``B`` windows of bench.py's rank-0 inputs (synth.make_windows with the bench's seed) and its initial parameters:
+    what both sides of the ELBO comparison start from."""
+    import numpy as np
+
+    from midi_vae_amd.layout import ModelSpec, init_params
+    from midi_vae_amd.synth import make_windows
+    spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=2, Ld=2)
+    w = make_windows(max(B, 256), T, 61, V, 16, C, Z, seed=seed, epsilon_std=spec.epsilon_std)
+    w = {k: v[:B] for k, v in w.items()}
+    return spec, w, init_params(spec, seed)
+
+
+def elbo_epsilon(step, B, Z, epsilon_std, seed=1234):
+    """the fresh draw of optimizer step ``step`` (seed s + step), already scaled"""
+    import numpy as np
+    return (np.random.default_rng(seed + 1 + step).standard_normal((B, Z)) * epsilon_std).astype(np.float32)
+
+
+def elbo_trajectory(cell, T, B, V, Z, C, steps, threads=16):
+    """``steps`` real optimizer steps (forward, analytic backward, Keras-Adam) in float64 torch-CPU arithmetic on the first B windows
+    of the bench's inputs, a fresh epsilon per step: the ELBO (Keras total loss) and its parts after every step - the CPU side of
+    bench.py's ``elbo`` block (north_star: 'ELBO within 1e-3 of reference after equal steps')."""
+    import numpy as np
+
+    from oracle.vae_oracle import make_cfg
+    torch.set_num_threads(threads)
+    spec, w, params = elbo_inputs(cell, T, B, V, Z, C)
+    oh = lambda idx, n: np.eye(n)[idx.astype(np.int64)]
+    tv = TorchCPUVAE(make_cfg(**spec.oracle_cfg()), dtype=torch.float64)
+    batch = dict(X=oh(w["x_idx"], 61), I=oh(w["i_idx"], 16), Vel=w["vel"][..., None].astype(np.float64), Hist=w["hist"].astype(np.float64),
+                 Y=oh(w["x_idx"], 61), C=oh(w["c_idx"], C))
+    P = tv.tensors(params)
+    st = tv.new_opt_state(P)
+    out = []
+    for i in range(steps):
+        m = tv.train_step(P, st, batch, elbo_epsilon(i, B, Z, spec.epsilon_std).astype(np.float64))
+        out.append({k: float(m[k]) for k in ("loss", "notes_loss", "instr_loss", "vel_loss", "style_loss", "kl")})
+    return out
+
+
 if __name__ == "__main__":
     import argparse
     import json
@@ -363,5 +404,9 @@ if __name__ == "__main__":
     ap.add_argument("--C", type=int, default=2)
     ap.add_argument("--budget", type=float, default=15.0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--elbo-steps", type=int, default=0, help="> 0: print the ELBO trajectory of that many optimizer steps instead")
     a = ap.parse_args()
-    print(json.dumps(timed_sample(a.cell, a.T, a.B, a.V, a.Z, a.C, a.budget, a.threads)))
+    if a.elbo_steps:
+        print(json.dumps(elbo_trajectory(a.cell, a.T, a.B, a.V, a.Z, a.C, a.elbo_steps, a.threads or 16)))
+    else:
+        print(json.dumps(timed_sample(a.cell, a.T, a.B, a.V, a.Z, a.C, a.budget, a.threads)))
