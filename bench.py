@@ -261,8 +261,10 @@ def main():
     # of 9.1 ms per step over 10 timed steps when the brackets first appeared inside the timed region).
     # Bracket only the dominant kernel's launches, and of those the two stacked decoder layers (plus one forward layer for the
     # critical-path figure): every event pair costs launch slots - all 26 BPTT launches bracketed slow the step by 0.5 ms.
-    KINDS = ({("rnn_fwd", "dec.notes.1")} if decode else
-             {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1")})
+    # (with phase launches - the engine's default - a decoder stack's two layers are ONE launch: keys (*_multi, "dec"))
+    KINDS = ({("rnn_fwd", "dec.notes.1"), ("rnn_fwd_multi", "dec")} if decode else
+             {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1"), ("rnn_bwd_multi", "dec"),
+              ("rnn_fwd_multi", "dec")})
     eng.prof_kinds = KINDS
     if args.warmup:
         eng.prof = {}
@@ -270,12 +272,15 @@ def main():
         step()
     torch.cuda.synchronize()
     if eng.prof is not None:
-        eng.prof_summary()
+        eng.prof_summary_last = eng.prof_summary()
         eng.prof = None
     first_loss = eng.metrics(B)["loss"] if (args.warmup and not decode) else float("nan")
 
-    # One more event per step boundary on the critical stream gives the per-step times (median).
-    eng.prof_kinds = KINDS
+    # One more event per step boundary on the critical stream gives the per-step times (median).  In the timed region only the
+    # DOMINANT kernel's launches are bracketed (a pair of events is two packets on the critical queue, ~30 us each: the forward
+    # figure of the critical-path bound comes from the warmup steps, which bracket both).
+    fwd_prof = {k: v for k, v in (eng.prof_summary_last if hasattr(eng, "prof_summary_last") else {}).items() if k[0].startswith("rnn_fwd")}
+    eng.prof_kinds = KINDS if decode else {k for k in KINDS if k[0].startswith("rnn_bwd")}
     eng.prof = {}               # HIP events on the launch streams
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
@@ -283,7 +288,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    timed_kinds, every = eng.prof_kinds, 4       # every 4th step carries the brackets (two packets on the critical queue each)
     for i in range(args.steps):
+        eng.prof_kinds = timed_kinds if i % every == 0 else set()
         step()
         marks[i + 1].record()
     torch.cuda.synchronize()
@@ -298,6 +305,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
     prof = eng.prof_summary()
+    for k, v in fwd_prof.items():           # (forward launches: timed over the warmup steps)
+        prof.setdefault(k, v)
     eng.prof = None
     m = eng.metrics(B) if not decode else None
     eng.check_pipeline()        # raises if a time-pipelined kernel ever gave up waiting for its producer (invalid results)
@@ -308,7 +317,7 @@ def main():
         # bracketed launch of it in the timed region was timed with HIP events on its stream.  Algorithmic work = the recurrent
         # GEMM only: 2 * B * H * (G*H) flop per time step, summed over the steps each launch covers - SURVEY section 8d.
         dom = "rnn_fwd" if decode else "rnn_bwd"
-        longk = {k: v for k, v in prof.items() if k[0] == dom}
+        longk = {k: v for k, v in prof.items() if k[0] in (dom, dom + "_multi")}
         launches = sum(n for n, _, _ in longk.values())
         tot_ms = sum(n * ms for n, ms, _ in longk.values())
         tot_steps = sum(n * st for n, _, st in longk.values())
@@ -317,10 +326,12 @@ def main():
         avg_ms = tot_ms / launches
         achieved = flop_step * tot_steps / (tot_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        cus = Bp // 16                      # one workgroup (= one CU) per 16 batch rows
-        us_dom = tot_ms * 1e3 / tot_steps
-        fwdk = [v for k, v in prof.items() if k[0] == "rnn_fwd"]
-        us_fwd = sum(n * ms for n, ms, _ in fwdk) * 1e3 / max(sum(n * st for n, _, st in fwdk), 1) if fwdk else float("nan")
+        # a phase launch holds BOTH layers of the stack: its work counts layer-steps, its latency per time step is launch / T
+        lpl = spec.Ld if any(k[0].endswith("_multi") for k in longk) else 1
+        cus = Bp // 16 * lpl                # one workgroup (= one CU) per 16 batch rows and layer
+        us_dom = tot_ms * 1e3 / tot_steps * lpl
+        fwdk = [v for k, v in prof.items() if k[0] in ("rnn_fwd", "rnn_fwd_multi")]
+        us_fwd = sum(n * ms for n, ms, _ in fwdk) * 1e3 / max(sum(n * st for n, _, st in fwdk), 1) * lpl if fwdk else float("nan")
         ms_step = elapsed / args.steps * 1e3
         # HBM traffic of the dominant kernel from the PMC counters: bench.py cannot run a counter pass over itself, so the pass over
         # THIS command (tools/collect_profiles_r03.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
@@ -357,13 +368,14 @@ def main():
                          # per time step and row: LSTM BPTT reads gates 4H + cell state H + upstream gradient H, writes da 4H;
                          # GRU reads gates 3H + h H + upstream gradient H, writes da 3H + r*h H; the
                          # inference forward reads x*W + b (G*H) and writes h (H)
-                         "algorithmic_bytes_per_launch": Bp * T * H * bytes_per_row * (2 if args.dtype == "bf16" else 4),
+                         "algorithmic_bytes_per_launch": lpl * Bp * T * H * bytes_per_row * (2 if args.dtype == "bf16" else 4),
+                         "layers_per_launch": lpl,
                          "avg_launch_ms": avg_ms, "launches": launches,
                          "avg_steps_per_launch": tot_steps / launches, "us_per_time_step": us_dom,
                          "flop_per_time_step": flop_step,
                          # the recurrence is latency-bound by design: B/16 workgroups, one per CU, step after step
                          "cus_occupied": cus, "frac_of_occupied_cus": achieved / (peak * min(cus, 256) / 256.0),
-                         "launch_ms_per_step_by_layer": {"%s:%s" % k: n * ms / args.steps for k, (n, ms, _) in prof.items()},
+                         "launch_ms_by_layer": {"%s:%s" % k: ms for k, (n, ms, _) in prof.items()},
                          # the two figures beside the per-kernel fraction
                          "whole_step": {"algorithmic_tflop": step_flop / 1e12, "tflops": step_flop / (ms_step * 1e-3) / 1e12,
                                         "frac_of_peak": step_flop / (ms_step * 1e-3) / 1e12 / peak}},

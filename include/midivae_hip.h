@@ -206,6 +206,12 @@ int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n, void* str
  * memory): `stream` proceeds once *addr >= value / writes value to *addr after everything enqueued before it on `stream`. */
 int mvae_stream_wait_value32(void* stream, const uint32_t* addr, uint32_t value);
 int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t value);
+/* Do streams a and b share a hardware queue (1) or not (0; < 0: error)?  Synchronises both, then runs a bounded waiter (~2 ms) on
+ * a and, enqueued after it, a setter on b: on one queue the setter cannot start before the waiter gives up.  `scratch`: 2 device
+ * words, `tag` != 0 a value not used before on them.  The engine calls it when it creates its streams - kernels of one stack that
+ * wait for each other across two streams need two queues (the reference has no counterpart: Keras runs one op at a time). */
+int mvae_streams_alias(void* stream_a, void* stream_b, uint32_t* scratch, uint32_t tag);
+
 /* Workgroups per CU of the library's RESIDENT kernels as the loaded code object and the device report it
  * (hipOccupancyMaxActiveBlocksPerMultiprocessor with the launch's dynamic LDS size): which = 0 the persistent dX GEMM between two
  * pipelined layers (mvae_gemm chunk_*, NT), 1 the weights-stationary forward projection, 2 a K-streaming workgroup
@@ -221,6 +227,28 @@ int mvae_colsum_weighted(const void* X, int32_t kind, const float* wgt, int32_t 
                          void* stream);
 /* out[b, n] (+)= sum_t X[t, b, n]   (gradient of an X_CONST row; accumulate != 0 adds to out, e.g. per time chunk) */
 int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float* out, int32_t accumulate, void* stream);
+
+/* PHASE launches: every recurrence of one phase of the step (reference vae_definition.py:443-480 - the encoder's notes stack and
+ * its instrument / velocity / held-notes rolls - or :519-726 - the decoder's cell stacks - forward or backward) as ONE launch:
+ * n <= 8 problems of the slot-interleaved kernels (H = 256, bf16, seq_layout MVAE_TILE16P, LSTM or GRU, dense / indexed / constant
+ * inputs; all of one cell type, all saving activations or none), workgroups in problem order - list producers first.  The time-
+ * pipelined hand-over fields of each problem work as in the single launches.  ``xpand``: up to 2 expansions of a 1-feature roll
+ * (mvae_outer_bias_tile16) as chunk-publishing producers inside the forward launch: out (R, N) bf16 MVAE_TILE16 = xs[r] w[n] +
+ * bias[n], chunk_done[c] += 4 * blocks when rows [c * chunk_rows, (c+1) * chunk_rows) are written (write-through); the problem that
+ * reads `out` as its xp names chunk_done as wait_ready with wait_value = previous total + 4 * blocks.
+ * MVAE_E_UNSUPPORTED: some problem is not one of these kernels' (launch them one by one with mvae_rnn_fwd / mvae_rnn_bwd). */
+typedef struct {
+    const float* xs;           /* (R) f32 */
+    const float* w;            /* (N) f32, 16-byte aligned */
+    const float* bias;         /* (N) f32, 16-byte aligned */
+    void* out;                 /* (R, N) out_kind (MVAE_BF16), MVAE_TILE16 */
+    int32_t out_kind, R, N;
+    int32_t chunk_rows;        /* rows per published chunk (% 16 == 0, divides R): chunk_steps * B of the consumer */
+    uint32_t* chunk_done;      /* [R / chunk_rows] counters */
+    int32_t blocks, reserved;  /* workgroups of this producer (<= 256) */
+} mvae_xpand_args;
+int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand, void* stream);
+int mvae_rnn_bwd_multi(const mvae_rnn_bwd_args* problems, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Output heads: Dense(H -> N) + activation + Keras weighted loss + metric + d(logits), fused, over all
@@ -342,9 +370,12 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  *   MVAE_PREP_ADD_I32          src = NULL or a guard word (uint32)            -> *(int32_t*)dst += a unless *src != 0 (the
  *                              optimizer's step count after mvae_adam_step_dev(MVAE_ADAM_KEEP_COUNT): no launch of its own);
  *                              src2 = NULL or a latch word (uint32): a non-zero *src is then moved there (max) and CLEARED -
- *                              the status word of the time-pipelined stacks lives for one step, the latch until the host reads it */
+ *                              the status word of the time-pipelined stacks lives for one step, the latch until the host reads it
+ *   MVAE_PREP_BROADCAST_ROWS   src (b) f32                                    -> dst (a, b) kind: every row = src.  start*W + b of a
+ *                              decoder cell whose constant input is all zeros - what the reference's packers always pass
+ *                              (vae_definition.py:820,916): the bias row, no GEMM */
 enum { MVAE_PREP_PACK_RECURRENT = 0, MVAE_PREP_MAKE_TABLE = 1, MVAE_PREP_TRANSPOSE_CONVERT = 2, MVAE_PREP_CONVERT = 3,
-       MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5, MVAE_PREP_ADD_I32 = 6 };
+       MVAE_PREP_ZERO = 4, MVAE_PREP_CONVERT_PAD = 5, MVAE_PREP_ADD_I32 = 6, MVAE_PREP_BROADCAST_ROWS = 7 };
 typedef struct {
     int32_t op, kind;          /* MVAE_PREP_*, element kind of dst (MVAE_F32 / MVAE_BF16) */
     int32_t a, b, c, reserved;

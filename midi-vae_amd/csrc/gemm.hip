@@ -594,6 +594,10 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;             // XCD, index within the XCD's workgroups
     const int bx = j % tiles_n, g = j / tiles_n, G = (gridDim.x >> 3) / tiles_n;
     const int n0 = bx * FBN;
+    // The first chunk is waited for BEFORE anything is read: the launch may sit on its queue ahead of the weight preparation of
+    // its step (no event orders it - one packet less on the critical queue per phase); the producer it polls runs behind that
+    // preparation, so a published chunk says the weights are in place.
+    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + (a.chunk_reverse ? nchunks - 1 : 0), a.chunk_wait_value, a.chunk_status, 3u);
     {   // the weight panel: rows n0 .. n0+127 of B (N, K) k-contiguous
         f_stage<false, false> sb;
 #pragma unroll

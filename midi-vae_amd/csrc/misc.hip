@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_k(const bf16_t* __restrict_
                                                        int Nv /* N rounded up to 8: columns read */, int ldx, int rows_per_block,
                                                        float* __restrict__ out) {
     __shared__ float red[256 * 8];
-    const int c8 = Nv / 8, lanes_r = 256 / c8;          // c8 in {1,2,4,...,256}: callers check Nv/8 divides 256
+    const int c8 = Nv / 8, lanes_r = 256 / c8;          // c8 <= 256; threads beyond lanes_r * c8 (c8 = 96: a GRU's 768 columns) idle
     const int col = (threadIdx.x % c8) * 8, rsub = threadIdx.x / c8;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    const int r0 = blockIdx.x * rows_per_block, r1 = rsub < lanes_r ? min(R, r0 + rows_per_block) : 0;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rr = r0 + rsub;
     for (; rr + 3 * lanes_r < r1; rr += 4 * lanes_r) {        // 4 independent 16-byte loads in flight
@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_k(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]) * w;
     }
+    if (rsub < lanes_r) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[(rsub * c8 + threadIdx.x % c8) * 8 + e] = s[e];
+        for (int e = 0; e < 8; ++e) red[(rsub * c8 + threadIdx.x % c8) * 8 + e] = s[e];
+    }
     __syncthreads();
     for (int n = threadIdx.x; n < N; n += 256) {
         float t = 0.0f;
@@ -413,7 +415,7 @@ static int colsum_impl(const void* X, int32_t kind, const float* wgt, int32_t R,
     if (!X || !out || R <= 0 || N <= 0 || ldx < N) return MVAE_E_ARG;
     // (N not a multiple of 8 - 61 note classes in rows of 64: the pad columns are read and not written)
     const int Nv = (N + 7) / 8 * 8, c8 = Nv / 8;
-    const bool vec = kind == MVAE_BF16 && Nv <= ldx && c8 <= 256 && (256 % c8) == 0 && (ldx % 8) == 0 &&
+    const bool vec = kind == MVAE_BF16 && Nv <= ldx && c8 <= 256 && (ldx % 8) == 0 &&
                      (reinterpret_cast<uintptr_t>(X) & 15) == 0;
     if (vec) {
         // enough blocks to fill the chip, enough rows per block to amortise the LDS reduction and the atomics
@@ -520,6 +522,35 @@ extern "C" int mvae_stream_write_value32(void* stream, uint32_t* addr, uint32_t 
     return hipStreamWriteValue32(reinterpret_cast<hipStream_t>(stream), addr, value, 0) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
 }
 
+// ---- do two streams share a hardware queue? ---------------------------------------------------------------------------
+// The HIP runtime maps streams onto a fixed number of hardware queues (GPU_MAX_HW_QUEUES); two streams on ONE queue run their
+// kernels one after the other.  A phase launch on the critical stream contains BOTH the producer and the consumer of the
+// persistent GEMM that runs on another stream beside it: on a shared queue the GEMM could only start when the launch has ended,
+// and the launch would wait for it (bounded - a time-out and the per-launch schedule - but 2-4 s late).  So the engine asks
+// once, when it creates its streams: a waiter on `a` (bounded: ~2 ms) and, enqueued AFTER it, a setter on `b`.
+__global__ void alias_wait_k(const uint32_t* flag, uint32_t value, uint32_t max_spins, uint32_t* seen) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != value && spins < max_spins) {
+        __builtin_amdgcn_s_sleep(32);
+        ++spins;
+    }
+    *seen = spins < max_spins ? 1u : 0u;
+}
+__global__ void alias_set_k(uint32_t* flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+extern "C" int mvae_streams_alias(void* stream_a, void* stream_b, uint32_t* scratch /* 2 device words */, uint32_t tag) {
+    if (!scratch || tag == 0u) return MVAE_E_ARG;
+    hipStream_t a = reinterpret_cast<hipStream_t>(stream_a), b = reinterpret_cast<hipStream_t>(stream_b);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return MVAE_E_LAUNCH;
+    hipLaunchKernelGGL(alias_wait_k, dim3(1), dim3(1), 0, a, scratch, tag, 20000u, scratch + 1);
+    hipLaunchKernelGGL(alias_set_k, dim3(1), dim3(1), 0, b, scratch, tag);
+    MVAE_CHECK_LAUNCH();
+    uint32_t seen = 0;
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+        hipMemcpy(&seen, scratch + 1, sizeof(seen), hipMemcpyDeviceToHost) != hipSuccess)
+        return MVAE_E_LAUNCH;
+    return seen ? 0 : 1;
+}
+
 // ---- batched weight preparation: every derived copy of the parameters in ONE launch ------------------------------
 // Workgroups [base[j], base[j+1]) run job j: a job gets workgroups in proportion to its output (a 256 x 1024 fragment pack 64,
 // a 32-word fill one).
@@ -587,6 +618,15 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
                 }
             }
             break;
+        case MVAE_PREP_BROADCAST_ROWS: {    // dst (a, b) = the row src (b) repeated: start*W + b of a cell stepped on an all-zero input
+            const size_t n = (size_t)job.a * job.b;
+            for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
+                const float v = src[e % job.b];
+                if (bf) st<bf16_t>::store(reinterpret_cast<bf16_t*>(job.dst) + e, v);
+                else reinterpret_cast<float*>(job.dst)[e] = v;
+            }
+            break;
+        }
         case MVAE_PREP_ZERO: {
             const size_t n = (size_t)job.a * job.b * (bf ? 2 : 4) / 4;       // 32-bit words
             uint32_t* d = reinterpret_cast<uint32_t*>(job.dst);
@@ -606,7 +646,7 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
             const mvae_prep_job& job = jobs[j0 + j];
             if ((!job.src && job.op != MVAE_PREP_ZERO && job.op != MVAE_PREP_ADD_I32) || !job.dst || job.op < 0 ||
                 (job.op == MVAE_PREP_ADD_I32 && job.src2 && !job.src) ||
-                job.op > MVAE_PREP_ADD_I32 ||
+                job.op > MVAE_PREP_BROADCAST_ROWS ||
                 (job.op == MVAE_PREP_CONVERT_PAD && job.c < job.b) ||
                 (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
                 (job.op == MVAE_PREP_ZERO && job.kind == MVAE_BF16 && (((size_t)job.a * job.b) & 1)))

@@ -33,6 +33,7 @@
 //    exposed.  Backward has a true dependency (all of dh before any gate gradient) and stays phased.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 // Phase stamps (build with -DRES_STAMPS): block 0 / wave 0 / lane 0 records s_memtime at marked points of steps
@@ -579,7 +580,7 @@ struct lstm_group_map {
 #endif
 
 template <int XMODE, int SAVE, int NA, int NV>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args a) {
+__device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, const unsigned bx) {
     constexpr int G = 4, GH = G * RH;
     constexpr int FPW = G * RNT * RS, NGRP = FPW / 4;
     // Residency class of fragment f (f = order of use: (tile*8 + kgroup)*4 + gate):
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
-    const int b = blockIdx.x * 16 + r;
+    const int b = bx * 16 + r;
     const size_t tps = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
     frag* myl = ulds + (size_t)w * NLc * 64 + l;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
         *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(h0v);
         if (SAVE == SAVE_ALL)      // c_0 -> slot 0 of the (T+1, B, H) TILE16P array: 8 bytes of the lane's 16 per tile pair
             *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned char*>(a.cs) +
-                                      ((size_t)blockIdx.x * (RH / 32) + w * 2 + (n >> 1)) * 1024 + (unsigned)l * 16u + (n & 1) * 8) = pack4(creg[n]);
+                                      ((size_t)bx * (RH / 32) + w * 2 + (n >> 1)) * 1024 + (unsigned)l * 16u + (n & 1) * 8) = pack4(creg[n]);
     }
 
     // ---- x queue (packed bf16x4 per tile and gate) for the step about to be computed --------------------------
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     const unsigned char* xbase0;                // wave-uniform base (step 0 for DENSE)
     if (XMODE == MVAE_X_DENSE) {
         xoff = lane8;
-        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)blockIdx.x * (GH / 16) + w * RNT) * 512;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w * RNT) * 512;
     } else if (XMODE == MVAE_X_INDEX) {
         xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
@@ -691,11 +692,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+        acts_p[g] = to_global(a.acts) + ((size_t)bx * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
         x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
     }
-    cs_p = to_global(a.cs) + ((tps + blockIdx.x) * (RH / 32) + w * 2) * 1024;
-    hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
+    cs_p = to_global(a.cs) + ((tps + bx) * (RH / 32) + w * 2) * 1024;
+    hs_p = to_global(a.hs) + (size_t)bx * 16 * (RH * 2);
 
     for (int t = 0; t < T; ++t) {
         const int tstep = t;
@@ -896,6 +897,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
     }
     vm_drain();
 }
+template <int XMODE, int SAVE, int NA, int NV>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args a) {
+    lstm_fwd_il_body<XMODE, SAVE, NA, NV>(a, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // GRU forward, slot-interleaved (Keras 2.0.x GRU: reset gate applied BEFORE the candidate matmul)
@@ -912,7 +917,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args 
 //          -  tanh + h update of tiles 2,3, barrier
 // Inputs are TILE16, saved activations (z, r, candidate) TILE16P: one 16-byte store per gate and tile pair.
 template <int XMODE, int SAVE>
-__global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a) {
+__device__ __forceinline__ void gru_fwd_il_body(const mvae_rnn_fwd_args& a, const unsigned bx) {
     constexpr int G = 3, GH = G * RH, NLc = RNT * RS;             // 32 candidate fragments per wave in LDS
     static_assert(XMODE != MVAE_X_SCALAR, "scalar inputs run on the phased kernel");
 
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
-    const int b = blockIdx.x * 16 + r;
+    const int b = bx * 16 + r;
     const size_t tps = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
     frag* myl = ulds + (size_t)w * NLc * 64 + l;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     const unsigned char* xbase0;
     if (XMODE == MVAE_X_DENSE) {
         xoff = lane8;
-        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)blockIdx.x * (GH / 16) + w * RNT) * 512;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w * RNT) * 512;
     } else if (XMODE == MVAE_X_INDEX) {
         xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
@@ -1006,11 +1011,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
     const size_t acts_step = tps * (GH / 16) * 512, hs_step = (size_t)B * RH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        acts_p[g] = to_global(a.acts) + ((size_t)blockIdx.x * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+        acts_p[g] = to_global(a.acts) + ((size_t)bx * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
         x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE ? (T > 2 ? 2 : T - 1) * acts_step : 0);
     }
     hh_prev_p = acts_p[2];
-    hs_p = to_global(a.hs) + (size_t)blockIdx.x * 16 * (RH * 2);
+    hs_p = to_global(a.hs) + (size_t)bx * 16 * (RH * 2);
 
     constexpr float K2 = 2.8853900817779268f;
     f32x4 accA[4], accB[4], zg[RNT];
@@ -1218,6 +1223,10 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a
         if (cs_steps && a.signal_done) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
     }
     vm_drain();
+}
+template <int XMODE, int SAVE>
+__global__ __launch_bounds__(256, 1) void gru_fwd_il_k(const mvae_rnn_fwd_args a) {
+    gru_fwd_il_body<XMODE, SAVE>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1430,7 +1439,7 @@ __global__ __launch_bounds__(256, 1) void rnn_bwd_res_k(const mvae_rnn_bwd_args 
 // Fragment classes in order of use: T (first k-group; streamed from L2 during E into the registers that stage
 // LDS-resident fragments during M), A accumulator registers, V vector registers, L LDS.
 template <bool HAS_EXT, int NA, int NV>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args a) {
+__device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, const unsigned bx) {
     constexpr int G = 4, GH = G * RH, S2 = GH / 32, FPW = RNT * S2;
     constexpr int NT = 4, NLc = FPW - NT - NA - NV;
     static_assert(NA % 4 == 0 && NV % 4 == 0 && NLc >= 0 && NA <= 64 && NLc <= 32, "fragment classes");
@@ -1441,7 +1450,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
-    const int b = blockIdx.x * 16 + r;
+    const int b = bx * 16 + r;
     const size_t tps = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
     frag* myl = ulds + (size_t)w * NLc * 64 + l;
@@ -1483,10 +1492,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, da_step = (size_t)B * GH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g)
-        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
-    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 32) + w * 2) * 1024;      // c_{t-1} of step T-1
-    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
-    da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + bx) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + bx) * (RH / 32) + w * 2) * 1024;      // c_{t-1} of step T-1
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + bx) * (RH / 16) + w * RNT) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + bx * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
 
     // pipelined stack bookkeeping: chunk pk (first step plo) is the one being processed; one division, before the loop
     const int cs_steps = a.chunk_steps;
@@ -1649,6 +1658,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
     }
     vm_drain();
 }
+template <bool HAS_EXT, int NA, int NV>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args a) {
+    lstm_bwd_il_body<HAS_EXT, NA, NV>(a, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // GRU backward, slot-interleaved
@@ -1674,7 +1687,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_il_k(const mvae_rnn_bwd_args 
 #define GB_NODAZ 0
 #endif
 template <bool HAS_EXT>
-__global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a) {
+__device__ __forceinline__ void gru_bwd_il_body(const mvae_rnn_bwd_args& a, const unsigned bx) {
     constexpr int G = 3, GH = G * RH, S2 = GH / 32, NLc = RNT * (RH / 32);      // 24 k-groups; 32 LDS fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* dabuf = smem;                                              // [16][GH] bf16, swizzled (24 KiB)
@@ -1683,7 +1696,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
     const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = a.T, B = a.B;
-    const int b = blockIdx.x * 16 + r;
+    const int b = bx * 16 + r;
     const size_t tps = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
     frag* myl = ulds + (size_t)w * NLc * 64 + l;
@@ -1723,11 +1736,11 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
                  da_step = (size_t)B * GH * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g)
-        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + blockIdx.x) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
-    hs_p = to_global(a.hs) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (RH * 2) + w * 128;             // h_{t-1} = slot t
-    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + blockIdx.x) * (RH / 16) + w * RNT) * 512;
-    da_p = to_global(a.da) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
-    rh_p = to_global(a.rh) + ((size_t)(T - 1) * B + blockIdx.x * 16) * (RH * 2);
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + bx) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
+    hs_p = to_global(a.hs) + ((size_t)(T - 1) * B + bx * 16) * (RH * 2) + w * 128;             // h_{t-1} = slot t
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + bx) * (RH / 16) + w * RNT) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + bx * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
+    rh_p = to_global(a.rh) + ((size_t)(T - 1) * B + bx * 16) * (RH * 2);
 
     // pipelined stack bookkeeping, as lstm_bwd_il_k: chunk pk (first step plo) is the one being processed
     const int cs_steps = a.chunk_steps;
@@ -1980,6 +1993,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a
         if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 16 * n) = dh[n];
     vm_drain();
 }
+template <bool HAS_EXT>
+__global__ __launch_bounds__(256, 1) void gru_bwd_il_k(const mvae_rnn_bwd_args a) {
+    gru_bwd_il_body<HAS_EXT>(a, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // dispatch
@@ -2153,6 +2170,126 @@ int launch_bwd_res(const mvae_rnn_bwd_args& a, hipStream_t s) {
     return MVAE_OK;
 }
 
+
+// ===========================================================================================================
+// PHASE launches (round 3): every recurrence of one phase of the step - the notes stack's layers AND the velocity / instrument /
+// held-notes branches beside it - as ONE launch on ONE queue.  Each recurrence used to be a launch on a queue of its own, forked
+// from and joined into the critical queue by events: a cross-queue dependency costs the command processors 40-120 us to resolve
+// when it resolves late (kernel timeline, profiles/r03_b_timeline_lstm_step.txt: ~0.5 ms of a 7.7 ms step between the phases),
+// a same-queue boundary ~2-8 us.  Workgroups [base[i], base[i+1]) run problem i with the SAME code as the single launches (the
+// kernel bodies above; problems of one launch share the cell type and the save mode and may differ in input mode and length).
+// Problems are listed producers first - workgroups are dispatched in index order - and the hand-over between the layers of a
+// stack (device-side counters) is what it was.  An XPAND problem is the x*W + b expansion of a 1-feature roll (mvae_outer_bias_
+// tile16) as a chunk-publishing producer inside the launch: the recurrence that consumes it follows it chunk by chunk instead
+// of waiting for a 0.12 ms launch in front of it.
+// ===========================================================================================================
+constexpr int RM_MAX = 8, RM_XP_MAX = 2;
+struct rnn_fwd_multi {
+    mvae_rnn_fwd_args p[RM_MAX];
+    mvae_xpand_args xp[RM_XP_MAX];
+    int32_t base[RM_XP_MAX + RM_MAX + 1];      // xpand problems first, then the recurrences
+    int32_t nx, n;
+};
+struct rnn_bwd_multi {
+    mvae_rnn_bwd_args p[RM_MAX];
+    int32_t base[RM_MAX + 1];
+    int32_t n;
+};
+__device__ __forceinline__ void xpand_body(const mvae_xpand_args& x, const int bid, const int nb) {
+    // out (R, N) bf16 in TILE16 = xs[r] * w[n] + bias[n], chunk after chunk of chunk_rows rows (a chunk is contiguous in TILE16);
+    // stored write-through, every wave publishes each chunk once (the consumer expects 4 * nb increments per chunk)
+    const int N = x.N, nchunks = x.R / x.chunk_rows;
+    const size_t per = (size_t)x.chunk_rows * N / 4;                 // quads (4 consecutive n of one row) per chunk
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(x.out) + (size_t)c * per * 8;
+        for (size_t q = (size_t)bid * 256 + threadIdx.x; q < per; q += (size_t)nb * 256) {
+            const size_t e = (size_t)c * per + q, tile = e >> 6;
+            const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
+            const float xv = x.xs[m];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(x.w + n), bv = *reinterpret_cast<const f32x4*>(x.bias + n);
+            store4_bf16_wt(cbase, (unsigned)(q * 8), xv * wv + bv);
+        }
+        wave_signal_done<false>(x.chunk_done + c);
+    }
+}
+template <int CELL, int SAVE>
+__global__ __launch_bounds__(256, 1) void rnn_fwd_multi_k(const rnn_fwd_multi m) {
+    const int bid = (int)blockIdx.x, nx = m.nx;
+    int i = 0;
+    while (i + 1 < nx + m.n && bid >= m.base[i + 1]) ++i;
+    const unsigned bx = (unsigned)(bid - m.base[i]);
+    if (i < nx) {
+        xpand_body(m.xp[i], (int)bx, m.base[i + 1] - m.base[i]);
+        return;
+    }
+    // (a COPY: the fields then live in scalar registers for the whole launch, as a single launch's kernel arguments do - read
+    //  through the reference they are re-loaded from the argument segment inside the step loop, each load behind an lgkmcnt wait)
+    const mvae_rnn_fwd_args a = m.p[i - nx];
+    const int xm = __builtin_amdgcn_readfirstlane(a.xmode);
+    if constexpr (CELL == MVAE_LSTM) {
+        typedef res_cfg<MVAE_LSTM> C;
+        if (xm == MVAE_X_DENSE) lstm_fwd_il_body<MVAE_X_DENSE, SAVE, C::IA, C::IV>(a, bx);
+        else if (xm == MVAE_X_INDEX) lstm_fwd_il_body<MVAE_X_INDEX, SAVE, C::IA, C::IV>(a, bx);
+        else lstm_fwd_il_body<MVAE_X_CONST, SAVE, C::IA, C::IV>(a, bx);
+    } else {
+        if (xm == MVAE_X_DENSE) gru_fwd_il_body<MVAE_X_DENSE, SAVE>(a, bx);
+        else if (xm == MVAE_X_INDEX) gru_fwd_il_body<MVAE_X_INDEX, SAVE>(a, bx);
+        else gru_fwd_il_body<MVAE_X_CONST, SAVE>(a, bx);
+    }
+}
+template <int CELL>
+__global__ __launch_bounds__(256, 1) void rnn_bwd_multi_k(const rnn_bwd_multi m) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < m.n && bid >= m.base[i + 1]) ++i;
+    const unsigned bx = (unsigned)(bid - m.base[i]);
+    const mvae_rnn_bwd_args a = m.p[i];        // (a copy: see rnn_fwd_multi_k)
+    const bool ext = __builtin_amdgcn_readfirstlane(a.dhs_ext != nullptr);
+    if constexpr (CELL == MVAE_LSTM) {
+        typedef res_cfg<MVAE_LSTM> C;
+        if (ext) lstm_bwd_il_body<true, C::JA, C::JV>(a, bx);
+        else lstm_bwd_il_body<false, C::JA, C::JV>(a, bx);
+    } else {
+        if (ext) gru_bwd_il_body<true>(a, bx);
+        else gru_bwd_il_body<false>(a, bx);
+    }
+}
+template <int CELL, int SAVE>
+int launch_fwd_multi(const rnn_fwd_multi& m, int total, hipStream_t s) {
+    typedef res_cfg<MVAE_LSTM> C;
+    constexpr int NL = 4 * RNT * RS - 4 - C::IA - C::IV;
+    const size_t lds = CELL == MVAE_LSTM ? (size_t)2 * 16 * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag)
+                                         : (size_t)3 * 16 * RH * sizeof(bf16_t) + (size_t)4 * RNT * RS * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_multi_k<CELL, SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((rnn_fwd_multi_k<CELL, SAVE>), dim3(total), dim3(256), lds, s, m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+template <int CELL>
+int launch_bwd_multi(const rnn_bwd_multi& m, int total, hipStream_t s) {
+    typedef res_cfg<MVAE_LSTM> C;
+    constexpr int NL = RNT * (4 * RH / 32) - 4 - C::JA - C::JV;
+    const size_t lds = CELL == MVAE_LSTM ? (size_t)16 * 4 * RH * sizeof(bf16_t) + (size_t)4 * NL * 64 * sizeof(frag)
+                                         : (size_t)16 * 3 * RH * sizeof(bf16_t) + (size_t)16 * RH * sizeof(bf16_t) +
+                                               (size_t)4 * RNT * (RH / 32) * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_multi_k<CELL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((rnn_bwd_multi_k<CELL>), dim3(total), dim3(256), lds, s, m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 }  // namespace
 
 // Entry points used by rnn.hip's dispatch.  Return MVAE_E_UNSUPPORTED when the shape is not this file's.
@@ -2172,4 +2309,71 @@ int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s) {
     }
     if (a.cell == MVAE_GRU) return a.dhs_ext ? launch_bwd_res<MVAE_GRU, true>(a, s) : launch_bwd_res<MVAE_GRU, false>(a, s);
     return MVAE_E_UNSUPPORTED;
+}
+
+// (see rnn_fwd_multi_k)  MVAE_E_UNSUPPORTED: a problem is not one the slot-interleaved kernels take - launch them one by one
+extern "C" int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand,
+                                  void* stream) {
+    if (!problems || n <= 0 || n > RM_MAX || n_xpand < 0 || n_xpand > RM_XP_MAX || (n_xpand && !xpand)) return MVAE_E_ARG;
+    rnn_fwd_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    m.nx = n_xpand;
+    int total = 0;
+    for (int i = 0; i < n_xpand; ++i) {
+        const mvae_xpand_args& x = xpand[i];
+        if (!x.xs || !x.w || !x.bias || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || x.N <= 0 || (x.N % 16) ||
+            x.chunk_rows <= 0 || (x.chunk_rows % 16) || (x.R % x.chunk_rows) || x.blocks <= 0 || x.blocks > 256 ||
+            (reinterpret_cast<uintptr_t>(x.w) & 15) || (reinterpret_cast<uintptr_t>(x.bias) & 15) ||
+            (size_t)x.chunk_rows * x.N * 2 > 0x7fffffffull)
+            return MVAE_E_ARG;
+        m.xp[i] = x;
+        m.base[i] = total;
+        total += x.blocks;
+    }
+    const mvae_rnn_fwd_args& f = problems[0];
+    for (int i = 0; i < n; ++i) {
+        const mvae_rnn_fwd_args& a = problems[i];
+        if (!a.u_pack || a.T <= 0 || a.B <= 0 || (a.B % 16) || a.chunk_steps < 0 ||
+            ((a.wait_ready || a.signal_done) && a.chunk_steps == 0) || (a.wait_ready && a.xmode != MVAE_X_DENSE) ||
+            (a.signal_done && !a.hs))
+            return MVAE_E_ARG;
+        if (a.H != RH || a.dtype != MVAE_BF16 || a.seq_layout != MVAE_TILE16P || (a.cell != MVAE_LSTM && a.cell != MVAE_GRU) ||
+            a.cell != f.cell || a.xmode == MVAE_X_SCALAR || !a.hs || (a.acts != nullptr) != (f.acts != nullptr) ||
+            (a.acts && a.cell == MVAE_LSTM && !a.cs) || (!a.acts && a.cs))
+            return MVAE_E_UNSUPPORTED;
+        if ((a.xmode == MVAE_X_DENSE && !a.xp) || (a.xmode == MVAE_X_INDEX && !(a.idx && a.table)) || (a.xmode == MVAE_X_CONST && !a.xp0))
+            return MVAE_E_ARG;
+        m.p[i] = a;
+        m.base[n_xpand + i] = total;
+        total += a.B / 16;
+    }
+    m.base[n_xpand + n] = total;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (f.cell == MVAE_LSTM) return f.acts ? launch_fwd_multi<MVAE_LSTM, SAVE_ALL>(m, total, s) : launch_fwd_multi<MVAE_LSTM, SAVE_HS>(m, total, s);
+    return f.acts ? launch_fwd_multi<MVAE_GRU, SAVE_ALL>(m, total, s) : launch_fwd_multi<MVAE_GRU, SAVE_HS>(m, total, s);
+}
+extern "C" int mvae_rnn_bwd_multi(const mvae_rnn_bwd_args* problems, int32_t n, void* stream) {
+    if (!problems || n <= 0 || n > RM_MAX) return MVAE_E_ARG;
+    rnn_bwd_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    int total = 0;
+    const mvae_rnn_bwd_args& f = problems[0];
+    for (int i = 0; i < n; ++i) {
+        const mvae_rnn_bwd_args& a = problems[i];
+        if (!a.ut_pack || !a.hs || !a.acts || !a.da || a.T <= 0 || a.B <= 0 || (a.B % 16) || a.chunk_steps < 0 ||
+            ((a.wait_ready || a.signal_done) && a.chunk_steps == 0) || (a.wait_ready && !a.dhs_ext))
+            return MVAE_E_ARG;
+        if (a.H != RH || a.dtype != MVAE_BF16 || a.seq_layout != MVAE_TILE16P || (a.cell != MVAE_LSTM && a.cell != MVAE_GRU) ||
+            a.cell != f.cell)
+            return MVAE_E_UNSUPPORTED;
+        if (a.cell == MVAE_LSTM && !a.cs) return MVAE_E_ARG;
+        m.p[i] = a;
+        m.base[i] = total;
+        total += a.B / 16;
+    }
+    m.base[n] = total;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return f.cell == MVAE_LSTM ? launch_bwd_multi<MVAE_LSTM>(m, total, s) : launch_bwd_multi<MVAE_GRU>(m, total, s);
 }

@@ -27,6 +27,7 @@ from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
 
 from .engine_io import ArrayStaging, Results
 from .engine_optional import OptionalGraph
+from .engine_phases import PhaseLaunches
 from .slots import *        # noqa: F401,F403  (scalar slots S_*, N_SCALARS, X_EXT)
 from .slots import N_SCALARS, X_EXT
 
@@ -70,7 +71,7 @@ class _Aux(object):
         self.head.T, self.head.out = 1, key + ".out"
 
 
-class Engine(ArrayStaging, OptionalGraph, Results):
+class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
                  training: bool = True, share: "Engine | None" = None):
         """``share``: another Engine of the same spec on the same device whose PARAMETERS (the flat f32 buffer itself) and HIP
@@ -125,7 +126,7 @@ class Engine(ArrayStaging, OptionalGraph, Results):
                 self.s_next = torch.cuda.Stream() if spec.meta_next else None
                 self.s_grad2 = torch.cuda.Stream()      # second gradient stream: input-kernel / bias gradients
                 self.s_layer = [torch.cuda.Stream() for _ in range(nl)]
-                self.s_proj = [torch.cuda.Stream() for _ in range(nl)]     # x*W / dX of pipelined stacks
+                self.s_proj = [self._own_queue_stream() for _ in range(nl)]     # x*W / dX of pipelined stacks
         self.multi_stream = True
         self._prefork = None
         self._branches_stay_forked = False
@@ -174,12 +175,18 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self._occ = {k: max(1, hl.load().mvae_occupancy(i)) for i, k in enumerate(("dx", "proj", "kstream"))}
         self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
+        # the recurrences of a phase as ONE launch on the critical queue instead of one launch per queue (engine_phases.py)
+        self.phase_multi = os.environ.get("MVAE_PHASE_MULTI", "1") == "1"
+        self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
         if share is None:
             self.set_params(self._initial_params(seed))
         self._build_graph_description()
         self._alloc(self.maxB)
         self._views_cache = {}
         self._prep = None                # PrepBatch per (step count pending): prepare_weights
+        self._deferred_side = None       # (phase launches) side-queue work to be released by a device counter instead of an event
+        self._xp0_bias = set()           # constant-input cells whose xp0 rows hold the bias (written by the last weight preparation)
+        self.start_zero = {}             # layer prefix -> the staged start rows of its head are all zero (staging)
         self._count_only = None
         self._count_pending = False
         self._sync_cum = {}
@@ -189,6 +196,23 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         self.norm_B = float(self.maxB)   # windows the batch-mean losses are normalised by (the GLOBAL minibatch under data parallelism)
         self._have_staged_targets = False
         self.acc = torch.zeros(N_SCALARS, dtype=torch.float32, device=self.device)     # epoch accumulators (accumulate_metrics)
+
+    def _own_queue_stream(self):
+        """a new stream that does NOT share its hardware queue with the current (critical) stream: the runtime deals streams onto
+        GPU_MAX_HW_QUEUES queues round-robin, and a phase launch on the critical stream holds both the producer and the consumer
+        of the persistent GEMM running on this one (engine_phases.py) - on one queue they would wait for each other until the
+        time-out.  Asked of the runtime by experiment (mvae_streams_alias), once, here."""
+        cur = torch.cuda.current_stream()
+        scratch = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._aliased = getattr(self, "_aliased", [])          # (kept alive: a released stream's queue slot would be dealt again)
+        for attempt in range(1, 33):
+            st = torch.cuda.Stream()
+            rc = hl.load().mvae_streams_alias(cur.cuda_stream, st.cuda_stream, scratch.data_ptr(), attempt)
+            if rc == 0:
+                return st
+            hl.check(min(rc, 0), "mvae_streams_alias")
+            self._aliased.append(st)
+        raise RuntimeError("no stream with a hardware queue of its own after 32 attempts (GPU_MAX_HW_QUEUES too small?)")
 
     @property
     def _weights_dirty(self):
@@ -226,11 +250,13 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         return r.xmode == hl.X_SCALAR and self._seq_layout(r) == hl.TILE16P
 
     def _mark(self, name):
-        """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect)"""
+        """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect): (name, host time of
+        the enqueue, event) - tools/host_vs_device.py"""
         if getattr(self, "marks", None) is not None:
+            import time
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            self.marks.append((name, e))
+            self.marks.append((name, time.perf_counter(), e))
 
     # ---- stream helpers -------------------------------------------------------------------------------------
     def _fork(self, *streams):
@@ -283,9 +309,14 @@ class Engine(ArrayStaging, OptionalGraph, Results):
 
     def _side(self, fn):
         """Run ``fn`` (parameter-gradient work nobody waits for before the optimizer) on the second gradient stream,
-        ordered after everything enqueued so far on the current stream."""
+        ordered after everything enqueued so far on the current stream.  While a list is collecting (``_deferred_side``: the
+        phase launch that follows releases the work by a device counter - an event record here is one more packet, ~30 us, on
+        the critical queue) the work is only noted."""
         if not self.multi_stream:
             fn()
+            return
+        if self._deferred_side is not None:
+            self._deferred_side.append(fn)
             return
         self.s_grad2.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.s_grad2):
@@ -412,7 +443,8 @@ class Engine(ArrayStaging, OptionalGraph, Results):
 
         esz = dict(dtype=dt, device=dev)
         # time-pipelined stacks: progress counters / ready flags (4 stack slots x 1024 words) and the time-out status word
-        st["sync"] = torch.zeros(5 * 1024, dtype=torch.int32, device=dev)     # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch
+        # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch; 5: the expansion of a 1-feature roll
+        st["sync"] = torch.zeros(12 * 1024, dtype=torch.int32, device=dev)     # (6.. : single-layer problems of a phase launch)
         words = torch.zeros(2, dtype=torch.int32, device=dev)     # [live status of the running step, latched status since the last check]
         st["pipe_words"], st["pipe_status"], st["pipe_latched"] = words, words[0:1], words[1:2]
         for r in self.all_rec:
@@ -582,6 +614,9 @@ class Engine(ArrayStaging, OptionalGraph, Results):
                         pb.convert(P[p + ".W"], self._v(p + ".wc", s.H, s.GH))
             for h in self.heads:
                 pb.transpose_convert(P[h.out + ".W"], self._v(h.name + ".wt", h.NP, s.H), n_pad=h.NP)
+            for r in self.all_rec:          # start*W + b of the cells on a constant input, for an all-zero start (= the bias row)
+                if r.xmode == hl.X_CONST:
+                    pb.broadcast_rows(P[r.prefix + ".b"], self._v(r.prefix + ".xp0", self.maxB, s.GH), self.maxB)
             pb.zero(self.scal)              # the step's loss / metric accumulators (else a fill launch of its own)
             if self.training:
                 for h in self.heads:
@@ -596,6 +631,7 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         pb.run()
         self._count_pending = False
         self._weights_dirty = False
+        self._xp0_bias = {r.prefix for r in self.all_rec if r.xmode == hl.X_CONST}      # (their xp0 rows hold the bias now)
 
     # ------------------------------------------------------------------------------------------------------
     # forward
@@ -608,9 +644,10 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         return n
 
     def _rec_forward(self, r, B, k=0, nch=1, *, h0=None, c0=None, h0_ld=0, h_last=None, h_last_ld=0, idx=None, xs=None,
-                     start=None, pipe=None, xp_external=False):
+                     start=None, pipe=None, xp_external=False, build=False):
         """Time chunk k of nch of one recurrent layer (B = padded batch).  Chunk 0 starts from (h0, c0); later chunks
-        from the f32 state the previous launch left in <layer>.sh/.sc; the last chunk also writes ``h_last``."""
+        from the f32 state the previous launch left in <layer>.sh/.sc; the last chunk also writes ``h_last``.
+        ``build``: return the launch's arguments as a problem of a phase launch (engine_phases.py) instead of launching."""
         s, P, p = self.spec, self.P, r.prefix
         H, GH, T = s.H, s.GH, r.T
         Tc = T // nch
@@ -621,7 +658,8 @@ class Engine(ArrayStaging, OptionalGraph, Results):
             kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
         elif self._scalar_as_dense(r):
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
-            ops.outer_bias_tile16(xs[t0:t0 + Tc], P[p + ".W"].view(-1), P[p + ".b"], xp, Tc * B, GH)
+            if not xp_external:      # (a phase launch expands the roll inside the launch: PhaseLaunches._xpand_problem)
+                ops.outer_bias_tile16(xs[t0:t0 + Tc], P[p + ".W"].view(-1), P[p + ".b"], xp, Tc * B, GH)
             kw.update(xp=xp)
         elif r.xmode == hl.X_SCALAR:
             kw.update(xs=xs[t0:t0 + Tc], w_row=P[p + ".W"].view(-1), bias=P[p + ".b"])
@@ -629,8 +667,11 @@ class Engine(ArrayStaging, OptionalGraph, Results):
             kw.update(xp=self._v(p + ".xp", T, B, GH)[t0:t0 + Tc])
         elif r.xmode == hl.X_CONST:
             xp0 = self._v(p + ".xp0", B, GH)
-            if k == 0:
-                ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])      # start W + b (Appendix A.6)
+            if k == 0 and not (self.start_zero.get(p, False) and p in self._xp0_bias):
+                # start W + b (Appendix A.6); an all-zero start - what the reference's packers always pass - finds the bias rows
+                # the weight-preparation launch left in xp0 (every row the same: any batch's view of the buffer holds them)
+                ops.gemm(start, P[p + ".W"], xp0, B, GH, r.K, bias=P[p + ".b"])
+                self._xp0_bias.discard(p)
             kw.update(xp0=xp0)
         else:
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
@@ -643,13 +684,16 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         last = k == nch - 1
         if k > 0:
             h0, c0, h0_ld = sh, (sc if lstm else None), 0
-        self._timed(("rnn_fwd", p), lambda: ops.rnn_fwd(
+        launch = lambda **bk: ops.rnn_fwd(
             self.cell, self.kind, Tc, B, H, self.store[p + ".u_pack"], h0=h0, c0=c0, h0_ld=h0_ld,
             hs=self._v(p + ".hs", T + 1, B, H)[t0:t0 + Tc + 1],
             cs=self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if (lstm and self.training) else None,   # (backward only)
             acts=self._v(p + ".acts", T, B, GH)[t0:t0 + Tc] if self.training else None,
             h_last=(h_last if last else sh), h_last_ld=(h_last_ld if last else 0),
-            c_last=(sc if (lstm and not last) else None), seq_layout=self._seq_layout(r), **kw), steps=Tc)
+            c_last=(sc if (lstm and not last) else None), seq_layout=self._seq_layout(r), **kw, **bk)
+        if build:
+            return launch(build_only=True)
+        self._timed(("rnn_fwd", p), launch, steps=Tc)
 
     def _rec_xp(self, r, B, k=0, nch=1, **chunked):
         """Input projection x*W + b of a stacked layer (x = the lower layer's h sequence), time chunk k of nch; or, with
@@ -780,18 +824,19 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         cat = self._v("cat", B, self.ncat * H)
         ldc = self.ncat * H
         self._cur_B, self._n_side = B, len(self.enc_meta)
-        self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
-        for k, (r, st, src) in enumerate(self.enc_meta, 1):
-            with self._on(st):
-                inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
-                self._rec_forward(r, B, h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc, **inp)
-        if self.enc_bi:
-            self._enc_bi_forward(B, cat[:, 0:H], ldc)
-        else:
-            self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
-        self._prefork = None
+        if not self._encoder_forward_multi(B, cat, ldc):      # (one launch for all of them: engine_phases.py)
+            self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
+            for k, (r, st, src) in enumerate(self.enc_meta, 1):
+                with self._on(st):
+                    inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
+                    self._rec_forward(r, B, h_last=cat[:, k * H:(k + 1) * H], h_last_ld=ldc, **inp)
+            if self.enc_bi:
+                self._enc_bi_forward(B, cat[:, 0:H], ldc)
+            else:
+                self._stack_forward(self.enc_notes, B, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H], h_last_ld=ldc, slot=0)
+            self._prefork = None
+            self._join(*[st for _, st, _ in self.enc_meta])
         self._n_side = 0
-        self._join(*[st for _, st, _ in self.enc_meta])
         self._mark("  encoder recurrences")
         self._S_done = False
         fused_hist = self._hist_fused            # (history of this minibatch from this very forward pass: train_step_begin)
@@ -858,7 +903,11 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         side = [h for h in self.dec_heads if h.stream is not None]
         aux_src = {a.src for a in self.aux}
         self._cur_B, self._n_side = B, len(side)
-        self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
+        if len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ()):      # (the notes stack is ONE launch on this queue)
+            if side:
+                self._fork(*[h.stream for h in side])
+        else:
+            self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
         for h in side:
             with self._on(h.stream):
                 self._head_forward(h, B, Breal, states, tg, want_probs or h.name in aux_src, slot=None)
@@ -876,7 +925,8 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         H, n = s.H, h.name
         start = self._v("in.start_" + n, B, h.layers[0].K)
         if len(h.layers) > 1 and slot is not None:
-            self._stack_forward(h.layers, B, states=states, start=start, slot=slot)
+            if not self._notes_forward_multi(h, B, states, start):      # (both layers as one launch: engine_phases.py)
+                self._stack_forward(h.layers, B, states=states, start=start, slot=slot)
         else:
             for r in h.layers:           # (a stack off the critical stream - the next-notes head - runs layer after layer)
                 self._rec_forward(r, B, start=start, **states(r))
@@ -900,7 +950,7 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         return int(min(16, max(1, K // 8192)))
 
     def _rec_bptt(self, r, B, k=0, nch=1, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dh0=None, dc0=None, dh0_ld=0,
-                  pipe=None):
+                  pipe=None, build=False):
         """BPTT over time chunk k (chunks run from the LAST to the first) + the gradient for the layer below."""
         s, p = self.spec, r.prefix
         H, GH, T = s.H, s.GH, r.T
@@ -910,7 +960,7 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         sh, sc = self._v(p + ".sh", B, H), self._v(p + ".sc", B, H)
         first, final = k == nch - 1, k == 0
         da = self._v(p + ".da", T, B, GH)[t0:t0 + Tc]
-        self._timed(("rnn_bwd", p), lambda: ops.rnn_bwd(
+        launch = lambda **bk: ops.rnn_bwd(
             self.cell, self.kind, Tc, B, H, self.store[p + ".ut_pack"], self._v(p + ".hs", T + 1, B, H)[t0:t0 + Tc + 1],
             self._v(p + ".cs", T + 1, B, H)[t0:t0 + Tc + 1] if lstm else None, self._v(p + ".acts", T, B, GH)[t0:t0 + Tc],
             da, dhs_ext=None if dhs_ext is None else dhs_ext[t0:t0 + Tc],
@@ -918,7 +968,10 @@ class Engine(ArrayStaging, OptionalGraph, Results):
             dc_last=(None if (first or not lstm) else sc),
             rh=self._v(p + ".rh", T, B, H)[t0:t0 + Tc] if s.cell == "GRU" else None,
             dh0=(dh0 if final else sh), dc0=((dc0 if final else sc) if lstm else None), dh0_ld=(dh0_ld if final else 0),
-            seq_layout=self._seq_layout(r), **(pipe or {})), steps=Tc)
+            seq_layout=self._seq_layout(r), **(pipe or {}), **bk)
+        if build:
+            return launch(build_only=True)
+        self._timed(("rnn_bwd", p), launch, steps=Tc)
 
     def _rec_dx(self, r, B, k=0, nch=1, **chunked):
         """Gradient w.r.t. the input sequence of layer ``r`` (= what the layer below receives at its h_t), time chunk k.
@@ -933,9 +986,12 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False):
+    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None):
         """Parameter gradients of one layer from its da, accumulated into the f32 gradient buffer: off the critical path, on
-        the two gradient streams, once per layer after its BPTT."""
+        the two gradient streams, once per layer after its BPTT.  ``gate`` = (counter word, value): the layer's BPTT is a problem
+        of a phase launch that is still RUNNING - the gradient queues wait, on the device, for the layer's last published chunk
+        of da instead of for the whole launch.  (No event: the launch sits on the critical queue behind everything the gradient
+        work reads, so its first published chunk implies all of that; an event record would be one more packet there.)"""
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
         R = T * B
@@ -943,7 +999,11 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         da2, hprev = da.view(R, GH), self._v(p + ".hs", T + 1, B, H)[:T].reshape(R, H)
         sk = self._split_k(R)
         sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
-        self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
+        if gate is None:
+            self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
+        else:
+            for st in ((sg1,) if sg1 is sg2 else (sg1, sg2)):
+                ops.stream_wait_value32(gate[0], gate[1], stream=st)
         # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
         fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
         gb = G[p + ".b"]
@@ -965,7 +1025,8 @@ class Engine(ArrayStaging, OptionalGraph, Results):
                 dxp0 = self._v(p + ".dxp0", B, GH)
                 ops.sum_over_time(da, T, B * GH, dxp0, accumulate=self._dxp0_clean)
                 ops.colsum(dxp0, B, GH, G[p + ".b"])
-                ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+                if not self.start_zero.get(p, False):        # (dW = start^T dxp0 = 0 for an all-zero start)
+                    ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
             else:
                 if not fuse_b:
                     ops.colsum(da2, R, GH, G[p + ".b"])
@@ -1149,8 +1210,12 @@ class Engine(ArrayStaging, OptionalGraph, Results):
 
     def _head_stack_backward(self, h, B, dstates, slot):
         """output Dense backward + BPTT through one decoder head's cell stack"""
-        dext = self._head_backward(B, h.name, h.layers[-1], h.N, h.NP, h.out + ".W", h.out + ".b")
         start = self._v("in.start_" + h.name, B, h.layers[0].K)
+        if len(h.layers) > 1 and slot is not None and self._phase_ok(h.layers, ()):
+            dext, head_grads = self._head_backward(B, h.name, h.layers[-1], h.N, h.NP, h.out + ".W", h.out + ".b", defer=True)
+            self._notes_backward_multi(h, B, dext, dstates, start, head_grads)
+            return
+        dext = self._head_backward(B, h.name, h.layers[-1], h.N, h.NP, h.out + ".W", h.out + ".b")
         if len(h.layers) > 1 and slot is not None:
             self._stack_backward(h.layers, B, dhs_ext=dext, start=start, dstates=dstates, slot=slot)
             return
@@ -1160,8 +1225,9 @@ class Engine(ArrayStaging, OptionalGraph, Results):
                 self._rec_dx(r, B)
                 dext = self._v(r.prefix + ".dx", r.T, B, self.spec.H)
 
-    def _head_backward(self, B, name, r, N, NP, outW, outb):
-        """d(logits) -> gradient of the output Dense and of the top cell's h sequence."""
+    def _head_backward(self, B, name, r, N, NP, outW, outb, defer=False):
+        """d(logits) -> gradient of the output Dense and of the top cell's h sequence.  ``defer``: return (dhs, the Dense's
+        parameter-gradient work) instead of enqueueing the latter behind an event."""
         s, G = self.spec, self.G
         H, T = s.H, r.T
         R = T * B
@@ -1170,10 +1236,14 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         dhs = self._v(name + ".dhs", T, B, H)
         if not self._fused_head_bwd(name, True):
             ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
-        self._fork(self.s_grad)
-        with self._on(self.s_grad):
+        def grads():
             ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
             ops.colsum(dl, R, N, G[outb], ldx=NP)
+        if defer:
+            return dhs, grads
+        self._fork(self.s_grad)
+        with self._on(self.s_grad):
+            grads()
         return dhs
 
     def backward(self, B):
@@ -1195,8 +1265,13 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         self._cur_B, self._n_side = B, len(side)
         for a in self.aux:
             self._aux_backward(a, B)
+        notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
-            self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
+            if not notes_multi:
+                self._fork_with_stack(self.dec_notes, also=(self.s_grad,))
+        elif notes_multi:
+            if side:
+                self._fork(*[h.stream for h in side])
         else:
             self._fork_with_stack(self.dec_notes, *[h.stream for h in side], also=(self.s_grad,))
         for h in side:
@@ -1207,10 +1282,13 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         self._join(*[h.stream for h in side])
         self._mark("  decoder BPTT")
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
+        enc_multi = not self.enc_bi and self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta]) and len(self.enc_notes) > 1
+        self._deferred_side = [] if enc_multi else None       # (released by the encoder launch's first published chunk)
         dcat = (self._latent_chain_backward(Breal, B)
                 if (self.fused_latent and self._chain_ok() and not s.signature) else None)
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
+        latent_grads, self._deferred_side = self._deferred_side, None
         ldc = self.ncat * H
         self._mark("  latent block backward")
         hook = self._bucket_hook
@@ -1225,28 +1303,37 @@ class Engine(ArrayStaging, OptionalGraph, Results):
                 hook.early(self.grads[self.layout.dec_begin:self.layout.total])
         # ---- encoder recurrences: the notes stack and the meta rolls, independent branches ---------------------------
         self._cur_B, self._n_side = B, len(self.enc_meta)
-        ks_extra = None
-        if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
-            self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
-            ks_extra = self._kstream_extra = []
-        self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
-        for k, (r, st, src) in enumerate(self.enc_meta, 1):
-            with self._on(st):
-                inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
-                follow = (ks_extra is not None and not ks_extra and self.kstream_singles and r.T == T and self._seq_layout(r) == hl.TILE16P and
-                          r.xmode != hl.X_CONST and (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 8)
-                self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
-                                     kstream_extra=ks_extra if follow else None, **inp)
-        if self.enc_bi:
-            self._enc_bi_backward(B, dcat[:, 0:H], ldc)
-        else:
-            self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
-        self._prefork = None
-        self._grad_streams = None
+        if not (enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads)):      # (one launch: engine_phases.py)
+            assert not latent_grads
+            ks_extra = None
+            if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
+                self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
+                ks_extra = self._kstream_extra = []
+            self._fork_with_stack(self.enc_notes, *[st for _, st, _ in self.enc_meta])
+            for k, (r, st, src) in enumerate(self.enc_meta, 1):
+                with self._on(st):
+                    inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
+                    follow = (ks_extra is not None and not ks_extra and self.kstream_singles and r.T == T and
+                              self._seq_layout(r) == hl.TILE16P and r.xmode != hl.X_CONST and
+                              (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 8)
+                    self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
+                                         kstream_extra=ks_extra if follow else None, **inp)
+            if self.enc_bi:
+                self._enc_bi_backward(B, dcat[:, 0:H], ldc)
+            else:
+                self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
+            self._prefork = None
+            self._grad_streams = None
         self._n_side = 0
         # the two gradient queues finish last and together: chained, they would put two cross-queue hops in series - the
         # early finishers are chained into one of them, the other is waited for directly
-        self._join(*[st for _, st, _ in self.enc_meta], self.s_grad)
+        # Phase launches: the persistent projection / dX GEMMs on their own queue are NOT waited for here - the launch that consumed
+        # their last chunk has ended on this queue, so they have written everything (they exit behind their last publish), and their
+        # queue orders them against the next step's GEMMs; the encoder rolls' queues carried nothing in this phase.  Every stream
+        # in this join is one more cross-queue hop (40-60 us each, in series) in front of the optimizer.
+        tail = self._tail_streams if enc_multi else [st for _, st, _ in self.enc_meta]
+        self._tail_streams = []
+        self._join(*tail, self.s_grad)
         self._join(self.s_grad2)
 
     def _latent_chain_backward(self, Breal, B):
@@ -1400,8 +1487,8 @@ class Engine(ArrayStaging, OptionalGraph, Results):
         redo()
         if int(self.store["pipe_status"].item()) != 0:
             import warnings
-            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers; falling back to chunked "
-                          "launches (Engine.pipeline = False)")
+            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers (status %d; call %r); falling "
+                          "back to chunked launches (Engine.pipeline = False)" % (int(self.store["pipe_status"].item()), key))
             self.store["pipe_status"].zero_()
             self.pipeline = False
             self._dxp0_clean = False

@@ -19,6 +19,13 @@ from .slots import N_SCALARS
 
 
 class ArrayStaging(object):
+    def _note_start(self, name, val):
+        """remember whether the start rows staged into ``name`` (in.start_<head>) are all zero: the head's first cell then reads the
+        bias rows the weight preparation wrote (no start*W GEMM, no dW GEMM)"""
+        h = self.head.get(name[len("in.start_"):])
+        if h is not None:
+            self.start_zero[h.layers[0].prefix] = val is None or not np.any(val)
+
     # ------------------------------------------------------------------------------------------------------
     # input staging (host NumPy -> device).  Layout conversion to time-major happens here, once, on the host.
     # ------------------------------------------------------------------------------------------------------
@@ -90,6 +97,7 @@ class ArrayStaging(object):
             if name not in self.store:
                 continue
             self._up_rows(name, np.zeros((B, width), np.float32) if val is None else np.asarray(val, np.float32), width)
+            self._note_start(name, val)
 
     def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None, n_idx=None,
                       w_held=None, w_next=None, sig=None, w_sig=None, w_cnotes=None, w_cinstr=None):

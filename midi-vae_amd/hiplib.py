@@ -57,13 +57,18 @@ class GemmArgs(C.Structure):
                 ("k_wait", _vp), ("k_wait_value", C.c_uint32), ("k_chunk_rows", C.c_int32), ("k_reverse", C.c_int32)]
 
 
+class XpandArgs(C.Structure):
+    _fields_ = [("xs", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("out_kind", _i32), ("R", _i32), ("N", _i32),
+                ("chunk_rows", _i32), ("chunk_done", _vp), ("blocks", _i32), ("reserved", _i32)]
+
+
 class PrepJob(C.Structure):
     _fields_ = [("op", _i32), ("kind", _i32), ("a", _i32), ("b", _i32), ("c", _i32), ("reserved", _i32),
                 ("src", _vp), ("src2", _vp), ("dst", _vp)]
 
 
 PREP_PACK_RECURRENT, PREP_MAKE_TABLE, PREP_TRANSPOSE_CONVERT, PREP_CONVERT, PREP_ZERO, PREP_CONVERT_PAD = 0, 1, 2, 3, 4, 5
-PREP_ADD_I32 = 6
+PREP_ADD_I32, PREP_BROADCAST_ROWS = 6, 7
 ADAM_ZERO_GRAD, ADAM_KEEP_COUNT = 1, 2
 
 
@@ -109,6 +114,8 @@ SIGNATURES = {
     "mvae_build_info": (C.c_char_p, []),
     "mvae_rnn_fwd": (_i32, [C.POINTER(RnnFwdArgs), _vp]),
     "mvae_rnn_bwd": (_i32, [C.POINTER(RnnBwdArgs), _vp]),
+    "mvae_rnn_fwd_multi": (_i32, [C.POINTER(RnnFwdArgs), _i32, C.POINTER(XpandArgs), _i32, _vp]),
+    "mvae_rnn_bwd_multi": (_i32, [C.POINTER(RnnBwdArgs), _i32, _vp]),
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_gemm_kstream_multi": (_i32, [C.POINTER(GemmArgs), _i32, _vp]),
@@ -116,6 +123,7 @@ SIGNATURES = {
     "mvae_stream_wait_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_stream_write_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_occupancy": (_i32, [_i32]),
+    "mvae_streams_alias": (_i32, [_vp, _vp, _vp, C.c_uint32]),
     "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),

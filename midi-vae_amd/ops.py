@@ -51,7 +51,7 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
             h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, c_last=None, h0_ld=0, h_last_ld=0, seq_layout=0,
-            chunk_steps=0, wait_ready=None, wait_value=0, signal_done=None, status=None):
+            chunk_steps=0, wait_ready=None, wait_value=0, signal_done=None, status=None, build_only=False):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -63,16 +63,46 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _pv(xp), _pv(idx), _p(table), _pv(xs), _p(w_row),
                       _p(bias), _p(xp0), _pv(h0), _pv(c0), _pv(hs), _pv(cs), _pv(acts), _pv(h_last), _pv(c_last), h0_ld, h_last_ld,
                       chunk_steps, _pv(wait_ready), int(wait_value), _pv(signal_done), _pv(status), seq_layout)
+    if build_only:          # (a problem of rnn_fwd_multi; the tensors must stay alive until that launch)
+        return a
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
 def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh_last=None, dc_last=None, rh=None,
             dh0=None, dc0=None, dh_last_ld=0, dh0_ld=0, seq_layout=0, chunk_steps=0, wait_ready=None, wait_value=0,
-            signal_done=None, status=None):
+            signal_done=None, status=None, build_only=False):
     a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _pv(hs), _pv(cs), _pv(acts), _pv(dhs_ext), _pv(dh_last),
                       _pv(dc_last), _pv(da), _pv(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, chunk_steps, _pv(wait_ready),
                       int(wait_value), _pv(signal_done), _pv(status), seq_layout)
+    if build_only:
+        return a
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
+
+
+def xpand(xs, w, bias, out, R, N, chunk_rows, chunk_done, blocks=64):
+    """an expansion of a 1-feature roll (outer_bias_tile16) as a chunk-publishing producer of rnn_fwd_multi"""
+    return hl.XpandArgs(_p(xs), _p(w), _p(bias), _p(out), kind_of(out), int(R), int(N), int(chunk_rows), _pv(chunk_done), int(blocks), 0)
+
+
+def rnn_fwd_multi(problems, xpands=()):
+    """every recurrence of a phase as ONE launch on the current stream (``rnn_fwd(..., build_only=True)`` problems, producers
+    first); False if the library does not take some problem (launch them singly)"""
+    arr = (hl.RnnFwdArgs * len(problems))(*problems)
+    xa = (hl.XpandArgs * len(xpands))(*xpands) if xpands else None
+    rc = hl.load().mvae_rnn_fwd_multi(arr, len(problems), xa, len(xpands), _stream())
+    if rc == hl.E_UNSUPPORTED:
+        return False
+    hl.check(rc, "mvae_rnn_fwd_multi")
+    return True
+
+
+def rnn_bwd_multi(problems):
+    arr = (hl.RnnBwdArgs * len(problems))(*problems)
+    rc = hl.load().mvae_rnn_bwd_multi(arr, len(problems), _stream())
+    if rc == hl.E_UNSUPPORTED:
+        return False
+    hl.check(rc, "mvae_rnn_bwd_multi")
+    return True
 
 
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
@@ -253,6 +283,10 @@ class PrepBatch:
         self.jobs.append(hl.PrepJob(hl.PREP_ADD_I32, hl.F32, int(value), 0, 0, 0, _p(guard), _p(latch), _p(counter)))
         self._keep += [counter, guard, latch]
         self._arr = None
+
+    def broadcast_rows(self, row, out, rows):
+        """out (rows, N) = ``row`` (N,) f32 repeated"""
+        self._add(hl.PREP_BROADCAST_ROWS, out, rows, row.numel(), 0, row)
 
     def convert_pad(self, W, out, n_pad):
         K, N = W.shape

@@ -177,6 +177,8 @@ class Stager(object):
         else:
             out[:B] = np.asarray(arr).reshape(-1, width)[lo:hi]
             out[B:] = 0.0
+        if name.startswith("in.start_"):
+            self.eng._note_start(name, None if arr is None else out[:B])
 
     # ---- one minibatch ------------------------------------------------------------------------------------------
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,

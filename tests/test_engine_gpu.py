@@ -566,3 +566,97 @@ def test_elbo_trajectory_fresh_epsilon_on_the_benched_schedule(cell):
         assert np.max(np.abs(du - du_o)) <= 2 * steps * spec.lr + 1e-7, k
     print("relative L2 error of the 10-step update, worst tensors:", sorted(rel.items(), key=lambda kv: -kv[1])[:5])
     assert max(rel.values()) < 0.35, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+@pytest.mark.parametrize("B", [32, 200])
+def test_phase_launches_equal_the_per_stream_schedule(cell, B):
+    """engine_phases.py: every recurrence of a phase as ONE launch on the critical queue (the velocity roll's x*W + b expansion a
+    producer inside the encoder-forward launch) against the per-stream schedule (one launch per recurrence and queue, events
+    between them).  Same kernel bodies, same arithmetic: the saved activations and every sequence the BPTT reads are bit-identical,
+    losses and gradients agree to the order of their atomic sums - over three train steps, ragged batch included (B = 200)."""
+    import torch
+    spec, params, batch, raw = _problem(cell, B, seed=57, H=256, Z=64, T=64)
+    res = {}
+    for multi in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.phase_multi = multi
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        eng.check_pipeline()
+        seqs = {k: eng.store[k].clone() for k in ("enc.vel.xp", "enc.vel.hs", "enc.notes.1.hs", "enc.notes.1.acts", "dec.notes.1.hs",
+                                                  "dec.notes.1.acts", "dec.notes.0.da", "enc.notes.0.da", "enc.vel.da", "enc.instr.da")}
+        m0, g0 = eng.metrics(B), eng.get_grads()
+        losses = []
+        for _ in range(3):
+            eng.train_step(B)
+            losses.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        res[multi] = (seqs, m0, g0, losses)
+    (s1, m1, g1, l1), (s0, m0, g0, l0) = res[True], res[False]
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]), k
+    for k in m0:
+        assert m1[k] == pytest.approx(m0[k], rel=1e-5, abs=1e-6), k
+    for k in g0:
+        assert _rel_l2(g1[k], g0[k]) < 1e-4 or np.linalg.norm(g0[k]) < 1e-9, k
+    for a, b in zip(l1, l0):
+        assert abs(a - b) <= 1e-4 * (1 + abs(b)), (l1, l0)
+
+
+@pytest.mark.parametrize("dtype,H", [("f32", 64), ("bf16", 256)])
+def test_nonzero_decoder_start_rows_match_oracle(dtype, H):
+    """the constant input of the decoder cells (reference vae_definition.py:820,916 always passes zeros): an
+    all-zero start reads the bias rows the weight preparation wrote, a NON-zero one takes the start*W + b GEMM and the
+    start^T dxp0 weight gradient - both against the oracle, alternating on one engine (zero, non-zero, zero)."""
+    B = 16
+    spec, params, batch, raw = _problem("LSTM", B, seed=71, H=H, Z=32, T=16)
+    rng = np.random.default_rng(5)
+    starts = dict(start_notes=rng.standard_normal((B, spec.Dout)).astype(np.float32) * 0.3,
+                  start_instr=rng.standard_normal((B, spec.ID)).astype(np.float32) * 0.3,
+                  start_vel=rng.standard_normal((B,)).astype(np.float32) * 0.3)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    eng = Engine(spec, max_batch=B, dtype=dtype)
+    eng.set_params(params)
+    tol_l, tol_g = (2e-4, 2e-3) if dtype == "f32" else (3e-2, 6e-2)
+    for use in (False, True, False):
+        b2 = dict(batch, **({k: v.astype(np.float64) for k, v in starts.items()} if use else {}))
+        m_o, cache = orc.forward(p64, b2, raw["eps"].astype(np.float64))
+        g_o = orc.backward(p64, cache)
+        _stage(eng, raw, B)
+        eng.stage_decoder_inputs(B, hist=raw["hist"], add=raw["add"], **(starts if use else {}))
+        assert eng.start_zero["dec.notes.0"] == (not use)
+        eng.forward_backward(B)
+        m, g = eng.metrics(B), eng.get_grads()
+        assert abs(m["loss"] - m_o["loss"]) <= tol_l * (1 + abs(m_o["loss"])), (use, m["loss"], m_o["loss"])
+        for k in ("dec.notes.0.W", "dec.notes.0.b", "dec.vel.cell.W", "dec.instr.cell.W", "dec.notes.0.U"):
+            n = np.linalg.norm(g_o[k])
+            if n < 1e-12:
+                assert np.linalg.norm(g[k]) < 1e-6, (use, k)
+            else:
+                assert _rel_l2(g[k], g_o[k]) < tol_g, (use, k, _rel_l2(g[k], g_o[k]))
+
+
+def test_twenty_engines_in_one_process_keep_their_queues_apart():
+    """The runtime deals streams onto a fixed number of hardware queues; an engine whose projection stream landed on the critical
+    stream's queue would stall its phase launches until the time-out (Engine._own_queue_stream asks the runtime by experiment when
+    the streams are created).  Twenty engines created and dropped in one process - every one a new set of streams - each run a
+    train step on the time-pipelined phase launches: no fallback warning, no time-out status."""
+    import gc
+    import warnings
+    spec, params, batch, raw = _problem("LSTM", 16, seed=3, H=256, Z=64, T=32)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for i in range(20):
+            eng = Engine(spec, max_batch=16, dtype="bf16")
+            eng.set_params(params)
+            _stage(eng, raw, 16)
+            eng.train_step(16)
+            assert np.isfinite(eng.metrics(16)["loss"])
+            eng.check_pipeline()
+            assert eng.pipeline
+            del eng
+            gc.collect()
+    assert not [str(w.message) for w in rec if "timed out" in str(w.message)], [str(w.message) for w in rec]
