@@ -177,6 +177,12 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
         # the recurrences of a phase as ONE launch on the critical queue instead of one launch per queue (engine_phases.py)
         self.phase_multi = os.environ.get("MVAE_PHASE_MULTI", "1") == "1"
+        # ... up to this many (padded) windows per call: measured (profiles/r03_j_*) 256 windows -6 % (LSTM) / -9 % (GRU) per train
+        # step, but 512 windows at T=2048 +6.5 % and decoding 1024 windows +4 % - there the recurrences themselves fill the chip
+        # and the per-queue launches (producers dispatched first) place them better than one launch's index order
+        self.phase_max_B = int(os.environ.get("MVAE_PHASE_MAX_B", "256"))
+        self._hold_dec_grads = os.environ.get("MVAE_HOLD_DEC_GRADS", "1") == "1"     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
+        self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
         if share is None:
             self.set_params(self._initial_params(seed))
@@ -1266,6 +1272,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         for a in self.aux:
             self._aux_backward(a, B)
         notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
+        self._after_chain = [] if (notes_multi and not self.enc_bi and len(self.enc_notes) > 1 and
+                                   self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta])) else None
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
             if not notes_multi:
                 self._fork_with_stack(self.dec_notes, also=(self.s_grad,))

@@ -27,7 +27,7 @@ class PhaseLaunches(object):
     def _phase_ok(self, stack, singles):
         """may ``stack`` (bottom -> top) and the single-layer recurrences ``singles`` run as one launch?"""
         recs = list(stack) + list(singles)
-        return (self.phase_multi and self.tile16 and self.multi_stream and 0 < len(recs) <= 8 and
+        return (self.phase_multi and self._cur_B <= self.phase_max_B and self.tile16 and self.multi_stream and 0 < len(recs) <= 8 and
                 all(self._seq_layout(r) == hl.TILE16P for r in recs) and (len(stack) < 2 or self._pipelined(stack)) and
                 all(r.xmode != hl.X_SCALAR or self._scalar_as_dense(r) for r in recs))
 
@@ -162,8 +162,14 @@ class PhaseLaunches(object):
         ops.stream_wait_value32(sync[0, 0][nchp - 1:nchp], da_target, stream=self.s_grad)
         with torch.cuda.stream(self.s_grad):
             head_grads()
+        L = len(h.layers)
         for li, r in enumerate(reversed(h.layers)):
-            self._rec_param_grads(r, B, start=start, gate=(sync[li, 0][0:1], da_target))
+            if li == L - 1 and self._hold_dec_grads and self._after_chain is not None:
+                # the bottom layer's da is complete when the launch ends - exactly when the latent chain (a latency-bound kernel
+                # between this phase and the next) starts: its gradient GEMMs wait for the ENCODER launch's first chunk instead
+                self._after_chain.append(lambda r=r: dict(r=r, B=B, start=start))
+            else:
+                self._rec_param_grads(r, B, start=start, gate=(sync[li, 0][0:1], da_target))
         return True
 
     def _encoder_backward_multi(self, B, dcat, ldc, latent_grads=()):
@@ -204,6 +210,10 @@ class PhaseLaunches(object):
                     fn()
             if lq is not self.s_grad:
                 self._tail_streams.append(lq)
+        held, self._after_chain = self._after_chain or [], None
+        for fn in held:         # (decoder gradient work held back behind the latent chain: _notes_backward_multi)
+            kw = fn()
+            self._rec_param_grads(kw["r"], kw["B"], start=kw["start"], gate=(sync[0, 0][nchp - 1:nchp], da_target))
         if kstream:
             cs = self.pipe_chunk
             problems = []
