@@ -280,6 +280,9 @@ typedef struct {
     void* dhs;                    /* (R,H) dtype in MVAE_TILE16 or NULL: d(logits) W^T, the gradient w.r.t. the top cell's
                                      h sequence, from the same launch (needs wc, want_grad, R % 16 == 0, H <= 256):
                                      no GEMM launch between the head and the decoder's BPTT                   */
+    const uint8_t* target_idx2;   /* kind 0, or NULL: (R) the SECOND hot column of a two-hot target row (attach_instruments,
+                                     reference import_midi.py:288-292: pitch one-hot | instrument one-hot), 255 = none:
+                                     loss -log p[t1] - log p[t2], accuracy against the first hot column             */
 } mvae_head_args;
 int mvae_head(const mvae_head_args* a, void* stream);
 /* padded column count NP used for `wt` rows and `dlogits` columns of an N-wide head (16/32/64/128; <0 = too wide) */
@@ -390,6 +393,11 @@ int mvae_prepare_batch(const mvae_prep_job* jobs /* host array */, int32_t n_job
  * (R % 16 == 0, N % 16 == 0, w and bias 16-byte aligned) */
 int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, void* out, int32_t out_kind, int32_t R, int32_t N,
                            void* stream);
+/* out (R, N) of `kind` in `layout` (MVAE_TILE16 / MVAE_ROWMAJOR) = table[idx[r]] + table2[idx2[r]] (tables (K, N) / (K2, N) of `kind`, mvae_make_table): x*W + b of
+ * TWO-hot input rows - attach_instruments appends the voice's instrument one-hot to every pitch row (reference import_midi.py:
+ * 288-292, settings.py:186-187,207-208) - written out so that the layer runs on the MVAE_X_DENSE kernels (R, N % 16 == 0) */
+int mvae_gather2_tile16(const uint8_t* idx, const uint8_t* idx2, const void* table, const void* table2, void* out, int32_t kind,
+                        int32_t R, int32_t N, int32_t layout, void* stream);
 /* (rows, cols) row-major <-> tiled, same element kind on both sides.
  * to_tile16: 0 TILE16 -> row-major, 1 row-major -> TILE16, 2 TILE16P -> row-major, 3 row-major -> TILE16P */
 int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16, void* stream);
@@ -479,6 +487,10 @@ int mvae_host_onehot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_
 /* the same for rows that already are indices: idx (n, T) uint8 */
 int mvae_host_index_to_tm(const uint8_t* idx, int64_t n, int32_t T, int64_t lo, int64_t hi, uint8_t* out, int32_t Bp,
                           uint8_t fill);
+/* two-hot rows (attach_instruments): x (n, T, K), the first K1 columns one-hot, the other K - K1 columns one-hot -> out1 / out2
+ * (T, Bp) uint8: the position of each 1 within its block.  MVAE_E_FORMAT / *bad_row as above for any other row. */
+int mvae_host_twohot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_t T, int32_t K, int32_t K1, int64_t lo, int64_t hi,
+                                 uint8_t* out1, uint8_t* out2, int32_t Bp, uint8_t fill, int64_t* bad_row);
 /* windows [lo, hi) of v (n, T) of vkind -> out (T, Bp) f32 = scale * v, pad columns zero (velocity roll, sample weights) */
 int mvae_host_rows_to_tm_f32(const void* v, int32_t vkind, int64_t n, int32_t T, int64_t lo, int64_t hi, float scale,
                              float* out, int32_t Bp);

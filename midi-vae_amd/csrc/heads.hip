@@ -102,26 +102,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(head_rb<WT,
             sum = group16_sum(sum);
             const float inv = 1.0f / sum;
             const int tg = a.target_idx ? (int)a.target_idx[rc] : 255;
-            float pt = 0.0f, pm = 0.0f;
+            // second hot column of a TWO-hot target row (attach_instruments: pitch + instrument, reference import_midi.py:288-292);
+            // Keras' categorical cross-entropy is then -log p[tg] - log p[tg2], each probability clipped on its own
+            const int tg2 = a.target_idx2 ? (int)a.target_idx2[rc] : 255;
+            float pt = 0.0f, pm = 0.0f, pt2 = 0.0f;
 #pragma unroll
             for (int n = 0; n < NTL; ++n) {
                 p[n] *= inv;
                 pm = fmaxf(pm, p[n]);
                 if (n * 16 + r == tg) pt = p[n];
+                if (n * 16 + r == tg2) pt2 = p[n];
             }
             pt = group16_sum(pt);
+            if (a.target_idx2) pt2 = group16_sum(pt2);
             pm = group16_max(pm);
             int am = 1 << 30;
 #pragma unroll
             for (int n = 0; n < NTL; ++n)
                 if (p[n] == pm && n * 16 + r < N) am = min(am, n * 16 + r);
             am = group16_min_i(am);                                    // first maximum (NumPy argmax tie rule)
-            const bool has_t = tg < N;
+            const bool has_t = tg < N, has_t2 = tg2 < N;
             const bool inside = has_t && pt >= CE_EPS && pt <= 1.0f - CE_EPS;
-            const float ce = has_t ? -0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
+            const bool inside2 = has_t2 && pt2 >= CE_EPS && pt2 <= 1.0f - CE_EPS;
+            float ce = has_t ? -0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(pt, CE_EPS), 1.0f - CE_EPS)) : 0.0f;
+            if (has_t2) ce += -0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(pt2, CE_EPS), 1.0f - CE_EPS));
+            const int tfirst = has_t ? (has_t2 ? min(tg, tg2) : tg) : (has_t2 ? tg2 : 0);     // NumPy argmax of the target row
             if (rv && r == 0) {
                 loss_acc += rw * ce;
-                hit_acc += (counted && am == (has_t ? tg : 0)) ? 1.0f : 0.0f;
+                hit_acc += (counted && am == tfirst) ? 1.0f : 0.0f;
                 if (a.argmax) a.argmax[row] = (uint8_t)am;
             }
             if (rv) {
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(head_rb<WT,
                     const int col = n * 16 + r;
                     if (a.probs && col < N) a.probs[(size_t)row * N + col] = p[n];
                     if (a.want_grad) {
-                        const float g = inside ? a.grad_scale * rw * (p[n] - (col == tg ? 1.0f : 0.0f)) : 0.0f;
+                        float g = inside ? a.grad_scale * rw * (p[n] - (col == tg ? 1.0f : 0.0f)) : 0.0f;
+                        if (inside2) g += a.grad_scale * rw * (p[n] - (col == tg2 ? 1.0f : 0.0f));
                         // staged in LDS: a lane owns single columns here, the row-major rows leave as 16-byte chunks
                         stage[(wb * 16 + q * 4 + i) * NP + col] = col < N ? g : 0.0f;
                     }

@@ -118,10 +118,12 @@ Pool& pool() {
 }
 
 template <typename T>
-inline int64_t onehot_rows(const T* x, int64_t n_rows, int K, uint8_t* out, int64_t out_stride) {
+inline int64_t onehot_rows(const T* x, int64_t n_rows, int K, uint8_t* out, int64_t out_stride, int64_t ldx = 0) {
     // returns -1, or the first row (relative) that is not one-hot: entries must be exactly 0 or 1, exactly one 1
+    // (ldx: elements between rows when the K columns are a block of wider rows)
+    if (ldx == 0) ldx = K;
     for (int64_t r = 0; r < n_rows; ++r) {
-        const T* row = x + r * K;
+        const T* row = x + r * ldx;
         int idx = 0, ones = 0, bad = 0;            // branch-free (vectorises): with exactly one non-zero, idx = its position
         for (int k = 0; k < K; ++k) {
             const T v = row[k];
@@ -169,6 +171,40 @@ int onehot_to_index_tm(const T* x, int64_t n, int T_, int K, int64_t lo, int64_t
 }
 
 template <typename T>
+int twohot_to_index_tm(const T* x, int64_t n, int T_, int K, int K1, int64_t lo, int64_t hi, uint8_t* out1, uint8_t* out2, int Bp,
+                       uint8_t fill, int64_t* bad_row) {
+    const int64_t B = hi - lo;
+    std::atomic<int64_t> bad(-1);
+    const int64_t bytes = B * (int64_t)T_ * K * (int64_t)sizeof(T);
+    int parts = (int)(bytes / (1 << 20)) + 1;
+    Pool& p = pool();
+    if (parts > p.size() + 1) parts = p.size() + 1;
+    if (parts > B) parts = B > 0 ? (int)B : 1;
+    p.parallel(parts, [&](int part, int nparts) {
+        const int64_t b0 = B * part / nparts, b1 = B * (part + 1) / nparts;
+        for (int64_t b = b0; b < b1; ++b) {
+            const T* win = x + (lo + b) * (int64_t)T_ * K;
+            int64_t r = onehot_rows<T>(win, T_, K1, out1 + b, Bp, K);
+            const int64_t r2 = onehot_rows<T>(win + K1, T_, K - K1, out2 + b, Bp, K);
+            if (r2 >= 0 && (r < 0 || r2 < r)) r = r2;
+            if (r >= 0) {
+                const int64_t mine = (lo + b) * (int64_t)T_ + r;
+                int64_t cur = bad.load();
+                while ((cur < 0 || mine < cur) && !bad.compare_exchange_weak(cur, mine)) {}
+                return;
+            }
+        }
+    });
+    for (int t = 0; t < T_; ++t)
+        for (int64_t b = B; b < Bp; ++b) out1[(int64_t)t * Bp + b] = out2[(int64_t)t * Bp + b] = fill;
+    if (bad.load() >= 0) {
+        if (bad_row) *bad_row = bad.load();
+        return MVAE_E_FORMAT;
+    }
+    return MVAE_OK;
+}
+
+template <typename T>
 void rows_to_tm(const T* v, int T_, int64_t lo, int64_t hi, float scale, float* out, int Bp) {
     const int64_t B = hi - lo;
     int parts = (int)(B * (int64_t)T_ / (1 << 17)) + 1;
@@ -203,6 +239,20 @@ extern "C" int mvae_host_onehot_to_index_tm(const void* x, int32_t xkind, int64_
         case MVAE_HOST_F64: return onehot_to_index_tm<double>(static_cast<const double*>(x), n, T, K, lo, hi, out, Bp, fill, bad_row);
         case MVAE_HOST_F32: return onehot_to_index_tm<float>(static_cast<const float*>(x), n, T, K, lo, hi, out, Bp, fill, bad_row);
         case MVAE_HOST_U8: return onehot_to_index_tm<uint8_t>(static_cast<const uint8_t*>(x), n, T, K, lo, hi, out, Bp, fill, bad_row);
+    }
+    return MVAE_E_ARG;
+}
+
+extern "C" int mvae_host_twohot_to_index_tm(const void* x, int32_t xkind, int64_t n, int32_t T, int32_t K, int32_t K1, int64_t lo,
+                                            int64_t hi, uint8_t* out1, uint8_t* out2, int32_t Bp, uint8_t fill, int64_t* bad_row) {
+    if (!x || !out1 || !out2 || n < 0 || T <= 0 || K1 <= 0 || K <= K1 || K1 > 255 || K - K1 > 255 || lo < 0 || hi < lo || hi > n ||
+        Bp < hi - lo)
+        return MVAE_E_ARG;
+    std::lock_guard<std::mutex> call(g_call_mutex);
+    switch (xkind) {
+        case MVAE_HOST_F64: return twohot_to_index_tm<double>(static_cast<const double*>(x), n, T, K, K1, lo, hi, out1, out2, Bp, fill, bad_row);
+        case MVAE_HOST_F32: return twohot_to_index_tm<float>(static_cast<const float*>(x), n, T, K, K1, lo, hi, out1, out2, Bp, fill, bad_row);
+        case MVAE_HOST_U8: return twohot_to_index_tm<uint8_t>(static_cast<const uint8_t*>(x), n, T, K, K1, lo, hi, out1, out2, Bp, fill, bad_row);
     }
     return MVAE_E_ARG;
 }

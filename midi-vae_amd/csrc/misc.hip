@@ -693,6 +693,40 @@ extern "C" int mvae_outer_bias_tile16(const float* xs, const float* w, const flo
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
+// out (R, N) in TILE16 = table[idx[r]] + table2[idx2[r]]: the input projection of TWO-hot rows (attach_instruments: a pitch column and
+// an instrument column per row, reference import_midi.py:288-292) written out for the dense-input recurrent kernels - a second
+// table gather per step inside those kernels would double their VMEM instructions.  One thread = 4 consecutive n of one row.
+template <typename D>
+__global__ void gather2_tile16_k(const uint8_t* __restrict__ idx, const uint8_t* __restrict__ idx2, const D* __restrict__ table,
+                                 const D* __restrict__ table2, D* __restrict__ out, int R, int N, int rowmajor) {
+    const size_t total = (size_t)R * N / 4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = e >> 6;
+        const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = st<D>::load(table + (size_t)idx[m] * N + n + i) + st<D>::load(table2 + (size_t)idx2[m] * N + n + i);
+        st<D>::store4(rowmajor ? out + (size_t)m * N + n : out + e * 4, v);
+    }
+}
+extern "C" int mvae_gather2_tile16(const uint8_t* idx, const uint8_t* idx2, const void* table, const void* table2, void* out,
+                                   int32_t kind, int32_t R, int32_t N, int32_t layout, void* stream) {
+    if (!idx || !idx2 || !table || !table2 || !out || R <= 0 || N <= 0 || (R % 16) || (N % 16) ||
+        (layout != MVAE_TILE16 && layout != MVAE_ROWMAJOR))
+        return MVAE_E_ARG;
+    const int rowmajor = layout == MVAE_ROWMAJOR;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(nblocks((size_t)R * N / 4)), b(256);
+    if (kind == MVAE_F32)
+        hipLaunchKernelGGL(gather2_tile16_k<float>, g, b, 0, s, idx, idx2, (const float*)table, (const float*)table2, (float*)out, R, N, rowmajor);
+    else if (kind == MVAE_BF16)
+        hipLaunchKernelGGL(gather2_tile16_k<bf16_t>, g, b, 0, s, idx, idx2, (const bf16_t*)table, (const bf16_t*)table2, (bf16_t*)out, R, N, rowmajor);
+    else
+        return MVAE_E_ARG;
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
 extern "C" int mvae_make_table(const float* W, const float* bias, void* table, int32_t K, int32_t N, int32_t dk,
                                void* stream) {
     if (!W || !bias || !table || K <= 0 || N <= 0) return MVAE_E_ARG;

@@ -29,7 +29,7 @@ from .engine_io import ArrayStaging, Results
 from .engine_optional import OptionalGraph
 from .engine_phases import PhaseLaunches
 from .slots import *        # noqa: F401,F403  (scalar slots S_*, N_SCALARS, X_EXT)
-from .slots import N_SCALARS, X_EXT
+from .slots import N_SCALARS, X_EXT, X_GATHER2
 
 
 class _NullCtx(object):
@@ -141,6 +141,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         # (_pipelined), as ONE launch per layer with device-side hand-over every pipe_chunk time steps (no relaunch, no weight
         # reload, layers pipe_chunk steps apart instead of T/4)
         self.pipeline = os.environ.get("MVAE_PIPELINE", "1") == "1"     # (0: one launch per (layer, chunk), e.g. several processes on ONE GPU)
+        if getattr(self, "_serial_queues", False) or (share is not None and not share.pipeline and getattr(share, "_serial_queues", False)):
+            self.pipeline = False
         # time steps per hand-over: a hand-over costs every workgroup a drained vmcnt and a counter, the persistent GEMM a wait - the
         # bigger the batch, the more rows a chunk should carry (A/B r02: 256 windows 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms;
         # 512 windows, T=2048: 35.7 / 34.5 / 35.4 at 16 / 32 / 64; decode of 1024 windows: 57.0 / 58.9 / 60.1 / 59.9 k at 16 / 32 / 64 / 128)
@@ -211,14 +213,21 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         cur = torch.cuda.current_stream()
         scratch = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._aliased = getattr(self, "_aliased", [])          # (kept alive: a released stream's queue slot would be dealt again)
-        for attempt in range(1, 33):
+        for attempt in range(1, 9):
             st = torch.cuda.Stream()
             rc = hl.load().mvae_streams_alias(cur.cuda_stream, st.cuda_stream, scratch.data_ptr(), attempt)
             if rc == 0:
                 return st
             hl.check(min(rc, 0), "mvae_streams_alias")
             self._aliased.append(st)
-        raise RuntimeError("no stream with a hardware queue of its own after 32 attempts (GPU_MAX_HW_QUEUES too small?)")
+        # Eight streams in a row that cannot run beside the critical one: kernels are being run ONE AT A TIME in this process
+        # (rocprofv3 counter collection does that).  Kernels that wait for each other cannot work then - say so now instead of
+        # through two 2-4 s time-outs: chunk-per-launch schedule.
+        import warnings
+        warnings.warn("kernels on different streams do not run concurrently in this process (counter collection?): time-pipelined "
+                      "stacks and phase launches are off (Engine.pipeline = False)")
+        self._serial_queues = True
+        return self._aliased.pop()
 
     @property
     def _weights_dirty(self):
@@ -379,7 +388,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             self.enc_notes = [self.enc_bi[-1][0]]
         else:           # (bidirectional with Le = 2 builds no Bidirectional layer at all: one plain layer - as written)
             for l, layer in enumerate(layers):
-                self.enc_notes.append(_Rec(layer[0][0], s.T, hl.X_INDEX if l == 0 else hl.X_DENSE, layer[0][2],
+                first = X_GATHER2 if s.attach else hl.X_INDEX        # (two-hot rows: two table rows per step, written out first)
+                self.enc_notes.append(_Rec(layer[0][0], s.T, first if l == 0 else hl.X_DENSE, layer[0][2],
                                            lower=self.enc_notes[-1] if l else None))
         self.enc_instr = _Rec("enc.instr", s.V, hl.X_INDEX, s.ID) if s.meta_instrument else None
         self.enc_vel = _Rec("enc.vel", s.T, hl.X_SCALAR, 1) if s.meta_velocity else None
@@ -469,6 +479,10 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                     buf(p + ".rh", r.T * B * H, **esz)
             if r.xmode == hl.X_INDEX:
                 buf(p + ".table", r.K * GH, **esz)
+            elif r.xmode == X_GATHER2:
+                buf(p + ".table", (r.K - s.attach) * GH, **esz)      # W[:D0] + b (pitch rows), W[D0:] (attached instrument rows)
+                buf(p + ".table2", s.attach * GH, **esz)
+                buf(p + ".xp", r.T * B * GH, **esz)
             elif self._scalar_as_dense(r):
                 buf(p + ".xp", r.T * B * GH, **esz)
             elif r.xmode == hl.X_DENSE:
@@ -556,6 +570,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                         ("in.start_next", B * s.Dout, torch.float32)]
         if self.enc_bi:
             regions += [("in.x_idx_rev", T * B, torch.uint8)]
+        if s.attach:         # the second hot column of every two-hot row: input (within its block) and target (absolute column)
+            regions += [("in.xa_idx", T * B, torch.uint8), ("in.ya_idx", T * B, torch.uint8)]
         if s.add_dim:
             regions += [("in.add", B * s.add_dim, torch.float32)]
         if s.signature:
@@ -565,7 +581,7 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             regions += [("in.rw_" + a.key, B, torch.float32)]
         # the targets / row weights only the decoder heads read go LAST: staging can upload them in a second copy, converted on
         # the host while the encoder recurrences already run (Stager.stage(defer_targets=True))
-        late = ("in.y_idx", "in.n_idx", "in.rw_notes", "in.rw_instr", "in.rw_vel", "in.rw_held", "in.rw_next")
+        late = ("in.y_idx", "in.ya_idx", "in.n_idx", "in.rw_notes", "in.rw_instr", "in.rw_vel", "in.rw_held", "in.rw_next")
         regions = [r for r in regions if r[0] not in late] + [r for r in regions if r[0] in late]
         self._in_regions, off = {}, 0
         self._in_late_off = None
@@ -608,6 +624,10 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                 pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
                 if r.xmode == hl.X_INDEX:
                     pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+                elif r.xmode == X_GATHER2:
+                    d0 = r.K - s.attach
+                    pb.make_table(P[p + ".W"][:d0], P[p + ".b"], self._v(p + ".table", d0, s.GH))
+                    pb.convert(P[p + ".W"][d0:], self._v(p + ".table2", s.attach, s.GH))
                 elif r.xmode == hl.X_DENSE:
                     pb.transpose_convert(P[p + ".W"], self._v(p + ".wt", s.GH, s.H))
                 if (p + ".wt2") in self.store:
@@ -662,6 +682,11 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         kw = {}
         if r.xmode == hl.X_INDEX:
             kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
+        elif r.xmode == X_GATHER2:       # table[pitch] + table2[instrument] written out, then the dense-input kernels
+            xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
+            ops.gather2_tile16(idx[t0:t0 + Tc], self._v("in.xa_idx", T, B)[t0:t0 + Tc], self.store[p + ".table"],
+                               self.store[p + ".table2"], xp, Tc * B, GH, layout=self.lay)
+            kw.update(xp=xp)
         elif self._scalar_as_dense(r):
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
             if not xp_external:      # (a phase launch expands the roll inside the launch: PhaseLaunches._xpand_problem)
@@ -942,6 +967,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         if tg:
             tgt = (dict(target_val=self._v(h.target, R)) if h.kind == 1 else dict(target_idx=self._v(h.target, R)))
             tgt["row_weight"] = self._v("in.rw_" + n, R)
+            if n == "notes" and s.attach:
+                tgt["target_idx2"] = self._v("in.ya_idx", R)
         ops.head(h.kind, self.kind, R, H, h.N, top, self._v(n + ".wt", h.NP, H), P[h.out + ".b"], grad_scale=h.weight,
                  probs=self._v("out.%s_p" % n, R, h.N) if want_probs else None, argmax=self._v(n + ".argmax", R),
                  dlogits=self._v(n + ".dl", R, h.NP) if (self.training and tg) else None, **self._fused_head_bwd(n, tg),
@@ -1040,6 +1067,11 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                     pass                                # (input-kernel gradient by the caller: _aux_backward)
                 elif r.xmode == hl.X_INDEX:
                     ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
+                elif r.xmode == X_GATHER2:      # two-hot rows: the pitch rows and the attached instrument rows of W
+                    d0 = r.K - s.attach
+                    ops.gemm(idx.reshape(-1), da2, G[p + ".W"][:d0], d0, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
+                    ops.gemm(self._v("in.xa_idx", R), da2, G[p + ".W"][d0:], s.attach, GH, R, trans_a=True, a_kind=hl.ONEHOT,
+                             accumulate=True, split_k=sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
                     ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"])
                 else:

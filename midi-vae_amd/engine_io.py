@@ -54,12 +54,14 @@ class ArrayStaging(object):
         out[:B] = arr
         self._up(name, out, tdtype)
 
-    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None, d_idx=None):
+    def stage_encoder_inputs(self, x_idx, i_idx=None, vel=None, eps=None, d_idx=None, xa_idx=None):
         """x_idx (B,T) uint8 note index per row; i_idx (B,V) uint8; vel (B,T) f32; d_idx (B,T) uint8 held-notes flag; eps (B,Z)
         f32 ALREADY scaled by epsilon_std (None -> zeros: deterministic encode, like the evaluation script's epsilon_std = 0)."""
         B = x_idx.shape[0]
         self.norm_B = float(B)
         self._up_tm("in.x_idx", np.asarray(x_idx, np.uint8), torch.uint8)
+        if self.spec.attach:            # (B,T) uint8: the attached instrument column of every row, 0 .. attach-1
+            self._up_tm("in.xa_idx", np.asarray(xa_idx, np.uint8), torch.uint8)
         if self.enc_bi:
             self._up_tm("in.x_idx_rev", np.asarray(x_idx, np.uint8)[:, ::-1], torch.uint8)
         if self.spec.meta_instrument:
@@ -100,7 +102,7 @@ class ArrayStaging(object):
             self._note_start(name, val)
 
     def stage_targets(self, B, y_idx, c_idx=None, w_notes=None, w_instr=None, w_vel=None, w_style=None, n_idx=None,
-                      w_held=None, w_next=None, sig=None, w_sig=None, w_cnotes=None, w_cinstr=None):
+                      w_held=None, w_next=None, sig=None, w_sig=None, w_cnotes=None, w_cinstr=None, ya_idx=None):
         """Targets and Keras sample weights.  Row weights are folded with the weighted-objective normalisers
         (score*w / mean(w != 0), then the mean over the axes) into one factor per row; padding
         rows get target 255 ("no target") and weight 0."""
@@ -108,6 +110,8 @@ class ArrayStaging(object):
         T, V = s.T, s.V
         self.norm_B = float(B)
         self._up_tm("in.y_idx", np.asarray(y_idx, np.uint8), torch.uint8, fill=255)
+        if s.attach:                    # second hot column of the two-hot target rows, as an ABSOLUTE column (D0 + instrument)
+            self._up_tm("in.ya_idx", (np.asarray(ya_idx, np.int64) + (s.Dout - s.attach)).astype(np.uint8), torch.uint8, fill=255)
 
         def norm(w, n_other):
             w = np.asarray(w, np.float64)

@@ -76,7 +76,7 @@ class HeadArgs(C.Structure):
     _fields_ = [("kind", _i32), ("dtype", _i32), ("R", _i32), ("H", _i32), ("N", _i32), ("want_grad", _i32),
                 ("hs", _vp), ("wt", _vp), ("bias", _vp), ("target_idx", _vp), ("target_val", _vp),
                 ("row_weight", _vp), ("grad_scale", _f32), ("probs", _vp), ("argmax", _vp), ("dlogits", _vp),
-                ("scalars", _vp), ("b_stride", _i32), ("b_valid", _i32), ("wc", _vp), ("dhs", _vp)]
+                ("scalars", _vp), ("b_stride", _i32), ("b_valid", _i32), ("wc", _vp), ("dhs", _vp), ("target_idx2", _vp)]
 
 
 class LatentFwdArgs(C.Structure):
@@ -126,6 +126,7 @@ SIGNATURES = {
     "mvae_streams_alias": (_i32, [_vp, _vp, _vp, C.c_uint32]),
     "mvae_prepare_batch": (_i32, [_vp, _i32, _vp]),
     "mvae_outer_bias_tile16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "mvae_gather2_tile16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_colsum_weighted": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "mvae_sum_over_time": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "mvae_head": (_i32, [C.POINTER(HeadArgs), _vp]),
@@ -153,6 +154,7 @@ SIGNATURES = {
     "mvae_host_threads": (_i32, [_i32]),
     "mvae_host_onehot_to_index_tm": (_i32, [_vp, _i32, _i64, _i32, _i32, _i64, _i64, _vp, _i32, C.c_uint8, C.POINTER(_i64)]),
     "mvae_host_index_to_tm": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _i32, C.c_uint8]),
+    "mvae_host_twohot_to_index_tm": (_i32, [_vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _i32, C.c_uint8, C.POINTER(_i64)]),
     "mvae_host_rows_to_tm_f32": (_i32, [_vp, _i32, _i64, _i32, _i64, _i64, _f32, _vp, _i32]),
 }
 

@@ -66,11 +66,15 @@ class ModelSpec:
     w_cinstr: float = 1.0
     add_dim: int = 0                 # width of decoder_additional_input (composer one-hot and / or signature vector)
     bidirectional: bool = False      # reference vae_definition.py:445-453 (Le-2 Bidirectional layers + one on top, as written)
+    # attach_instruments (reference import_midi.py:288-292, settings.py:186-187,207-208): every notes row carries the one-hot
+    # instrument category of its voice behind the pitch one-hot - Din and Dout INCLUDE these ``attach`` columns (two-hot rows)
+    attach: int = 0
 
     def oracle_cfg(self):
         """dict accepted by oracle.vae_oracle.make_cfg (tests only)."""
         d = dict(self.__dict__)
         d.pop("epsilon_std")
+        d.pop("attach")                 # (the oracle multiplies the dense two-hot rows: Din / Dout say it all)
         return d
 
     @property
@@ -172,7 +176,7 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         comp_instr=bool(g("composer_decoder_at_instrument_output", False)),
         w_cinstr=float(g("composer_decoder_at_instrument_weight", 1.0)),
         add_dim=int(g("decoder_additional_input_dim", 0)) if g("decoder_additional_input", False) else 0,
-        bidirectional=bool(g("bidirectional", False)))
+        bidirectional=bool(g("bidirectional", False)), attach=int(g("attach_dim", 0) or 0))
     # the asserts of reference vae_definition.py:177-208
     assert s.Le > 0 and s.Ld > 0 and s.T > 0 and s.H > 0 and s.Z > 0 and s.beta > 0
     assert int(g("input_length", s.T)) > 0
@@ -213,6 +217,12 @@ def spec_from_create_kwargs(kw: dict) -> ModelSpec:
         assert 0 < s.C <= min(s.Z, 64)
     if s.H % 64 or s.H > 256:
         raise NotImplementedError("lstm_size must be 64, 128 or 256 (got %d)" % s.H)
+    if s.attach:
+        if not (0 < s.attach < min(s.Din, s.Dout)) or s.Din != s.Dout:
+            raise ValueError("attach_dim must be the instrument columns appended to every notes row (input_dim == output_dim)")
+        if s.bidirectional or s.meta_next or s.comp_notes:
+            raise NotImplementedError("attach_instruments with a bidirectional encoder, the next-notes head or a classifier on the "
+                                      "notes output")
     if s.Dout > 128 or s.ID > 128 or s.Din > 255:
         raise NotImplementedError("one-hot widths above 128 are not built")
     return s

@@ -560,7 +560,7 @@ class Autoencoder(_ModelView):
                 b0 = min(n, batch_size)
                 if n > b0:      # histories of the later minibatches: before the first update, forward only, chip-filling; their
                     from .staging import host_onehot_to_index_tm      # windows are converted once for this pass and their train steps
-                    xtm = host_onehot_to_index_tm(a["X"], b0, n)
+                    xtm = host_onehot_to_index_tm(a["X"], b0, n) if not sp.attach else None
                     a["X_tm"] = (xtm, b0) if xtm is not None else None
                     self._s.encode_windows(a["X"], a.get("I"), a.get("Vel"), a.get("Held"), lat._root().eps, b0, n, lat._root()._z,
                                            X_tm=a["X_tm"])
@@ -672,10 +672,12 @@ class VAE(object):
     def __init__(self):
         self.encoder = self.decoder = self.autoencoder = self.composer_decoder = None
 
-    def create(self, compute_dtype="bf16", seed=0, device="cuda:0", **kw):
+    def create(self, compute_dtype="bf16", seed=0, device="cuda:0", attach_dim=0, **kw):
+        """``attach_dim``: settings.instrument_dim when ``attach_instruments`` is on (the reference's create call does not carry
+        it: its rows are then pitch one-hot | instrument one-hot, input_dim = output_dim = notes + silent + attach_dim)"""
         for k, v in kw.items():
             setattr(self, k, v)
-        self.spec = spec_from_create_kwargs(kw)
+        self.spec = spec_from_create_kwargs(dict(kw, attach_dim=attach_dim))
         shared = _Shared(self.spec, compute_dtype, seed, device)
         shared.teacher_force = bool(kw.get("teacher_force", False))
         shared.next_teacher_force = bool(kw.get("meta_next_notes_teacher_force", False))

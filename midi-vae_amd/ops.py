@@ -157,6 +157,12 @@ def outer_bias_tile16(xs, w, bias, out, R, N):
              "mvae_outer_bias_tile16")
 
 
+def gather2_tile16(idx, idx2, table, table2, out, R, N, layout=hl.TILE16):
+    """out (R, N) in ``layout`` = table[idx[r]] + table2[idx2[r]]: x*W + b of two-hot input rows (attach_instruments)"""
+    hl.check(hl.load().mvae_gather2_tile16(_p(idx), _p(idx2), _p(table), _p(table2), _p(out), kind_of(out), R, N, layout, _stream()),
+             "mvae_gather2_tile16")
+
+
 def colsum_weighted(X, wgt, R, N, out, ldx=None):
     """out[n] += sum_r wgt[r] * X[r, n]  (wgt f32)"""
     hl.check(hl.load().mvae_colsum_weighted(X.data_ptr(), kind_of(X), _p(wgt), R, N, N if ldx is None else ldx, _p(out),
@@ -173,10 +179,10 @@ def head_np(N):
 
 
 def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None, row_weight=None, grad_scale=1.0,
-         probs=None, argmax=None, dlogits=None, scalars=None, b_stride=0, b_valid=0, wc=None, dhs=None):
+         probs=None, argmax=None, dlogits=None, scalars=None, b_stride=0, b_valid=0, wc=None, dhs=None, target_idx2=None):
     a = hl.HeadArgs(kind, dtype, R, H, N, int(dlogits is not None), hs.data_ptr(), _p(wt), _p(bias), _p(target_idx),
                     _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars),
-                    b_stride, b_valid, _p(wc), _p(dhs))
+                    b_stride, b_valid, _p(wc), _p(dhs), _p(target_idx2))
     hl.check(hl.load().mvae_head(a, _stream()), "mvae_head")
 
 

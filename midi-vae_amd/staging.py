@@ -139,8 +139,9 @@ class Stager(object):
                                                        out.ctypes.data, Bp, fill, C.byref(bad))
             if rc == hl.E_FORMAT:
                 raise NotImplementedError(
-                    "%s must be one-hot rows (reference layout, import_midi.py:255-262): row %d of window %d is not; dense / "
-                    "multi-hot rows need the dense input projection, which is not built" % (what, bad.value % steps, bad.value // steps))
+                    "%s must be one-hot rows (reference layout, import_midi.py:255-262): row %d of window %d is not (rows with "
+                    "an attached instrument one-hot - attach_instruments - need VAE.create(attach_dim=settings.instrument_dim); other "
+                    "dense / multi-hot rows are not built)" % (what, bad.value % steps, bad.value // steps))
             hl.check(rc, "mvae_host_onehot_to_index_tm")
         else:
             a = a.reshape(a.shape[0], -1)
@@ -148,6 +149,25 @@ class Stager(object):
                 raise ValueError("%s: expected (n, %d) uint8 indices or one-hot rows, got %s %s" % (what, steps, a.shape, a.dtype))
             hl.check(self.lib.mvae_host_index_to_tm(a.ctypes.data, a.shape[0], steps, lo, hi, out.ctypes.data, Bp, fill),
                      "mvae_host_index_to_tm")
+
+    def _rows_twohot(self, k, name1, name2, arr, lo, hi, steps, width, attach, Bp, fill, what, absolute):
+        """two-hot (n, steps, width) rows - pitch one-hot | attached instrument one-hot (attach_instruments) -> two (steps, Bp)
+        uint8 index rolls; ``absolute``: the second index as a column of the full row (targets) instead of within its block"""
+        a = _c(arr)
+        if a.ndim != 3 or a.shape[-1] != width or a.shape[1] != steps:
+            raise ValueError("%s: expected (n, %d, %d) two-hot rows, got %s" % (what, steps, width, a.shape))
+        o1, o2 = self._view(k, name1, np.uint8, steps * Bp), self._view(k, name2, np.uint8, steps * Bp)
+        bad = C.c_int64(-1)
+        rc = self.lib.mvae_host_twohot_to_index_tm(a.ctypes.data, _host_kind(a), a.shape[0], steps, width, width - attach, lo, hi,
+                                                   o1.ctypes.data, o2.ctypes.data, Bp, fill, C.byref(bad))
+        if rc == hl.E_FORMAT:
+            raise NotImplementedError("%s must be pitch one-hot | instrument one-hot rows (attach_instruments with a 1hot "
+                                      "instrument_attach_method, reference import_midi.py:288-292): row %d of window %d is not"
+                                      % (what, bad.value % steps, bad.value // steps))
+        hl.check(rc, "mvae_host_twohot_to_index_tm")
+        if absolute:
+            o2r = o2.reshape(steps, Bp)
+            o2r[:, :hi - lo] += np.uint8(width - attach)
 
     def _rows_f32(self, k, name, arr, lo, hi, steps, Bp, scale=1.0):
         a = _c(arr)
@@ -210,7 +230,9 @@ class Stager(object):
         self._late = None
         if self.done[k] is not None:
             self.done[k].synchronize()              # the upload that last read this mirror has completed
-        if X_tm is not None and not batch_local and X_tm[1] <= lo and hi <= X_tm[1] + X_tm[0].shape[1]:
+        if s.attach:
+            self._rows_twohot(k, "in.x_idx", "in.xa_idx", X, lo, hi, T, s.Din, s.attach, Bp, 0, "notes input", False)
+        elif X_tm is not None and not batch_local and X_tm[1] <= lo and hi <= X_tm[1] + X_tm[0].shape[1]:
             out = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)
             out[:, :B] = X_tm[0][:, lo - X_tm[1]:hi - X_tm[1]]
             out[:, B:] = 0
@@ -246,7 +268,10 @@ class Stager(object):
             nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next, w_sig, w_cnotes,
                                                        w_cinstr)
             def late():
-                self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
+                if s.attach:
+                    self._rows_twohot(k, "in.y_idx", "in.ya_idx", Y, lo, hi, T, s.Dout, s.attach, Bp, 255, "notes target", True)
+                else:
+                    self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
                 if w_notes is None:
                     out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
                     out[:, :B] = 1.0 / nm.nz_notes

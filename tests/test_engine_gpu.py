@@ -660,3 +660,42 @@ def test_twenty_engines_in_one_process_keep_their_queues_apart():
             del eng
             gc.collect()
     assert not [str(w.message) for w in rec if "timed out" in str(w.message)], [str(w.message) for w in rec]
+
+
+@pytest.mark.parametrize("cell,dtype,H,T", [("GRU", "f32", 64, 12), ("LSTM", "f32", 64, 12), ("LSTM", "bf16", 256, 64)])
+def test_attach_instruments_two_hot_rows_match_oracle(cell, dtype, H, T):
+    """attach_instruments (reference import_midi.py:288-292, settings.py:186-187,207-208): every notes row carries its voice's
+    instrument one-hot behind the pitch one-hot - input_dim = output_dim = 61 + 16, two-hot rows.  Encoder layer 1 then sums two
+    rows of its kernel (written out by mvae_gather2_tile16), the notes head's cross-entropy has two target columns
+    (-log p[pitch] - log p[instrument], accuracy against the first hot column) and W's gradient two one-hot GEMMs.  Losses and
+    every gradient against the oracle, which multiplies the dense two-hot rows; f32: 2e-4 / 2e-3, bf16 resident path: 3e-2 / 6e-2."""
+    B, A = 16, 16
+    spec, params, batch, raw = _problem(cell, B, seed=91, H=H, Z=32, T=T, Din=77, Dout=77, attach=A)
+    D0 = spec.Din - A
+    rng = np.random.default_rng(4)
+    x_idx = rng.integers(0, D0, (B, T)).astype(np.uint8)
+    xa_idx = np.tile(raw["i_idx"][:, np.arange(T) % spec.V], 1).astype(np.uint8)         # row t = voice t % V's instrument category
+    X = np.concatenate([_onehot(x_idx, D0), _onehot(xa_idx, A)], -1)
+    batch = dict(batch, X=X, Y=X)
+    raw = dict(raw, x_idx=x_idx)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    eng = Engine(spec, max_batch=B, dtype=dtype)
+    eng.set_params(params)
+    eng.stage_encoder_inputs(x_idx, raw["i_idx"], raw["vel"], raw["eps"], d_idx=raw["d_idx"], xa_idx=xa_idx)
+    eng.stage_decoder_inputs(B, hist=raw["hist"], add=raw["add"])
+    eng.stage_targets(B, x_idx, raw["c_idx"], w_notes=raw["w_notes"], n_idx=raw["n_idx"], sig=raw["sig"], ya_idx=xa_idx)
+    eng.forward_backward(B)
+    eng.check_pipeline()
+    m, g = eng.metrics(B), eng.get_grads()
+    tol_l, tol_g = (2e-4, 2e-3) if dtype == "f32" else (3e-2, 6e-2)
+    for k in m_o:
+        assert abs(m[k] - m_o[k]) <= tol_l * (1 + abs(m_o[k])) + (1e-6 if k.endswith("_acc") else 0), (k, m[k], m_o[k])
+    for k in g_o:
+        n = np.linalg.norm(g_o[k])
+        if n < 1e-12:
+            assert np.linalg.norm(g[k]) < 1e-6, k
+        else:
+            assert _rel_l2(g[k], g_o[k]) < tol_g, (k, _rel_l2(g[k], g_o[k]))

@@ -88,3 +88,28 @@ def test_global_normalisers_of_a_minibatch():
     w[2:4, 1] = 0
     nm = Norm.of(2, 8, 4, w_notes=w, w_instr=np.array([1.0] * 5 + [0.0] * 5))
     assert (nm.B, nm.nz_notes, nm.nz_instr, nm.nz_vel, nm.nz_style) == (6, 22, 3, 6, 6)
+
+
+def test_twohot_rows_to_two_index_rolls():
+    """attach_instruments rows (pitch one-hot | instrument one-hot, reference import_midi.py:288-292): one pass gives both index
+    rolls, time-major and padded; any other row is refused with the LOWEST offending flat row."""
+    import ctypes as C
+    lib = hl.load()
+    n, T, K, K1, Bp = 7, 16, 77, 61, 16
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, K1, (n, T)), rng.integers(0, K - K1, (n, T))
+    for dt, kind in ((np.float64, hl.HOST_F64), (np.float32, hl.HOST_F32), (np.uint8, hl.HOST_U8)):
+        X = np.zeros((n, T, K), dt)
+        np.put_along_axis(X, a[..., None], 1, -1)
+        np.put_along_axis(X, (K1 + b)[..., None], 1, -1)
+        o1, o2 = np.zeros((T, Bp), np.uint8), np.zeros((T, Bp), np.uint8)
+        bad = C.c_int64(-1)
+        assert lib.mvae_host_twohot_to_index_tm(X.ctypes.data, kind, n, T, K, K1, 2, n, o1.ctypes.data, o2.ctypes.data, Bp, 255,
+                                                C.byref(bad)) == 0
+        assert np.array_equal(o1[:, :n - 2].T, a[2:]) and np.array_equal(o2[:, :n - 2].T, b[2:])
+        assert (o1[:, n - 2:] == 255).all() and (o2[:, n - 2:] == 255).all()
+        X[5, 3, K1 + int(b[5, 3])] = 0                         # no instrument column in window 5, row 3
+        X[6, 1, (int(a[6, 1]) + 1) % K1] = 1                    # two pitch columns in window 6, row 1
+        assert lib.mvae_host_twohot_to_index_tm(X.ctypes.data, kind, n, T, K, K1, 0, n, o1.ctypes.data, o2.ctypes.data, Bp, 255,
+                                                C.byref(bad)) == hl.E_FORMAT
+        assert bad.value == 5 * T + 3

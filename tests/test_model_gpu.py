@@ -402,3 +402,47 @@ def test_two_hundred_alternating_calls_never_time_out(cell):
     for eng in (m._shared.engine, m._shared.infer):
         eng.check_pipeline()
         assert eng.pipeline, "the engine fell back to chunked launches"
+
+
+def test_attach_instruments_through_the_reference_lists():
+    """the last live settings.py switch (attach_instruments=True, instrument_attach_method='1hot-category'): two-hot float64 rows
+    (reference import_midi.py:288-292) through the host packers (mvae_host_twohot_to_index_tm), fit / evaluate / predict on the
+    reference's lists; evaluate equals the oracle's forward pass on the same lists, the loss falls over two epochs."""
+    from midi_vae_amd.layout import init_params
+    s = build_settings(cell_type="GRU", lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=8,
+                       learning_rate=1e-3, attach_instruments=True, epsilon_std=0.0)
+    assert s["input_dim"] == s["output_dim"] == 77 and s["instrument_dim"] == 16
+    m = VAE().create(compute_dtype="f32", seed=2, attach_dim=s["instrument_dim"], **create_kwargs(s))
+    n = 13
+    w = make_windows(n, s["output_length"], 61, s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=8)
+    X0, _, C, I, V, D = to_reference_format(w)
+    T = X0.shape[1]
+    inst = np.tile(I, (T // s["max_voices"], 1))                       # (T, 16): row t = voice t % V (reference import_midi.py:291)
+    X = np.concatenate([X0, np.tile(inst[None], (n, 1, 1))], -1)
+    Y = X.copy()
+    Hh = np.random.default_rng(3).standard_normal((n, s["latent_dim"])) * 0.1
+    S = np.zeros((n, s["signature_vector_length"]))
+    x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, Hh, return_sample_weight=True)
+    res = m.autoencoder.evaluate(x, y, batch_size=8, verbose=False)
+    orc = OracleVAE(make_cfg(**m.spec.oracle_cfg()))
+    p = {k: v.astype(np.float64) for k, v in init_params(m.spec, 2).items()}
+    tot = {}
+    for lo in range(0, n, 8):
+        hi = min(n, lo + 8)
+        b = dict(X=x[0][lo:hi], Hist=x[2][lo:hi], I=x[4][lo:hi], Vel=x[6][lo:hi], Y=y[0][lo:hi], C=y[3][lo:hi])
+        mo, _ = orc.forward(p, b, np.zeros((hi - lo, m.spec.Z)))
+        for k, v in mo.items():
+            tot[k] = tot.get(k, 0.0) + v * (hi - lo) / n
+    names = m.autoencoder.metrics_names
+    got = dict(zip(["loss", "l1", "l2", "l3", "ls", "a1", "a2", "a3", "as"], res))
+    assert len(names) == 9
+    for gk, ok in (("loss", "loss"), ("l1", "notes_loss"), ("a1", "notes_acc"), ("l2", "instr_loss"), ("ls", "style_loss")):
+        assert abs(got[gk] - tot[ok]) <= 2e-4 * (1 + abs(tot[ok])), (gk, got[gk], tot[ok])
+    hist = m.autoencoder.fit(x, y, epochs=2, batch_size=8, shuffle=False, sample_weight=sw, verbose=False)
+    assert hist.history["loss"][1] < hist.history["loss"][0]
+    outs = m.autoencoder.predict(x, batch_size=8)
+    assert outs[0].shape == (n, T, 77) and np.allclose(outs[0].sum(-1), 1, atol=1e-5)
+    with pytest.raises(NotImplementedError):           # a model built without attach_dim names the switch when it meets such rows
+        s0 = build_settings(cell_type="GRU", lstm_size=64, latent_dim=32, input_length=4, output_length=4, batch_size=8,
+                            attach_instruments=True)
+        VAE().create(compute_dtype="f32", seed=2, **create_kwargs(s0)).autoencoder.evaluate(x, y, batch_size=8, verbose=False)

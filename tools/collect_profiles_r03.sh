@@ -1,0 +1,53 @@
+# Round 3: the exact command list behind profiles/r03_p_* (run on the GPU box: gpurun -- 'bash tools/collect_profiles_r03.sh')
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03p
+mkdir -p $O
+cd $R
+# 1. the bench line (CPU baseline + float64 CPU ELBO first, then the GPU phase), LSTM and GRU; the other BASELINE configs; f32 parity mode
+python bench.py > $O/bench_lstm.json 2> $O/bench_lstm.err
+python bench.py --cell GRU --no-cpu-baseline > $O/bench_gru.json 2> $O/bench_gru.err
+python bench.py --config 2 --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_config2_lstm.json 2> $O/bench_cfg.err
+python bench.py --config 2 --no-cpu-baseline --steps 10 --warmup 3 --cell GRU > $O/bench_config2_gru.json 2>> $O/bench_cfg.err
+python bench.py --config 4 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_config4_lstm.json 2>> $O/bench_cfg.err
+python bench.py --config 4 --no-cpu-baseline --steps 20 --warmup 5 --cell GRU > $O/bench_config4_gru.json 2>> $O/bench_cfg.err
+python bench.py --dtype f32 --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_lstm_f32.json 2> $O/bench_lstm_f32.err
+MVAE_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_lstm_one_rank_rccl.json
+# 2. kernel trace + stats of the SAME default command, and one step's timeline by queue (LSTM and GRU)
+for c in LSTM GRU; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -- python bench.py --no-cpu-baseline --cell $c > /dev/null 2>&1
+  cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) $O/bench_${c}_kernel_stats.csv
+  python tools/timeline.py $(find /tmp/ks_$c -name "*kernel_trace.csv" | head -1) --min-us 20 > $O/timeline_${c}_step.txt
+done
+# 3. HBM traffic of the dominant kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC has 4 counter slots: 3 + 2 do not fit)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0 > $O/pmc_$c.log 2>&1
+  grep "bwd_il_k" $(find /tmp/pmcb_$c -name "*counter_collection.csv" | head -1) | cut -c1-400 > $O/pmc_${c}_bwd_rows.csv
+done
+python tools/pmc_traffic.py --fetch $(find /tmp/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1) --write $(find /tmp/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1) --out $O/bench_traffic.json > $O/pmc_traffic.log 2>&1
+# 4. issue / MFMA counters: the recurrent kernels alone, the GEMM kernels alone, decoder inference (configs[4] share)
+GROUPS=("SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE")
+i=0
+for g in "${GROUPS[@]}"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_rnn_$i -- python tools/rnn_microbench.py --cell LSTM > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_gemm_$i -- python tools/gemm_microbench.py > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_dec_$i -- python tools/decode_bench.py --config 5 --reps 2 > /dev/null 2>&1
+done
+python tools/pmc_summary.py $(find /tmp/pmc_rnn_* -name "*counter_collection.csv") > $O/rnn_pmc_summary.txt 2>&1
+python tools/pmc_kernels.py --match "gemm|proj_ws" $(find /tmp/pmc_gemm_* -name "*counter_collection.csv") > $O/gemm_pmc_summary.txt 2>&1
+python tools/pmc_kernels.py --match "proj_ws|fwd_il_k|fwd_multi|head_k" $(find /tmp/pmc_dec_* -name "*counter_collection.csv") > $O/decode_pmc_summary.txt 2>&1
+# 5. the tools' own timings
+python tools/gemm_microbench.py 2>&1 | grep -v amdgpu > $O/gemm_microbench.txt
+python tools/rnn_microbench.py --cell LSTM 2>&1 | grep -v amdgpu > $O/rnn_microbench.txt
+python tools/rnn_microbench.py --cell GRU 2>&1 | grep -v amdgpu >> $O/rnn_microbench.txt
+for args in "" "--with-prepass" "--windows 256 --songs 8" "--windows 256 --songs 8 --with-prepass" "--with-prepass --lazy"; do
+  echo "== tools/fit_e2e_bench.py $args" >> $O/fit_e2e.txt
+  python tools/fit_e2e_bench.py $args 2>&1 | grep -v amdgpu >> $O/fit_e2e.txt
+done
+for args in "--config 2" "--config 5" "--config 5 --cell GRU"; do
+  python tools/decode_bench.py $args 2>&1 | grep -v amdgpu | head -1 >> $O/decode.txt
+done
+python tools/decode_product_bench.py 2>&1 | grep -v amdgpu >> $O/decode.txt
+python tools/large_shape_check.py 2>&1 | grep -v amdgpu > $O/large_shape.txt
+ls -la $O

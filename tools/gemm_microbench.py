@@ -44,3 +44,28 @@ daT = da.t().contiguous()
 t(lambda: ops.gemm(hsT, daT, dU, H, GH, R, trans_b=True, accumulate=True, split_k=16), f, "dU, both operands k-contiguous (NT split-K 16)")
 cs = torch.zeros((GH,), device=dev)
 t(lambda: ops.gemm(hs, da, dU, H, GH, R, trans_a=True, accumulate=True, split_k=16, colsum_b=cs), f, "dU + column sums of da (TN split-K 16)")
+# ---- the persistent / waiting variants of the step, run alone (their counters already satisfied: no producer beside them) --------
+B, cs = 256, 16
+Rc = cs * B                                                       # rows per published chunk
+nch = R // Rc
+ready = torch.full((nch,), 1 << 20, dtype=torch.int32, device=dev)     # every chunk "published"
+done = torch.zeros((nch,), dtype=torch.int32, device=dev)
+status = torch.zeros(1, dtype=torch.int32, device=dev)
+t(lambda: ops.gemm(hs, wt, xp, R, GH, H, trans_b=True, bias=bias, c_layout=hl.TILE16, max_blocks=64, chunk_rows=Rc, chunk_wait=ready,
+                   chunk_wait_value=1, chunk_done=done, chunk_status=status), f, "proj_ws_k: xp = hs W^T, weights-stationary, 64 workgroups")
+t(lambda: ops.gemm(da, wc, dx, R, H, GH, trans_b=True, c_layout=hl.TILE16, max_blocks=64, chunk_rows=Rc, chunk_reverse=True, chunk_wait=ready,
+                   chunk_wait_value=1, chunk_done=done, chunk_status=status), f, "dX = da W, persistent chunked gemm_fast_k, 64 workgroups")
+def kstream(n_wg):
+    def parts(M, N):
+        tiles = -(-M // 128) * -(-N // 128)
+        P = 1
+        while P * 2 * tiles <= n_wg and Rc % (P * 2 * 64) == 0:
+            P *= 2
+        return P
+    kw = dict(k_wait=ready, k_wait_value=1, k_chunk_rows=Rc, k_reverse=True, chunk_status=status, trans_a=True, accumulate=True, build_only=True)
+    probs = [ops.gemm(hs, da, dU, H, GH, R, split_k=parts(H, GH), colsum_b=cs_, **kw) for cs_ in (cs1, cs2)]
+    probs += [ops.gemm(hs, da, dU2, H, GH, R, split_k=parts(H, GH), **kw), ops.gemm(idx, da, dW, 61, GH, R, a_kind=hl.ONEHOT, split_k=parts(61, GH), **kw)]
+    ops.gemm_kstream_multi(probs)
+cs1, cs2 = torch.zeros((GH,), device=dev), torch.zeros((GH,), device=dev)
+t(lambda: kstream(32), 3 * f + 2.0 * R * 61 * GH, "gemm_kstream_multi_k: dU, dW of two layers (4 problems, 32 workgroups each)")
+assert int(status.item()) == 0
