@@ -343,7 +343,9 @@ def main():
                 try:
                     rec = json.load(open(tf)).get("%s_%s" % (args.cell, args.dtype))
                     if rec and rec.get("T") == T and rec.get("B") == B:
-                        traffic, traffic_src = rec["bytes_per_launch"], rec
+                        # (measured per T-step problem under counter collection, where the layers run as single launches; a phase
+                        #  launch holds lpl such problems)
+                        traffic, traffic_src = rec["bytes_per_launch"] * lpl, rec
                 except (ValueError, OSError):
                     pass
         fwd_flop = algorithmic_flops_per_window(spec)

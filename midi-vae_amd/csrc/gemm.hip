@@ -234,7 +234,13 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 // ===========================================================================================================
 #include "ablations.h"      // GEMM_ABL_* timing switches: all 0 in the product build
 constexpr int FBM = 128, FBN = 128, FBK = 64;
-constexpr int F_LDK = FBK + 8;        // k-contiguous image: [row][FBK + 8]  (144 B rows: conflict-free b128 reads)
+// k-contiguous image: [row][FBK + 8] (144-byte rows).  NOT conflict-free for ds_read_b128 - its four lane groups are non-contiguous
+// ({0-3, 12-15, 20-27}, ...: rows {0-3, 12-15} of one k chunk and rows {4-11} of the next share a group; PMC: SQ_LDS_BANK_CONFLICT 32-40 %
+// of the LDS cycles of the NT GEMMs and of proj_ws_k).  Round 3 measured the fix - 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7):
+// 0 % conflicts - and it bought nothing (proj_ws_k 0.535 -> 0.535 ms, dX 0.431 -> 0.434, decode 4.12 -> 4.14 us per step: these kernels
+// wait for their global loads and barriers, wait-any 38 %, not for LDS; profiles/r03_q_lds_swizzle.txt), while the split-K row
+// reduction of the epilogue is laid out for 18 KB images: the padded image stays.
+constexpr int F_LDK = FBK + 8;
 constexpr int F_LDR = 128 + 16;       // row-contiguous image: [k][128 + 16] (288 B rows = 32 mod 256: tr reads spread)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 

@@ -183,7 +183,7 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         # step, but 512 windows at T=2048 +6.5 % and decoding 1024 windows +4 % - there the recurrences themselves fill the chip
         # and the per-queue launches (producers dispatched first) place them better than one launch's index order
         self.phase_max_B = int(os.environ.get("MVAE_PHASE_MAX_B", "256"))
-        self._hold_dec_grads = os.environ.get("MVAE_HOLD_DEC_GRADS", "1") == "1"     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
+        self._hold_dec_grads = int(os.environ.get("MVAE_HOLD_DEC_GRADS", "1"))     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
         if share is None:

@@ -164,7 +164,7 @@ class PhaseLaunches(object):
             head_grads()
         L = len(h.layers)
         for li, r in enumerate(reversed(h.layers)):
-            if li == L - 1 and self._hold_dec_grads and self._after_chain is not None:
+            if (li == L - 1 or self._hold_dec_grads >= 2) and self._hold_dec_grads and self._after_chain is not None:
                 # the bottom layer's da is complete when the launch ends - exactly when the latent chain (a latency-bound kernel
                 # between this phase and the next) starts: its gradient GEMMs wait for the ENCODER launch's first chunk instead
                 self._after_chain.append(lambda r=r: dict(r=r, B=B, start=start))

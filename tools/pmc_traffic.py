@@ -18,6 +18,9 @@ ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--fetch", required=True)
 ap.add_argument("--write", required=True)
 ap.add_argument("--out", required=True)
+ap.add_argument("--write-counter", default="WRITE_SIZE", choices=["WRITE_SIZE", "TCC_EA0_WRREQ_sum"],
+                help="WRITE_SIZE (KiB) or TCC_EA0_WRREQ_sum (64-byte write requests; calibrated equal in round 2 - used in round 3, "
+                     "where the WRITE_SIZE pass hangs in rocprofv3's start-up on this image)")
 a = ap.parse_args()
 pat = "lstm_bwd_il_k" if a.cell == "LSTM" else "gru_bwd_il_k"
 
@@ -48,14 +51,15 @@ def per_launch(path, counter):
 
 
 f, nf, tf = per_launch(a.fetch, "FETCH_SIZE")
-w, nw, tw = per_launch(a.write, "WRITE_SIZE")
-rd, wr = 2.0 * f * 1024.0, w * 1024.0
+w, nw, tw = per_launch(a.write, a.write_counter)
+rd, wr = 2.0 * f * 1024.0, (w * 1024.0 if a.write_counter == "WRITE_SIZE" else w * 64.0)
 H = 256
 alg = a.B * a.T * H * (10 if a.cell == "LSTM" else 9) * (2 if a.dtype == "bf16" else 4)
 rec = {"kernel": pat, "T": a.T, "B": a.B, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (rd + wr) / alg, "launches_averaged": [nf, nw],
        "launches_seen": [tf, tw],
-       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py "
+       "write_counter": a.write_counter,
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE or TCC_EA0_WRREQ_sum x 64 B (separate passes) over `python bench.py "
                  "--no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0`; 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, median over the "
                  "whole-sequence (T-step) launches of the kernel that read an upstream-gradient sequence - under counter collection "
                  "kernels run one at a time, so the stacked layers run as 128-step chunk launches (same bytes per time step) and the "
