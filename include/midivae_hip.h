@@ -235,7 +235,9 @@ int mvae_sum_over_time(const void* X, int32_t kind, int32_t T, int32_t BN, float
  * pipelined hand-over fields of each problem work as in the single launches.  ``xpand``: up to 2 expansions of a 1-feature roll
  * (mvae_outer_bias_tile16) as chunk-publishing producers inside the forward launch: out (R, N) bf16 MVAE_TILE16 = xs[r] w[n] +
  * bias[n], chunk_done[c] += 4 * blocks when rows [c * chunk_rows, (c+1) * chunk_rows) are written (write-through); the problem that
- * reads `out` as its xp names chunk_done as wait_ready with wait_value = previous total + 4 * blocks.
+ * reads `out` as its xp names chunk_done as wait_ready with wait_value = previous total + 4 * blocks.  The same producer can write
+ * out the table rows of a one-hot input layer (idx / table): the indexed-input kernels gather 2 KB rows of the table every step
+ * (2.67 us per time step alone against 2.22 for a dense input), and the bottom layer of the encoder stack sets the pace of its phase.
  * MVAE_E_UNSUPPORTED: some problem is not one of these kernels' (launch them one by one with mvae_rnn_fwd / mvae_rnn_bwd). */
 typedef struct {
     const float* xs;           /* (R) f32 */
@@ -246,6 +248,8 @@ typedef struct {
     int32_t chunk_rows;        /* rows per published chunk (% 16 == 0, divides R): chunk_steps * B of the consumer */
     uint32_t* chunk_done;      /* [R / chunk_rows] counters */
     int32_t blocks, reserved;  /* workgroups of this producer (<= 256) */
+    const uint8_t* idx;        /* or NULL.  With idx (R) and table (K, N) of out_kind (mvae_make_table): out[r] = table[idx[r]] - the input */
+    const void* table;         /* projection of a ONE-HOT layer written out, so that the layer reads it like a dense one (xs / w / bias unused) */
 } mvae_xpand_args;
 int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand, void* stream);
 int mvae_rnn_bwd_multi(const mvae_rnn_bwd_args* problems, int32_t n, void* stream);

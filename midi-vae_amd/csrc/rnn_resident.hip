@@ -115,6 +115,18 @@ __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// LSTM BPTT filler slots (tools/build_variants.sh for A/B; profiles/r03_r_bptt_slots.txt): the write-through da stores as LATE as
+// the staging registers allow - slots 16.. cost +0.33 ms per train step, 44 +0.03, 50 (round 2) 0, 58 -0.05: stores in flight slow
+// the return of the next step's prefetched values more than their acknowledgement is missed at the T-fragment drain
+#ifndef BWL_LOAD_STRIDE
+#define BWL_LOAD_STRIDE 3
+#endif
+#ifndef BWL_COPY_SLOT
+#define BWL_COPY_SLOT 58
+#endif
+#ifndef BWL_COPY_STRIDE
+#define BWL_COPY_STRIDE 4
+#endif
 #ifndef GB_DRAIN
 #define GB_DRAIN 0
 #endif
@@ -1603,8 +1615,8 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
             __builtin_amdgcn_sched_barrier(0);
             // fillers.  Slots 1..40: step t-1's saved values, one load per 3 slots; then the row-major copy of the da
             // tile, 8 chunks per lane staged through the (until the last groups idle) lt registers.
-            if constexpr (!ABL_NOX && sl >= 1 && sl < 1 + 3 * 14 && (sl - 1) % 3 == 0) {
-                constexpr int k = (sl - 1) / 3;                // 0..7 gates (pair j = k/4), 8..9 c_{t-1}, 10..13 upstream gradient
+            if constexpr (!ABL_NOX && sl >= 1 && sl < 1 + BWL_LOAD_STRIDE * 14 && (sl - 1) % BWL_LOAD_STRIDE == 0) {
+                constexpr int k = (sl - 1) / BWL_LOAD_STRIDE;                // 0..7 gates (pair j = k/4), 8..9 c_{t-1}, 10..13 upstream gradient
                 if constexpr (k < 8) {
                     pinu(lane16);
                     qa[k >> 2][k & 3] = *reinterpret_cast<const g_u16x8*>(acts_p[k & 3] + (k >> 2) * 1024 + lane16);
@@ -1617,8 +1629,8 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
                     qd[k - 10] = *reinterpret_cast<const g_u16x4*>(dx_p + (k - 10) * 512 + l8);
                 }
             }
-            if constexpr (!ABL_NOTRG && sl >= 50 && sl < 50 + 4 * 8 + 8 && (sl - 50) % 4 == 0) {
-                constexpr int j = (sl - 50) / 4;               // read chunk j (j < 8), store chunk j - 2
+            if constexpr (!ABL_NOTRG && sl >= BWL_COPY_SLOT && sl < BWL_COPY_SLOT + BWL_COPY_STRIDE * 10 && (sl - BWL_COPY_SLOT) % BWL_COPY_STRIDE == 0) {
+                constexpr int j = (sl - BWL_COPY_SLOT) / BWL_COPY_STRIDE;               // read chunk j (j < 8), store chunk j - 2
                 if constexpr (j >= 2) {
                     constexpr int js = j - 2;
                     pinu(lane16);
@@ -2195,19 +2207,113 @@ struct rnn_bwd_multi {
     int32_t base[RM_MAX + 1];
     int32_t n;
 };
-__device__ __forceinline__ void xpand_body(const mvae_xpand_args& x, const int bid, const int nb) {
-    // out (R, N) bf16 in TILE16 = xs[r] * w[n] + bias[n], chunk after chunk of chunk_rows rows (a chunk is contiguous in TILE16);
-    // stored write-through, every wave publishes each chunk once (the consumer expects 4 * nb increments per chunk)
-    const int N = x.N, nchunks = x.R / x.chunk_rows;
-    const size_t per = (size_t)x.chunk_rows * N / 4;                 // quads (4 consecutive n of one row) per chunk
+// out (R, N) bf16 in TILE16 = xs[r] * w[n] + bias[n] - or, with idx, the rows table[idx[r]] of a one-hot layer's lookup table
+// (x*W + b already) - chunk after chunk of chunk_rows rows (a chunk is contiguous in TILE16); stored write-through, every
+// wave publishes each chunk once (the consumer expects 4 * nb increments per chunk).
+// A wave's unit of work is 16 rows x a quarter of the columns (TPS tiles of 16 columns; a tile is 512 contiguous bytes, lane =
+// 4 columns of one row): the row's scalar / table index is ONE load per unit and there is no division anywhere.  The loop is
+// software-pipelined around the one memory counter gfx950 has for loads AND stores (vmcnt, retired in issue order): a load
+// issued behind write-through stores is not usable before those stores are acknowledged by memory (~2-3 us), so the loads of
+// unit i+1 (and the key of unit i+2) are issued BEFORE the stores of unit i and waited for with the stores still in flight.
+// (history: one quad per thread and round with 64-bit index arithmetic moved 0.6 GB/s per workgroup, the unit loop with
+//  load-then-store batches 2.2 GB/s - 16 workgroups then took 3.5 ms for the 32 MB the encoder's bottom layer reads)
+template <int TPS, bool GATHER>
+__device__ __forceinline__ void xpand_pipe(const mvae_xpand_args& x, const int wave, const int nw, const int lane) {
+    const int N = x.N, ntn = N >> 4, nchunks = x.R / x.chunk_rows, rbs = x.chunk_rows >> 4, units = rbs << 2;
+    const int col = (lane >> 4) * 4, tn0 = (wave & 3) * TPS;        // (u & 3 == wave & 3 for every unit of this wave: nw % 4 == 0)
+    const size_t chunk_bytes = (size_t)x.chunk_rows * N * 2;
+    if (wave >= units) {
+        for (int c = 0; c < nchunks; ++c) wave_signal_done<false>(x.chunk_done + c);
+        return;
+    }
+    const bf16_t* __restrict__ table = reinterpret_cast<const bf16_t*>(x.table) + tn0 * 16 + col;
+    auto key_of = [&](int cc, int uu) -> unsigned {
+        const int m = (cc * rbs + (uu >> 2)) * 16 + (lane & 15);
+        // (the aligned WORD that holds the row's index byte, picked apart where it is used: a byte load is zero-extended
+        //  right behind the load - a full vmcnt(0) drain, stores included, in the middle of the pipeline)
+        if constexpr (GATHER) return reinterpret_cast<const unsigned*>(x.idx)[m >> 2];
+        else return __float_as_uint(x.xs[m]);
+    };
+    const int ksh = (lane & 3) * 8;
+    f32x4 w[GATHER ? 1 : TPS], bs[GATHER ? 1 : TPS];
+    mvae_u32x2 d[GATHER ? TPS : 1], dn[GATHER ? TPS : 1];
+    int c = 0, u = wave, c1 = 0, u1 = wave + nw;
+    if (u1 >= units) { u1 = wave; c1 = 1; }
+    unsigned k0 = key_of(c, u), k1 = c1 < nchunks ? key_of(c1, u1) : 0u;
+    if constexpr (GATHER) {
+#pragma unroll
+        for (int j = 0; j < TPS; ++j) d[j] = *reinterpret_cast<const mvae_u32x2*>(table + (size_t)((k0 >> ksh) & 255u) * N + j * 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TPS; ++j) {
+            w[j] = *reinterpret_cast<const f32x4*>(x.w + tn0 * 16 + col + j * 16);
+            bs[j] = *reinterpret_cast<const f32x4*>(x.bias + tn0 * 16 + col + j * 16);
+        }
+    }
+    while (c < nchunks) {
+        int c2 = c1, u2 = u1 + nw;
+        if (u2 >= units) { u2 = wave; ++c2; }
+        unsigned k2 = 0;
+        if (c1 < nchunks) {
+            if constexpr (GATHER) {
+#pragma unroll
+                for (int j = 0; j < TPS; ++j) dn[j] = *reinterpret_cast<const mvae_u32x2*>(table + (size_t)((k1 >> ksh) & 255u) * N + j * 16);
+            }
+            if (c2 < nchunks) k2 = key_of(c2, u2);
+        }
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(x.out) + (size_t)c * chunk_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(cbase), 0, -1, 0x00020000);
+        const int off = ((u >> 2) * ntn + tn0) * 512 + lane * 8;
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int j = 0; j < TPS; ++j) __builtin_amdgcn_raw_buffer_store_b64(d[j], rs, off + j * 512, 0, 16 /* sc1: write-through */);
+        } else {
+            const float xv = __uint_as_float(k0);
+#pragma unroll
+            for (int j = 0; j < TPS; ++j) store4_bf16_wt(cbase, (unsigned)(off + j * 512), xv * w[j] + bs[j]);
+        }
+        if (c1 != c) wave_signal_done<false>(x.chunk_done + c);        // (that was this wave's last unit of chunk c)
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int j = 0; j < TPS; ++j) d[j] = dn[j];
+        }
+        k0 = k1; k1 = k2; c = c1; u = u1; c1 = c2; u1 = u2;
+    }
+}
+__device__ __forceinline__ void xpand_body(const mvae_xpand_args x, const int bid, const int nb) {
+    const int N = x.N, ntn = N >> 4, nchunks = x.R / x.chunk_rows, rbs = x.chunk_rows >> 4;
+    const int lane = (int)(threadIdx.x & 63), wave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = nb * 4;
+    if (ntn == 64) {            // (G*H = 1024: LSTM, H = 256)
+        if (x.idx) xpand_pipe<16, true>(x, wave, nw, lane); else xpand_pipe<16, false>(x, wave, nw, lane);
+        return;
+    }
+    if (ntn == 48) {            // (768: GRU)
+        if (x.idx) xpand_pipe<12, true>(x, wave, nw, lane); else xpand_pipe<12, false>(x, wave, nw, lane);
+        return;
+    }
+    // any other width: the plain unit loop
+    const int sh = (ntn & 3) ? 0 : 2, tps = ntn >> sh, units = rbs << sh;
+    const int col = (lane >> 4) * 4;
+    const bf16_t* __restrict__ table = reinterpret_cast<const bf16_t*>(x.table);
+    const size_t chunk_bytes = (size_t)x.chunk_rows * N * 2;
     for (int c = 0; c < nchunks; ++c) {
-        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(x.out) + (size_t)c * per * 8;
-        for (size_t q = (size_t)bid * 256 + threadIdx.x; q < per; q += (size_t)nb * 256) {
-            const size_t e = (size_t)c * per + q, tile = e >> 6;
-            const int lane = (int)(e & 63), m = (int)(tile / (N >> 4)) * 16 + (lane & 15), n = (int)(tile % (N >> 4)) * 16 + (lane >> 4) * 4;
-            const float xv = x.xs[m];
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(x.w + n), bv = *reinterpret_cast<const f32x4*>(x.bias + n);
-            store4_bf16_wt(cbase, (unsigned)(q * 8), xv * wv + bv);
+        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(x.out) + (size_t)c * chunk_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(cbase), 0, -1, 0x00020000);
+        for (int u = wave; u < units; u += nw) {
+            const int rb = u >> sh, tn0 = (u & ((1 << sh) - 1)) * tps;
+            const int m = (c * rbs + rb) * 16 + (lane & 15);
+            unsigned off = (unsigned)((rb * ntn + tn0) * 512 + lane * 8);
+            if (x.idx) {
+                const bf16_t* src = table + (size_t)x.idx[m] * N + tn0 * 16 + col;
+                for (int t = 0; t < tps; ++t, off += 512)
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const mvae_u32x2*>(src + t * 16), rs, (int)off, 0, 16);
+            } else {
+                const float xv = x.xs[m];
+                const float* w = x.w + tn0 * 16 + col;
+                const float* bs = x.bias + tn0 * 16 + col;
+                for (int t = 0; t < tps; ++t, off += 512)
+                    store4_bf16_wt(cbase, off, xv * *reinterpret_cast<const f32x4*>(w + t * 16) + *reinterpret_cast<const f32x4*>(bs + t * 16));
+            }
         }
         wave_signal_done<false>(x.chunk_done + c);
     }
@@ -2322,9 +2428,10 @@ extern "C" int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, 
     int total = 0;
     for (int i = 0; i < n_xpand; ++i) {
         const mvae_xpand_args& x = xpand[i];
-        if (!x.xs || !x.w || !x.bias || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || x.N <= 0 || (x.N % 16) ||
+        if (!((x.xs && x.w && x.bias) || (x.idx && x.table)) || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || x.N <= 0 || (x.N % 16) ||
             x.chunk_rows <= 0 || (x.chunk_rows % 16) || (x.R % x.chunk_rows) || x.blocks <= 0 || x.blocks > 256 ||
-            (reinterpret_cast<uintptr_t>(x.w) & 15) || (reinterpret_cast<uintptr_t>(x.bias) & 15) ||
+            (!x.idx && ((reinterpret_cast<uintptr_t>(x.w) & 15) || (reinterpret_cast<uintptr_t>(x.bias) & 15))) ||
+            (x.idx && ((reinterpret_cast<uintptr_t>(x.table) & 7) || (reinterpret_cast<uintptr_t>(x.idx) & 3))) ||
             (size_t)x.chunk_rows * x.N * 2 > 0x7fffffffull)
             return MVAE_E_ARG;
         m.xp[i] = x;

@@ -183,6 +183,10 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         # step, but 512 windows at T=2048 +6.5 % and decoding 1024 windows +4 % - there the recurrences themselves fill the chip
         # and the per-queue launches (producers dispatched first) place them better than one launch's index order
         self.phase_max_B = int(os.environ.get("MVAE_PHASE_MAX_B", "256"))
+        # (_index_as_dense; measured r03_r: GRU step -0.07 ms, LSTM +0.09 ms - there the bottom layer does not set the pace)
+        self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "1" if spec.cell == "GRU" else "0") == "1"
+        self.index_dense_blocks = int(os.environ.get("MVAE_INDEX_DENSE_BLOCKS", "16"))
+        self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "64"))
         self._hold_dec_grads = int(os.environ.get("MVAE_HOLD_DEC_GRADS", "1"))     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
@@ -263,6 +267,14 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         """1-feature input layers (velocity roll) of an LSTM / GRU model: x*W + b is written out (T*B*G*H bf16, one streaming
         kernel, ~0.1 ms) so that the layer runs on the slot-interleaved dense-input kernels (2.1 instead of 3.9 us/step)."""
         return r.xmode == hl.X_SCALAR and self._seq_layout(r) == hl.TILE16P
+
+    def _index_as_dense(self, r):
+        """the bottom layer of the encoder notes stack (one-hot pitch rows) sets the pace of the encoder-forward phase, and the
+        indexed-input kernel - a dependent 2 KB table gather per row and step - takes 2.67 us per time step against 2.22 for
+        a dense input: inside a phase launch the table rows are written out by a chunk-publishing producer (PhaseLaunches.
+        _xpand_problem) and the layer reads them as a dense projection."""
+        return (self.index_dense and self.training and r.xmode == hl.X_INDEX and self.enc_notes and r is self.enc_notes[0] and
+                self._seq_layout(r) == hl.TILE16P)
 
     def _mark(self, name):
         """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect): (name, host time of
@@ -479,6 +491,8 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                     buf(p + ".rh", r.T * B * H, **esz)
             if r.xmode == hl.X_INDEX:
                 buf(p + ".table", r.K * GH, **esz)
+                if self._index_as_dense(r):
+                    buf(p + ".xp", r.T * B * GH, **esz)
             elif r.xmode == X_GATHER2:
                 buf(p + ".table", (r.K - s.attach) * GH, **esz)      # W[:D0] + b (pitch rows), W[D0:] (attached instrument rows)
                 buf(p + ".table2", s.attach * GH, **esz)
@@ -680,7 +694,9 @@ class Engine(ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         t0 = k * Tc
         sh, sc = self._v(p + ".sh", B, H), self._v(p + ".sc", B, H)
         kw = {}
-        if r.xmode == hl.X_INDEX:
+        if r.xmode == hl.X_INDEX and xp_external:       # (the table rows written out inside the phase launch: _index_as_dense)
+            kw.update(xp=self._v(p + ".xp", T, B, GH)[t0:t0 + Tc])
+        elif r.xmode == hl.X_INDEX:
             kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
         elif r.xmode == X_GATHER2:       # table[pitch] + table2[instrument] written out, then the dense-input kernels
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]

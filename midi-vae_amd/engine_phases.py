@@ -32,25 +32,31 @@ class PhaseLaunches(object):
                 all(r.xmode != hl.X_SCALAR or self._scalar_as_dense(r) for r in recs))
 
     # ---- forward ----------------------------------------------------------------------------------------------------
-    def _xpand_problem(self, r, B, xs):
-        """the x*W + b expansion of a 1-feature roll as a producer inside the launch: (xpand args, pipe fields of its consumer)"""
+    def _xpand_problem(self, r, B, xs=None, idx=None):
+        """the x*W + b expansion of a 1-feature roll - or the table rows of a one-hot layer (``idx``) - as a producer inside the
+        launch: (xpand args, pipe fields of its consumer)"""
         s, P, p = self.spec, self.P, r.prefix
         cs = self.pipe_chunk
         while r.T % cs:
             cs //= 2
-        blocks = 64
-        sync, target, _ = self._sync_region(5, 1, r.T // cs, 4 * blocks, 0)
+        blocks = self.xpand_blocks if idx is None else self.index_dense_blocks
+        sync, target, _ = self._sync_region(5 if idx is None else 9, 1, r.T // cs, 4 * blocks, 0)
         xp = self._v(p + ".xp", r.T, B, s.GH)
-        x = ops.xpand(xs, P[p + ".W"].view(-1), P[p + ".b"], xp, r.T * B, s.GH, cs * B, sync[0, 0], blocks)
+        if idx is None:
+            x = ops.xpand(xs, P[p + ".W"].view(-1), P[p + ".b"], xp, r.T * B, s.GH, cs * B, sync[0, 0], blocks)
+        else:
+            x = ops.xpand(None, None, None, xp, r.T * B, s.GH, cs * B, sync[0, 0], blocks, idx=idx,
+                          table=self._v(p + ".table", r.K, s.GH))
         return x, dict(chunk_steps=cs, status=self.store["pipe_status"], wait_ready=sync[0, 0], wait_value=target)
 
-    def _stack_problems_forward(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None):
-        """problems of a (pipelined) stack, bottom layer first, and the projection GEMM launches that go with them"""
+    def _stack_problems_forward(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, bottom=None):
+        """problems of a (pipelined) stack, bottom layer first, and the projection GEMM launches that go with them; ``bottom``:
+        pipe fields of a bottom layer whose input projection a producer of the launch writes out (_xpand_problem)"""
         L = len(layers)
         if L == 1:
             r = layers[0]
             return [self._rec_forward(r, B, idx=idx, start=start, h_last=h_last, h_last_ld=h_last_ld, build=True,
-                                      **(states(r) if states else {}))], []
+                                      pipe=bottom, xp_external=bottom is not None, **(states(r) if states else {}))], []
         cs, T = self.pipe_chunk, layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
@@ -62,10 +68,14 @@ class PhaseLaunches(object):
             pipe = dict(chunk_steps=cs, status=status)
             if li > 0:
                 pipe.update(wait_ready=sync[li - 1, 1], wait_value=xp_target)
+            elif bottom is not None:
+                assert bottom["chunk_steps"] == cs
+                pipe.update(bottom)
             if not top:
                 pipe["signal_done"] = sync[li, 0]
             probs.append(self._rec_forward(r, B, idx=idx, start=start, h_last=h_last if top else None,
-                                           h_last_ld=h_last_ld if top else 0, pipe=pipe, xp_external=li > 0, build=True,
+                                           h_last_ld=h_last_ld if top else 0, pipe=pipe, xp_external=li > 0 or bottom is not None,
+                                           build=True,
                                            **(states(r) if states else {})))
             if not top:
                 gemms.append((li, lambda li=li: self._rec_xp(
@@ -102,8 +112,11 @@ class PhaseLaunches(object):
                 probs.append(self._rec_forward(r, B, pipe=pipe, xp_external=True, **kw))
             else:
                 probs.append(self._rec_forward(r, B, idx=self._v(src, r.T, B), **kw))
-        sp, gemms = self._stack_problems_forward(self.enc_notes, B, 0, idx=self._v("in.x_idx", s.T, B), h_last=cat[:, 0:H],
-                                                 h_last_ld=ldc)
+        x_idx, bottom = self._v("in.x_idx", s.T, B), None
+        if self._index_as_dense(self.enc_notes[0]):
+            x, bottom = self._xpand_problem(self.enc_notes[0], B, idx=x_idx)
+            xpands.insert(0, x)
+        sp, gemms = self._stack_problems_forward(self.enc_notes, B, 0, idx=x_idx, h_last=cat[:, 0:H], h_last_ld=ldc, bottom=bottom)
         self._launch_phase_forward(("rnn_fwd_multi", "enc"), sp + probs, gemms, xpands, steps=s.T * len(self.enc_notes))
         return True
 

@@ -59,7 +59,7 @@ class GemmArgs(C.Structure):
 
 class XpandArgs(C.Structure):
     _fields_ = [("xs", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("out_kind", _i32), ("R", _i32), ("N", _i32),
-                ("chunk_rows", _i32), ("chunk_done", _vp), ("blocks", _i32), ("reserved", _i32)]
+                ("chunk_rows", _i32), ("chunk_done", _vp), ("blocks", _i32), ("reserved", _i32), ("idx", _vp), ("table", _vp)]
 
 
 class PrepJob(C.Structure):

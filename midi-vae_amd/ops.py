@@ -79,9 +79,11 @@ def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 
-def xpand(xs, w, bias, out, R, N, chunk_rows, chunk_done, blocks=64):
-    """an expansion of a 1-feature roll (outer_bias_tile16) as a chunk-publishing producer of rnn_fwd_multi"""
-    return hl.XpandArgs(_p(xs), _p(w), _p(bias), _p(out), kind_of(out), int(R), int(N), int(chunk_rows), _pv(chunk_done), int(blocks), 0)
+def xpand(xs, w, bias, out, R, N, chunk_rows, chunk_done, blocks=64, idx=None, table=None):
+    """an expansion of a 1-feature roll (outer_bias_tile16) - or, with idx / table, of a one-hot layer's table rows - as a
+    chunk-publishing producer of rnn_fwd_multi"""
+    return hl.XpandArgs(_p(xs), _p(w), _p(bias), _p(out), kind_of(out), int(R), int(N), int(chunk_rows), _pv(chunk_done), int(blocks), 0,
+                        _p(idx), _p(table))
 
 
 def rnn_fwd_multi(problems, xpands=()):
