@@ -8,9 +8,10 @@
 //   ABL_NOMATH  no gate arithmetic                                 ABL_NOBAR   no barriers
 //   ABL_NOB     B fragments: no LDS reads after the first two      ABL_NOTRANS exp / rcp replaced by multiplies
 //   GEMM_ABL_NOMFMA / NOLOAD / NOATOMIC                            the fast GEMM without its MFMAs / global loads / atomics
+//   WS_ABL_NOSTORE / NOLOAD / NOMFMA                               proj_ws_k without its epilogue stores / A requests / MFMAs
 #pragma once
 #define MVAE_ABL_LIST(X) X(ABL_NOL) X(ABL_NOTRG) X(ABL_NOSAVE) X(ABL_NOX) X(ABL_NOMATH) X(ABL_NOBAR) X(ABL_NOB) X(ABL_NOTRANS) \
-    X(GEMM_ABL_NOMFMA) X(GEMM_ABL_NOLOAD) X(GEMM_ABL_NOATOMIC)
+    X(GEMM_ABL_NOMFMA) X(GEMM_ABL_NOLOAD) X(GEMM_ABL_NOATOMIC) X(WS_ABL_NOSTORE) X(WS_ABL_NOLOAD) X(WS_ABL_NOMFMA)
 #ifndef ABL_NOL
 #define ABL_NOL 0
 #endif
@@ -43,6 +44,15 @@
 #endif
 #ifndef GEMM_ABL_NOATOMIC
 #define GEMM_ABL_NOATOMIC 0
+#endif
+#ifndef WS_ABL_NOSTORE
+#define WS_ABL_NOSTORE 0
+#endif
+#ifndef WS_ABL_NOLOAD
+#define WS_ABL_NOLOAD 0
+#endif
+#ifndef WS_ABL_NOMFMA
+#define WS_ABL_NOMFMA 0
 #endif
 #ifndef MVAE_VARIANT_BUILD
 #define MVAE_ABL_CHECK(name) static_assert((name) == 0, #name " is a timing ablation: variant builds only (tools/build_variants.sh)");

@@ -577,22 +577,54 @@ __global__ __launch_bounds__(256) void gemm_kstream_multi_k(const kstream_multi 
 }
 
 // ===========================================================================================================
-// Weights-stationary persistent projection (round 2): x*W + b of a stacked layer behind a time-pipelined lower layer, K = H = 256.
+// Weights-stationary persistent projection: x*W + b of a stacked layer behind a time-pipelined lower layer, K = H = 256.
 // In the fast kernel above a 128x128 tile with K = 256 is four k-iterations: prologue latency, the reload of the same 64 KB weight
 // panel for every tile and the epilogue dominate (~8 us per tile, 10 % of a CU's MFMA rate) - decoder inference at 1024 windows
-// per GPU was bound by THIS GEMM, not by the recurrences.  Here a workgroup owns ONE column tile for the
-// whole launch: its weight panel (128 x 256 bf16, four k-tile images) is staged in LDS once; per row block only the A tile
-// (128 x 256) moves - requested into registers while the previous tile's MFMAs run, so its latency hides behind them - and the
-// main loop touches no global memory.  Row blocks of residue x (mod 8) belong to the workgroups of XCD x (as xcd_rows above).
-// Same MFMA order over k as the fast kernel: bit-identical results.  LDS: 8 images x 18 KB = 144 KB, one workgroup per CU.
+// per GPU was bound by THIS GEMM, not by the recurrences.  A workgroup owns ONE column tile for the whole
+// launch.
+//   Round 2: weight panel AND the current A tile in LDS, the tile staged through registers behind two barriers, every phase
+//     (stage, multiply, store) serial: 4.2 us per 128-row block, 128 TFLOP/s on 64 workgroups.
+//   Round 3 (profiles/r03_t_proj_ws.txt for each step):
+//   * each wave's 32 weight fragments (its 64 columns x K) live in ACCUMULATOR registers for the whole launch, the 16 output
+//     accumulators too (named as "a" operands of inline-asm MFMAs: the compiler does not place MFMA operands there by itself):
+//     half the LDS fragment reads are gone, and LDS holds TWO A tiles - the next tile is written while this one multiplies, one
+//     barrier per row block;
+//   * the A tile is requested with UN-TRACKED loads (inline asm) and waited for by hand.  gfx950 counts loads and stores in ONE
+//     counter (vmcnt, retired in issue order); the compiler's own wait has to hold for every way into the loop and is vmcnt(0) -
+//     every row block then also waited for the previous block's 16 write-through stores to be acknowledged by memory.  Here
+//     the loads of block i+2 are issued in the middle of block i, in front of its stores, and `vmcnt(16)` in the middle of block
+//     i+1 says "they have arrived" with those stores still in flight;
+//   * LDS-only barriers (__syncthreads() releases global memory: vmcnt(0)).
+//   Tried: no LDS at all, A fragments straight from global memory in MFMA layout (a lane's fragment is 16 contiguous bytes): a
+//     wave's request then touches 16 rows x 64 bytes - 16 half-used cache lines per instruction, 3.5 us per block for the loads
+//     alone (WS_ABL_* ablations) against 0.85 us of MFMAs.  Row-contiguous requests (8 full lines per instruction) + LDS it is.
+// Row blocks of residue x (mod 8) belong to the workgroups of XCD x (as xcd_rows above): the eight column tiles that read the
+// same A rows share an L2.  Same MFMA order over k as the fast kernel: bit-identical results.
+// EPI: the output as 0 TILE16 written through (a pipelined stack's hand-over), 1 TILE16 plain stores, 2 row-major - a template
+// parameter, not three run-time branches per store.  The build fails if this kernel uses scratch (an asm load's output must
+// never be spilled before its data has landed): csrc/Makefile.
 // ===========================================================================================================
-constexpr int WS_KT = 4;                 // k-tiles of 64: K = 256
+constexpr int WS_K = 256, WS_KT = WS_K / FBK;       // K = H; k-tiles of 64
+// the hand-counted wait: vmcnt(16 * SEL), SEL a wave-uniform 0 / 1 - ONE statement with the branch inside (two statements in an
+// if / else make the compiler merge two versions of the 64 "modified" registers)
+#define WS_WAIT(SEL, B)                                                                                                           \
+    asm volatile("s_cmp_eq_u32 %16, 1\n\ts_cbranch_scc1 L_ws16_%=\n\ts_waitcnt vmcnt(0)\n\ts_branch L_wsd_%=\n"                    \
+                 "L_ws16_%=:\n\ts_waitcnt vmcnt(16)\nL_wsd_%=:"                                                                     \
+                 : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]), "+v"(B[4]), "+v"(B[5]), "+v"(B[6]), "+v"(B[7]), "+v"(B[8]),      \
+                   "+v"(B[9]), "+v"(B[10]), "+v"(B[11]), "+v"(B[12]), "+v"(B[13]), "+v"(B[14]), "+v"(B[15])                        \
+                 : "s"(SEL)                                                                                                         \
+                 : "memory", "scc")
+template <bool ZERO>
+__device__ __forceinline__ void ws_mfma(f32x4& c, const u16x8& wgt, const u16x8& x) {
+    if (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "a"(wgt), "v"(x));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "a"(wgt), "v"(x));
+}
+template <int EPI>
 __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IMG = f_img<false>();
-    bf16_t* Bs = reinterpret_cast<bf16_t*>(smem);                  // [WS_KT][IMG]   the weight panel, resident
-    bf16_t* As = Bs + WS_KT * IMG;                                 // [WS_KT][IMG]   the current A tile
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, q = l >> 4, r = l & 15;
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                  // [2][WS_KT][IMG]   two A tiles
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, q = l >> 4, r = l & 15;
     const int wm = w >> 1, wn = w & 1;
     const int N = a.N;
     const int tiles_n = N / FBN, tiles_m = a.M / FBM;
@@ -604,59 +636,86 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     // its step (no event orders it - one packet less on the critical queue per phase); the producer it polls runs behind that
     // preparation, so a published chunk says the weights are in place.
     if (a.chunk_wait) wave_wait_ge(a.chunk_wait + (a.chunk_reverse ? nchunks - 1 : 0), a.chunk_wait_value, a.chunk_status, 3u);
-    {   // the weight panel: rows n0 .. n0+127 of B (N, K) k-contiguous
-        f_stage<false, false> sb;
+    u16x8 fb[4][8];                      // this wave's weights: column tile jj, k-group ks (32 k) - accumulator registers
 #pragma unroll
-        for (int kt = 0; kt < WS_KT; ++kt) {
-            sb.load(a.B, a.ldb, n0, kt * FBK, tid);
-            sb.store(Bs + kt * IMG, tid);
-        }
+    for (int jj = 0; jj < 4; ++jj) {
+        const unsigned char* pb = reinterpret_cast<const unsigned char*>(a.B) +
+                                  ((size_t)(n0 + wn * 64 + jj * 16 + r) * a.ldb + q * 8) * 2;
+        asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:64\n\t"
+                     "global_load_dwordx4 %2, %8, off offset:128\n\tglobal_load_dwordx4 %3, %8, off offset:192\n\t"
+                     "global_load_dwordx4 %4, %8, off offset:256\n\tglobal_load_dwordx4 %5, %8, off offset:320\n\t"
+                     "global_load_dwordx4 %6, %8, off offset:384\n\tglobal_load_dwordx4 %7, %8, off offset:448\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&a"(fb[jj][0]), "=&a"(fb[jj][1]), "=&a"(fb[jj][2]), "=&a"(fb[jj][3]), "=&a"(fb[jj][4]), "=&a"(fb[jj][5]),
+                       "=&a"(fb[jj][6]), "=&a"(fb[jj][7])
+                     : "v"(pb)
+                     : "memory");
     }
     f32x4 bias[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
         bias[jj] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * 64 + jj * 16 + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f_stage<false, false> sa[WS_KT];
-    const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16;        // (see gemm_fast_k)
+    constexpr bool wt = EPI == 0;        // (see gemm_fast_k)
+    u16x8 sa[16];                        // the tile in flight: chunk tid + i * 256 (row = chunk / 8, 8 k at (chunk % 8) * 8) of k-tile kt at [kt * 4 + i]
+    f32x4 acc[4][4];
+    const size_t row_bytes = (size_t)a.lda * 2;
     for (int ci = 0; ci < nchunks; ++ci) {
         const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
         if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
         const int nloc = tiles_mc >> 3;                            // row blocks of this chunk on this XCD
-        if (g < nloc) {
+        const int nt = g < nloc ? (nloc - g + G - 1) / G : 0;      // ... of this workgroup
+        auto block_row = [&](const int t) { return (chunk * tiles_mc + x + 8 * (g + t * G)) * FBM; };
+        auto request = [&](const int t) __attribute__((always_inline)) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(a.A) + (size_t)(block_row(t) + (tid >> 3)) * row_bytes +
+                                     (size_t)((tid & 7) * 8) * 2;
 #pragma unroll
-            for (int kt = 0; kt < WS_KT; ++kt) sa[kt].load(a.A, a.lda, (chunk * tiles_mc + x + 8 * g) * FBM, kt * FBK, tid);
-        }
-        for (int bl = g; bl < nloc; bl += G) {
-            const int m0 = (chunk * tiles_mc + x + 8 * bl) * FBM;
-            __syncthreads();                                       // the previous tile's fragment reads of As are done
-#pragma unroll
-            for (int kt = 0; kt < WS_KT; ++kt) sa[kt].store(As + kt * IMG, tid);
-            __syncthreads();
-            if (bl + G < nloc) {                                   // the next tile's A: in flight while this tile multiplies
-#pragma unroll
-                for (int kt = 0; kt < WS_KT; ++kt) sa[kt].load(a.A, a.lda, (chunk * tiles_mc + x + 8 * (bl + G)) * FBM, kt * FBK, tid);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* pi = p + (size_t)i * 32 * row_bytes;
+                asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                             "global_load_dwordx4 %1, %4, off offset:128\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:256\n\t"
+                             "global_load_dwordx4 %3, %4, off offset:384"
+                             : "=&v"(sa[0 * 4 + i]), "=&v"(sa[1 * 4 + i]), "=&v"(sa[2 * 4 + i]), "=&v"(sa[3 * 4 + i])
+                             : "v"(pi)
+                             : "memory");
             }
-            f32x4 acc[4][4];
+        };
+        auto to_lds = [&](const int t, const int younger) __attribute__((always_inline)) {
+            WS_WAIT(younger, sa);
+            bf16_t* img = As + (t & 1) * WS_KT * IMG;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int kt = 0; kt < WS_KT; ++kt)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < WS_KT; ++kt) {
-#pragma unroll
-                for (int kg = 0; kg < FBK / 32; ++kg) {
-                    u16x8 fa[4], fb[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[i] = f_frag<false>(As + kt * IMG, wm * 64 + i * 16, kg, q, r);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) fb[jj] = f_frag<false>(Bs + kt * IMG, wn * 64 + jj * 16, kg, q, r);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = mfma_bf16(fb[jj], fa[i], acc[i][jj]);   // rows: n, cols: m
+                for (int i = 0; i < 4; ++i) {
+                    const int c = tid + i * 256;
+                    *reinterpret_cast<u16x8*>(img + kt * IMG + (c >> 3) * F_LDK + (c & 7) * 8) = sa[kt * 4 + i];
                 }
+        };
+        auto multiply = [&](const int t, auto part_c) __attribute__((always_inline)) {
+            constexpr int PART = decltype(part_c)::value;
+            const bf16_t* img = As + (t & 1) * WS_KT * IMG;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ks = PART * 4 + kk;
+                u16x8 fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = f_frag<false>(img + (ks >> 1) * IMG, wm * 64 + i * 16, ks & 1, q, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (WS_ABL_NOMFMA && (i || jj)) continue;
+                        if (PART == 0 && kk == 0) ws_mfma<true>(acc[i][jj], fb[jj][ks], fa[i]);      // rows: n, cols: m
+                        else ws_mfma<false>(acc[i][jj], fb[jj][ks], fa[i]);
+                    }
             }
-            // epilogue: lane holds C[m = .. + r][n = .. + q*4 + 0..3]
+        };
+        auto epilogue = [&](const int t) __attribute__((always_inline)) {      // lane holds C[m = .. + r][n = .. + q*4 + 0..3]
+            const int m0 = block_row(t);
+            asm volatile("s_nop 9"
+                         : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                           "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
+                           "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + r;
@@ -664,9 +723,9 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
                 for (int jj = 0; jj < 4; ++jj) {
                     const int n = n0 + wn * 64 + jj * 16 + q * 4;
                     const f32x4 v = acc[i][jj] * a.alpha + bias[jj];
-                    if (a.c_layout == MVAE_TILE16) {
+                    if constexpr (EPI < 2) {
                         const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
-                        if (wt) {
+                        if constexpr (wt) {
                             const size_t off0 = (((size_t)(m0 >> 4) * (N >> 4) + (n0 >> 4)) * 64) * 4;
                             store4_bf16_wt(reinterpret_cast<bf16_t*>(a.C) + off0, (unsigned)(off - off0) * 2u, v);
                         } else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
@@ -675,18 +734,39 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
                     }
                 }
             }
+        };
+        typedef std::integral_constant<int, 0> P0;
+        typedef std::integral_constant<int, 1> P1;
+        if (nt > 0) {
+            if (!WS_ABL_NOLOAD) request(0);
+            to_lds(0, 0);
+            if (nt > 1 && !WS_ABL_NOLOAD) request(1);
+            lds_barrier();
+        }
+        for (int t = 0; t < nt; ++t) {
+            // block t is in LDS[t & 1]; block t+1 in flight to the registers (requested in the middle of block t-1, or above)
+            multiply(t, P0{});
+            if (t + 1 < nt) {
+                // younger than block t+1's loads: block t-1's 16 stores (none in front of the chunk's second block)
+                to_lds(t + 1, __builtin_amdgcn_readfirstlane(t > 0 && !WS_ABL_NOSTORE ? 1 : 0));       // LDS[(t+1) & 1]: last read by block t-1, before the barrier that ended it
+                if (t + 2 < nt && !WS_ABL_NOLOAD) request(t + 2);
+            }
+            multiply(t, P1{});
+            if (!WS_ABL_NOSTORE) epilogue(t);
+            lds_barrier();               // block t+1 is complete in LDS; every wave is done reading block t
         }
         if (a.chunk_done) {
-            if (wt) wave_signal_done<false>(a.chunk_done + chunk);
+            if constexpr (wt) wave_signal_done<false>(a.chunk_done + chunk);
             else wave_signal_done<true>(a.chunk_done + chunk);
         }
     }
     if (a.sys_release) __threadfence_system();
 }
+#undef WS_WAIT
 // the problems proj_ws_k takes: the forward projection of a pipelined stack (A (M,256) and B (N,256) k-contiguous bf16, bf16 output)
 bool ws_ok(const mvae_gemm_args& a) {
     static const bool off = getenv("MVAE_NO_WS_GEMM") != nullptr;
-    if (off || !a.chunk_rows || a.trans_a || !a.trans_b || a.K != WS_KT * FBK || a.c_kind != MVAE_BF16 || a.accumulate ||
+    if (off || !a.chunk_rows || a.trans_a || !a.trans_b || a.K != WS_K || a.c_kind != MVAE_BF16 || a.accumulate ||
         a.act != MVAE_ACT_NONE || a.split_k > 1)
         return false;
     const int tiles_n = a.N / FBN, tiles_mc = a.chunk_rows / FBM;
@@ -696,12 +776,15 @@ int launch_ws(const mvae_gemm_args& a, hipStream_t s) {
     const size_t lds = (size_t)2 * WS_KT * f_img<false>() * sizeof(bf16_t);
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_ws_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return MVAE_E_LAUNCH;
+        for (const void* f : {reinterpret_cast<const void*>(&proj_ws_k<0>), reinterpret_cast<const void*>(&proj_ws_k<1>),
+                              reinterpret_cast<const void*>(&proj_ws_k<2>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MVAE_E_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL(proj_ws_k, dim3((unsigned)a.max_blocks), dim3(256), lds, s, a);
+    const dim3 grid((unsigned)a.max_blocks);
+    if (a.c_layout != MVAE_TILE16) hipLaunchKernelGGL(proj_ws_k<2>, grid, dim3(256), lds, s, a);
+    else if (a.chunk_done) hipLaunchKernelGGL(proj_ws_k<0>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(proj_ws_k<1>, grid, dim3(256), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
@@ -845,7 +928,7 @@ extern "C" int mvae_occupancy(int32_t which) {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds);
     } else if (which == 1) {
         const size_t lds = (size_t)2 * WS_KT * f_img<false>() * sizeof(bf16_t);
-        const void* f = reinterpret_cast<const void*>(&proj_ws_k);
+        const void* f = reinterpret_cast<const void*>(&proj_ws_k<0>);
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MVAE_E_LAUNCH;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, lds);
     } else if (which == 2) {

@@ -15,24 +15,26 @@ python bench.py --dtype f32 --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_l
 MVAE_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_lstm_one_rank_rccl.json
 # 2. kernel trace + stats of the SAME default command, and one step's timeline by queue (LSTM and GRU)
 for c in LSTM GRU; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -- python bench.py --no-cpu-baseline --cell $c > /dev/null 2>&1
+  timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -- python bench.py --no-cpu-baseline --cell $c > /dev/null 2>&1
   cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) $O/bench_${c}_kernel_stats.csv
   python tools/timeline.py $(find /tmp/ks_$c -name "*kernel_trace.csv" | head -1) --min-us 20 > $O/timeline_${c}_step.txt
 done
-# 3. HBM traffic of the dominant kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC has 4 counter slots: 3 + 2 do not fit)
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0 > $O/pmc_$c.log 2>&1
+# 3. HBM traffic of the dominant kernel: reads (FETCH_SIZE) and writes in SEPARATE passes.  Writes as TCC_EA0_WRREQ_sum x 64 B:
+#    a `--pmc WRITE_SIZE` pass hangs in rocprofv3's start-up on this image (it cost a whole gpurun limit once); the two were
+#    calibrated equal in round 2.  Every profiler pass under `timeout -k`: a hung one must not eat the passes behind it.
+for c in FETCH_SIZE TCC_EA0_WRREQ_sum; do
+  timeout -k 5 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 --prewarm-max 0 > $O/pmc_$c.log 2>&1
   grep "bwd_il_k" $(find /tmp/pmcb_$c -name "*counter_collection.csv" | head -1) | cut -c1-400 > $O/pmc_${c}_bwd_rows.csv
 done
-python tools/pmc_traffic.py --fetch $(find /tmp/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1) --write $(find /tmp/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1) --out $O/bench_traffic.json > $O/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py --fetch $(find /tmp/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1) --write $(find /tmp/pmcb_TCC_EA0_WRREQ_sum -name "*counter_collection.csv" | head -1) --write-counter TCC_EA0_WRREQ_sum --out $O/bench_traffic.json > $O/pmc_traffic.log 2>&1
 # 4. issue / MFMA counters: the recurrent kernels alone, the GEMM kernels alone, decoder inference (configs[4] share)
-GROUPS=("SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE")
+GROUPS=("SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "TCC_EA0_WRREQ_sum")
 i=0
 for g in "${GROUPS[@]}"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_rnn_$i -- python tools/rnn_microbench.py --cell LSTM > /dev/null 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_gemm_$i -- python tools/gemm_microbench.py > /dev/null 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_dec_$i -- python tools/decode_bench.py --config 5 --reps 2 > /dev/null 2>&1
+  timeout -k 5 170 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_rnn_$i -- python tools/rnn_microbench.py --cell LSTM > /dev/null 2>&1
+  timeout -k 5 170 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_gemm_$i -- python tools/gemm_microbench.py > /dev/null 2>&1
+  timeout -k 5 170 rocprofv3 --kernel-trace --pmc $g --output-format csv -d /tmp/pmc_dec_$i -- python tools/decode_bench.py --config 5 --reps 2 > /dev/null 2>&1
 done
 python tools/pmc_summary.py $(find /tmp/pmc_rnn_* -name "*counter_collection.csv") > $O/rnn_pmc_summary.txt 2>&1
 python tools/pmc_kernels.py --match "gemm|proj_ws" $(find /tmp/pmc_gemm_* -name "*counter_collection.csv") > $O/gemm_pmc_summary.txt 2>&1

@@ -53,6 +53,10 @@ done = torch.zeros((nch,), dtype=torch.int32, device=dev)
 status = torch.zeros(1, dtype=torch.int32, device=dev)
 t(lambda: ops.gemm(hs, wt, xp, R, GH, H, trans_b=True, bias=bias, c_layout=hl.TILE16, max_blocks=64, chunk_rows=Rc, chunk_wait=ready,
                    chunk_wait_value=1, chunk_done=done, chunk_status=status), f, "proj_ws_k: xp = hs W^T, weights-stationary, 64 workgroups")
+Rd = 64 * 1024                                                     # decode at 1024 windows: 64-step chunks, 64 row blocks per workgroup
+if R % Rd == 0:
+    t(lambda: ops.gemm(hs, wt, xp, R, GH, H, trans_b=True, bias=bias, c_layout=hl.TILE16, max_blocks=64, chunk_rows=Rd, chunk_wait=ready,
+                       chunk_wait_value=1, chunk_done=done, chunk_status=status), f, "proj_ws_k, 65536-row chunks (decode at 1024 windows), 64 workgroups")
 t(lambda: ops.gemm(da, wc, dx, R, H, GH, trans_b=True, c_layout=hl.TILE16, max_blocks=64, chunk_rows=Rc, chunk_reverse=True, chunk_wait=ready,
                    chunk_wait_value=1, chunk_done=done, chunk_status=status), f, "dX = da W, persistent chunked gemm_fast_k, 64 workgroups")
 def kstream(n_wg):
