@@ -614,6 +614,13 @@ constexpr int WS_K = 256, WS_KT = WS_K / FBK;       // K = H; k-tiles of 64
                    "+v"(B[9]), "+v"(B[10]), "+v"(B[11]), "+v"(B[12]), "+v"(B[13]), "+v"(B[14]), "+v"(B[15])                        \
                  : "s"(SEL)                                                                                                         \
                  : "memory", "scc")
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <bool ZERO>
 __device__ __forceinline__ void ws_mfma(f32x4& c, const u16x8& wgt, const u16x8& x) {
     if (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "a"(wgt), "v"(x));
@@ -680,80 +687,105 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
                              : "memory");
             }
         };
-        auto to_lds = [&](const int t, const int younger) __attribute__((always_inline)) {
-            WS_WAIT(younger, sa);
-            bf16_t* img = As + (t & 1) * WS_KT * IMG;
+        // The MFMA pipe runs by itself once an MFMA is issued (16 cycles each, 4 to issue): what else a row block needs - the
+        // previous block's epilogue, this wave's share of the next block's LDS image, the requests for the block after - is issued
+        // BETWEEN the k-groups of the multiply instead of behind it (one wave per SIMD: nothing else would overlap it).
+        //   first half  (k 0..127):   after k-group kk the epilogue of row tile kk of the PREVIOUS block (accumulators copied out)
+        //   second half (k 128..255): after k-group kk the LDS writes of k-tile kk of block t+1, then the requests of k-tile kk of t+2
+        auto lds_part = [&](const int t, const int kt) __attribute__((always_inline)) {
+            bf16_t* img = As + (t & 1) * WS_KT * IMG + kt * IMG;
 #pragma unroll
-            for (int kt = 0; kt < WS_KT; ++kt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = tid + i * 256;
-                    *reinterpret_cast<u16x8*>(img + kt * IMG + (c >> 3) * F_LDK + (c & 7) * 8) = sa[kt * 4 + i];
-                }
-        };
-        auto multiply = [&](const int t, auto part_c) __attribute__((always_inline)) {
-            constexpr int PART = decltype(part_c)::value;
-            const bf16_t* img = As + (t & 1) * WS_KT * IMG;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ks = PART * 4 + kk;
-                u16x8 fa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = f_frag<false>(img + (ks >> 1) * IMG, wm * 64 + i * 16, ks & 1, q, r);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        if (WS_ABL_NOMFMA && (i || jj)) continue;
-                        if (PART == 0 && kk == 0) ws_mfma<true>(acc[i][jj], fb[jj][ks], fa[i]);      // rows: n, cols: m
-                        else ws_mfma<false>(acc[i][jj], fb[jj][ks], fa[i]);
-                    }
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + i * 256;
+                *reinterpret_cast<u16x8*>(img + (c >> 3) * F_LDK + (c & 7) * 8) = sa[kt * 4 + i];
             }
         };
-        auto epilogue = [&](const int t) __attribute__((always_inline)) {      // lane holds C[m = .. + r][n = .. + q*4 + 0..3]
+        auto request_part = [&](const int t, const int kt) __attribute__((always_inline)) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(a.A) + (size_t)(block_row(t) + (tid >> 3)) * row_bytes +
+                                     (size_t)(kt * FBK + (tid & 7) * 8) * 2;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                         "global_load_dwordx4 %1, %5, off\n\t"
+                         "global_load_dwordx4 %2, %6, off\n\t"
+                         "global_load_dwordx4 %3, %7, off"
+                         : "=&v"(sa[kt * 4 + 0]), "=&v"(sa[kt * 4 + 1]), "=&v"(sa[kt * 4 + 2]), "=&v"(sa[kt * 4 + 3])
+                         : "v"(p), "v"(p + 32 * row_bytes), "v"(p + 64 * row_bytes), "v"(p + 96 * row_bytes)
+                         : "memory");
+        };
+        f32x4 cv[4][4];                  // the previous block's accumulators, read out of the accumulator registers
+        auto epilogue_part = [&](const int t, const int i) __attribute__((always_inline)) {   // lane holds C[m = .. + r][n = .. + q*4 + 0..3]
             const int m0 = block_row(t);
+            const int m = m0 + wm * 64 + i * 16 + r;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = n0 + wn * 64 + jj * 16 + q * 4;
+                const f32x4 v = cv[i][jj] * a.alpha + bias[jj];
+                if constexpr (EPI < 2) {
+                    const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
+                    if constexpr (wt) {
+                        const size_t off0 = (((size_t)(m0 >> 4) * (N >> 4) + (n0 >> 4)) * 64) * 4;
+                        store4_bf16_wt(reinterpret_cast<bf16_t*>(a.C) + off0, (unsigned)(off - off0) * 2u, v);
+                    } else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
+                } else {
+                    st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, v);
+                }
+            }
+        };
+        auto kgroup = [&](const int t, auto ks_c) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ks_c)::value;
+            const bf16_t* img = As + (t & 1) * WS_KT * IMG;
+            u16x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = f_frag<false>(img + (ks >> 1) * IMG, wm * 64 + i * 16, ks & 1, q, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (WS_ABL_NOMFMA && (i || jj)) continue;
+                    if (ks == 0) ws_mfma<true>(acc[i][jj], fb[jj][ks], fa[i]);      // rows: n, cols: m
+                    else ws_mfma<false>(acc[i][jj], fb[jj][ks], fa[i]);
+                }
+        };
+        auto read_out = [&]() __attribute__((always_inline)) {
             asm volatile("s_nop 9"
                          : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
                            "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
                            "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + r;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int n = n0 + wn * 64 + jj * 16 + q * 4;
-                    const f32x4 v = acc[i][jj] * a.alpha + bias[jj];
-                    if constexpr (EPI < 2) {
-                        const size_t off = ((((size_t)(m >> 4) * (N >> 4) + (n >> 4)) * 64) + (size_t)(q * 16 + (m & 15))) * 4;
-                        if constexpr (wt) {
-                            const size_t off0 = (((size_t)(m0 >> 4) * (N >> 4) + (n0 >> 4)) * 64) * 4;
-                            store4_bf16_wt(reinterpret_cast<bf16_t*>(a.C) + off0, (unsigned)(off - off0) * 2u, v);
-                        } else st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + off, v);
-                    } else {
-                        st<bf16_t>::store4(reinterpret_cast<bf16_t*>(a.C) + (size_t)m * a.ldc + n, v);
-                    }
-                }
-            }
+                for (int jj = 0; jj < 4; ++jj) cv[i][jj] = acc[i][jj];
         };
-        typedef std::integral_constant<int, 0> P0;
-        typedef std::integral_constant<int, 1> P1;
         if (nt > 0) {
             if (!WS_ABL_NOLOAD) request(0);
-            to_lds(0, 0);
+            WS_WAIT(0, sa);
+#pragma unroll
+            for (int kt = 0; kt < WS_KT; ++kt) lds_part(0, kt);
             if (nt > 1 && !WS_ABL_NOLOAD) request(1);
             lds_barrier();
         }
         for (int t = 0; t < nt; ++t) {
-            // block t is in LDS[t & 1]; block t+1 in flight to the registers (requested in the middle of block t-1, or above)
-            multiply(t, P0{});
-            if (t + 1 < nt) {
-                // younger than block t+1's loads: block t-1's 16 stores (none in front of the chunk's second block)
-                to_lds(t + 1, __builtin_amdgcn_readfirstlane(t > 0 && !WS_ABL_NOSTORE ? 1 : 0));       // LDS[(t+1) & 1]: last read by block t-1, before the barrier that ended it
-                if (t + 2 < nt && !WS_ABL_NOLOAD) request(t + 2);
-            }
-            multiply(t, P1{});
-            if (!WS_ABL_NOSTORE) epilogue(t);
+            // block t is in LDS[t & 1]; block t+1 in flight to the registers (requested in the second half of block t-1, or above)
+            static_for<0, 4>([&](auto kk) __attribute__((always_inline)) {
+                kgroup(t, kk);
+                if (t > 0 && !WS_ABL_NOSTORE) epilogue_part(t - 1, decltype(kk)::value);
+            });
+            // younger than block t+1's loads: block t-1's 16 stores (none in the chunk's first block).  LDS[(t+1) & 1] was last read
+            // by block t-1, before the barrier that ended it.
+            if (t + 1 < nt) WS_WAIT(__builtin_amdgcn_readfirstlane(t > 0 && !WS_ABL_NOSTORE ? 1 : 0), sa);
+            static_for<0, 4>([&](auto kk) __attribute__((always_inline)) {
+                constexpr int k = decltype(kk)::value;
+                kgroup(t, std::integral_constant<int, 4 + k>{});
+                if (t + 1 < nt) {
+                    lds_part(t + 1, k);
+                    if (t + 2 < nt && !WS_ABL_NOLOAD) request_part(t + 2, k);
+                }
+            });
+            read_out();
             lds_barrier();               // block t+1 is complete in LDS; every wave is done reading block t
+        }
+        if (nt > 0 && !WS_ABL_NOSTORE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) epilogue_part(nt - 1, i);
         }
         if (a.chunk_done) {
             if constexpr (wt) wave_signal_done<false>(a.chunk_done + chunk);

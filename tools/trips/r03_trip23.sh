@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03u
+O=$R/gpurun_out/r03v
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q --timeout 600 -x -k "gemm or proj or chunk or kstream" > $O/pytest_gemm.txt 2>&1
