@@ -244,11 +244,11 @@ typedef struct {
     const float* w;            /* (N) f32, 16-byte aligned */
     const float* bias;         /* (N) f32, 16-byte aligned */
     void* out;                 /* (R, N) out_kind (MVAE_BF16), MVAE_TILE16 */
-    int32_t out_kind, R, N;
+    int32_t out_kind, R, N;    /* N = the consumer's G*H: 1024 (LSTM) or 768 (GRU), H = 256 */
     int32_t chunk_rows;        /* rows per published chunk (% 16 == 0, divides R): chunk_steps * B of the consumer */
     uint32_t* chunk_done;      /* [R / chunk_rows] counters */
     int32_t blocks, reserved;  /* workgroups of this producer (<= 256) */
-    const uint8_t* idx;        /* or NULL.  With idx (R) and table (K, N) of out_kind (mvae_make_table): out[r] = table[idx[r]] - the input */
+    const uint8_t* idx;        /* or NULL (4-byte aligned).  With idx (R) and table (K, N) of out_kind (mvae_make_table): out[r] = table[idx[r]] - the input */
     const void* table;         /* projection of a ONE-HOT layer written out, so that the layer reads it like a dense one (xs / w / bias unused) */
 } mvae_xpand_args;
 int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand, void* stream);

@@ -2281,42 +2281,14 @@ __device__ __forceinline__ void xpand_pipe(const mvae_xpand_args& x, const int w
     }
 }
 __device__ __forceinline__ void xpand_body(const mvae_xpand_args x, const int bid, const int nb) {
-    const int N = x.N, ntn = N >> 4, nchunks = x.R / x.chunk_rows, rbs = x.chunk_rows >> 4;
+    const int ntn = x.N >> 4;            // (64 or 48: mvae_rnn_fwd_multi takes nothing else)
     const int lane = (int)(threadIdx.x & 63), wave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = nb * 4;
     if (ntn == 64) {            // (G*H = 1024: LSTM, H = 256)
         if (x.idx) xpand_pipe<16, true>(x, wave, nw, lane); else xpand_pipe<16, false>(x, wave, nw, lane);
         return;
     }
-    if (ntn == 48) {            // (768: GRU)
-        if (x.idx) xpand_pipe<12, true>(x, wave, nw, lane); else xpand_pipe<12, false>(x, wave, nw, lane);
-        return;
-    }
-    // any other width: the plain unit loop
-    const int sh = (ntn & 3) ? 0 : 2, tps = ntn >> sh, units = rbs << sh;
-    const int col = (lane >> 4) * 4;
-    const bf16_t* __restrict__ table = reinterpret_cast<const bf16_t*>(x.table);
-    const size_t chunk_bytes = (size_t)x.chunk_rows * N * 2;
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned char* cbase = reinterpret_cast<const unsigned char*>(x.out) + (size_t)c * chunk_bytes;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(cbase), 0, -1, 0x00020000);
-        for (int u = wave; u < units; u += nw) {
-            const int rb = u >> sh, tn0 = (u & ((1 << sh) - 1)) * tps;
-            const int m = (c * rbs + rb) * 16 + (lane & 15);
-            unsigned off = (unsigned)((rb * ntn + tn0) * 512 + lane * 8);
-            if (x.idx) {
-                const bf16_t* src = table + (size_t)x.idx[m] * N + tn0 * 16 + col;
-                for (int t = 0; t < tps; ++t, off += 512)
-                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const mvae_u32x2*>(src + t * 16), rs, (int)off, 0, 16);
-            } else {
-                const float xv = x.xs[m];
-                const float* w = x.w + tn0 * 16 + col;
-                const float* bs = x.bias + tn0 * 16 + col;
-                for (int t = 0; t < tps; ++t, off += 512)
-                    store4_bf16_wt(cbase, off, xv * *reinterpret_cast<const f32x4*>(w + t * 16) + *reinterpret_cast<const f32x4*>(bs + t * 16));
-            }
-        }
-        wave_signal_done<false>(x.chunk_done + c);
-    }
+    // (768: GRU)
+    if (x.idx) xpand_pipe<12, true>(x, wave, nw, lane); else xpand_pipe<12, false>(x, wave, nw, lane);
 }
 template <int CELL, int SAVE>
 __global__ __launch_bounds__(256, 1) void rnn_fwd_multi_k(const rnn_fwd_multi m) {
@@ -2428,7 +2400,7 @@ extern "C" int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, 
     int total = 0;
     for (int i = 0; i < n_xpand; ++i) {
         const mvae_xpand_args& x = xpand[i];
-        if (!((x.xs && x.w && x.bias) || (x.idx && x.table)) || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || x.N <= 0 || (x.N % 16) ||
+        if (!((x.xs && x.w && x.bias) || (x.idx && x.table)) || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || (x.N != 4 * RH && x.N != 3 * RH) ||
             x.chunk_rows <= 0 || (x.chunk_rows % 16) || (x.R % x.chunk_rows) || x.blocks <= 0 || x.blocks > 256 ||
             (!x.idx && ((reinterpret_cast<uintptr_t>(x.w) & 15) || (reinterpret_cast<uintptr_t>(x.bias) & 15))) ||
             (x.idx && ((reinterpret_cast<uintptr_t>(x.table) & 7) || (reinterpret_cast<uintptr_t>(x.idx) & 3))) ||

@@ -605,6 +605,46 @@ def test_phase_launches_equal_the_per_stream_schedule(cell, B):
         assert abs(a - b) <= 1e-4 * (1 + abs(b)), (l1, l0)
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_one_hot_bottom_layer_written_out_equals_the_indexed_kernel(cell, monkeypatch):
+    """Engine._index_as_dense: inside the encoder-forward phase launch the table rows of the one-hot bottom layer are written out
+    by a chunk-publishing producer (mvae_xpand_args.idx / table) and the layer runs on the dense-input kernel; the default is
+    per cell (GRU on, LSTM off - profiles/r03_r_index_dense.txt).  Both settings for both cells: the written-out projection
+    equals the gathered table rows bit for bit, so every saved sequence and the whole train step do too (ragged batch)."""
+    import torch
+    B = 200
+    spec, params, batch, raw = _problem(cell, B, seed=61, H=256, Z=64, T=64)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MVAE_INDEX_DENSE", flag)
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        assert eng.index_dense == (flag == "1")
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        eng.check_pipeline()
+        seqs = {k: eng.store[k].clone() for k in ("enc.notes.0.hs", "enc.notes.0.acts", "enc.notes.2.hs", "enc.notes.0.da")}
+        if flag == "1":     # the producer's output against the table rows it names
+            Bp = eng._cur_B
+            xp = eng._v("enc.notes.0.xp", spec.T, Bp, spec.GH)
+            idx = eng._v("in.x_idx", spec.T, Bp).long()
+            table = eng._v("enc.notes.0.table", eng.enc_notes[0].K, spec.GH)
+            R, N = spec.T * Bp, spec.GH      # TILE16: 16x16 tiles, lane = row % 16 + 16 * (col % 16 // 4), 4 columns per lane
+            rows = xp.reshape(R // 16, N // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(R, N)
+            assert torch.equal(rows, table[idx.view(-1)])
+        m, g = eng.metrics(B), eng.get_grads()
+        eng.train_step(B)
+        res[flag] = (seqs, m, g, eng.metrics(B)["loss"])
+    (s1, m1, g1, l1), (s0, m0, g0, l0) = res["1"], res["0"]
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]), k
+    for k in m0:
+        assert m1[k] == pytest.approx(m0[k], rel=1e-5, abs=1e-6), k
+    for k in g0:
+        assert _rel_l2(g1[k], g0[k]) < 1e-4 or np.linalg.norm(g0[k]) < 1e-9, k
+    assert abs(l1 - l0) <= 1e-4 * (1 + abs(l0))
+
+
 @pytest.mark.parametrize("dtype,H", [("f32", 64), ("bf16", 256)])
 def test_nonzero_decoder_start_rows_match_oracle(dtype, H):
     """the constant input of the decoder cells (reference vae_definition.py:820,916 always passes zeros): an
