@@ -623,7 +623,7 @@ def test_one_hot_bottom_layer_written_out_equals_the_indexed_kernel(cell, monkey
         _stage(eng, raw, B)
         eng.forward_backward(B)
         eng.check_pipeline()
-        seqs = {k: eng.store[k].clone() for k in ("enc.notes.0.hs", "enc.notes.0.acts", "enc.notes.2.hs", "enc.notes.0.da")}
+        seqs = {k: eng.store[k].clone() for k in ("enc.notes.0.hs", "enc.notes.0.acts", "enc.notes.1.hs", "enc.notes.0.da")}
         if flag == "1":     # the producer's output against the table rows it names
             Bp = eng._cur_B
             xp = eng._v("enc.notes.0.xp", spec.T, Bp, spec.GH)

@@ -217,6 +217,44 @@ def test_gemm(ta, tb, dtype, tol, M, N, K):
         close(host(C3), want, 2e-2 * np.sqrt(K), "bf16 out")
 
 
+@pytest.mark.parametrize("N", [1024, 768])
+@pytest.mark.parametrize("chunk_tiles,reverse", [(8, False), (16, True), (24, False), (40, True)])
+@pytest.mark.parametrize("epi", ["tile16_handover", "tile16_plain", "rowmajor"])
+def test_weights_stationary_projection_equals_the_tiled_gemm(N, chunk_tiles, reverse, epi):
+    """proj_ws_k (csrc/gemm.hip): x*W + b between two time-pipelined layers as a persistent launch of 8 * N/128 workgroups - weight
+    fragments and accumulators in accumulator registers, A tiles double-buffered in LDS, requested with un-tracked loads and a
+    hand-counted vmcnt.  Against the tiled kernel on the same operands: same MFMA order over k, so BIT-identical - with 1, 2, 3 and
+    5 row blocks per workgroup and chunk (the prologue, the first block without stores in flight, the steady state, an odd tail),
+    both chunk orders, all three epilogues; the chunk counters say every wave published every chunk."""
+    rng = np.random.default_rng(N + chunk_tiles)
+    H, nchunks = 256, 3
+    rows = chunk_tiles * 128
+    M = nchunks * rows
+    A = dev(rng.standard_normal((M, H)), torch.bfloat16)
+    W = dev(rng.standard_normal((N, H)) * 0.1, torch.bfloat16)
+    bias = dev(rng.standard_normal((N,)))
+    lay = hl.ROWMAJOR if epi == "rowmajor" else hl.TILE16
+    want = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, W, want, M, N, H, trans_b=True, bias=bias, c_layout=lay)
+    blocks = 8 * (N // 128)
+    ready = torch.full((nchunks,), 7, dtype=torch.int32, device=DEV)
+    done = torch.zeros((nchunks,), dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for rep in range(2):
+        ops.gemm(A, W, got, M, N, H, trans_b=True, bias=bias, c_layout=lay, max_blocks=blocks, chunk_rows=rows, chunk_reverse=reverse,
+                 chunk_wait=ready, chunk_wait_value=7, chunk_done=done if epi != "tile16_plain" else None, chunk_status=status)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert int(status.item()) == 0
+    if epi != "tile16_plain":
+        assert done.tolist() == [2 * 4 * blocks] * nchunks
+    # close to the float64 product as well (the tiled kernel is itself checked against the oracle in test_gemm)
+    ref = host(A) @ host(W).T + host(bias)
+    out = host(tile16(got, M, N, False) if lay == hl.TILE16 else got)
+    close(out, ref, 2e-2 * np.sqrt(H) * 0.1 + 1e-2, "projection")
+
+
 @pytest.mark.parametrize("dtype", [hl.F32, hl.BF16])
 def test_gemm_tile16_output_and_relayout_roundtrip(dtype):
     rng = np.random.default_rng(1)
