@@ -2213,7 +2213,7 @@ struct rnn_bwd_multi {
 // A wave's unit of work is 16 rows x a quarter of the columns (TPS tiles of 16 columns; a tile is 512 contiguous bytes, lane =
 // 4 columns of one row): the row's scalar / table index is ONE load per unit and there is no division anywhere.  The loop is
 // software-pipelined around the one memory counter gfx950 has for loads AND stores (vmcnt, retired in issue order): a load
-// issued behind write-through stores is not usable before those stores are acknowledged by memory (~2-3 us), so the loads of
+// issued behind write-through stores is not usable before those stores are acknowledged by memory, so the loads of
 // unit i+1 (and the key of unit i+2) are issued BEFORE the stores of unit i and waited for with the stores still in flight.
 // (history: one quad per thread and round with 64-bit index arithmetic moved 0.6 GB/s per workgroup, the unit loop with
 //  load-then-store batches 2.2 GB/s - 16 workgroups then took 3.5 ms for the 32 MB the encoder's bottom layer reads)

@@ -157,6 +157,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "1" if spec.cell == "GRU" else "0") == "1"
         self.index_dense_blocks = int(os.environ.get("MVAE_INDEX_DENSE_BLOCKS", "16"))
         self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
+        self.gate_side_heads = os.environ.get("MVAE_GATE_SIDE_HEADS", "1") == "1"   # (decoder_forward: counter instead of event)
+        self._last_stack_gate = None
+        self.value_join = os.environ.get("MVAE_VALUE_JOIN", "1") == "1"           # (_join; r03_z: -0.02 / -0.04 ms)
+        self._join_seq = {}
         self._hold_dec_grads = int(os.environ.get("MVAE_HOLD_DEC_GRADS", "1"))     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
@@ -282,8 +286,23 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self._fork(*streams, *extra)
         self._prefork = (torch.cuda.current_stream(), list(extra)) if extra else None
 
-    def _join(self, *streams):
+    def _join(self, *streams, word=None):
+        """the current stream waits for ``streams``.  ``word`` (an index into the engine's join words; MVAE_VALUE_JOIN=1): the last
+        hop is a value written behind the side queue's work (hipStreamWriteValue32) and waited for here (hipStreamWaitValue32)
+        instead of an event record + a barrier packet on that event"""
         cur = torch.cuda.current_stream()
+        if word is not None and self.value_join and self.multi_stream and streams:
+            for a, b in zip(streams, streams[1:]):
+                b.wait_stream(a)
+            self._join_seq[word] = seq = self._join_seq.get(word, 0) + 1
+            if seq >= 1 << 30:
+                torch.cuda.synchronize()
+                self.store["join_words"][word:word + 1].zero_()
+                self._join_seq[word] = seq = 1
+            w = self.store["join_words"][word:word + 1]
+            ops.stream_write_value32(w, seq, stream=streams[-1])
+            ops.stream_wait_value32(w, seq, stream=cur)
+            return
         if self.lean_sync and len(streams) > 1:
             # chained: every side queue takes its barrier packet when ITS work ends; the joining queue (the critical one)
             # processes one barrier packet instead of len(streams)
@@ -696,15 +715,25 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         side = [h for h in self.dec_heads if h.stream is not None]
         aux_src = {a.src for a in self.aux}
         self._cur_B, self._n_side = B, len(side)
-        if len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ()):      # (the notes stack is ONE launch on this queue)
-            if side:
-                self._fork(*[h.stream for h in side])
+        multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())      # (the notes stack is ONE launch on this queue)
+        if multi and side and self.gate_side_heads:
+            # the side heads leave the critical queue WITHOUT an event (a record is a packet of ~50 us between the latent chain and the
+            # decoder launch): their queues wait for the first chunk the notes stack publishes - it runs behind the latent chain
+            self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
+            word, value = self._last_stack_gate
+            for h in side:
+                ops.stream_wait_value32(word, value, stream=h.stream)
         else:
-            self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
+            if multi:
+                if side:
+                    self._fork(*[h.stream for h in side])
+            else:
+                self._fork_with_stack(self.dec_notes, *[h.stream for h in side])
         for h in side:
             with self._on(h.stream):
                 self._head_forward(h, B, Breal, states, tg, want_probs or h.name in aux_src, slot=None)
-        self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
+        if not (multi and side and self.gate_side_heads):
+            self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
         self._prefork = None
         self._n_side = 0
         if not self._branches_stay_forked or self.aux:
@@ -1081,7 +1110,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                 self._head_stack_backward(h, B, dstates, slot=None)
         self._head_stack_backward(self.head["notes"], B, dstates, slot=2)
         self._prefork = None
-        self._join(*[h.stream for h in side])
+        self._join(*[h.stream for h in side], word=0)
         self._mark("  decoder BPTT")
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
         enc_multi = not self.enc_bi and self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta]) and len(self.enc_notes) > 1
@@ -1135,8 +1164,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         # in this join is one more cross-queue hop (40-60 us each, in series) in front of the optimizer.
         tail = self._tail_streams if enc_multi else [st for _, st, _ in self.enc_meta]
         self._tail_streams = []
-        self._join(*tail, self.s_grad)
-        self._join(self.s_grad2)
+        self._join(*tail, self.s_grad, word=1)
+        self._join(self.s_grad2, word=2)
 
     def _latent_chain_backward(self, Breal, B):
         """The same as ONE launch (csrc/latent.hip) followed by the parameter-gradient GEMMs on the side streams; None if

@@ -133,6 +133,7 @@ class Buffers(object):
         # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch; 5: the expansion of a 1-feature roll
         st["sync"] = torch.zeros(12 * 1024, dtype=torch.int32, device=dev)     # (6.. : single-layer problems of a phase launch)
         words = torch.zeros(2, dtype=torch.int32, device=dev)     # [live status of the running step, latched status since the last check]
+        st["join_words"] = torch.zeros(8, dtype=torch.int32, device=dev)       # (Engine._join, MVAE_VALUE_JOIN)
         st["pipe_words"], st["pipe_status"], st["pipe_latched"] = words, words[0:1], words[1:2]
         for r in self.all_rec:
             p = r.prefix

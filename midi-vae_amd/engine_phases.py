@@ -60,6 +60,7 @@ class PhaseLaunches(object):
         cs, T = self.pipe_chunk, layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
+        self._last_stack_gate = (sync[0, 0][0:1], hs_target)       # the bottom layer's first published chunk of THIS call
         status = self.store["pipe_status"]
         self._pipe_used = True
         probs, gemms = [], []

@@ -14,6 +14,8 @@ for f in a.csv:
         if re.search(a.match, k):
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 m = lambda k, c: (sum(agg[(k, c)]) / len(agg[(k, c)])) if (k, c) in agg else float("nan")
+# writes: WRITE_SIZE (KiB) or - its pass hangs in rocprofv3's start-up on this image - TCC_EA0_WRREQ_sum x 64 B
+written_mb = lambda k: m(k, "WRITE_SIZE") * 1024 / 1e6 if (k, "WRITE_SIZE") in agg else m(k, "TCC_EA0_WRREQ_sum") * 64 / 1e6
 print("rocprofv3 --pmc, one pass per counter group; means per launch.  SQ_*_CYCLES are quad-cycles summed over waves except")
 print("SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES (cycles); FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE x 2 on gfx950).\n")
 for k in sorted({k for k, _ in agg}):
@@ -29,4 +31,4 @@ for k in sorted({k for k, _ in agg}):
         print("  LDS bank-conflict cycles %.3g of %.3g LDS-active cycles (%.1f %%)" % (
             m(k, "SQ_LDS_BANK_CONFLICT"), m(k, "SQ_LDS_IDX_ACTIVE"), 100 * m(k, "SQ_LDS_BANK_CONFLICT") / max(m(k, "SQ_LDS_IDX_ACTIVE"), 1)))
     if (k, "FETCH_SIZE") in agg or (k, "WRITE_SIZE") in agg:
-        print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (2 * m(k, "FETCH_SIZE") * 1024 / 1e6, m(k, "WRITE_SIZE") * 1024 / 1e6))
+        print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (2 * m(k, "FETCH_SIZE") * 1024 / 1e6, written_mb(k)))

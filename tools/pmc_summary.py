@@ -13,6 +13,8 @@ for f in sys.argv[1:]:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 kernels = sorted({k for k, _ in agg})
 m = lambda k, c: (sum(agg[(k, c)]) / len(agg[(k, c)])) if (k, c) in agg else float("nan")
+# writes: WRITE_SIZE (KiB) or - its pass hangs in rocprofv3's start-up on this image - TCC_EA0_WRREQ_sum x 64 B
+written_mb = lambda k: m(k, "WRITE_SIZE") * 1024 / 1e6 if (k, "WRITE_SIZE") in agg else m(k, "TCC_EA0_WRREQ_sum") * 64 / 1e6
 print("rocprofv3 --pmc, one pass per counter group; tools/rnn_microbench.py --cell LSTM / GRU (T=%d steps, B=%d rows, H=256, bf16)" % (T, B))
 print("per launch: %d workgroups x 4 waves; SQ_*_CYCLES counters are quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles)" % (B // 16))
 print("FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950\n")
@@ -26,4 +28,4 @@ for k in kernels:
     print("  per wave per step: MFMA %.0f  VALU %.0f  LDS %.0f  VMEM %.0f" % tuple(
         m(k, c) / waves / T for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")))
     print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (
-        2 * m(k, "FETCH_SIZE") * 1024 / 1e6, m(k, "WRITE_SIZE") * 1024 / 1e6))
+        2 * m(k, "FETCH_SIZE") * 1024 / 1e6, written_mb(k)))

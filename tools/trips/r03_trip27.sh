@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03z
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_engine_gpu.py -m gpu -q --timeout 600 -x -k "phase_launches or elbo or alternating or kstream_gate" > $O/pytest_eng.txt 2>&1
+tail -3 $O/pytest_eng.txt
+b() { timeout 300 python bench.py --no-cpu-baseline --cell $1 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$1 $2', round(d['ms_per_step'],3), round(d['median_ms_per_step'],3))" | tee -a $O/ab.txt; }
+for rep in 1 2; do
+  for c in LSTM GRU; do
+    MVAE_GATE_SIDE_HEADS=0 b $c "event fork"
+    MVAE_GATE_SIDE_HEADS=1 b $c "counter gate"
+  done
+done
