@@ -159,7 +159,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
         self.gate_side_heads = os.environ.get("MVAE_GATE_SIDE_HEADS", "1") == "1"   # (decoder_forward: counter instead of event)
         self._last_stack_gate = None
-        self.value_join = os.environ.get("MVAE_VALUE_JOIN", "1") == "1"           # (_join; r03_z: -0.02 / -0.04 ms)
+        # (_join; r03_z: -0.02 / -0.04 ms.  NOT when kernels are run one at a time - rocprofv3 counter collection: a critical queue parked
+        #  in a value wait and a writer queue held back behind it never finish; event joins work there)
+        serial = getattr(self, "_serial_queues", False) or (share is not None and getattr(share, "_serial_queues", False))
+        self.value_join = os.environ.get("MVAE_VALUE_JOIN", "1") == "1" and not serial and len(self.s_proj) > 0     # (no stacked layer: no probe was run)
         self._join_seq = {}
         self._hold_dec_grads = int(os.environ.get("MVAE_HOLD_DEC_GRADS", "1"))     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None

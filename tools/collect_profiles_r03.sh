@@ -16,6 +16,8 @@ python bench.py --config 4 --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_co
 python bench.py --config 4 --no-cpu-baseline --steps 20 --warmup 5 --cell GRU > $O/bench_config4_gru.json 2>> $O/bench_cfg.err
 python bench.py --dtype f32 --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_lstm_f32.json 2> $O/bench_lstm_f32.err
 MVAE_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_lstm_one_rank_rccl.json
+# ... and with the overlap schedule that bench.py uses for --gpus > 1 (decoder-side bucket reduced beside the encoder BPTT)
+MVAE_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 1 --no-cpu-baseline --dp-overlap 1 2>/dev/null | tail -1 > $O/bench_lstm_one_rank_rccl_overlap.json
 fi; if want 2; then
 # 2. kernel trace + stats of the SAME default command, and one step's timeline by queue (LSTM and GRU)
 for c in LSTM GRU; do
