@@ -722,7 +722,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         if multi and side and self.gate_side_heads:
             # the side heads leave the critical queue WITHOUT an event (a record is a packet of ~50 us between the latent chain and the
             # decoder launch): their queues wait for the first chunk the notes stack publishes - it runs behind the latent chain
+            self._last_stack_gate = None
             self._head_forward(self.head["notes"], B, Breal, states, tg, want_probs or "notes" in aux_src, slot=1)
+            assert self._last_stack_gate is not None, "the notes stack did not run as a phase launch"
             word, value = self._last_stack_gate
             for h in side:
                 ops.stream_wait_value32(word, value, stream=h.stream)
