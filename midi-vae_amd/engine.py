@@ -23,7 +23,7 @@ import torch
 
 from . import hiplib as hl
 from . import ops
-from .layout import ModelSpec, ParamLayout, dec_init_blocks, init_params
+from .layout import ModelSpec, ParamLayout, init_params
 
 from .engine_io import ArrayStaging, Results
 from .engine_optional import OptionalGraph

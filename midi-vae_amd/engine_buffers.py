@@ -3,14 +3,13 @@ the model has (reference vae_definition.py:443-480 encoder branches, 519-726 dec
 writes, sized for the engine's maximum batch."""
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from . import hiplib as hl
 from . import ops
 from .layout import dec_init_blocks
 from .slots import *        # noqa: F401,F403
-from .slots import N_SCALARS, X_EXT, X_GATHER2
+from .slots import X_EXT, X_GATHER2
 
 
 class _Rec(object):
