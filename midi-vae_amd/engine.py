@@ -159,6 +159,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
         self.gate_side_heads = os.environ.get("MVAE_GATE_SIDE_HEADS", "1") == "1"   # (decoder_forward: counter instead of event)
         self._last_stack_gate = None
+        # (_head_forward: inference on per-queue pipelined stacks.  profiles/r03_zz_decode_head_slices.txt: decode configs[4] LSTM
+        #  -3..5 % with 2 slices, -1..3 % with 4; GRU -3 % / -6..7 %: the slices take memory bandwidth from the recurrences they follow)
+        self.head_slices = int(os.environ.get("MVAE_HEAD_SLICES", "2" if spec.cell == "LSTM" else "4"))
+        self._top_publish = None
         # (_join; r03_z: -0.02 / -0.04 ms.  NOT when kernels are run one at a time - rocprofv3 counter collection: a critical queue parked
         #  in a value wait and a writer queue held back behind it never finish; event joins work there)
         serial = getattr(self, "_serial_queues", False) or (share is not None and getattr(share, "_serial_queues", False))
@@ -567,7 +571,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         cum[1] += pwaves
         return reg, cum[0], cum[1]
 
-    def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None):
+    def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None,
+                            publish_top=False):
         cs = self.pipe_chunk
         T = layers[0].T
         nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
@@ -586,6 +591,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                 pipe.update(wait_ready=sync[li - 1, 1], wait_value=xp_target)
             if not top:
                 pipe["signal_done"] = sync[li, 0]
+            elif publish_top:
+                # (inference: the head follows the top layer slice by slice - _head_forward; a slot of its own: these counters
+                #  advance only in calls that publish)
+                sync_t, target_t, _ = self._sync_region(10, 1, nchp, nwaves, 0)
+                pipe["signal_done"] = sync_t[0, 0]
+                self._top_publish = (sync_t[0, 0], target_t, cs)
             def run():
                 self._rec_forward(r, B, 0, 1, idx=idx, start=start, xs=xs, h_last=h_last if top else None,
                                   h_last_ld=h_last_ld if top else 0, pipe=pipe, xp_external=li > 0, **st)
@@ -599,12 +610,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                                  chunk_wait=sync[li, 0], chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status)
         self._join(*lower_streams, *gemm_streams)
 
-    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0, xs=None):
+    def _stack_forward(self, layers, B, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, slot=0, xs=None,
+                       publish_top=False):
         """A stack of recurrent layers, pipelined over time chunks: layer l on stream l."""
         self._cur_B = B
         if self._pipelined(layers):
             return self._stack_forward_pipe(layers, B, slot, states=states, h_last=h_last, h_last_ld=h_last_ld, idx=idx,
-                                            start=start, xs=xs)
+                                            start=start, xs=xs, publish_top=publish_top)
         nch = self._nchunks(layers)
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[torch.cuda.Event() for _ in range(nch)] for _ in layers]
@@ -751,9 +763,17 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         s, P = self.spec, self.P
         H, n = s.H, h.name
         start = self._v("in.start_" + n, B, h.layers[0].K)
+        self._top_publish = None
         if len(h.layers) > 1 and slot is not None:
             if not self._notes_forward_multi(h, B, states, start):      # (both layers as one launch: engine_phases.py)
-                self._stack_forward(h.layers, B, states=states, start=start, slot=slot)
+                # Inference on the per-queue pipelined schedule (a decode of 1024 windows x 4096 steps: the head's pass over 2 GB
+                # of h is 1.06 ms behind a 10.3 ms stack): the top layer publishes its chunks too and the head runs slice by
+                # slice on the (idle) gradient queue, each slice released by the chunk that completes it - only the last slice
+                # is left when the recurrence ends
+                nsl = self.head_slices
+                sliced = (not self.training and not tg and not want_probs and nsl > 1 and h.T % nsl == 0 and
+                          (h.T // nsl) % self.pipe_chunk == 0)
+                self._stack_forward(h.layers, B, states=states, start=start, slot=slot, publish_top=sliced)
         else:
             for r in h.layers:           # (a stack off the critical stream - the next-notes head - runs layer after layer)
                 self._rec_forward(r, B, start=start, **states(r))
@@ -765,6 +785,28 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             tgt["row_weight"] = self._v("in.rw_" + n, R)
             if n == "notes" and s.attach:
                 tgt["target_idx2"] = self._v("in.ya_idx", R)
+        if self._top_publish is not None:
+            word, target, cs = self._top_publish
+            self._top_publish = None
+            nsl = self.head_slices
+            Ts = h.T // nsl
+            am = self._v(n + ".argmax", R)
+            for i in range(nsl):
+                r0, r1 = i * Ts * B, (i + 1) * Ts * B
+                last = i == nsl - 1
+                def run():
+                    ops.head(h.kind, self.kind, r1 - r0, H, h.N, top[i * Ts:(i + 1) * Ts], self._v(n + ".wt", h.NP, H), P[h.out + ".b"],
+                             grad_scale=h.weight, probs=None, argmax=am[r0:r1], dlogits=None,
+                             scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=Breal)
+                if last:        # (behind the stack on this queue: complete by queue order)
+                    run()
+                else:
+                    k = (i + 1) * Ts // cs - 1
+                    ops.stream_wait_value32(word[k:k + 1], target, stream=self.s_grad)
+                    with torch.cuda.stream(self.s_grad):
+                        run()
+            self._join(self.s_grad, word=3)
+            return
         ops.head(h.kind, self.kind, R, H, h.N, top, self._v(n + ".wt", h.NP, H), P[h.out + ".b"], grad_scale=h.weight,
                  probs=self._v("out.%s_p" % n, R, h.N) if want_probs else None, argmax=self._v(n + ".argmax", R),
                  dlogits=self._v(n + ".dl", R, h.NP) if (self.training and tg) else None, **self._fused_head_bwd(n, tg),

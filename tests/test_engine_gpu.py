@@ -289,6 +289,38 @@ def test_inference_engine_matches_training_engine_h256_bf16(cell):
     assert np.array_equal(i0, d0)              # decode on the same z reproduces the autoencoder's notes
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+@pytest.mark.parametrize("slices", [2, 4])
+def test_decode_head_following_the_top_layer_slice_by_slice(cell, slices):
+    """Engine._head_forward, inference on the per-queue pipelined schedule: the top layer of the notes stack publishes its chunks
+    and the argmax head runs slice by slice on the idle gradient queue, each slice released by the chunk that completes it.
+    Same kernel on the same rows: the indices equal those of the single head launch behind the stack bit for bit - on a ragged
+    batch, twice on one engine (the counters are cumulative), and alternating with the unsliced path."""
+    B = 40
+    spec, params, batch, raw = _problem(cell, B, seed=29, H=256, Z=64, T=64)
+    rng = np.random.default_rng(5)
+    zs = [rng.standard_normal((B, spec.Z)).astype(np.float32) for _ in range(3)]
+    out = {}
+    for n in (1, slices):
+        eng = Engine(spec, max_batch=B, dtype="bf16", training=False)
+        eng.phase_multi = False              # (the per-queue schedule: what calls of more than phase_max_B windows run)
+        eng.head_slices = n
+        eng.set_params(params)
+        res = []
+        for i, z in enumerate(zs):
+            if n > 1 and i == 1:
+                eng.head_slices = 1          # an unsliced call in between must not disturb the counters of the sliced ones
+            eng.stage_decoder_inputs(B, hist=raw["hist"], z=z)
+            eng.decode(B, want_probs=False)
+            eng.check_pipeline()
+            res.append(eng.note_indices(B).copy())
+            eng.head_slices = n
+        out[n] = res
+    for a, b in zip(out[1], out[slices]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(out[1][0], out[1][2])     # (different latents decode differently: the comparison is not vacuous)
+
+
 def test_full_size_step_properties():
     """BASELINE configs[1] at full size (T=512, 256 windows, z=64, LSTM bf16) - too large for the oracle in a test, so
     size-independent properties: the forward pass is deterministic (two evaluations give the same argmax decode bit for bit,
