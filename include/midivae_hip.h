@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 4
+#define MVAE_ABI_VERSION 5
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -472,6 +472,45 @@ int mvae_bi_concat(const void* f, const void* r, void* cat, void* cat_rev, int32
 /* dst[t] = (a ? a[t] : 0) + b[T-1-t] for T contiguous slabs of `slab` elements (% 4 == 0) of `kind`: gradients that cross between
  * the two time directions.  A time step of a (T*B, H) sequence is one slab in row-major AND in MVAE_TILE16 layout (B % 16 == 0). */
 int mvae_add_time_reversed(void* dst, const void* a, const void* b, int32_t kind, int32_t T, size_t slab, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * STEP PLANS (csrc/plan.cpp): the enqueue of a whole step as ONE call.
+ * The reference reaches the device through ONE Python call per minibatch - the Keras train_function behind
+ * autoencoder.fit (reference vae_training.py:804-809; test_function :300, predict_function :289,795) - and Keras
+ * replays a graph it compiled once.  Here a step is ~70 launches of the entry points above plus the stream / event
+ * packets that order them across the engine's queues; enqueued one by one from the host language they cost 2.5-3.1 ms
+ * per step in CPython (profiles/r03_d_host_vs_device.txt) - more than the device needs at the reference's shipped
+ * configuration (T=64).  A plan is that list recorded once - entry point, argument values, a private copy of every
+ * argument struct - and replayed by mvae_plan_run on the host thread that calls it: same entry points, same streams,
+ * same order, nothing else (no graph capture: kernels that wait for each other across queues must be launched the way
+ * they were).  Values that advance from step to step - the cumulative progress counters the
+ * time-pipelined kernels wait for, the sequence numbers of value joins - are PATCHES: a 32-bit field of an argument
+ * struct (or a scalar argument) := key_values[key] + offset at every run; everything else is constant.
+ *
+ * Events for cross-queue ordering inside a plan are plain entry points too (mvae_event_record / mvae_stream_wait_event).
+ * --------------------------------------------------------------------------------------------------------- */
+int mvae_event_create(void** event);                 /* hipEventCreateWithFlags(hipEventDisableTiming) */
+int mvae_event_destroy(void* event);
+int mvae_event_record(void* event, void* stream);
+int mvae_stream_wait_event(void* stream, void* event);
+
+typedef struct mvae_plan mvae_plan;
+int mvae_plan_create(mvae_plan** out);
+int mvae_plan_destroy(mvae_plan* p);
+/* Append a call of `entry_point` (the name of any stream-taking entry point of this header, e.g. "mvae_gemm").  `slots`: one 64-bit
+ * value per argument, in order: pointers and integers as they are, a float as its 32 bits, an argument-struct pointer as 0 (its
+ * contents follow with mvae_plan_set_blob).  Returns the index of the call (>= 0) or MVAE_E_ARG (unknown name, wrong count). */
+int mvae_plan_add_call(mvae_plan* p, const char* entry_point, const uint64_t* slots, int32_t n_slots);
+/* argument `slot` of call `call` points at a struct (or array of structs, or a host job array): `bytes` bytes are copied into the plan */
+int mvae_plan_set_blob(mvae_plan* p, int32_t call, int32_t slot, const void* data, size_t bytes);
+/* at every run: the 32-bit word at byte `offset` of the blob of (`call`, `slot`) - or, with offset < 0, the scalar argument itself -
+ * := (uint32_t)(key_values[key] + add) */
+int mvae_plan_add_patch(mvae_plan* p, int32_t call, int32_t slot, int64_t offset, int32_t key, int64_t add);
+/* enqueue calls [first, last) in order (last < 0: to the end).  Returns 0, or the first non-zero return value of an entry point
+ * (nothing after it is enqueued; mvae_plan_failed_call tells which). */
+int mvae_plan_run(mvae_plan* p, int32_t first, int32_t last, const uint64_t* key_values, int32_t n_keys);
+int mvae_plan_size(const mvae_plan* p);              /* number of calls */
+int mvae_plan_failed_call(const mvae_plan* p);       /* index of the call whose return value the last failing run reported (-1: none) */
 
 /* ---------------------------------------------------------------------------------------------------------
  * HOST-side packers (csrc/hostpack.cpp): every pointer below is a HOST pointer, nothing touches the device.

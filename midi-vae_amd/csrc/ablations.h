@@ -7,10 +7,11 @@
 //   ABL_NOSAVE  no saved-activation stores                         ABL_NOX     no input prefetch
 //   ABL_NOMATH  no gate arithmetic                                 ABL_NOBAR   no barriers
 //   ABL_NOB     B fragments: no LDS reads after the first two      ABL_NOTRANS exp / rcp replaced by multiplies
+//   ABL_FILL=k  LSTM BPTT: k semantically empty VALU instructions per MFMA slot (how much filler room the M phase has)
 //   GEMM_ABL_NOMFMA / NOLOAD / NOATOMIC                            the fast GEMM without its MFMAs / global loads / atomics
 //   WS_ABL_NOSTORE / NOLOAD / NOMFMA                               proj_ws_k without its epilogue stores / A requests / MFMAs
 #pragma once
-#define MVAE_ABL_LIST(X) X(ABL_NOL) X(ABL_NOTRG) X(ABL_NOSAVE) X(ABL_NOX) X(ABL_NOMATH) X(ABL_NOBAR) X(ABL_NOB) X(ABL_NOTRANS) \
+#define MVAE_ABL_LIST(X) X(ABL_NOL) X(ABL_NOTRG) X(ABL_NOSAVE) X(ABL_NOX) X(ABL_NOMATH) X(ABL_NOBAR) X(ABL_NOB) X(ABL_NOTRANS) X(ABL_FILL) \
     X(GEMM_ABL_NOMFMA) X(GEMM_ABL_NOLOAD) X(GEMM_ABL_NOATOMIC) X(WS_ABL_NOSTORE) X(WS_ABL_NOLOAD) X(WS_ABL_NOMFMA)
 #ifndef ABL_NOL
 #define ABL_NOL 0
@@ -35,6 +36,9 @@
 #endif
 #ifndef ABL_NOTRANS
 #define ABL_NOTRANS 0
+#endif
+#ifndef ABL_FILL
+#define ABL_FILL 0
 #endif
 #ifndef GEMM_ABL_NOMFMA
 #define GEMM_ABL_NOMFMA 0

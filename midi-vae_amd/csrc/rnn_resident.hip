@@ -224,6 +224,21 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
 #define RES_NOHOOK(gi)
 
 enum { SAVE_NONE = 0, SAVE_HS = 1, SAVE_ALL = 2 };
+// Wave skew (round 4): the four waves of a workgroup leave every barrier together and run the same instruction stream, so their
+// memory instructions reach the CU's one address unit (and their LDS accesses the LDS) in the same cycles and queue behind each
+// other.  Wave w idles RES_WSKEW x 16 x w cycles behind the barrier that opens a memory-heavy phase: the streams stay de-phased
+// until the next barrier (A/B: profiles/r04_b_wave_skew.txt).
+#ifndef RES_WSKEW
+#define RES_WSKEW 0
+#endif
+__device__ __forceinline__ void res_skew(int w) {
+#if RES_WSKEW > 0
+    for (int i = 0; i < w; ++i) {
+#pragma unroll
+        for (int j = 0; j < RES_WSKEW; ++j) asm volatile("s_nop 15" ::: "memory");
+    }
+#endif
+}
 __device__ __forceinline__ void res_barrier() {
     if (ABL_NOBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else lds_barrier();
@@ -894,6 +909,7 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
         tl0 ^= 8192u;
         STAMP(6);
         res_barrier();
+        res_skew(w);
         STAMP(7);
         // pipelined stack: hs slot t (= h_{t-1}) left this step, so the chunk ending at step t-1 is complete
         if (cs_steps && t == phi) {
@@ -1537,6 +1553,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
     cs_p -= (T > 1 ? cs_step : 0);
     dx_p -= (T > 1 ? cs_step : 0);
 
+    float fillr = 0.f; (void)fillr;      // (ABL_FILL probe)
     frag bq[2], lt[4];      // B fragments: one k-group ahead (a third ring slot costs 4 registers this kernel lacks)
     vm_drain();
     lds_barrier();
@@ -1577,13 +1594,17 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
             if (HAS_EXT) d += unpack4(qd[n]);
             // whole-vector expressions: no MFMA is in flight in this phase, so packed f32 instructions (two elements
             // each) are pure gain here - unlike in the MFMA gaps, where they cost issue slots
-            const f32x4 tc = tanh_fast4(c);
-            const f32x4 dct = dc[n] + d * og * (1.0f - tc * tc);
-            const f32x4 di = dct * (gg * dhard_sigmoid4(ig));
-            const f32x4 df = dct * (cp * dhard_sigmoid4(fg));
-            const f32x4 dg = dct * ig * (1.0f - gg * gg);
-            const f32x4 dO = d * (tc * dhard_sigmoid4(og));
-            dc[n] = dct * fg;
+            f32x4 di, df, dg, dO;
+            if (ABL_NOMATH) { di = d; df = d; dg = d; dO = d; dc[n] = d; }     // (timing ablation: the E phase without its arithmetic)
+            else {
+                const f32x4 tc = tanh_fast4(c);
+                const f32x4 dct = dc[n] + d * og * (1.0f - tc * tc);
+                di = dct * (gg * dhard_sigmoid4(ig));
+                df = dct * (cp * dhard_sigmoid4(fg));
+                dg = dct * ig * (1.0f - gg * gg);
+                dO = d * (tc * dhard_sigmoid4(og));
+                dc[n] = dct * fg;
+            }
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (1 * 512 + n * 32))) = pack4(df);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
@@ -1594,6 +1615,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
         vm_drain();                                   // the T fragments (L2 hits issued a whole E phase ago)
         pinq(lt[0]); pinq(lt[1]); pinq(lt[2]); pinq(lt[3]);
         res_barrier();
+        res_skew(w);
         STAMP(3);
 
         // ---- M -------------------------------------------------------------------------------------------------
@@ -1603,7 +1625,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
         bq[0] = *reinterpret_cast<const frag*>(dabuf + bb0);
         static_for<0, FPW>(SF_LAMBDA(sc) {
             constexpr int sl = decltype(sc)::value, gi = sl >> 2, n = sl & 3, ci = sl - NT;
-            if constexpr (n == 0 && gi + 1 < S2)
+            if constexpr (n == 0 && gi + 1 < S2 && !(ABL_NOB && gi >= 1))
                 bq[(gi + 1) & 1] = *reinterpret_cast<const frag*>(dabuf + (bb0 ^ (((gi + 1) & 3) << 6)) + 256 * ((gi + 1) >> 2));
             if constexpr (sl == 0) asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
             if constexpr (sl < NT) mfma1<false>(acc[n], lt[n], bq[gi & 1]);
@@ -1638,6 +1660,12 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
                 }
                 if constexpr (j < 8)
                     lt[j & 3] = *reinterpret_cast<const frag*>(dabuf + (tc0 ^ ((j >> 1) << 4)) + (j >> 1) * 2048 + (j & 1) * 1024);
+            }
+            if constexpr (ABL_FILL > 0) {       // (timing probe: ABL_FILL semantically empty VALU instructions per MFMA slot)
+                if constexpr (ABL_FILL > 0) asm volatile("v_max_f32 %0, %0, %0" : "+v"(fillr));
+                if constexpr (ABL_FILL > 1) asm volatile("v_max_f32 %0, %0, %0" : "+v"(fillr));
+                if constexpr (ABL_FILL > 2) asm volatile("v_max_f32 %0, %0, %0" : "+v"(fillr));
+                if constexpr (ABL_FILL > 3) asm volatile("v_max_f32 %0, %0, %0" : "+v"(fillr));
             }
             __builtin_amdgcn_sched_barrier(0);
         });

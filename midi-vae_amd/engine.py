@@ -28,6 +28,7 @@ from .layout import ModelSpec, ParamLayout, init_params
 from .engine_io import ArrayStaging, Results
 from .engine_optional import OptionalGraph
 from .engine_phases import PhaseLaunches
+from .engine_plan import PlannedSteps
 from .engine_buffers import Buffers, _Rec, _Head, _Aux        # noqa: F401  (the records of the layer description)
 from .slots import *        # noqa: F401,F403  (scalar slots S_*, N_SCALARS, X_EXT)
 from .slots import N_SCALARS, X_EXT, X_GATHER2
@@ -41,7 +42,7 @@ class _NullCtx(object):
         return False
 
 
-class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
+class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, Results):
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
                  training: bool = True, share: "Engine | None" = None):
         """``share``: another Engine of the same spec on the same device whose PARAMETERS (the flat f32 buffer itself) and HIP
@@ -61,6 +62,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR          # what the GEMM epilogues write (xp, dX)
         self.maxB = (int(max_batch) + 15) // 16 * 16
         self.layout = self._make_layout()
+        self._plan_init()      # step plans + the event ring behind _fork / _join (engine_plan.py)
         self.prof = None       # dict -> per-kernel HIP-event pairs are recorded on the launch stream (bench.py)
         self.prof_kinds = None # None = every timed launch, else a set of kinds ("rnn_fwd", "rnn_bwd")
         L, dev = self.layout, self.device
@@ -177,6 +179,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self._alloc(self.maxB)
         self._views_cache = {}
         self._prep = None                # PrepBatch per (step count pending): prepare_weights
+        self._zero_scal_job = None
         self._deferred_side = None       # (phase launches) side-queue work to be released by a device counter instead of an event
         self._xp0_bias = set()           # constant-input cells whose xp0 rows hold the bias (written by the last weight preparation)
         self.start_zero = {}             # layer prefix -> the staged start rows of its head are all zero (staging)
@@ -275,12 +278,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             return
         cur = torch.cuda.current_stream()
         if self.lean_sync and len(streams) > 1:
-            ev = cur.record_event()         # ONE marker packet on this queue, however many streams branch off
+            ev = self._ev_record(cur)       # ONE marker packet on this queue, however many streams branch off
             for st in streams:
-                st.wait_event(ev)
+                self._ev_wait(st, ev)
             return
         for st in streams:
-            st.wait_stream(cur)
+            self._wait_stream(st, cur)
 
     def _fork_with_stack(self, layers, *streams, also=()):
         """fork ``streams`` AND the streams a pipelined stack over ``layers`` will use (and ``also``) with one event; the
@@ -300,12 +303,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         cur = torch.cuda.current_stream()
         if word is not None and self.value_join and self.multi_stream and streams:
             for a, b in zip(streams, streams[1:]):
-                b.wait_stream(a)
+                self._wait_stream(b, a)
             self._join_seq[word] = seq = self._join_seq.get(word, 0) + 1
             if seq >= 1 << 30:
                 torch.cuda.synchronize()
                 self.store["join_words"][word:word + 1].zero_()
                 self._join_seq[word] = seq = 1
+            self._note_counter(("join", word), seq)
             w = self.store["join_words"][word:word + 1]
             ops.stream_write_value32(w, seq, stream=streams[-1])
             ops.stream_wait_value32(w, seq, stream=cur)
@@ -314,17 +318,17 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             # chained: every side queue takes its barrier packet when ITS work ends; the joining queue (the critical one)
             # processes one barrier packet instead of len(streams)
             for a, b in zip(streams, streams[1:]):
-                b.wait_stream(a)
-            cur.wait_stream(streams[-1])
+                self._wait_stream(b, a)
+            self._wait_stream(cur, streams[-1])
             return
         for st in streams:
-            cur.wait_stream(st)
+            self._wait_stream(cur, st)
 
     def _join_into(self, stream):
         """``stream`` waits for everything enqueued so far on the current stream and on every side stream"""
-        stream.wait_stream(torch.cuda.current_stream())
+        self._wait_stream(stream, torch.cuda.current_stream())
         for st in (*self._side_streams(), self.s_grad, self.s_grad2, *self.s_layer, *self.s_proj):
-            stream.wait_stream(st)
+            self._wait_stream(stream, st)
 
     def _side_streams(self):
         """the streams of the independent encoder / decoder branches beside the notes stack"""
@@ -341,7 +345,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         if self._deferred_side is not None:
             self._deferred_side.append(fn)
             return
-        self.s_grad2.wait_stream(torch.cuda.current_stream())
+        self._wait_stream(self.s_grad2, torch.cuda.current_stream())
         with torch.cuda.stream(self.s_grad2):
             fn()
 
@@ -569,6 +573,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             cum[0] = cum[1] = 0
         cum[0] += nwaves
         cum[1] += pwaves
+        self._note_counter(("sync", slot, 0), cum[0])        # (step plans: these values are patches, engine_plan.py)
+        self._note_counter(("sync", slot, 1), cum[1])
         return reg, cum[0], cum[1]
 
     def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None,
@@ -619,7 +625,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                                             start=start, xs=xs, publish_top=publish_top)
         nch = self._nchunks(layers)
         streams = [None] + self.s_layer[:len(layers) - 1]
-        done = [[torch.cuda.Event() for _ in range(nch)] for _ in layers]
+        done = [[None] * nch for _ in layers]
         if nch > 1:
             self._fork(*streams[1:])
         for k in range(nch):
@@ -628,11 +634,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                 st = states(r) if states else {}
                 def run():
                     if li > 0 and nch > 1:
-                        torch.cuda.current_stream().wait_event(done[li - 1][k])
+                        self._ev_wait(torch.cuda.current_stream(), done[li - 1][k])
                     self._rec_forward(r, B, k, nch, idx=idx, start=start, xs=xs, h_last=h_last if top else None,
                                       h_last_ld=h_last_ld if top else 0, **st)
                     if nch > 1:
-                        done[li][k].record()
+                        done[li][k] = self._ev_record(torch.cuda.current_stream())
                 if li > 0 and nch > 1:
                     with torch.cuda.stream(streams[li]):
                         run()
@@ -974,7 +980,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         L = len(order)
         kstream = self._kstream_ok(layers, B)
         if kstream:
-            before = torch.cuda.current_stream().record_event()      # the layers' saved inputs and the zeroed gradient buffers
+            before = self._ev_record(torch.cuda.current_stream())      # the layers' saved inputs and the zeroed gradient buffers
         sync, da_target, dx_target = self._sync_region(slot, L, nchp, nwaves, pwaves)     # (row L-1: the bottom layer's da)
         status = self.store["pipe_status"]
         self._pipe_used = True
@@ -1016,7 +1022,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                     problems += extra
                     gates.append((word, value))
             self._kstream_extra = None
-            self.s_grad2.wait_event(before)
+            self._ev_wait(self.s_grad2, before)
             for word, value in gates:
                 ops.stream_wait_value32(word, value, stream=self.s_grad2)
             # Its workgroups wait, resident, for the whole BPTT: they may only take CUs once EVERY kernel they wait for is running
@@ -1049,7 +1055,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, skip_dU=True)
             return
         streams = [None] + self.s_layer[:len(layers) - 1]
-        done = [[torch.cuda.Event() for _ in range(nch)] for _ in order]
+        done = [[None] * nch for _ in order]
         if nch > 1:
             self._fork(*streams[1:])
         for k in range(nch - 1, -1, -1):
@@ -1059,13 +1065,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
                 def run():
                     if li > 0:
                         if nch > 1:
-                            torch.cuda.current_stream().wait_event(done[li - 1][k])
+                            self._ev_wait(torch.cuda.current_stream(), done[li - 1][k])
                         self._rec_dx(order[li - 1], B, k, nch)
                     ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
                     self._rec_bptt(r, B, k, nch, dhs_ext=ext, dh_last=dh_last if top else None,
                                    dh_last_ld=dh_last_ld if top else 0, **ds)
                     if nch > 1:
-                        done[li][k].record()
+                        done[li][k] = self._ev_record(torch.cuda.current_stream())
                     if k == 0:
                         self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
                 if li > 0 and nch > 1:
@@ -1315,11 +1321,19 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             self.prepare_weights()          # (also zeroes the loss / metric accumulators and the constant-input cells' dxp0 sums)
             self._dxp0_clean = True
         else:
-            self.scal.zero_()
+            self._zero_scal()
             self._dxp0_clean = False
         if not self._grads_clean:
             self.grads.zero_()
         self._grads_clean = False
+
+    def _zero_scal(self):
+        """the loss / metric accumulators of a call that does not prepare weights (a one-job mvae_prepare_batch: part of a step
+        plan, which a torch fill would not be)"""
+        if self._zero_scal_job is None:
+            self._zero_scal_job = ops.PrepBatch()
+            self._zero_scal_job.zero(self.scal)
+        self._zero_scal_job.run()
 
     def _redo_step(self, B):
         self.scal.zero_()
@@ -1384,6 +1398,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         forward (eps2: (Bp, Z) device view, already scaled; z_out: (>= B, Z) device rows that receive z'), is rolled into the
         history columns of [z | history] (window 0: zeros) and the decoder's initial-state Denses follow as a separate GEMM.
         Only for a minibatch that starts at window 0 of its song."""
+        if hist_fused is None:
+            return self._planned(("train_begin", B), lambda: self._train_step_begin(B, None))
+        return self._train_step_begin(B, hist_fused)
+
+    def _train_step_begin(self, B, hist_fused):
         self._step_begin()
         self._hist_fused = hist_fused
         try:
@@ -1392,6 +1411,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
             self._hist_fused = None
 
     def train_step_finish(self, B, allreduce=None):
+        """the rest of the step; without a gradient hook (single GPU) it is one replayable call (engine_plan.py)"""
+        if allreduce is None:
+            return self._planned(("train_finish", B), lambda: self._train_step_finish(B, None))
+        return self._train_step_finish(B, allreduce)
+
+    def _train_step_finish(self, B, allreduce):
         self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
         self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
@@ -1405,7 +1430,14 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
         self.optimizer_step(gs if gs is not None else 1.0)
 
     def train_step(self, B, allreduce=None):
-        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch."""
+        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.  Without a hook the
+        whole step is one replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run
+        (engine_plan.py; reference: ONE Keras train_function call per minibatch, vae_training.py:804-809)."""
+        if allreduce is None:
+            return self._planned(("train", B), lambda: self._train_step(B, None))
+        return self._train_step(B, allreduce)
+
+    def _train_step(self, B, allreduce):
         self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
         try:
             self.forward_backward(B)
@@ -1439,10 +1471,14 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
 
     def eval_step(self, B, want_probs=False):
         """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""
+        self._planned(("eval", B, bool(want_probs)), lambda: self._eval_step(B, want_probs))
+
+    def _eval_step(self, B, want_probs):
         self._have_targets = True
-        self.scal.zero_()
         if self._weights_dirty:
             self.prepare_weights()
+        else:
+            self._zero_scal()
         self.encoder_forward(B, with_init=True)
         self.decoder_forward(B, want_probs=want_probs)
         self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B, with_init=True),
@@ -1450,20 +1486,28 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, Results):
 
     def encode(self, B):
         """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
+        self._planned(("encode", B), lambda: self._encode(B))
+        return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
+
+    def _encode(self, B):
         self._have_targets = False
-        self.scal.zero_()
         if self._weights_dirty:
             self.prepare_weights()
+        else:
+            self._zero_scal()
         self.encoder_forward(B)
         self._verify_pipeline(lambda: (self.scal.zero_(), self.encoder_forward(B)), key="encode")
-        return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
 
     def decode(self, B, want_probs=True):
         """``decoder.predict`` on the staged [z|history]; argmax note indices are always produced on device."""
+        self._planned(("decode", B, bool(want_probs)), lambda: self._decode(B, want_probs))
+
+    def _decode(self, B, want_probs):
         self._have_targets = False
         self._S_done = False
-        self.scal.zero_()
         if self._weights_dirty:
             self.prepare_weights()
+        else:
+            self._zero_scal()
         self.decoder_forward(B, want_probs=want_probs)
         self._verify_pipeline(lambda: (self.scal.zero_(), self.decoder_forward(B, want_probs=want_probs)), key="decode")

@@ -1,0 +1,145 @@
+"""Engine mixin: stream / event helpers that go through the C ABI (so a step plan can hold them) and the record -> arm ->
+replay life cycle of step plans (plan.py; include/midivae_hip.h 'STEP PLANS').
+
+Reference counterpart: one backend call per minibatch - Keras' compiled train / test / predict functions behind
+``autoencoder.fit`` (reference vae_training.py:804-809), ``evaluate`` (:300), ``encoder.predict`` (:289,795).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import hiplib as hl
+from . import plan as _plan
+
+
+class _PlanSlot(object):
+    """recordings / the armed plan of one kind of call on one engine"""
+    __slots__ = ("recs", "plan", "dead", "post", "runs")
+
+    def __init__(self):
+        self.recs, self.plan, self.dead, self.post, self.runs = [], None, None, None, 0
+
+
+class PlannedSteps(object):
+    # attributes whose value decides which launches a call makes (part of the plan key) and which a call leaves changed (restored
+    # after a replay to what the recorded calls left)
+    _PLAN_STATE = ("_count_pending", "_grads_clean", "_dxp0_clean", "_have_targets", "_S_done", "_pipe_used", "pipeline",
+                   "multi_stream", "norm_B", "_have_staged_targets", "lean_sync", "value_join", "phase_multi")
+
+    def _plan_init(self):
+        self.use_plans = os.environ.get("MVAE_PLANS", "1") == "1"
+        self._plans = {}
+        self._ev_pool, self._ev_i = [], 0
+        self.plan_stats = {"recorded": 0, "replayed": 0, "refused": {}}
+
+    # ---- events / stream ordering through the C ABI ---------------------------------------------------------------------------
+    def _ev_next(self):
+        """the next event of the engine's ring (reused call after call: a wait takes the record that precedes it in program order)"""
+        if self._ev_i >= len(self._ev_pool):
+            h = C.c_void_p()
+            hl.check(hl.load().mvae_event_create(C.byref(h)), "mvae_event_create")
+            self._ev_pool.append(h.value)
+        ev = self._ev_pool[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % 512
+        return ev
+
+    def _ev_record(self, stream):
+        ev = self._ev_next()
+        hl.check(hl.load().mvae_event_record(ev, stream.cuda_stream), "mvae_event_record")
+        return ev
+
+    def _ev_wait(self, stream, ev):
+        hl.check(hl.load().mvae_stream_wait_event(stream.cuda_stream, ev), "mvae_stream_wait_event")
+
+    def _wait_stream(self, waiter, waited):
+        """``waiter`` waits for everything enqueued so far on ``waited`` (torch's Stream.wait_stream through the C ABI)"""
+        self._ev_wait(waiter, self._ev_record(waited))
+
+    def _note_counter(self, key, value):
+        rec = _plan.active()
+        if rec is not None:
+            rec.note_counter(key, value)
+
+    # ---- plans ------------------------------------------------------------------------------------------------------------
+    def _plan_counters(self):
+        d = {("sync", slot, i): v for slot, cum in self._sync_cum.items() for i, v in enumerate(cum)}
+        d.update({("join", w): v for w, v in self._join_seq.items()})
+        return d
+
+    def _plan_set_counters(self, d):
+        for k, v in d.items():
+            if k[0] == "sync":
+                self._sync_cum.setdefault(k[1], [0, 0])[k[2]] = v
+            else:
+                self._join_seq[k[1]] = v
+
+    def _plan_state(self):
+        return (tuple(getattr(self, n, None) for n in self._PLAN_STATE) +
+                (frozenset(self._xp0_bias), tuple(sorted(self.start_zero.items())), bool(self._weights_dirty),
+                 frozenset(self._pipe_verified), self._prep is None))
+
+    def _plan_post(self, before):
+        """what a call left changed, as (attribute values, weight-version moves) relative to the state ``before`` it"""
+        return (tuple(getattr(self, n, None) for n in self._PLAN_STATE), frozenset(self._xp0_bias),
+                self._pver[0] - before[0], self._prepared_ver - self._pver[0])
+
+    def _planned(self, kind, fn):
+        """run ``fn`` (the Python enqueue of one call of kind ``kind``, a hashable that names everything the launch list depends
+        on besides the engine's state) - or, once three recordings of it agreed, replay its plan"""
+        if (not self.use_plans or self.prof is not None or getattr(self, "marks", None) is not None or
+                _plan.active() is not None or self._hist_fused is not None):
+            return fn()
+        self._ev_i = 0
+        key = (kind, torch.cuda.current_stream().cuda_stream, self._plan_state())
+        slot = self._plans.get(key)
+        if slot is None:
+            slot = self._plans[key] = _PlanSlot()
+        if slot.plan is not None:
+            # (a counter about to wrap is re-based by the Python path: _sync_region / _join)
+            cnt = self._plan_counters()
+            if all(cnt.get(k, 0) + d < (1 << 30) for k, d in slot.plan.inc.items()):
+                self._plan_set_counters(slot.plan.run(cnt))
+                vals, xp0, dver, dprep = slot.post
+                for n, v in zip(self._PLAN_STATE, vals):
+                    setattr(self, n, v)
+                self._xp0_bias = set(xp0)
+                self._pver[0] += dver
+                self._prepared_ver = self._pver[0] + dprep
+                slot.runs += 1
+                self.plan_stats["replayed"] += 1
+                return None
+        if slot.dead is not None:
+            return fn()
+        pre, ver = self._plan_counters(), (self._pver[0], self._prepared_ver)
+        with _plan.Recorder() as rec:
+            out = fn()
+        post_state = self._plan_post(ver)
+        slot.recs.append((rec.calls, rec.tags, pre, self._plan_counters(), post_state))
+        self.plan_stats["recorded"] += 1
+        if rec.tainted is not None:      # (a kernel torch itself launched would be missing from the replay)
+            slot.dead = "the call runs the torch operation %r" % rec.tainted
+            self.plan_stats["refused"][repr(kind)] = slot.dead
+            slot.recs = []
+        elif len(slot.recs) >= 3:
+            a, b, c = slot.recs[-3:]
+            if not (a[4] == b[4] == c[4]):
+                slot.dead = "the call leaves the engine in different states"
+            else:
+                try:
+                    slot.plan, slot.post = _plan.StepPlan([r[:4] for r in (a, b, c)]), c[4]
+                except _plan.NotReplayable as e:
+                    slot.dead = str(e)
+            if slot.dead is not None:
+                self.plan_stats["refused"][repr(kind)] = slot.dead
+            slot.recs = []
+        return out
+
+    def drop_plans(self):
+        """forget every plan (buffers re-allocated, streams changed, ...)"""
+        for s in self._plans.values():
+            if s.plan is not None:
+                s.plan.close()
+        self._plans = {}

@@ -23,7 +23,7 @@ CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -151,6 +151,18 @@ SIGNATURES = {
     "mvae_softmax_bwd_add": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_bi_concat": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_add_time_reversed": (_i32, [_vp, _vp, _vp, _i32, _i32, _sz, _vp]),
+    "mvae_event_create": (_i32, [C.POINTER(_vp)]),
+    "mvae_event_destroy": (_i32, [_vp]),
+    "mvae_event_record": (_i32, [_vp, _vp]),
+    "mvae_stream_wait_event": (_i32, [_vp, _vp]),
+    "mvae_plan_create": (_i32, [C.POINTER(_vp)]),
+    "mvae_plan_destroy": (_i32, [_vp]),
+    "mvae_plan_add_call": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_uint64), _i32]),
+    "mvae_plan_set_blob": (_i32, [_vp, _i32, _i32, _vp, _sz]),
+    "mvae_plan_add_patch": (_i32, [_vp, _i32, _i32, _i64, _i32, _i64]),
+    "mvae_plan_run": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_uint64), _i32]),
+    "mvae_plan_size": (_i32, [_vp]),
+    "mvae_plan_failed_call": (_i32, [_vp]),
     "mvae_host_threads": (_i32, [_i32]),
     "mvae_host_onehot_to_index_tm": (_i32, [_vp, _i32, _i64, _i32, _i32, _i64, _i64, _vp, _i32, C.c_uint8, C.POINTER(_i64)]),
     "mvae_host_index_to_tm": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _i32, C.c_uint8]),

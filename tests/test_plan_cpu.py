@@ -1,0 +1,102 @@
+"""Step plans without a GPU: the C-side container (csrc/plan.cpp) validates what it is given, and plan.StepPlan turns three
+recordings into constants + counter patches - or refuses (include/midivae_hip.h 'STEP PLANS').  No entry point is executed here:
+running a plan needs the device (tests/test_plan_gpu.py)."""
+import ctypes as C
+
+import pytest
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd import hiplib as hl
+from midi_vae_amd import plan as P
+
+
+def _new():
+    lib = hl.load()
+    h = C.c_void_p()
+    assert lib.mvae_plan_create(C.byref(h)) == 0
+    return lib, h
+
+
+def test_container_validates_names_arity_blobs_and_patches():
+    lib, h = _new()
+    slots = (C.c_uint64 * 3)(0, 0, 7)
+    assert lib.mvae_plan_add_call(h, b"mvae_no_such_entry", slots, 3) == hl.E_ARG
+    assert lib.mvae_plan_add_call(h, b"mvae_stream_wait_value32", slots, 2) == hl.E_ARG          # three arguments, not two
+    assert lib.mvae_plan_add_call(h, b"mvae_host_threads", slots, 1) == hl.E_ARG                 # not a stream-taking entry point
+    assert lib.mvae_plan_add_call(h, b"mvae_stream_wait_value32", slots, 3) == 0
+    two = (C.c_uint64 * 2)(0, 0)
+    assert lib.mvae_plan_add_call(h, b"mvae_gemm", two, 2) == 1
+    assert lib.mvae_plan_size(h) == 2
+    g = hl.GemmArgs()
+    assert lib.mvae_plan_set_blob(h, 1, 0, C.addressof(g), C.sizeof(g)) == 0
+    assert lib.mvae_plan_set_blob(h, 1, 0, C.addressof(g), C.sizeof(g)) == hl.E_ARG             # one blob per argument
+    assert lib.mvae_plan_set_blob(h, 5, 0, C.addressof(g), C.sizeof(g)) == hl.E_ARG
+    off = hl.GemmArgs.chunk_wait_value.offset
+    assert lib.mvae_plan_add_patch(h, 1, 0, off, 0, 0) == 0
+    assert lib.mvae_plan_add_patch(h, 1, 0, C.sizeof(g), 0, 0) == hl.E_ARG                       # beyond the struct
+    assert lib.mvae_plan_add_patch(h, 1, 0, off + 2, 0, 0) == hl.E_ARG                           # not a 32-bit word
+    assert lib.mvae_plan_add_patch(h, 0, 2, -1, 1, 4) == 0                                       # a scalar argument
+    # running: the patches need their key values; a rejected call stops the run and is reported
+    assert lib.mvae_plan_run(h, 0, -1, None, 0) == hl.E_ARG
+    keys = (C.c_uint64 * 2)(10, 20)
+    assert lib.mvae_plan_run(h, 0, -1, keys, 2) == hl.E_ARG        # mvae_stream_wait_value32(NULL address) rejects: nothing is enqueued
+    assert lib.mvae_plan_failed_call(h) == 0
+    assert lib.mvae_plan_run(h, 1, 2, keys, 2) == hl.E_ARG and lib.mvae_plan_failed_call(h) == 1     # (an all-zero mvae_gemm_args)
+    assert lib.mvae_plan_run(h, 2, 2, keys, 2) == 0 and lib.mvae_plan_failed_call(h) == -1           # an empty range
+    assert lib.mvae_plan_destroy(h) == 0
+
+
+def _recording(base, seq):
+    """the calls a step with counter ("sync", 0, 0) = base (before the step) and join sequence seq would make"""
+    g = hl.GemmArgs(M=128, N=64, K=32, A=0x1000, B=0x2000, C=0x3000, chunk_wait=0x4000, chunk_wait_value=base + 64)
+    calls = [("mvae_gemm", [0, 0x77], {0: C.string_at(C.addressof(g), C.sizeof(g))}),
+             ("mvae_stream_write_value32", [0x77, 0x5000, seq + 1], {}),
+             ("mvae_stream_wait_value32", [0x78, 0x5000, seq + 1], {}),
+             ("mvae_adam_step_dev", P._encode(hl.SIGNATURES["mvae_adam_step_dev"][1],
+                                              (1, 2, 3, 4, 100, 2e-4, 0.9, 0.999, 1e-8, 5, 1.0, 3, 6, 0x77))[0], {})]
+    tags = {base + 64: ("sync", 0, 0), seq + 1: ("join", 2)}
+    before = {("sync", 0, 0): base, ("join", 2): seq}
+    after = {("sync", 0, 0): base + 64, ("join", 2): seq + 1}
+    return calls, tags, before, after
+
+
+def test_three_recordings_become_constants_and_counter_patches():
+    # (the recordings need not be consecutive steps: the patches are relative to the counters, not to a run index)
+    p = P.StepPlan([_recording(0, 0), _recording(64, 1), _recording(640, 17)])
+    assert p.n_calls == 4 and p.n_patches == 3
+    assert p.inc == {("sync", 0, 0): 64, ("join", 2): 1}
+    p.close()
+
+
+def test_floats_travel_as_their_bits():
+    slots, _ = P._encode([C.c_void_p, C.c_float, C.c_int32], (None, 0.5, -1))
+    assert slots == [0, 0x3F000000, (1 << 64) - 1]
+
+
+@pytest.mark.parametrize("what", ["pointer", "untagged", "length", "offset"])
+def test_anything_else_that_differs_is_refused(what):
+    a, b, c = _recording(0, 0), _recording(64, 1), _recording(128, 2)
+    if what == "pointer":            # a buffer that moved between steps
+        c[0][1] = ("mvae_stream_write_value32", [0x77, 0x9000_0000_0000, 3], {})
+    elif what == "untagged":         # a 32-bit value that changes but was never announced as a counter value
+        c[0][3][1][4] = 101
+    elif what == "length":
+        c[0].pop()
+    else:                            # the same counter, but at another distance from its value before the step
+        g = hl.GemmArgs(M=128, N=64, K=32, A=0x1000, B=0x2000, C=0x3000, chunk_wait=0x4000, chunk_wait_value=128 + 65)
+        c[0][0] = ("mvae_gemm", [0, 0x77], {0: C.string_at(C.addressof(g), C.sizeof(g))})
+        c[1][128 + 65] = ("sync", 0, 0)
+    with pytest.raises(P.NotReplayable):
+        P.StepPlan([a, b, c])
+
+
+def test_recorder_notes_accepted_calls_only_and_restores_the_library():
+    lib = hl.load()
+    real = lib.mvae_gemm
+    with P.Recorder() as rec:
+        assert lib.mvae_gemm is not real
+        assert lib.mvae_gemm(None, None) == hl.E_ARG          # rejected: enqueued nothing, not part of the step
+        rec.note_counter(("sync", 1, 0), 7)
+        rec.note_counter(("sync", 2, 0), 7)                   # two counters with one value: never used for a patch
+    assert lib.mvae_gemm is real and rec.calls == [] and rec.tags == {7: None} and rec.tainted is None
+    assert P.active() is None

@@ -1,0 +1,160 @@
+"""Step plans on the device (include/midivae_hip.h 'STEP PLANS'; midi-vae_amd/plan.py, engine_plan.py): a replayed step enqueues
+what the Python enqueue would have - same losses, same parameters, counters in step with the kernels that wait for them - and
+every kind of call the drop-in makes (fit's two halves, evaluate, encoder.predict, decoder.predict) is replayable.
+Reference: ONE backend call per minibatch behind autoencoder.fit / evaluate / predict (vae_training.py:804-809, :300, :289,795)."""
+import numpy as np
+import pytest
+import torch
+
+import midi_vae_amd  # noqa: F401
+from midi_vae_amd import plan as P
+from midi_vae_amd.engine import Engine
+from test_engine_gpu import _problem, _stage
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, params, raw, B, plans, dtype="bf16", **kw):
+    eng = Engine(spec, max_batch=B, dtype=dtype, seed=0, **kw)
+    eng.use_plans = plans
+    eng.set_params(params)
+    _stage(eng, raw, B)
+    return eng
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+@pytest.mark.parametrize("H,T,dtype", [(256, 64, "bf16"), (64, 12, "f32")])
+def test_replayed_train_steps_equal_the_python_enqueue(cell, H, T, dtype):
+    """8 optimizer steps: enqueued from Python / 3 recorded then 5 replayed.  The resident H=256 path runs its time-pipelined
+    phase launches (kernels waiting on counters the plan patches): a mis-advanced counter is a time-out, which check_pipeline
+    raises on."""
+    B = 32
+    spec, params, _, raw = _problem(cell, B, seed=3, H=H, Z=32, T=T)
+    losses = {}
+    for plans in (False, True):
+        eng = _engine(spec, params, raw, B, plans, dtype)
+        out = []
+        for _ in range(8):
+            eng.train_step(B)
+            out.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        losses[plans] = (out, eng.get_params())
+        if plans:
+            assert eng.plan_stats["refused"] == {} or all("torch operation" in v for v in eng.plan_stats["refused"].values()), eng.plan_stats
+            assert eng.plan_stats["replayed"] >= 4, eng.plan_stats
+    (la, pa), (lb, pb) = losses[False], losses[True]
+    # (the gradient GEMMs reduce with f32 atomics: two runs of the SAME enqueue differ in the last bits, so not bit-identical)
+    np.testing.assert_allclose(lb, la, rtol=2e-5, atol=2e-6)
+    for k in pa:
+        assert np.abs(pa[k] - pb[k]).max() <= 2e-5 + 1e-3 * np.abs(pa[k] - params[k]).max(), k
+
+
+def test_replays_and_python_steps_alternate_on_one_engine():
+    """the plan's patches are relative to the engine's counters, not to a run index: Python-enqueued steps (here: every step whose
+    launches are bracketed for profiling, as bench.py does every 4th step) may come between replays"""
+    B = 32
+    spec, params, _, raw = _problem("LSTM", B, seed=4, H=256, Z=32, T=64)
+    eng = _engine(spec, params, raw, B, True)
+    for i in range(12):
+        if i >= 4 and i % 3 == 0:
+            eng.prof, eng.prof_kinds = {}, {("rnn_bwd_multi", "dec")}
+        eng.train_step(B)
+        eng.prof = None
+    torch.cuda.synchronize()
+    eng.check_pipeline()
+    assert eng.plan_stats["replayed"] >= 5 and np.isfinite(eng.metrics(B)["loss"])
+
+
+def test_the_plan_holds_what_python_would_enqueue_next():
+    """arm a plan, then let Python enqueue the next step under a Recorder: the calls it makes are the calls the plan holds, the
+    fields that differ are exactly the plan's patches evaluated at the current counters"""
+    B = 16
+    spec, params, _, raw = _problem("GRU", B, seed=5, H=256, Z=32, T=32)
+    eng = _engine(spec, params, raw, B, True)
+    for _ in range(4):          # (step 1 zeroes the gradient buffer with a torch fill: recorded under another key, refused)
+        eng.train_step(B)
+    slot = [s for s in eng._plans.values() if s.plan is not None]
+    assert len(slot) == 1, eng.plan_stats
+    plan = slot[0].plan
+    before = eng._plan_counters()
+    eng.use_plans = False
+    with P.Recorder() as rec:
+        eng.train_step(B)
+    assert rec.tainted is None
+    assert len(rec.calls) == plan.n_calls
+    # the same step through the constructor's own comparison: recording it three times over must give the same patches
+    again = P.StepPlan([(rec.calls, rec.tags, before, eng._plan_counters())] * 3)
+    assert again.n_patches == 0 and again.n_calls == plan.n_calls       # (identical recordings: everything constant)
+    again.close()
+    eng.check_pipeline()
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_fit_halves_evaluate_encode_decode_are_replayable(cell):
+    """the calls model.py makes: train_step_begin / train_step_finish (targets staged between them), eval_step, encode, decode -
+    five of each, outputs of the replays equal to the recorded calls' (forward kernels are deterministic: bit for bit)"""
+    B = 32
+    spec, params, _, raw = _problem(cell, B, seed=6, H=256, Z=32, T=64)
+    eng = _engine(spec, params, raw, B, True)
+    for _ in range(6):
+        eng.train_step_begin(B)
+        eng.train_step_finish(B)
+    eng.check_pipeline()
+    assert eng.plan_stats["replayed"] >= 4, eng.plan_stats
+    inf = Engine(spec, max_batch=B, dtype="bf16", seed=0, training=False)
+    inf.set_params(params)
+    _stage(inf, raw, B)
+    outs = {"eval": [], "encode": [], "decode": []}
+    for _ in range(6):
+        inf.eval_step(B)
+        outs["eval"].append(inf.metrics(B)["loss"])
+        outs["encode"].append(inf.encode(B).float().cpu().numpy().copy())
+        inf.stage_decoder_inputs(B, hist=raw["hist"], z=raw["hist"], add=raw["add"])
+        inf.decode(B, want_probs=False)
+        outs["decode"].append(inf.note_indices(B).copy())
+    inf.check_pipeline()
+    assert inf.plan_stats["replayed"] >= 6, inf.plan_stats
+    for k, v in outs.items():
+        for x in v[1:]:
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(v[0]), err_msg=k)
+
+
+def test_reference_shipped_configuration_matches_the_oracle_and_replays():
+    """the configuration the reference ships (settings.py:108-112,140,155; models/BvM/params.txt): GRU, T = 16 x 4 = 64, latent
+    256, batch 256 - on the resident bf16 path against the float64 oracle: losses, every gradient tensor, and the parameters
+    after 3 optimizer steps (the third and later steps of a run are plan replays)."""
+    from oracle.vae_oracle import OracleVAE, make_cfg
+    B = 256
+    spec, params, batch, raw = _problem("GRU", B, seed=7, H=256, Z=256, T=64)
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, raw["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    eng = _engine(spec, params, raw, B, True)
+    assert eng._pipelined(eng.enc_notes), "the resident time-pipelined path is off"
+    eng.forward_backward(B)
+    m, g = eng.metrics(B), eng.get_grads()
+    for k in m_o:
+        if not k.endswith("_acc"):
+            assert abs(m[k] - m_o[k]) <= 3e-2 * (1 + abs(m_o[k])), (k, m[k], m_o[k])
+    for k in g_o:
+        if np.linalg.norm(g_o[k]) > 1e-8:
+            err = np.linalg.norm(g[k] - g_o[k]) / np.linalg.norm(g_o[k])
+            assert err < 6e-2, (k, err)
+    # 3 optimizer steps (Keras Adam) against the oracle's: ELBO at every step, the parameter update afterwards; 3 more steps are replays
+    eng2 = _engine(spec, params, raw, B, True)
+    p, st = {k: v.copy() for k, v in p64.items()}, None
+    st = orc.new_opt_state(p)
+    for i in range(6):
+        eng2.train_step(B)
+        if i < 3:
+            m_o = orc.train_step(p, st, batch, raw["eps"].astype(np.float64))
+            assert abs(eng2.metrics(B)["loss"] - m_o["loss"]) <= 1e-3 * (1 + abs(m_o["loss"])), (i, eng2.metrics(B)["loss"], m_o["loss"])
+        if i == 2:
+            got = eng2.get_params()
+            for k in p:
+                d = p[k] - p64[k]
+                if np.linalg.norm(d) > 1e-9:
+                    assert np.linalg.norm(got[k].astype(np.float64) - p[k]) <= 8e-2 * np.linalg.norm(d) + 1e-7, k
+    eng2.check_pipeline()
+    assert eng2.plan_stats["replayed"] >= 2, eng2.plan_stats
