@@ -124,6 +124,9 @@ __device__ __forceinline__ void pin4(u16x4& a, u16x4& b, u16x4& c, u16x4& d) {
 #ifndef BWL_COPY_SLOT
 #define BWL_COPY_SLOT 58
 #endif
+#ifndef BWL_OLD_DHS
+#define BWL_OLD_DHS 0
+#endif
 #ifndef BWL_COPY_STRIDE
 #define BWL_COPY_STRIDE 4
 #endif
@@ -156,6 +159,42 @@ __device__ __forceinline__ f32x4 dhard_sigmoid4(f32x4 y) {
     const f32x4 sq = (y - y * y) * 0x1p100f;
     return f32x4{__builtin_amdgcn_fmed3f(sq[0], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[1], 0.0f, 0.2f),
                  __builtin_amdgcn_fmed3f(sq[2], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[3], 0.0f, 0.2f)};
+}
+// The derivative of hard_sigmoid at a saved gate value y in [0, 1] is 0.2 where 0 < y < 1.  sat4(y) = 0.2 * 2^-100 there, else 0:
+// y - y^2 is 0 exactly at the two clipped values and >= 2^-26 anywhere else a bf16 hard_sigmoid output can be, so one clamp
+// against a tiny constant selects (round 4: the factor 2^100 that makes it 0.2 rides on the OTHER factor of the product - one
+// multiply per element for all gates - and the negation is an operand modifier instead of the two v_xor hipcc emits).
+// bf16 -> f32 on the MATRIX pipe (round 4).  In the gate-gradient phase of the backward kernels no MFMA is in flight and the one
+// wave per SIMD is VALU-bound; a quarter of its instructions only widen saved bf16 values (v_lshlrev / v_and per element).
+// v_mfma_f32_16x16x16_bf16 with the 16x16 IDENTITY as A returns its B operand widened: lane (q, r) holds B[k = 4q + i][n = r] and
+// receives C[m = 4q + i][n = r] = sum_k I[m][k] B[k][r] = its own four elements, exactly (1.0 * x, fifteen zero products), plus the
+// accumulator operand - one issue slot for four elements and an addition.  (A non-finite value anywhere in the 16 lanes of a
+// column would spread as 0 * inf = NaN; saved activations are finite, or the step is lost already.)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 identity_fragment(int l) {
+    const int q = l >> 4, r = l & 15, j = r - 4 * q;
+    return s16x4{(short)(j == 0 ? 0x3F80 : 0), (short)(j == 1 ? 0x3F80 : 0), (short)(j == 2 ? 0x3F80 : 0), (short)(j == 3 ? 0x3F80 : 0)};
+}
+__device__ __forceinline__ f32x4 widen4(s16x4 ident, u16x4 packed, f32x4 plus) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ident, __builtin_bit_cast(s16x4, packed), plus, 0, 0, 0);
+}
+#ifndef BWL_E_TILE_FENCE
+#define BWL_E_TILE_FENCE 0
+#endif
+#ifndef BWL_MFMA_WIDEN
+#define BWL_MFMA_WIDEN 0      /* 1: the upstream gradient only, 2: every saved value - both spill in the LSTM kernel (254 VGPRs + 256 AGPRs without them): profiles/r04_d_bptt_e_phase.txt */
+#endif
+#define DHS_TINY 0x1.99999ap-103f      /* 0.2f * 2^-100 */
+#define DHS_BIG 0x1p100f
+__device__ __forceinline__ f32x2 y_minus_y2(f32x2 y) {
+    f32x2 t;
+    asm("v_pk_fma_f32 %0, %1, %1, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(t) : "v"(y));
+    return t;
+}
+__device__ __forceinline__ f32x4 sat4(f32x4 y) {
+    const f32x2 a = y_minus_y2(lo_hi<0>(y)), b = y_minus_y2(lo_hi<2>(y));
+    return f32x4{__builtin_amdgcn_fmed3f(a[0], 0.0f, DHS_TINY), __builtin_amdgcn_fmed3f(a[1], 0.0f, DHS_TINY),
+                 __builtin_amdgcn_fmed3f(b[0], 0.0f, DHS_TINY), __builtin_amdgcn_fmed3f(b[1], 0.0f, DHS_TINY)};
 }
 __device__ __forceinline__ u16x8 cat8(u16x4 a, u16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
@@ -1554,6 +1593,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
     dx_p -= (T > 1 ? cs_step : 0);
 
     float fillr = 0.f; (void)fillr;      // (ABL_FILL probe)
+    const s16x4 ident = identity_fragment(l);
     frag bq[2], lt[4];      // B fragments: one k-group ahead (a third ring slot costs 4 registers this kernel lacks)
     vm_drain();
     lds_barrier();
@@ -1586,12 +1626,15 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
         for (int n = 0; n < RNT; ++n) {
             auto half = [&](const u16x8& v) -> f32x4 {
                 const int o = (n & 1) * 4;
+                if (BWL_MFMA_WIDEN > 1)
+                    return widen4(ident, (n & 1) ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3),
+                                  f32x4{0.f, 0.f, 0.f, 0.f});
                 return f32x4{bf2f(v[o]), bf2f(v[o + 1]), bf2f(v[o + 2]), bf2f(v[o + 3])};
             };
             const f32x4 ig = half(qa[n >> 1][0]), fg = half(qa[n >> 1][1]), gg = half(qa[n >> 1][2]), og = half(qa[n >> 1][3]);
             const f32x4 c = half(carry[n >> 1]), cp = half(qs[n >> 1]);
             f32x4 d = dh[n];
-            if (HAS_EXT) d += unpack4(qd[n]);
+            if (HAS_EXT) d = BWL_MFMA_WIDEN ? widen4(ident, qd[n], d) : d + unpack4(qd[n]);
             // whole-vector expressions: no MFMA is in flight in this phase, so packed f32 instructions (two elements
             // each) are pure gain here - unlike in the MFMA gaps, where they cost issue slots
             f32x4 di, df, dg, dO;
@@ -1599,10 +1642,17 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
             else {
                 const f32x4 tc = tanh_fast4(c);
                 const f32x4 dct = dc[n] + d * og * (1.0f - tc * tc);
+#if BWL_OLD_DHS
                 di = dct * (gg * dhard_sigmoid4(ig));
                 df = dct * (cp * dhard_sigmoid4(fg));
-                dg = dct * ig * (1.0f - gg * gg);
                 dO = d * (tc * dhard_sigmoid4(og));
+#else
+                const f32x4 dctK = dct * DHS_BIG, dK = d * DHS_BIG;       // (powers of two: exact; |dct| < 2^27 or the step is lost anyway)
+                di = (dctK * gg) * sat4(ig);
+                df = (dctK * cp) * sat4(fg);
+                dO = (dK * tc) * sat4(og);
+#endif
+                dg = dct * ig * (1.0f - gg * gg);
                 dc[n] = dct * fg;
             }
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);
@@ -1610,6 +1660,9 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
             *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (3 * 512 + n * 32))) = pack4(dO);
             if (n & 1) carry[n >> 1] = qs[n >> 1];      // c_{t-1} is the next step's c_t
+#if BWL_E_TILE_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         STAMP(2);
         vm_drain();                                   // the T fragments (L2 hits issued a whole E phase ago)

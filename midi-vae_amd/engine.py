@@ -309,7 +309,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 torch.cuda.synchronize()
                 self.store["join_words"][word:word + 1].zero_()
                 self._join_seq[word] = seq = 1
-            self._note_counter(("join", word), seq)
+            seq = ops.CounterValue(seq, ("join", word))
             w = self.store["join_words"][word:word + 1]
             ops.stream_write_value32(w, seq, stream=streams[-1])
             ops.stream_wait_value32(w, seq, stream=cur)
@@ -573,9 +573,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             cum[0] = cum[1] = 0
         cum[0] += nwaves
         cum[1] += pwaves
-        self._note_counter(("sync", slot, 0), cum[0])        # (step plans: these values are patches, engine_plan.py)
-        self._note_counter(("sync", slot, 1), cum[1])
-        return reg, cum[0], cum[1]
+        # (step plans, engine_plan.py: the fields these values land in are patches - they travel as ops.CounterValue)
+        return reg, ops.CounterValue(cum[0], ("sync", slot, 0)), ops.CounterValue(cum[1], ("sync", slot, 1))
 
     def _stack_forward_pipe(self, layers, B, slot, *, states=None, h_last=None, h_last_ld=0, idx=None, start=None, xs=None,
                             publish_top=False):

@@ -58,11 +58,6 @@ class PlannedSteps(object):
         """``waiter`` waits for everything enqueued so far on ``waited`` (torch's Stream.wait_stream through the C ABI)"""
         self._ev_wait(waiter, self._ev_record(waited))
 
-    def _note_counter(self, key, value):
-        rec = _plan.active()
-        if rec is not None:
-            rec.note_counter(key, value)
-
     # ---- plans ------------------------------------------------------------------------------------------------------------
     def _plan_counters(self):
         d = {("sync", slot, i): v for slot, cum in self._sync_cum.items() for i, v in enumerate(cum)}

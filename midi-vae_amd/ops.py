@@ -5,9 +5,13 @@ torch's CURRENT stream and returns immediately.  Shapes follow include/midivae_h
 """
 from __future__ import annotations
 
+import ctypes as _C
+
 import torch
 
 from . import hiplib as hl
+
+C_sizeof = _C.sizeof
 
 _TORCH_DT = {hl.F32: torch.float32, hl.BF16: torch.bfloat16}
 
@@ -26,6 +30,44 @@ def kind_of(t):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+class CounterValue(int):
+    """a 32-bit wait / write value derived from one of the engine's monotonic counters (``key``): the fields it lands in are the
+    patches of a step plan (plan.py) - field := counter before the step + offset.  Arithmetic on it gives a plain int."""
+    def __new__(cls, value, key):
+        self = int.__new__(cls, int(value))
+        self.key = key
+        return self
+
+
+def _tag(struct, field, value):
+    """remember on an argument struct that ``field`` holds a counter value (consumed by _launch / the *_multi wrappers)"""
+    key = getattr(value, "key", None)
+    if key is not None:
+        struct.__dict__.setdefault("_counter_fields", {})[field] = key
+
+
+def _note_fields(arg_index, structs):
+    """announce the counter fields of the struct argument(s) of the NEXT library call to the active plan recorder"""
+    from . import plan
+    rec = plan.active()
+    if rec is None:
+        return
+    off = 0
+    for st in structs:
+        for field, key in getattr(st, "_counter_fields", {}).items():
+            rec.note_field(arg_index, off + getattr(type(st), field).offset, key)
+        off += C_sizeof(st)
+
+
+def _note_scalar(arg_index, value):
+    key = getattr(value, "key", None)
+    if key is not None:
+        from . import plan
+        rec = plan.active()
+        if rec is not None:
+            rec.note_field(arg_index, -1, key)
 
 
 def _p(t):
@@ -63,8 +105,10 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _pv(xp), _pv(idx), _p(table), _pv(xs), _p(w_row),
                       _p(bias), _p(xp0), _pv(h0), _pv(c0), _pv(hs), _pv(cs), _pv(acts), _pv(h_last), _pv(c_last), h0_ld, h_last_ld,
                       chunk_steps, _pv(wait_ready), int(wait_value), _pv(signal_done), _pv(status), seq_layout)
+    _tag(a, "wait_value", wait_value)
     if build_only:          # (a problem of rnn_fwd_multi; the tensors must stay alive until that launch)
         return a
+    _note_fields(0, [a])
     hl.check(hl.load().mvae_rnn_fwd(a, _stream()), "mvae_rnn_fwd")
 
 
@@ -74,8 +118,10 @@ def rnn_bwd(cell, dtype, T, B, H, ut_pack, hs, cs, acts, da, *, dhs_ext=None, dh
     a = hl.RnnBwdArgs(cell, dtype, T, B, H, _p(ut_pack), _pv(hs), _pv(cs), _pv(acts), _pv(dhs_ext), _pv(dh_last),
                       _pv(dc_last), _pv(da), _pv(rh), _pv(dh0), _pv(dc0), dh_last_ld, dh0_ld, chunk_steps, _pv(wait_ready),
                       int(wait_value), _pv(signal_done), _pv(status), seq_layout)
+    _tag(a, "wait_value", wait_value)
     if build_only:
         return a
+    _note_fields(0, [a])
     hl.check(hl.load().mvae_rnn_bwd(a, _stream()), "mvae_rnn_bwd")
 
 
@@ -91,6 +137,7 @@ def rnn_fwd_multi(problems, xpands=()):
     first); False if the library does not take some problem (launch them singly)"""
     arr = (hl.RnnFwdArgs * len(problems))(*problems)
     xa = (hl.XpandArgs * len(xpands))(*xpands) if xpands else None
+    _note_fields(0, problems)
     rc = hl.load().mvae_rnn_fwd_multi(arr, len(problems), xa, len(xpands), _stream())
     if rc == hl.E_UNSUPPORTED:
         return False
@@ -100,6 +147,7 @@ def rnn_fwd_multi(problems, xpands=()):
 
 def rnn_bwd_multi(problems):
     arr = (hl.RnnBwdArgs * len(problems))(*problems)
+    _note_fields(0, problems)
     rc = hl.load().mvae_rnn_bwd_multi(arr, len(problems), _stream())
     if rc == hl.E_UNSUPPORTED:
         return False
@@ -125,25 +173,31 @@ def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, 
                     int(accumulate), act, split_k, float(alpha), A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), c_layout, max_blocks,
                     int(sys_release), int(chunk_rows), int(chunk_reverse), _pv(chunk_wait), int(chunk_wait_value), _pv(chunk_done),
                     _pv(chunk_status), _pv(colsum_b), _pv(k_wait), int(k_wait_value), int(k_chunk_rows), int(k_reverse))
+    _tag(g, "chunk_wait_value", chunk_wait_value)
+    _tag(g, "k_wait_value", k_wait_value)
     if build_only:          # (for gemm_kstream_multi; the tensors must stay alive until that launch)
         return g
+    _note_fields(0, [g])
     hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
 
 
 def gemm_kstream_multi(problems):
     """several K-streaming GEMMs (``gemm(..., k_wait=..., build_only=True)``) as ONE launch on the current stream"""
     arr = (hl.GemmArgs * len(problems))(*problems)
+    _note_fields(0, problems)
     hl.check(hl.load().mvae_gemm_kstream_multi(arr, len(problems), _stream()), "mvae_gemm_kstream_multi")
 
 
 def stream_wait_value32(word, value, stream=None):
     """the current (or given) stream proceeds once the 32-bit device word ``word`` (a 1-element view) is >= value"""
+    _note_scalar(2, value)
     hl.check(hl.load().mvae_stream_wait_value32(_stream() if stream is None else stream.cuda_stream, _p(word), int(value)),
              "mvae_stream_wait_value32")
 
 
 def stream_write_value32(word, value, stream=None):
     """writes ``value`` to the 32-bit device word after everything enqueued so far on the stream"""
+    _note_scalar(2, value)
     hl.check(hl.load().mvae_stream_write_value32(_stream() if stream is None else stream.cuda_stream, _p(word), int(value)),
              "mvae_stream_write_value32")
 

@@ -7,9 +7,10 @@ ABI plus the event / value packets that order them over 7 queues; issued from CP
 
 How: while a ``Recorder`` is active every stream-taking entry point called through ``hiplib`` is executed as usual AND noted
 (name, argument values, a copy of every argument struct).  Three recordings of the same kind of step are compared field by field:
-whatever is equal in all three is a constant of the plan; a 32-bit field that differs must be a COUNTER VALUE the engine
-announced while it built the call (``Recorder.note_counter``: the cumulative progress counters of the time-pipelined kernels,
-the sequence numbers of value joins) and becomes a patch ``field = counter_before_the_step + offset``.  Anything else that
+whatever is equal in all three is a constant of the plan; a 32-bit field that differs must hold a COUNTER VALUE - the engine
+hands those around as ``ops.CounterValue`` (the cumulative progress counters of the time-pipelined kernels, the sequence numbers
+of value joins), whose fields the marshalling layer announces (``Recorder.note_field``) - and becomes a patch
+``field = counter_before_the_step + offset``.  Anything else that
 differs - a pointer that moved, a changed shape - means the step is not replayable and the engine keeps enqueueing from Python.
 Replay (``StepPlan.run``) hands the current counter values to ``mvae_plan_run`` and advances them by what one step adds.
 Nothing here computes: no oracle, no fallback arithmetic.
@@ -77,19 +78,16 @@ def _taint_mode(rec):
 
 
 class Recorder(object):
-    """``with Recorder() as rec: <enqueue a step>`` - rec.calls = [(name, slots, {slot: bytes})], rec.tags = {value: counter key},
-    rec.tainted = name of the first torch operation (other than a view) the step ran, or None"""
+    """``with Recorder() as rec: <enqueue a step>`` - rec.calls = [(name, slots, {slot: bytes})], rec.tags = {(call, argument,
+    byte offset or -1): counter key}, rec.tainted = name of the first torch operation (other than a view) the step ran, or None"""
 
     def __init__(self):
-        self.calls, self.tags, self._saved, self.tainted, self._mode = [], {}, {}, None, None
+        self.calls, self.tags, self._saved, self.tainted, self._mode, self._pending = [], {}, {}, None, None, []
 
-    def note_counter(self, key, value):
-        """the engine derived ``value`` from its counter ``key`` (a 32-bit wait / write value of this step)"""
-        v = int(value) & 0xFFFFFFFF
-        if self.tags.get(v, key) != key:
-            self.tags[v] = None          # two counters with the same value in one step: ambiguous, never used for a patch
-        else:
-            self.tags[v] = key
+    def note_field(self, arg_index, offset, key):
+        """the NEXT library call carries a value of the engine's counter ``key`` in argument ``arg_index`` (at byte ``offset`` of
+        the struct(s) it points at; -1: the scalar argument itself) - ops.CounterValue announces itself here"""
+        self._pending.append((arg_index, offset, key))
 
     def __enter__(self):
         global _active
@@ -101,8 +99,11 @@ class Recorder(object):
 
             def wrapper(*args, _real=real, _name=name, _argtypes=argtypes):
                 rc = _real(*args)
+                pending, self._pending = self._pending, []
                 if rc == 0:          # (a rejected call enqueued nothing: the engine takes another path)
                     slots, blobs = _encode(_argtypes, args)
+                    for arg_index, offset, key in pending:
+                        self.tags[(len(self.calls), arg_index, offset)] = key
                     self.calls.append((_name, slots, blobs))
                 return rc
             setattr(lib, name, wrapper)
@@ -152,9 +153,9 @@ class StepPlan(object):
         self._h, self._lib = h, lib
         self.n_patches = 0
 
-        def patch_for(where, va, vb, vc):
+        def patch_for(where, field, va, vb, vc):
             """the counter key + offset that explains a field taking the values va / vb / vc in the three recordings"""
-            ka, kb, kc = ta.get(va), tb.get(vb), tc.get(vc)
+            ka, kb, kc = ta.get(field), tb.get(field), tc.get(field)
             if ka is None or ka != kb or ka != kc or ka not in kidx:
                 raise NotReplayable("%s differs between recordings (%d / %d / %d) and is not a counter value" % (where, va, vb, vc))
             off = [(v - p.get(ka, 0)) & 0xFFFFFFFF for v, p in ((va, pa), (vb, pb), (vc, pc))]
@@ -181,7 +182,7 @@ class StepPlan(object):
                         continue
                     if max(va, vb, vc) >> 32:
                         raise NotReplayable("call %d (%s): argument %d (a pointer?) differs between recordings" % (i, na, j))
-                    patches.append((j, -1) + patch_for("call %d (%s) argument %d" % (i, na, j), va, vb, vc))
+                    patches.append((j, -1) + patch_for("call %d (%s) argument %d" % (i, na, j), (i, j, -1), va, vb, vc))
                 for slot in sorted(ba):
                     if ba[slot] == bb[slot] == bc[slot]:
                         continue
@@ -191,7 +192,7 @@ class StepPlan(object):
                         raise NotReplayable("call %d (%s): argument %d differs in its tail bytes" % (i, na, slot))
                     for w in np.nonzero((wa != wb) | (wa != wc))[0]:
                         patches.append((slot, int(w) * 4) + patch_for("call %d (%s) argument %d byte %d" % (i, na, slot, int(w) * 4),
-                                                                      int(wa[w]), int(wb[w]), int(wc[w])))
+                                                                      (i, slot, int(w) * 4), int(wa[w]), int(wb[w]), int(wc[w])))
                 for slot, off, key, add in patches:
                     hl.check(lib.mvae_plan_add_patch(h, i, slot, off, key, add), "mvae_plan_add_patch")
                     self.n_patches += 1

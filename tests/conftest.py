@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:          # (test files share problem builders: from test_engine_gpu import _problem)
+    sys.path.insert(1, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):

@@ -54,14 +54,15 @@ def _recording(base, seq):
              ("mvae_stream_wait_value32", [0x78, 0x5000, seq + 1], {}),
              ("mvae_adam_step_dev", P._encode(hl.SIGNATURES["mvae_adam_step_dev"][1],
                                               (1, 2, 3, 4, 100, 2e-4, 0.9, 0.999, 1e-8, 5, 1.0, 3, 6, 0x77))[0], {})]
-    tags = {base + 64: ("sync", 0, 0), seq + 1: ("join", 2)}
+    tags = {(0, 0, hl.GemmArgs.chunk_wait_value.offset): ("sync", 0, 0), (1, 2, -1): ("join", 2), (2, 2, -1): ("join", 2)}
     before = {("sync", 0, 0): base, ("join", 2): seq}
     after = {("sync", 0, 0): base + 64, ("join", 2): seq + 1}
     return calls, tags, before, after
 
 
 def test_three_recordings_become_constants_and_counter_patches():
-    # (the recordings need not be consecutive steps: the patches are relative to the counters, not to a run index)
+    # (the recordings need not be consecutive steps: the patches are relative to the counters, not to a run index; two counters
+    #  that happen to hold the same value are no problem either: a field is tied to its counter by name, not by value)
     p = P.StepPlan([_recording(0, 0), _recording(64, 1), _recording(640, 17)])
     assert p.n_calls == 4 and p.n_patches == 3
     assert p.inc == {("sync", 0, 0): 64, ("join", 2): 1}
@@ -85,7 +86,6 @@ def test_anything_else_that_differs_is_refused(what):
     else:                            # the same counter, but at another distance from its value before the step
         g = hl.GemmArgs(M=128, N=64, K=32, A=0x1000, B=0x2000, C=0x3000, chunk_wait=0x4000, chunk_wait_value=128 + 65)
         c[0][0] = ("mvae_gemm", [0, 0x77], {0: C.string_at(C.addressof(g), C.sizeof(g))})
-        c[1][128 + 65] = ("sync", 0, 0)
     with pytest.raises(P.NotReplayable):
         P.StepPlan([a, b, c])
 
@@ -96,7 +96,24 @@ def test_recorder_notes_accepted_calls_only_and_restores_the_library():
     with P.Recorder() as rec:
         assert lib.mvae_gemm is not real
         assert lib.mvae_gemm(None, None) == hl.E_ARG          # rejected: enqueued nothing, not part of the step
-        rec.note_counter(("sync", 1, 0), 7)
-        rec.note_counter(("sync", 2, 0), 7)                   # two counters with one value: never used for a patch
-    assert lib.mvae_gemm is real and rec.calls == [] and rec.tags == {7: None} and rec.tainted is None
+        rec.note_field(0, 8, ("sync", 1, 0))                  # announced for a call that was then rejected: dropped with it
+        assert lib.mvae_gemm(None, None) == hl.E_ARG
+    assert lib.mvae_gemm is real and rec.calls == [] and rec.tags == {} and rec.tainted is None
     assert P.active() is None
+
+
+def test_counter_values_announce_the_fields_they_land_in():
+    """ops.CounterValue -> the marshalling layer tags the struct field -> the recorder learns (call, argument, byte offset)"""
+    from midi_vae_amd import ops
+    v = ops.CounterValue(192, ("sync", 3, 1))
+    assert int(v) == 192 and v.key == ("sync", 3, 1) and not hasattr(v + 1, "key")
+    g = hl.GemmArgs()
+    ops._tag(g, "k_wait_value", v)
+    ops._tag(g, "chunk_wait_value", 5)                       # a plain int: not a counter
+    assert g._counter_fields == {"k_wait_value": ("sync", 3, 1)}
+    g2 = hl.GemmArgs()
+    with P.Recorder() as rec:
+        ops._note_fields(0, [g2, g])
+        assert rec._pending == [(0, C.sizeof(hl.GemmArgs) + hl.GemmArgs.k_wait_value.offset, ("sync", 3, 1))]
+        ops._note_scalar(2, v)
+        assert rec._pending[-1] == (2, -1, ("sync", 3, 1))
