@@ -99,11 +99,11 @@ def cpu_elbo(spec, B, steps, limit_s=150.0):
 
 
 def gpu_elbo(spec, B, steps, dtype, device):
-    """the same trajectory on the engine: same windows, same initial parameters, same draws (torch_cpu.elbo_inputs / elbo_epsilon
-    are data generators shared by both sides, not arithmetic)"""
+    """the same trajectory on the engine: same windows, same initial parameters, same draws (synth.elbo_inputs / elbo_epsilon:
+    data generators both sides import - this GPU leg imports nothing from oracle/)"""
     import torch
     from midi_vae_amd.engine import Engine
-    from oracle.torch_cpu import elbo_epsilon, elbo_inputs
+    from midi_vae_amd.synth import elbo_epsilon, elbo_inputs
     _, w, params = elbo_inputs(spec.cell, spec.T, B, spec.V, spec.Z, spec.C)
     eng = Engine(spec, max_batch=B, dtype=dtype, device=device, seed=1234)
     eng.set_params(params)
@@ -122,6 +122,9 @@ def gpu_elbo(spec, B, steps, dtype, device):
 
 
 CONFIGS = {     # BASELINE.json configs[i]: (seq_len, voices, latent, classes, windows per GPU, mode, global batch the config names, GPUs)
+    # 0 is NOT a BASELINE config: the configuration the reference ships (settings.py:108-112,140,155; models/BvM/params.txt) -
+    # T = 16 x 4 = 64 rows, latent 256, batch 256, GRU - what `python vae_training.py` runs first
+    0: (16, 4, 256, 2, 256, "train", 256, 1),
     1: (128, 4, 64, 2, 256, "train", 256, 1),
     2: (256, 8, 128, 4, 512, "train", 1024, 2),
     3: (256, 8, 128, 4, 512, "train", 4096, 8),
@@ -151,13 +154,98 @@ def decoder_flops_per_window(spec):
             T * mm(H, D) + (mm(ID, GH) + V * (mm(H, GH) + mm(H, ID))) + (mm(1, GH) + T * (mm(H, GH) + mm(H, 1))))
 
 
+def workload_name(config, C, seq, voices, T, latent, B, named_batch, named_gpus, cell, decode):
+    what = ("%s: %d-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU (%s) %s H=256 2+2 layers, " % (
+        "BASELINE configs[%d]" % config if config else "the reference's shipped configuration (settings.py:108-112,140,155)", C, seq,
+        voices, T, latent, B, "the config names %d windows on %d GPU%s" % (named_batch, named_gpus, "s" if named_gpus > 1 else ""),
+        cell))
+    return what + ("decoder forward on swapped latents + fused argmax decode (one byte per row leaves the chip)" if decode else
+                   "notes+instrument+velocity+style heads, Keras-Adam")
+
+
+def side_workload(config, cell, dtype, device, steps, warmup):
+    """One of the OTHER workloads, measured in this process after the headline region (the driver then
+    observes them): K steps bracketed by synchronize, the dominant kernel's launches of every 4th step bracketed with HIP events
+    on their stream - the same measurement as the headline, shorter.  Returns the member of the line's ``other_configs`` array."""
+    import numpy as np
+    import torch
+    from midi_vae_amd.engine import Engine
+    from midi_vae_amd.layout import ModelSpec
+    from midi_vae_amd.synth import make_windows
+    seq, voices, latent, C, B, mode, named_batch, named_gpus = CONFIGS[config]
+    T, decode = seq * voices, mode == "decode"
+    spec = ModelSpec(cell=cell, H=256, Z=latent, Din=61, Dout=61, T=T, V=voices, ID=16, C=C, Le=2, Ld=2)
+    eng = Engine(spec, max_batch=B, dtype=dtype, device=device, seed=1234, training=not decode)
+    w = make_windows(B, T, 61, voices, 16, C, latent, seed=1234, epsilon_std=spec.epsilon_std)
+    if decode:
+        z = np.random.default_rng(1234).standard_normal((B, latent)).astype(np.float32)
+        z[:, [0, 1]] = z[:, [1, 0]]
+        eng.stage_decoder_inputs(B, z=z, hist=np.concatenate([np.zeros((1, latent), np.float32), z[:-1]]))
+        step = lambda: eng.decode(B, want_probs=False)
+        kinds = {("rnn_fwd", "dec.notes.1"), ("rnn_fwd_multi", "dec")}
+    else:
+        eng.stage_encoder_inputs(w["x_idx"], w["i_idx"], w["vel"], w["eps"])
+        eng.stage_decoder_inputs(B, hist=w["hist"])
+        eng.stage_targets(B, w["x_idx"], w["c_idx"])
+        step = lambda: eng.train_step(B)
+        kinds = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_bwd_multi", "dec")}
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.7:          # clocks up, first launches done, step plans armed
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+    eng.prof_kinds = kinds
+    for i in range(warmup):
+        eng.prof = {} if i % 4 == 0 else None
+        step()
+    eng.prof = None
+    torch.cuda.synchronize()
+    host = 0.0
+    prof = {}
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.prof = prof if i % 4 == 0 else None        # (a bracketed step is enqueued from Python, the others are plan replays)
+        h0 = time.perf_counter()
+        step()
+        host += time.perf_counter() - h0
+    eng.prof = None
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng.prof = prof
+    summary = eng.prof_summary()
+    eng.prof = None
+    eng.check_pipeline()
+    dom = "rnn_fwd" if decode else "rnn_bwd"
+    longk = {k: v for k, v in summary.items() if k[0] in (dom, dom + "_multi")}
+    tot_ms = sum(n * ms for n, ms, _ in longk.values())
+    tot_steps = sum(n * st for n, _, st in longk.values())
+    Bp = (B + 15) // 16 * 16
+    lpl = spec.Ld if any(k[0].endswith("_multi") for k in longk) else 1
+    achieved = 2.0 * Bp * spec.H * spec.G * spec.H * tot_steps / (tot_ms * 1e-3) / 1e12 if tot_ms else float("nan")
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    ms_step = elapsed / steps * 1e3
+    flop = (3.0 * algorithmic_flops_per_window(spec) if not decode else decoder_flops_per_window(spec)) * B
+    out = {"workload": workload_name(config, C, seq, voices, T, latent, B, named_batch, named_gpus, cell, decode),
+           "baseline_config": config, "cell": cell, "mode": mode, "steps": steps, "ms_per_step": ms_step,
+           "value": B * steps / elapsed, "unit": "windows/s", "host_ms_per_step": host / steps * 1e3,
+           "bound": "host" if host > 0.9 * elapsed else "device",
+           "roofline": {"kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                        "us_per_time_step": tot_ms * 1e3 / tot_steps * lpl if tot_steps else float("nan")},
+           "whole_step": {"tflops": flop / (ms_step * 1e-3) / 1e12, "frac_of_peak": flop / (ms_step * 1e-3) / 1e12 / peak},
+           "plan": dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]))}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs (module docstring)")
-    ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"])
+    ap.add_argument("--cell", default=None, choices=["LSTM", "GRU"], help="default: LSTM (north_star); GRU for --config 0")
+    ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the other workloads measured after the headline")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (0 = the config's)")
     ap.add_argument("--seq-len", type=int, default=0)
@@ -172,6 +260,8 @@ def main():
                          "policy (dp.DataParallel: on with RCCL and more than one rank)")
     ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
     args = ap.parse_args()
+    if args.cell is None:
+        args.cell = "GRU" if args.config == 0 else "LSTM"
 
     import torch
     import midi_vae_amd  # noqa: F401
@@ -226,6 +316,7 @@ def main():
         from midi_vae_amd.dp import make_allreduce
         overlap = (world > 1) if args.dp_overlap < 0 else bool(args.dp_overlap)
         allreduce = make_allreduce(eng, dist, world, overlap=overlap)
+        allreduce.timing = []          # (HIP-event pairs around the early and the late collective: dp.BucketedAllReduce)
 
     def step():
         if decode:
@@ -300,7 +391,26 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if args.steps % 2 else 0.5 * (step_ms[args.steps // 2 - 1] + step_ms[args.steps // 2])
+    dp_stats = None
     if dist is not None:
+        # per-rank step times (each rank's own event marks) and the collectives' durations: what a scaling curve is read with
+        mine = torch.tensor([elapsed / args.steps * 1e3, median_ms], device="cuda", dtype=torch.float64)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        per = sorted(float(t[1].item()) for t in every_rank)
+        ar = {}
+        for tag in ("early", "late"):
+            ms = [e0.elapsed_time(e1) for tg, e0, e1 in (allreduce.timing if allreduce is not None else []) if tg == tag]
+            t = torch.tensor([sum(ms) / len(ms) if ms else -1.0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ar[tag] = float(t.item()) if float(t.item()) >= 0 else None
+        dp_stats = {"rccl_ranks": dist.get_world_size(), "backend": str(dist.get_backend()),
+                    "rank_median_ms_per_step": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
+                    "allreduce_ms": {"early_decoder_bucket": ar["early"], "late": ar["late"],
+                                     "what": "HIP-event time of the collectives on their streams, mean over the timed steps, max "
+                                             "over ranks (early: the decoder-side bucket beside the encoder BPTT, null when the "
+                                             "overlap is off; late: what is reduced after the backward pass)"},
+                    "overlap": bool(getattr(allreduce, "overlap", False))}
         tt = torch.tensor([elapsed, median_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
@@ -351,11 +461,7 @@ def main():
         fwd_flop = algorithmic_flops_per_window(spec)
         step_flop = (3.0 * fwd_flop if not decode else decoder_flops_per_window(spec)) * B
         bytes_per_row = (10 if args.cell == "LSTM" else 9) if not decode else (5 if args.cell == "LSTM" else 4)
-        what = ("BASELINE configs[%d]: %d-style seq_len=%d voices=%d (T=%d rows) z=%d batch=%d/GPU (the config names %d windows on %d "
-                "GPU%s) %s H=256 2+2 layers, " % (args.config, C, seq, voices, T, latent, B, named_batch, named_gpus,
-                                                "s" if named_gpus > 1 else "", args.cell))
-        what += ("decoder forward on swapped latents + fused argmax decode (one byte per row leaves the chip)" if decode else
-                 "notes+instrument+velocity+style heads, Keras-Adam")
+        what = workload_name(args.config, C, seq, voices, T, latent, B, named_batch, named_gpus, args.cell, decode)
         out = {
             "metric": "MIDI roll windows/sec (%s)" % ("decode" if decode else "train step"), "value": B * world * args.steps / elapsed,
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -406,6 +512,24 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port",
                                    "sample": "not timed for the decode configuration: oracle/torch_cpu.py covers the train step (the "
                                              "default --config 1 run carries the CPU baseline)"}
+        out["plan"] = dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]),
+                           what="step plans (include/midivae_hip.h): steps of the timed region enqueued by ONE mvae_plan_run call "
+                                "('replayed') - every 4th step, whose dominant launches are bracketed with HIP events, by Python")
+        if dp_stats is not None:
+            out["dp"] = dp_stats
+        if world == 1 and not args.no_other_configs and args.config == 1 and args.dtype == "bf16" and not (args.batch or args.seq_len
+                                                                                                          or args.voices or args.latent):
+            # the other workloads, in this process, AFTER the headline region (which is exactly what it was without them)
+            del eng
+            torch.cuda.empty_cache()
+            others = []
+            for cfg, cell_o, k, wu in ((1, "GRU" if args.cell == "LSTM" else "LSTM", 20, 8), (2, args.cell, 10, 4),
+                                       (4, args.cell, 20, 4), (0, "GRU", 60, 12)):
+                try:
+                    others.append(side_workload(cfg, cell_o, args.dtype, device, k, wu))
+                except Exception as e:          # (a side measurement must never cost the headline line)
+                    others.append({"baseline_config": cfg, "cell": cell_o, "error": "%s: %s" % (type(e).__name__, e)})
+            out["other_configs"] = others
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -520,7 +520,9 @@ int mvae_plan_failed_call(const mvae_plan* p);       /* index of the call whose 
  * staging block the engine uploads with a single asynchronous copy (64 MB of float64 -> 128 KB per 256 x 512 rows).
  * --------------------------------------------------------------------------------------------------------- */
 enum { MVAE_HOST_F64 = 0, MVAE_HOST_F32 = 1, MVAE_HOST_U8 = 2 };
-/* size of the worker pool: n > 0 sets it, 0 restores the default (min(16, cores)), < 0 only queries; returns the size */
+/* size of the worker pool: n > 0 sets it, 0 restores the default, < 0 only queries; returns the size.  Default: a quarter of the
+ * hardware threads this process may run on (its affinity mask) divided by LOCAL_WORLD_SIZE (one process per GPU under data
+ * parallelism), at least 4 and at most 64 - 64 alone on a 256-thread host, 8 per rank with 8 ranks. */
 int mvae_host_threads(int32_t n);
 /* windows [lo, hi) of x (n, T, K) one-hot rows of xkind -> out (T, Bp) uint8: out[t*Bp + (b-lo)] = position of the 1;
  * columns hi-lo .. Bp-1 = fill.  A row that is not exactly one 1 among zeros: MVAE_E_FORMAT, *bad_row = the LOWEST such flat row.

@@ -21,4 +21,15 @@ import os as _os
 # gradient GEMMs delayed the lower layer's BPTT by milliseconds).  Must be set before the HIP runtime initialises.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
+# One process per GPU (torch.distributed.run sets LOCAL_WORLD_SIZE): the host's threads are shared between the ranks of the node.
+# Without a limit each rank's OpenMP / torch intra-op pool is sized for the whole host (8 x 256 threads); the packer pool of the C
+# library applies the same rule (csrc/hostpack.cpp default_threads).  An explicit OMP_NUM_THREADS wins.
+_lws = int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+if _lws > 1 and "OMP_NUM_THREADS" not in _os.environ:
+    try:
+        _cores = len(_os.sched_getaffinity(0))
+    except AttributeError:
+        _cores = _os.cpu_count() or 1
+    _os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, _cores // _lws // 4 or 1)))
+
 __version__ = "0.1.0"

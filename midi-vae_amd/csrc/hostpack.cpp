@@ -12,6 +12,8 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <sched.h>
+#include <cstdlib>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -98,11 +100,28 @@ Pool* g_pool = nullptr;
 int g_threads = 0;          // 0 = default
 
 int default_threads() {
-    unsigned hc = std::thread::hardware_concurrency();
-    int n = hc ? (int)hc : 4;
+    // The hardware threads THIS process may use: its affinity mask (a launcher that pins ranks to cores is honoured), shared between
+    // the processes of the node - one per GPU under data parallelism (LOCAL_WORLD_SIZE, set by torch.distributed.run): eight ranks
+    // each sizing their pool for the whole host were 512 threads on a 256-thread box.
+    int hw = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = CPU_COUNT(&set);
+    if (hw <= 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        hw = hc ? (int)hc : 4;
+    }
+    int local = 1;
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int v = std::atoi(e);
+        if (v > 1) local = v;
+    }
+    const int share = hw / local > 1 ? hw / local : 1;
     // memory-bound: a quarter of the hardware threads saturates what the sockets deliver to one process (measured on the 256-thread
-    // host of an MI355X box: 16 threads convert a 256 x 512 x 61 float64 minibatch in ~4 ms, a train step takes 8.9)
-    n = n > 16 ? (n / 4 > 16 ? n / 4 : 16) : n;
+    // host of an MI355X box: 16 threads convert a 256 x 512 x 61 float64 minibatch in ~4 ms, a train step takes 8.9); at least 4
+    // (or all of a smaller share), at most 64
+    int n;
+    if (local == 1) n = share > 16 ? (share / 4 > 16 ? share / 4 : 16) : share;        // alone on the host: round 2's measured optimum
+    else n = share / 4 > 4 ? share / 4 : (share < 4 ? share : 4);                     // max(4, threads / ranks / 4), within the share
     return n > 64 ? 64 : n;
 }
 

@@ -84,16 +84,29 @@ class BucketedAllReduce:
         self.overlap = bool(overlap) and 0 < self.dec_begin
         self.scale = (1.0 / world) if scale is None else float(scale)
         self._work = None
+        self.timing = None          # a list: (tag, start event, end event) per collective, on the stream it was issued from (bench.py)
+
+    def _timed(self, tag, fn):
+        if self.timing is None:
+            return fn()
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.timing.append((tag, e0, e1))
+        return out
 
     def early(self, bucket):
         if self.overlap:
-            self._work = self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work = self._timed("early", lambda: self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group,
+                                                                           async_op=True))
 
     def __call__(self, grads):
         if self._work is None:
-            self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._timed("late", lambda: self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM, group=self.group))
         else:
-            self.dist.all_reduce(grads[:self.dec_begin], op=self.dist.ReduceOp.SUM, group=self.group)
+            self._timed("late", lambda: self.dist.all_reduce(grads[:self.dec_begin], op=self.dist.ReduceOp.SUM, group=self.group))
             self._work.wait()           # device-side: the current stream waits for the collective's stream
             self._work = None
         return self.scale

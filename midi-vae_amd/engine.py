@@ -149,6 +149,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self._occ = {k: max(1, hl.load().mvae_occupancy(i)) for i, k in enumerate(("dx", "proj", "kstream"))}
         self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
+        self._redo_hist = None           # ... kept until the step is verified (_redo_step)
         # the recurrences of a phase as ONE launch on the critical queue instead of one launch per queue (engine_phases.py)
         self.phase_multi = os.environ.get("MVAE_PHASE_MULTI", "1") == "1"
         # ... up to this many (padded) windows per call: measured (profiles/r03_j_*) 256 windows -6 % (LSTM) / -9 % (GRU) per train
@@ -1296,7 +1297,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def optimizer_step(self, grad_scale=1.0):
         s = self.spec
-        if self.status_allreduce is not None and self.pipeline:
+        # (data parallel: whenever the hook is set, whatever THIS rank's schedule - a rank that fell back to chunked launches
+        #  must still take part in the collective the others issue)
+        if self.status_allreduce is not None:
             self.status_allreduce(self.store["pipe_status"])
         # (the gradients are zeroed as they are consumed: the next step starts without a 17 MB fill launch in front of it)
         if s.optimizer == "Adam":
@@ -1335,9 +1338,16 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._zero_scal_job.run()
 
     def _redo_step(self, B):
+        """the forward + backward pass of a train step once more (first use of the pipelined kernels stalled: _verify_pipeline).
+        A fused history pre-pass is redone with it (the history rows came out of the timed-out forward); the gradient hook is
+        out of the way (_overlap_hook: no early bucket is in flight on an unverified step), so the buffer may be zeroed"""
         self.scal.zero_()
         self.grads.zero_()
-        self.encoder_forward(B, with_init=True)
+        self._hist_fused = self._redo_hist
+        try:
+            self.encoder_forward(B, with_init=True)
+        finally:
+            self._hist_fused = None
         self.decoder_forward(B)
         self.backward(B)
 
@@ -1371,12 +1381,19 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if not self.pipeline or key in self._pipe_verified or not self._pipe_used:
             return                     # (a call whose batch did not run any stack pipelined verifies nothing)
         self._pipe_verified.add(key)
-        if int(self.store["pipe_status"].item()) == 0:
+
+        def status():
+            # (data parallel: the decision stays rank-local - a rank whose shard is empty never gets here, so a collective in
+            #  this place could hang - and that is safe: a redo issues no collective (no early bucket on an unverified step,
+            #  _overlap_hook), recomputes the same gradients, and the per-step status all-reduce of optimizer_step is issued by
+            #  every rank whatever schedule it ended up with)
+            return int(self.store["pipe_status"].item())
+        if status() == 0:
             return
         self.store["pipe_status"].zero_()
         self._dxp0_clean = False
         redo()
-        if int(self.store["pipe_status"].item()) != 0:
+        if status() != 0:
             import warnings
             warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers (status %d; call %r); falling "
                           "back to chunked launches (Engine.pipeline = False)" % (int(self.store["pipe_status"].item()), key))
@@ -1403,7 +1420,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def _train_step_begin(self, B, hist_fused):
         self._step_begin()
-        self._hist_fused = hist_fused
+        self._hist_fused = self._redo_hist = hist_fused
         try:
             self.encoder_forward(B, with_init=True)
         finally:
@@ -1415,8 +1432,15 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             return self._planned(("train_finish", B), lambda: self._train_step_finish(B, None))
         return self._train_step_finish(B, allreduce)
 
+    def _overlap_hook(self, allreduce):
+        """the hook whose decoder bucket is reduced beside the encoder BPTT - not on a step that may still be redone (the first
+        pipelined train step of an engine, _verify_pipeline): the redo zeroes and recomputes the gradients, which must not race a
+        collective already in flight on part of them; that one step reduces the whole buffer afterwards"""
+        unverified = self.pipeline and "train" not in self._pipe_verified
+        return allreduce if (getattr(allreduce, "overlap", False) and not unverified) else None
+
     def _train_step_finish(self, B, allreduce):
-        self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
+        self._bucket_hook = self._overlap_hook(allreduce)
         self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
             self.decoder_forward(B)
@@ -1437,7 +1461,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         return self._train_step(B, allreduce)
 
     def _train_step(self, B, allreduce):
-        self._bucket_hook = allreduce if getattr(allreduce, "overlap", False) else None
+        self._redo_hist = None
+        self._bucket_hook = self._overlap_hook(allreduce)
         try:
             self.forward_backward(B)
         finally:

@@ -103,13 +103,33 @@ class DeviceLatent(object):
             raise RuntimeError("the model's weights changed between encoder.predict(device=True) and the use of its result: the "
                                "history pre-pass must see the weights fit starts from (reference vae_training.py:795-809)")
 
-    def matches(self, X, n):
-        """is ``X`` (the notes input of a fit call) the window array this latent was requested for - or a prefix of it?"""
+    @staticmethod
+    def _same_array(A, A0, rows=None):
+        """the same memory, shape (up to a row prefix), dtype and strides - or both absent"""
+        if A is None or A0 is None:
+            return A is None and A0 is None
+        return (isinstance(A, np.ndarray) and isinstance(A0, np.ndarray) and A.shape[1:] == A0.shape[1:] and A.dtype == A0.dtype and
+                A.__array_interface__["data"][0] == A0.__array_interface__["data"][0] and A.strides == A0.strides and
+                (rows is None or A.shape[0] == rows))
+
+    def matches(self, X, n, I=None, Vel=None, Held=None):
+        """may a fit call on these arrays take its history out of its own encoder forward?  Only if they ARE the arrays this latent
+        was requested for (the pre-pass of the later minibatches and the first minibatch's own forward must encode what
+        encoder.predict was given: notes AND instrument / velocity / held rolls - ADVICE r03) and the view covers the WHOLE
+        root: a prefix view (H[:-1] with the next-notes head) would leave the root's last row unencoded but marked valid."""
         r = self._root()
-        X0 = r._arrays[0]
-        return (n == self.shape[0] and isinstance(X, np.ndarray) and isinstance(X0, np.ndarray) and X.shape[1:] == X0.shape[1:] and
-                X.dtype == X0.dtype and X.__array_interface__["data"][0] == X0.__array_interface__["data"][0] and
-                X.strides == X0.strides)
+        if r._arrays is None or n != self.shape[0] or self.shape[0] != r.shape[0]:
+            return False
+        X0, I0, Vel0, Held0 = r._arrays
+
+        def same(A, A0):
+            # the reference's packers build the encoder list and the autoencoder list separately (prepare_encoder_input_list /
+            # prepare_autoencoder_input_and_output_list, vae_definition.py:770-1045): X is passed through (same memory), the meta
+            # rolls are fresh copies - compared by content (a few MB per song)
+            if A is None or A0 is None:
+                return A is None and A0 is None
+            return self._same_array(A, A0) or (np.shape(A) == np.shape(A0) and np.array_equal(A, A0))
+        return self._same_array(X, X0, n) and same(I, I0) and same(Vel, Vel0) and same(Held, Held0)
 
     def mark_valid(self):
         r = self._root()
@@ -555,7 +575,7 @@ class Autoencoder(_ModelView):
         fused = None
         if lat is not None and lat.deferred:
             lat.check_version()
-            if dp is None and epochs == 1 and n > 0 and lat.matches(a["X"], n):
+            if dp is None and epochs == 1 and n > 0 and lat.matches(a["X"], n, a.get("I"), a.get("Vel"), a.get("Held")):
                 fused = lat
                 b0 = min(n, batch_size)
                 if n > b0:      # histories of the later minibatches: before the first update, forward only, chip-filling; their

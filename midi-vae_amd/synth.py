@@ -32,3 +32,19 @@ def to_reference_format(w, D=61, ID=16):
     I = np.zeros((w["i_idx"].shape[1], ID))
     I[np.arange(I.shape[0]), w["i_idx"][0]] = 1
     return X, X.copy(), int(w["c_idx"][0]), I, w["vel"].astype(np.float64), np.zeros((n, T))
+
+
+def elbo_inputs(cell, T, B, V, Z, C, seed=1234):
+    """The first ``B`` windows of bench.py's rank-0 inputs (make_windows with the bench's seed) and its initial parameters: what
+    both sides of bench.py's ELBO comparison start from - the engine directly, the float64 torch-CPU restatement
+    (oracle/torch_cpu.py elbo_trajectory) by importing this.  Data only, no arithmetic."""
+    from .layout import ModelSpec, init_params
+    spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=2, Ld=2)
+    w = make_windows(max(B, 256), T, 61, V, 16, C, Z, seed=seed, epsilon_std=spec.epsilon_std)
+    w = {k: v[:B] for k, v in w.items()}
+    return spec, w, init_params(spec, seed)
+
+
+def elbo_epsilon(step, B, Z, epsilon_std, seed=1234):
+    """the fresh draw of optimizer step ``step`` (seed s + step), already scaled"""
+    return (np.random.default_rng(seed + 1 + step).standard_normal((B, Z)) * epsilon_std).astype(np.float32)

@@ -347,23 +347,15 @@ def timed_sample(cell, T, B, V, Z, C, budget_s=15.0, threads=0):
                       % (cell, B, n_thr, Ts, T, dt, step_s, t8)}
 
 
-def elbo_inputs(cell, T, B, V, Z, C, seed=1234):
-    """The first ``B`` windows of bench.py's rank-0 inputs (synth.make_windows with the bench's seed) and its initial parameters:
-    what both sides of the ELBO comparison start from."""
-    import numpy as np
-
-    from midi_vae_amd.layout import ModelSpec, init_params
-    from midi_vae_amd.synth import make_windows
-    spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=2, Ld=2)
-    w = make_windows(max(B, 256), T, 61, V, 16, C, Z, seed=seed, epsilon_std=spec.epsilon_std)
-    w = {k: v[:B] for k, v in w.items()}
-    return spec, w, init_params(spec, seed)
+def elbo_inputs(*a, **k):
+    """data generator shared with bench.py's GPU leg (midi_vae_amd.synth.elbo_inputs: no arithmetic)"""
+    from midi_vae_amd.synth import elbo_inputs as f
+    return f(*a, **k)
 
 
-def elbo_epsilon(step, B, Z, epsilon_std, seed=1234):
-    """the fresh draw of optimizer step ``step`` (seed s + step), already scaled"""
-    import numpy as np
-    return (np.random.default_rng(seed + 1 + step).standard_normal((B, Z)) * epsilon_std).astype(np.float32)
+def elbo_epsilon(*a, **k):
+    from midi_vae_amd.synth import elbo_epsilon as f
+    return f(*a, **k)
 
 
 def elbo_trajectory(cell, T, B, V, Z, C, steps, threads=16):

@@ -59,7 +59,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     pairs = {"mvae_rnn_fwd_args": hl.RnnFwdArgs, "mvae_rnn_bwd_args": hl.RnnBwdArgs, "mvae_gemm_args": hl.GemmArgs,
              "mvae_head_args": hl.HeadArgs, "mvae_latent_fwd_args": hl.LatentFwdArgs, "mvae_latent_bwd_args": hl.LatentBwdArgs,
              "mvae_latent_chain_fwd_args": hl.LatentChainFwdArgs, "mvae_latent_chain_bwd_args": hl.LatentChainBwdArgs,
-             "mvae_prep_job": hl.PrepJob}
+             "mvae_prep_job": hl.PrepJob, "mvae_xpand_args": hl.XpandArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "midivae_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -76,3 +76,31 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert got[(cname, "sizeof")] == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_problem_arrays_of_the_multi_launches_are_plain_c_arrays():
+    """mvae_rnn_fwd_multi / mvae_rnn_bwd_multi / mvae_gemm_kstream_multi take arrays of the argument structs: the ctypes array
+    stride must be the C sizeof (no padding between problems), element i at i * sizeof"""
+    import ctypes
+    for cls in (hl.RnnFwdArgs, hl.RnnBwdArgs, hl.GemmArgs, hl.XpandArgs, hl.PrepJob):
+        arr = (cls * 3)()
+        assert ctypes.sizeof(arr) == 3 * ctypes.sizeof(cls)
+        assert ctypes.addressof(arr[2]) - ctypes.addressof(arr[0]) == 2 * ctypes.sizeof(cls)
+        assert ctypes.sizeof(cls) % 8 == 0, cls          # every struct holds pointers: 8-byte aligned, so arrays need no tail padding
+
+
+def test_integration_snippet_matches_the_header():
+    """INTEGRATION.md section 2 shows the binding a reference maintainer would write; its struct must be the header's (VERDICT r03:
+    the snippet had fallen 48 bytes behind).  The snippet's class definition is executed and compared with hiplib.RnnFwdArgs,
+    which test_ctypes_structs_match_the_header_layout pins to the header itself."""
+    import ctypes
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class RnnFwdArgs(C.Structure):"):]
+    block = block[:block.index("\nlib.mvae_rnn_fwd.restype")]
+    ns = {"C": ctypes}
+    exec(block, ns)
+    snip = ns["RnnFwdArgs"]
+    assert ctypes.sizeof(snip) == ctypes.sizeof(hl.RnnFwdArgs)
+    assert [(n, getattr(snip, n).offset) for n, _ in snip._fields_] == [(n, getattr(hl.RnnFwdArgs, n).offset) for n, _ in hl.RnnFwdArgs._fields_]
+    # the plan example names real entry points / fields
+    assert "mvae_plan_add_call" in text and hasattr(hl.RnnFwdArgs, "wait_value")

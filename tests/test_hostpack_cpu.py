@@ -113,3 +113,24 @@ def test_twohot_rows_to_two_index_rolls():
         assert lib.mvae_host_twohot_to_index_tm(X.ctypes.data, kind, n, T, K, K1, 0, n, o1.ctypes.data, o2.ctypes.data, Bp, 255,
                                                 C.byref(bad)) == hl.E_FORMAT
         assert bad.value == 5 * T + 3
+
+
+def test_default_pool_is_a_share_of_the_cores_this_process_may_use():
+    """one process per GPU under data parallelism: the packer pool is sized from the affinity mask divided by LOCAL_WORLD_SIZE
+    (8 ranks x 64 threads on a 256-thread host), never more than the share, never more than 64"""
+    import os
+    import subprocess
+    import sys
+    code = "import midi_vae_amd; from midi_vae_amd import hiplib as hl; print(hl.load().mvae_host_threads(-1))"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cores = len(os.sched_getaffinity(0))
+
+    def threads(**env):
+        e = dict(os.environ)
+        e.pop("LOCAL_WORLD_SIZE", None)
+        e.update(env)
+        return int(subprocess.check_output([sys.executable, "-c", code], env=e, cwd=root).decode().split()[-1])
+    alone, eight = threads(), threads(LOCAL_WORLD_SIZE="8")
+    assert 1 <= alone <= min(cores, 64)
+    assert 1 <= eight <= max(cores // 8, 1) or eight == 4 and cores // 8 >= 4
+    assert eight <= alone

@@ -116,7 +116,10 @@ def test_fit_halves_evaluate_encode_decode_are_replayable(cell):
     assert inf.plan_stats["replayed"] >= 6, inf.plan_stats
     for k, v in outs.items():
         for x in v[1:]:
-            np.testing.assert_array_equal(np.asarray(x), np.asarray(v[0]), err_msg=k)
+            if k == "eval":      # (the loss is a sum of f32 atomics over the rows: equal to the last bits, not bit for bit)
+                np.testing.assert_allclose(x, v[0], rtol=1e-6, err_msg=k)
+            else:
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(v[0]), err_msg=k)
 
 
 def test_reference_shipped_configuration_matches_the_oracle_and_replays():
