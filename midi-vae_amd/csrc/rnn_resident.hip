@@ -178,6 +178,9 @@ __device__ __forceinline__ s16x4 identity_fragment(int l) {
 __device__ __forceinline__ f32x4 widen4(s16x4 ident, u16x4 packed, f32x4 plus) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ident, __builtin_bit_cast(s16x4, packed), plus, 0, 0, 0);
 }
+#ifndef FWL_MFMA_WIDEN
+#define FWL_MFMA_WIDEN 0     /* LSTM forward, single-launch inference variants: tiles 1..3 start their accumulators at x through widen4 (48 VALU per step less) - measured SLOWER (const input, no saves: 2.01 vs 1.94 us per step: 12 more MFMAs on a pipe the step is already waiting for); the training variants (252 VGPRs) and the phase launches spill with it */
+#endif
 #ifndef BWL_E_TILE_FENCE
 #define BWL_E_TILE_FENCE 0
 #endif
@@ -645,7 +648,7 @@ struct lstm_group_map {
 #define LSTM_L_FIRST 12
 #endif
 
-template <int XMODE, int SAVE, int NA, int NV>
+template <int XMODE, int SAVE, int NA, int NV, bool WIDEN = false>
 __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, const unsigned bx) {
     constexpr int G = 4, GH = G * RH;
     constexpr int FPW = G * RNT * RS, NGRP = FPW / 4;
@@ -745,6 +748,7 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
     constexpr float K2 = 2.8853900817779268f;   // 2 / ln 2
     f32x4 accA[4], accB[4], hn = {0.f, 0.f, 0.f, 0.f};
     frag bq[3], lt[4];
+    const s16x4 ident = identity_fragment(l);   // (FWL_MFMA_WIDEN: x -> f32 accumulators on the matrix pipe)
     auto request_t = [&]() __attribute__((always_inline)) {      // T fragments into the idle accumulator set
 #pragma unroll
         for (int g = 0; g < 4; ++g) accB[g] = __builtin_bit_cast(f32x4, tsrc[(size_t)g * (RH / 16) * RS * 64]);
@@ -886,7 +890,8 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
                 // cannot: its x would have to be waited for at the very top of the step, behind the previous tail's stores.
                 if constexpr (n == 1) asm volatile("s_nop 3");     // the T fragments were MFMA operands a moment ago
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = unpack4(xq[n][g]);
+                for (int g = 0; g < 4; ++g)
+                    acc[g] = WIDEN ? widen4(ident, xq[n][g], f32x4{0.f, 0.f, 0.f, 0.f}) : unpack4(xq[n][g]);
             }
             static_for<0, 32>(SF_LAMBDA(slc) {
                 constexpr int sl = decltype(slc)::value;
@@ -966,7 +971,9 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
 }
 template <int XMODE, int SAVE, int NA, int NV>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_il_k(const mvae_rnn_fwd_args a) {
-    lstm_fwd_il_body<XMODE, SAVE, NA, NV>(a, blockIdx.x);
+    // (x -> accumulators through widen4 in the single-launch inference variants: the training variants sit at 252 VGPRs and the phase
+    //  launches' bodies share their registers with the dispatch - both spill with it)
+    lstm_fwd_il_body<XMODE, SAVE, NA, NV, FWL_MFMA_WIDEN && SAVE != SAVE_ALL>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1655,10 +1662,13 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
                 dg = dct * ig * (1.0f - gg * gg);
                 dc[n] = dct * fg;
             }
-            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (0 * 512 + n * 32))) = pack4(di);
-            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (1 * 512 + n * 32))) = pack4(df);
-            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (2 * 512 + n * 32))) = pack4(dg);
-            *reinterpret_cast<u16x4*>(dabuf + (da0 ^ (3 * 512 + n * 32))) = pack4(dO);
+            // (da0's 16-byte chunk index is < 32: the gate's 512 bytes never meet a set bit, so they are an instruction immediate
+            //  instead of an exclusive-or per store: 12 v_xor + 12 v_add per step less)
+            unsigned char* dan = dabuf + (da0 ^ (unsigned)(n * 32));
+            *reinterpret_cast<u16x4*>(dan + 0 * 512) = pack4(di);
+            *reinterpret_cast<u16x4*>(dan + 1 * 512) = pack4(df);
+            *reinterpret_cast<u16x4*>(dan + 2 * 512) = pack4(dg);
+            *reinterpret_cast<u16x4*>(dan + 3 * 512) = pack4(dO);
             if (n & 1) carry[n >> 1] = qs[n >> 1];      // c_{t-1} is the next step's c_t
 #if BWL_E_TILE_FENCE
             __builtin_amdgcn_sched_barrier(0);
@@ -1914,7 +1924,7 @@ __device__ __forceinline__ void gru_bwd_il_body(const mvae_rnn_bwd_args& a, cons
     };
     // 0.2 * [0 < y < 1] for two elements: med3(2^100 (y - y^2), 0, 0.2) as in dhard_sigmoid
     auto dhs2 = [&](f32x2 y) __attribute__((always_inline)) -> f32x2 {
-        const f32x2 sq = (y - y * y) * 0x1p100f;
+        const f32x2 sq = y_minus_y2(y) * 0x1p100f;       // (the negation as an operand modifier: hipcc emits two v_xor for y - y*y)
         return f32x2{__builtin_amdgcn_fmed3f(sq[0], 0.0f, 0.2f), __builtin_amdgcn_fmed3f(sq[1], 0.0f, 0.2f)};
     };
 #pragma unroll

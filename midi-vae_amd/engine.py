@@ -102,7 +102,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.multi_stream = True
         self._prefork = None
         self._branches_stay_forked = False
-        self.lean_sync = os.environ.get("MVAE_LEAN_SYNC", "1") == "1"     # fork / join with one packet on the critical queue
+        self.lean_sync = True            # fork / join with one packet on the critical queue (settled: r01 9.3 -> 8.86 ms; an attribute for tests)
         self._bucket_hook = None         # data parallel: dp.BucketedAllReduce of the running train_step
         self.s_comm = None               # ... and the stream its early bucket starts on (created on first use)
         self.status_allreduce = None     # data parallel: MAX of the pipeline status word over the ranks (dp.DataParallel)
@@ -121,7 +121,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "0")) or (16 if self.maxB <= 256 else 32 if self.maxB <= 512 else 64)
         while self.pipe_chunk > 16 and spec.T % self.pipe_chunk:
             self.pipe_chunk //= 2
-        self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
+        self.pipe_gemm_blocks = int(os.environ.get("MVAE_PIPE_GEMM_BLOCKS", "64"))       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
         # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:
         # 64 for LSTM, 48 for GRU.  (Round 1's kernel reloaded the panel per tile; decoder inference at 1024 windows was bound by it:
@@ -141,7 +141,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # kstream_wgs workgroups per GEMM: they wait beside the recurrences, one per CU (_kstream_ok: residency).
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "0")) or (24 if spec.cell == "GRU" else 32)   # (GRU: 3 GEMMs per layer)
-        self.kstream_singles = os.environ.get("MVAE_KSTREAM_SINGLES", "1") == "1"   # ... and the dU GEMM of a full-length single-layer encoder branch
+        self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
         self._n_side = 0                 # recurrences running beside the stack being scheduled (residency, _pipelined)
@@ -160,7 +160,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "1" if spec.cell == "GRU" else "0") == "1"
         self.index_dense_blocks = int(os.environ.get("MVAE_INDEX_DENSE_BLOCKS", "16"))
         self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
-        self.gate_side_heads = os.environ.get("MVAE_GATE_SIDE_HEADS", "1") == "1"   # (decoder_forward: counter instead of event)
+        self.gate_side_heads = True      # (settled r03_z: -0.03 ms)   # (decoder_forward: counter instead of event)
         self._last_stack_gate = None
         # (_head_forward: inference on per-queue pipelined stacks.  profiles/r03_zz_decode_head_slices.txt: decode configs[4] LSTM
         #  -3..5 % with 2 slices, -1..3 % with 4; GRU -3 % / -6..7 %: the slices take memory bandwidth from the recurrences they follow)
@@ -169,9 +169,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # (_join; r03_z: -0.02 / -0.04 ms.  NOT when kernels are run one at a time - rocprofv3 counter collection: a critical queue parked
         #  in a value wait and a writer queue held back behind it never finish; event joins work there)
         serial = getattr(self, "_serial_queues", False) or (share is not None and getattr(share, "_serial_queues", False))
-        self.value_join = os.environ.get("MVAE_VALUE_JOIN", "1") == "1" and not serial and len(self.s_proj) > 0     # (no stacked layer: no probe was run)
+        self.value_join = not serial and len(self.s_proj) > 0     # (no stacked layer: no probe was run)
         self._join_seq = {}
-        self._hold_dec_grads = int(os.environ.get("MVAE_HOLD_DEC_GRADS", "1"))     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
+        self._diag_no_param_grads = os.environ.get("MVAE_DIAG_NO_PARAM_GRADS", "0") == "1"
+        self._hold_dec_grads = 1     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
         if share is None:
@@ -869,6 +870,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         of a phase launch that is still RUNNING - the gradient queues wait, on the device, for the layer's last published chunk
         of da instead of for the whole launch.  (No event: the launch sits on the critical queue behind everything the gradient
         work reads, so its first published chunk implies all of that; an event record would be one more packet there.)"""
+        if self._diag_no_param_grads:       # (MVAE_DIAG_NO_PARAM_GRADS=1, timing experiments only: the gradients are WRONG)
+            return
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
         R = T * B

@@ -84,7 +84,8 @@ class PlannedSteps(object):
     def _planned(self, kind, fn):
         """run ``fn`` (the Python enqueue of one call of kind ``kind``, a hashable that names everything the launch list depends
         on besides the engine's state) - or, once three recordings of it agreed, replay its plan"""
-        if (not self.use_plans or self.prof is not None or getattr(self, "marks", None) is not None or
+        profiling = self.prof is not None and (self.prof_kinds is None or len(self.prof_kinds) > 0)      # (launches get bracketed)
+        if (not self.use_plans or profiling or getattr(self, "marks", None) is not None or
                 _plan.active() is not None or self._hist_fused is not None):
             return fn()
         self._ev_i = 0

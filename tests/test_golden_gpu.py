@@ -69,16 +69,25 @@ def test_golden_lists_through_evaluate_fit_and_decode_equal_the_oracle(golden, d
     spec = m.spec
     assert (spec.T, spec.Z, spec.cell) == (64, 256, "GRU")            # the reference's shipped settings
     orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
-    p = {k: v.astype(np.float64) for k, v in init_params(spec, 11).items()}
+    # Untrained, the decoder's cells relax to h = 0 and every softmax is uniform to 1e-8 (median top-2 gap 9e-9 measured): an
+    # argmax comparison would test rounding noise.  Non-zero biases and larger output kernels make the outputs decisive.
+    rng = np.random.default_rng(5)
+    named = init_params(spec, 11)
+    for k in named:
+        if k.endswith(".b"):
+            named[k] = (rng.standard_normal(named[k].shape) * 0.2).astype(np.float32)
+        if k.endswith(".out.W"):
+            named[k] = (named[k] * 8.0).astype(np.float32)
+    m._shared.set_params(named)
+    p = {k: v.astype(np.float64) for k, v in named.items()}
     batch = dict(X=x[0], Hist=x[2], I=x[4], Vel=x[6], Y=y[0], C=y[3], w_notes=w[0])
     eps = np.zeros((n, spec.Z))
     m_o, cache = orc.forward(p, batch, eps)
     # evaluate: [total, notes, instrument, velocity, style losses, accuracies...] (Keras metrics_names order)
-    res = dict(zip(m.autoencoder.metrics_names, m.autoencoder.evaluate(x, y, batch_size=8, verbose=False)))
-    assert abs(res["loss"] - m_o["loss"]) <= 2e-4 * (1 + abs(m_o["loss"])), (res["loss"], m_o["loss"])
-    for a, b in (("decoder_loss_1", "notes_loss"), ("decoder_loss_2", "instr_loss"), ("decoder_loss_3", "vel_loss"),
-                 ("composer_decoder_loss", "style_loss")):
-        assert abs(res[a] - m_o[b]) <= 2e-4 * (1 + abs(m_o[b])), (a, res[a], m_o[b])
+    res = m.autoencoder.evaluate(x, y, batch_size=8, verbose=False)
+    assert m.autoencoder.metrics_names[:5] == ["loss", "decoder_loss", "decoder_loss", "decoder_loss", "composer_decoder_loss"]
+    for i, b in enumerate(("loss", "notes_loss", "instr_loss", "vel_loss", "style_loss")):
+        assert abs(res[i] - m_o[b]) <= 2e-4 * (1 + abs(m_o[b])), (i, b, res[i], m_o[b])
     # decoder.predict on the lists' decoder inputs -> the reference's post-processing == the same applied to the oracle's outputs
     dec_in = [g["dec_in_autoH_%d" % i] for i in range(int(g["dec_in_n"]))]
     outs = m.decoder.predict(dec_in, batch_size=8)
@@ -90,6 +99,8 @@ def test_golden_lists_through_evaluate_fit_and_decode_equal_the_oracle(golden, d
             np.testing.assert_allclose(a, b, atol=2e-5, err_msg=name)
         else:
             np.testing.assert_array_equal(a, b, err_msg=name)
+    srt = np.sort(o_out["notes"], -1)
+    assert (srt[..., -1] - srt[..., -2]).min() > 1e-5, "the oracle's outputs are not decisive enough to compare an argmax in f32"
     idx = m.decoder.predict_note_indices(dec_in, batch_size=8)
     np.testing.assert_array_equal(idx, np.argmax(o_out["notes"], -1))
     # one fit on the lists (Keras Adam) == the oracle's train step

@@ -45,8 +45,11 @@ def test_replayed_train_steps_equal_the_python_enqueue(cell, H, T, dtype):
     (la, pa), (lb, pb) = losses[False], losses[True]
     # (the gradient GEMMs reduce with f32 atomics: two runs of the SAME enqueue differ in the last bits, so not bit-identical)
     np.testing.assert_allclose(lb, la, rtol=2e-5, atol=2e-6)
+    # parameters: per tensor, the two runs' 8-step updates agree to a few percent in L2 (Keras Adam turns the sign of a gradient
+    # element that is rounding noise into a full +-lr step, so single elements may differ by what two runs of the same enqueue do)
     for k in pa:
-        assert np.abs(pa[k] - pb[k]).max() <= 1e-4 + 2e-2 * np.abs(pa[k] - params[k]).max(), k
+        upd = np.linalg.norm(pa[k] - params[k])
+        assert np.linalg.norm(pa[k] - pb[k]) <= 5e-2 * upd + 1e-6, (k, np.linalg.norm(pa[k] - pb[k]), upd)
 
 
 def test_replays_and_python_steps_alternate_on_one_engine():
