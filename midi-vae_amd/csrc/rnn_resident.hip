@@ -181,6 +181,12 @@ __device__ __forceinline__ f32x4 widen4(s16x4 ident, u16x4 packed, f32x4 plus) {
 #ifndef FWL_MFMA_WIDEN
 #define FWL_MFMA_WIDEN 0     /* LSTM forward, single-launch inference variants: tiles 1..3 start their accumulators at x through widen4 (48 VALU per step less) - measured SLOWER (const input, no saves: 2.01 vs 1.94 us per step: 12 more MFMAs on a pipe the step is already waiting for); the training variants (252 VGPRs) and the phase launches spill with it */
 #endif
+#ifndef BWL_ASM_1MSQ
+#define BWL_ASM_1MSQ 1
+#endif
+#ifndef BWL_MFMA_FIRST
+#define BWL_MFMA_FIRST 0      /* C = 0 inline in the first MFMA of each chain instead of zeroed accumulators: 8 v_mov_b64 less, but 2.78 vs 2.71 us per step (profiles/r04_h_bptt_ab.txt) */
+#endif
 #ifndef BWL_E_TILE_FENCE
 #define BWL_E_TILE_FENCE 0
 #endif
@@ -193,6 +199,16 @@ __device__ __forceinline__ f32x2 y_minus_y2(f32x2 y) {
     f32x2 t;
     asm("v_pk_fma_f32 %0, %1, %1, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(t) : "v"(y));
     return t;
+}
+// 1 - y^2 for two elements with the negation as an operand modifier (hipcc: two v_xor + v_pk_fma)
+__device__ __forceinline__ f32x2 one_minus_sq(f32x2 y) {
+    f32x2 t;
+    asm("v_pk_fma_f32 %0, %1, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(t) : "v"(y));
+    return t;
+}
+__device__ __forceinline__ f32x4 one_minus_sq4(f32x4 y) {
+    const f32x2 a = one_minus_sq(lo_hi<0>(y)), b = one_minus_sq(lo_hi<2>(y));
+    return f32x4{a[0], a[1], b[0], b[1]};
 }
 __device__ __forceinline__ f32x4 sat4(f32x4 y) {
     const f32x2 a = y_minus_y2(lo_hi<0>(y)), b = y_minus_y2(lo_hi<2>(y));
@@ -606,6 +622,11 @@ template <bool AG>
 __device__ __forceinline__ void mfma1(f32x4& c, const frag& u, const frag& b) {
     if (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(u), "v"(b));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(u), "v"(b));
+}
+// the first MFMA of an accumulation chain: C = 0 as the instruction's inline constant instead of a zeroed register quad
+// (round 4: 8 v_mov_b64 per step and four registers of zeros less in the LSTM BPTT kernel)
+__device__ __forceinline__ void mfma1_first(f32x4& c, const frag& u, const frag& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(u), "v"(b));
 }
 __device__ __forceinline__ void pinv(f32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pinq(frag& v) { asm volatile("" : "+v"(v)); }
@@ -1648,7 +1669,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
             if (ABL_NOMATH) { di = d; df = d; dg = d; dO = d; dc[n] = d; }     // (timing ablation: the E phase without its arithmetic)
             else {
                 const f32x4 tc = tanh_fast4(c);
-                const f32x4 dct = dc[n] + d * og * (1.0f - tc * tc);
+                const f32x4 dct = dc[n] + d * og * (BWL_ASM_1MSQ ? one_minus_sq4(tc) : 1.0f - tc * tc);
 #if BWL_OLD_DHS
                 di = dct * (gg * dhard_sigmoid4(ig));
                 df = dct * (cp * dhard_sigmoid4(fg));
@@ -1659,7 +1680,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
                 df = (dctK * cp) * sat4(fg);
                 dO = (dK * tc) * sat4(og);
 #endif
-                dg = dct * ig * (1.0f - gg * gg);
+                dg = dct * ig * (BWL_ASM_1MSQ ? one_minus_sq4(gg) : 1.0f - gg * gg);
                 dc[n] = dct * fg;
             }
             // (da0's 16-byte chunk index is < 32: the gate's 512 bytes never meet a set bit, so they are an instruction immediate
@@ -1683,15 +1704,22 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
 
         // ---- M -------------------------------------------------------------------------------------------------
         f32x4 acc[RNT];
+#if !BWL_MFMA_FIRST
 #pragma unroll
         for (int n = 0; n < RNT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         bq[0] = *reinterpret_cast<const frag*>(dabuf + bb0);
         static_for<0, FPW>(SF_LAMBDA(sc) {
             constexpr int sl = decltype(sc)::value, gi = sl >> 2, n = sl & 3, ci = sl - NT;
             if constexpr (n == 0 && gi + 1 < S2 && !(ABL_NOB && gi >= 1))
                 bq[(gi + 1) & 1] = *reinterpret_cast<const frag*>(dabuf + (bb0 ^ (((gi + 1) & 3) << 6)) + 256 * ((gi + 1) >> 2));
+#if BWL_MFMA_FIRST
+            if constexpr (sl == 0) asm volatile("s_nop 1");
+            if constexpr (sl < NT) mfma1_first(acc[n], lt[n], bq[gi & 1]);       // (the accumulators start here: C = 0 inline)
+#else
             if constexpr (sl == 0) asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
             if constexpr (sl < NT) mfma1<false>(acc[n], lt[n], bq[gi & 1]);
+#endif
             else if constexpr (ci < NA) mfma1<true>(acc[n], ua[ci < NA ? ci : 0], bq[gi & 1]);
             else if constexpr (ci < NA + NV) mfma1<false>(acc[n], uv[(ci >= NA && ci < NA + NV) ? ci - NA : 0], bq[gi & 1]);
             else mfma1<false>(acc[n], lt[n], bq[gi & 1]);
