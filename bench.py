@@ -259,6 +259,9 @@ def main():
                     help="N>1: reduce the decoder gradient bucket beside the encoder BPTT (dp.BucketedAllReduce); -1 = the product "
                          "policy (dp.DataParallel: on with RCCL and more than one rank)")
     ap.add_argument("--chunks", type=int, default=0, help="time chunks of the stacked-layer pipeline (0 = engine default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo: two ranks on ONE GPU in tests/test_dp_gpu.py)")
+    ap.add_argument("--hidden", type=int, default=256, help="(tests) cell width")
     args = ap.parse_args()
     if args.cell is None:
         args.cell = "GRU" if args.config == 0 else "LSTM"
@@ -275,6 +278,8 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.backend == "gloo":
+        local = 0                      # (test mode: every rank on the one GPU of the box)
     torch.cuda.set_device(local)
     dist = None
     # MVAE_BENCH_FORCE_DIST=1: go through RCCL even with one rank (checks the collective path on a 1-GPU box)
@@ -282,13 +287,16 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     seq, voices, latent, C, B, mode, named_batch, named_gpus = CONFIGS[args.config]
     seq, voices, latent, B = args.seq_len or seq, args.voices or voices, args.latent or latent, args.batch or B
     T = seq * voices
     decode = mode == "decode"
-    spec = ModelSpec(cell=args.cell, H=256, Z=latent, Din=61, Dout=61, T=T, V=voices, ID=16, C=C, Le=2, Ld=2)
+    spec = ModelSpec(cell=args.cell, H=args.hidden, Z=latent, Din=61, Dout=61, T=T, V=voices, ID=16, C=C, Le=2, Ld=2)
     device = "cuda:%d" % local
     # the CPU legs FIRST (rank 0, N=1 only): the GPU phase then runs last, undisturbed, and an idle-GPU sampler watching the
     # process sees the GPU busy at the end of the run rather than idle
@@ -404,7 +412,13 @@ def main():
             t = torch.tensor([sum(ms) / len(ms) if ms else -1.0], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ar[tag] = float(t.item()) if float(t.item()) >= 0 else None
-        dp_stats = {"rccl_ranks": dist.get_world_size(), "backend": str(dist.get_backend()),
+        # every rank started from the same parameters and applied the same all-reduced gradients: the replicas must be identical
+        pmax = eng.params.clone()
+        pmin = eng.params.clone()
+        dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pmin, op=dist.ReduceOp.MIN)
+        replica_diff = float((pmax - pmin).abs().max().item())
+        dp_stats = {"rccl_ranks": dist.get_world_size(), "backend": str(dist.get_backend()), "replicas_max_abs_diff": replica_diff,
                     "rank_median_ms_per_step": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
                     "allreduce_ms": {"early_decoder_bucket": ar["early"], "late": ar["late"],
                                      "what": "HIP-event time of the collectives on their streams, mean over the timed steps, max "

@@ -54,3 +54,36 @@ def test_bucketed_allreduce_beside_the_encoder_bptt(one_rank_rccl, cell):
         for a, b in zip(losses[mode], losses["none"]):
             assert abs(a - b) <= 2e-3 * (1 + abs(b)), losses
     assert losses["bucketed"][2] < losses["bucketed"][0]
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_bench_dp_code_path_on_two_ranks_keeps_the_replicas_identical(overlap, tmp_path):
+    """bench.py's own data-parallel path - make_allreduce / BucketedAllReduce with and without the early decoder bucket, the
+    per-rank statistics, the collective timings - as the driver launches it (python -m torch.distributed.run, one process per
+    rank), on TWO ranks sharing the one GPU of the test box over gloo, at a tiny shape: every rank trains on its own windows,
+    the gradients are averaged, so after the run the parameters of the two replicas must be IDENTICAL.
+    MVAE_PIPELINE=0: two processes on one GPU cannot keep a time-pipelined stack's kernels resident together."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MVAE_PIPELINE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--hidden", "64", "--seq-len", "8", "--voices", "2", "--latent", "16", "--batch", "16", "--prewarm-max", "0",
+           "--no-cpu-baseline", "--dp-overlap", str(overlap)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_batch"] == 32
+    dp = line["dp"]
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["overlap"] == bool(overlap)
+    assert dp["replicas_max_abs_diff"] == 0.0, dp
+    assert dp["rank_median_ms_per_step"]["min"] <= dp["rank_median_ms_per_step"]["max"]
+    assert dp["allreduce_ms"]["late"] is not None and (dp["allreduce_ms"]["early_decoder_bucket"] is not None) == bool(overlap)
+    assert np.isfinite(line["elbo"]["loss_final"])
