@@ -150,6 +150,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._occ = {k: max(1, hl.load().mvae_occupancy(i)) for i, k in enumerate(("dx", "proj", "kstream"))}
         self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
         self._redo_hist = None           # ... kept until the step is verified (_redo_step)
+        self._fused_dst = None           # (caller's rows, engine buffer) of a fused pre-pass whose z' is still to be handed over
         # the recurrences of a phase as ONE launch on the critical queue instead of one launch per queue (engine_phases.py)
         self.phase_multi = os.environ.get("MVAE_PHASE_MULTI", "1") == "1"
         # ... up to this many (padded) windows per call: measured (profiles/r03_j_*) 256 windows -6 % (LSTM) / -9 % (GRU) per train
@@ -1419,7 +1420,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         Only for a minibatch that starts at window 0 of its song."""
         if hist_fused is None:
             return self._planned(("train_begin", B), lambda: self._train_step_begin(B, None))
-        return self._train_step_begin(B, hist_fused)
+        # z' goes to a fixed engine buffer - the launch list then holds no per-song address and the step replays as a plan like
+        # any other - and to the caller's rows by one copy behind the step (train_step_finish)
+        eps2, z_dst = hist_fused
+        zbuf = self._v("hist_zout", self.pad16(B), self.spec.Z)
+        self._fused_dst = (z_dst, zbuf)
+        return self._planned(("train_begin_fused", B, eps2.data_ptr()), lambda: self._train_step_begin(B, (eps2, zbuf)))
 
     def _train_step_begin(self, B, hist_fused):
         self._step_begin()
@@ -1431,9 +1437,14 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def train_step_finish(self, B, allreduce=None):
         """the rest of the step; without a gradient hook (single GPU) it is one replayable call (engine_plan.py)"""
-        if allreduce is None:
-            return self._planned(("train_finish", B), lambda: self._train_step_finish(B, None))
-        return self._train_step_finish(B, allreduce)
+        try:
+            if allreduce is None:
+                return self._planned(("train_finish", B), lambda: self._train_step_finish(B, None))
+            return self._train_step_finish(B, allreduce)
+        finally:
+            if self._fused_dst is not None:          # (behind a possible redo of the step: the rows are final here)
+                (z_dst, zbuf), self._fused_dst = self._fused_dst, None
+                z_dst.copy_(zbuf[:z_dst.shape[0]])
 
     def _overlap_hook(self, allreduce):
         """the hook whose decoder bucket is reduced beside the encoder BPTT - not on a step that may still be redone (the first

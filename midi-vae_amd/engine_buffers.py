@@ -133,6 +133,9 @@ class Buffers(object):
         st["sync"] = torch.zeros(12 * 1024, dtype=torch.int32, device=dev)     # (6.. : single-layer problems of a phase launch)
         words = torch.zeros(2, dtype=torch.int32, device=dev)     # [live status of the running step, latched status since the last check]
         st["join_words"] = torch.zeros(8, dtype=torch.int32, device=dev)       # (Engine._join, MVAE_VALUE_JOIN)
+        # z' of a fused history pre-pass lands here (a FIXED address: the step is then a replayable plan) and is copied to the
+        # caller's rows afterwards (Engine.train_step_begin hist_fused)
+        st["hist_zout"] = torch.zeros(B * getattr(self.spec, "Z", 0) if self.training else 0, dtype=torch.float32, device=dev)
         st["pipe_words"], st["pipe_status"], st["pipe_latched"] = words, words[0:1], words[1:2]
         for r in self.all_rec:
             p = r.prefix

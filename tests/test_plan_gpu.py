@@ -164,3 +164,39 @@ def test_reference_shipped_configuration_matches_the_oracle_and_replays():
                     assert np.linalg.norm(got[k].astype(np.float64) - p[k]) <= 8e-2 * np.linalg.norm(d) + 1e-7, k
     eng2.check_pipeline()
     assert eng2.plan_stats["replayed"] >= 2, eng2.plan_stats
+
+
+def test_fused_history_prepass_steps_replay(monkeypatch):
+    """the reference's loop on songs of one minibatch (vae_training.py:788-809: encoder.predict, roll, fit) with the history
+    pre-pass fused into the train step: z' lands in a fixed engine buffer, so these steps are plans too - same histories and
+    weights as the Python enqueue, song after song"""
+    from midi_vae_amd import packers as pk
+    from midi_vae_amd.config import build_settings, create_kwargs
+    from midi_vae_amd.model import VAE
+    from midi_vae_amd.synth import make_windows, to_reference_format
+    s = build_settings(cell_type="GRU", lstm_size=256, latent_dim=32, input_length=8, output_length=8, batch_size=16,
+                       learning_rate=1e-3)
+    n = 16
+    songs = []
+    for i in range(7):
+        w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=20 + i)
+        songs.append(to_reference_format(w))
+    res = {}
+    for plans in ("0", "1"):
+        monkeypatch.setenv("MVAE_PLANS", plans)
+        m = VAE().create(compute_dtype="bf16", seed=2, **create_kwargs(s))
+        losses = []
+        for (X, Y, C, I, V, D) in songs:
+            H = m.encoder.predict(pk.prepare_encoder_input_list(s, X, I, V, D), batch_size=16, device=True)
+            x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, np.zeros((n, s["signature_vector_length"])), H,
+                                                                    return_sample_weight=True)
+            h = m.autoencoder.fit(x, y, epochs=1, batch_size=16, shuffle=False, sample_weight=sw, verbose=False)
+            losses.append(h.history["loss"][0])
+            assert np.all(np.isfinite(H.latent()))          # z' of the fused pre-pass reached the caller's rows
+        eng = m._shared.engine
+        eng.check_pipeline()
+        res[plans] = (losses, m.autoencoder.get_weights(), dict(eng.plan_stats))
+    assert res["0"][2]["replayed"] == 0 and res["1"][2]["replayed"] >= 4, (res["0"][2], res["1"][2])
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=3e-5, atol=3e-6)
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert np.linalg.norm(a - b) <= 5e-2 * np.linalg.norm(a) * 1e-2 + 1e-4, np.linalg.norm(a - b)

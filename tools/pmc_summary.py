@@ -25,7 +25,9 @@ for k in kernels:
     print("  MFMA pipe busy                     %8.1f %% of wave cycles" % (100 * mf / (wc * 4)))
     print("  issue: active %4.1f %%  wait-inst %4.1f %%  wait-any (s_waitcnt/barrier) %4.1f %%" % (
         100 * m(k, "SQ_ACTIVE_INST_ANY") / wc, 100 * m(k, "SQ_WAIT_INST_ANY") / wc, 100 * m(k, "SQ_WAIT_ANY") / wc))
-    print("  per wave per step: MFMA %.0f  VALU %.0f  LDS %.0f  VMEM %.0f" % tuple(
-        m(k, c) / waves / T for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")))
+    # SQ_INSTS_VALU counts the MFMAs too (they are VALU-encoded): the other vector instructions are the difference
+    n_mfma, n_valu, n_lds, n_vmem = (m(k, c) / waves / T for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM"))
+    print("  per wave per step: MFMA %.0f  other VALU %.0f (SQ_INSTS_VALU %.0f includes the MFMAs)  LDS %.0f  VMEM %.0f" % (
+        n_mfma, n_valu - n_mfma, n_valu, n_lds, n_vmem))
     print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (
         2 * m(k, "FETCH_SIZE") * 1024 / 1e6, written_mb(k)))
