@@ -86,4 +86,5 @@ def test_bench_dp_code_path_on_two_ranks_keeps_the_replicas_identical(overlap, t
     assert dp["replicas_max_abs_diff"] == 0.0, dp
     assert dp["rank_median_ms_per_step"]["min"] <= dp["rank_median_ms_per_step"]["max"]
     assert dp["allreduce_ms"]["late"] is not None and (dp["allreduce_ms"]["early_decoder_bucket"] is not None) == bool(overlap)
-    assert np.isfinite(line["elbo"]["loss_final"])
+    import math
+    assert math.isfinite(line["elbo"]["loss_final"])
