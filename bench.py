@@ -458,10 +458,10 @@ def main():
         us_fwd = sum(n * ms for n, ms, _ in fwdk) * 1e3 / max(sum(n * st for n, _, st in fwdk), 1) * lpl if fwdk else float("nan")
         ms_step = elapsed / args.steps * 1e3
         # HBM traffic of the dominant kernel from the PMC counters: bench.py cannot run a counter pass over itself, so the pass over
-        # THIS command (tools/collect_profiles_r03.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
+        # THIS command (tools/collect_profiles_r04.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950) is committed as profiles/<round>_bench_traffic.json and embedded
         traffic, traffic_src = None, None
-        for tf in ("r03_bench_traffic.json", "r02_bench_traffic.json"):
+        for tf in ("r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"):
             tf = os.path.join(ROOT, "profiles", tf)
             if traffic is None and os.path.exists(tf) and not decode:
                 try:

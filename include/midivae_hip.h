@@ -61,6 +61,7 @@ enum {
  *                   As a seq_layout it means: xp and dhs_ext TILE16, the saved activations (acts, cs) TILE16P - the
  *                   layout the slot-interleaved LSTM / GRU kernels use; forward and backward of a layer must agree. */
 enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1, MVAE_TILE16P = 2 };
+enum { MVAE_TABLE_ROWMAJOR = 0, MVAE_TABLE_PAIRED = 1 };       /* lookup tables of one-hot input layers (mvae_rnn_fwd_args.table_layout) */
 
 int mvae_abi_version(void);
 /* human-readable build string (arch, compile date) */
@@ -109,6 +110,11 @@ typedef struct {
                               MVAE_TILE16P.  The tiled layouts need B % 16 == 0 and select the resident-weights kernels
                               (H=256, bf16): TILE16 the phased ones, TILE16P the slot-interleaved ones (LSTM, GRU; not
                               for MVAE_X_SCALAR inputs)                                                            */
+    int32_t table_layout;  /* MVAE_X_INDEX: MVAE_TABLE_ROWMAJOR (0), or MVAE_TABLE_PAIRED (1: MVAE_PREP_MAKE_TABLE with c = 1) -
+                              what the slot-interleaved LSTM kernel (MVAE_LSTM, MVAE_TILE16P) REQUIRES: one lane's values of two
+                              neighbouring unit tiles are 16 contiguous bytes, 8 gathers per row and step instead of 16
+                              (a memory instruction costs the CU's address unit the same whatever its width); every other
+                              kernel takes the row-major table                                                          */
 } mvae_rnn_fwd_args;
 int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream);
 
@@ -368,7 +374,8 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
 /* Every derived copy of the parameters a step needs, in ONE launch (25 tiny dependent kernels cost 0.3 - 0.8 ms of queue
  * latency per training step otherwise).  Each job is one of the single calls above:
  *   MVAE_PREP_PACK_RECURRENT   src = U (a=H, b=G*H) f32, c = direction        -> dst as mvae_pack_recurrent(kind)
- *   MVAE_PREP_MAKE_TABLE       src = W (a=K, b=N), src2 = bias (N)            -> dst (K, N) kind     (mvae_make_table)
+ *   MVAE_PREP_MAKE_TABLE       src = W (a=K, b=N), src2 = bias (N), c = layout -> dst (K, N) kind    (mvae_make_table; c = 1:
+ *                              MVAE_TABLE_PAIRED, see mvae_rnn_fwd_args.table_layout)
  *   MVAE_PREP_TRANSPOSE_CONVERT src = W (a=K, b=N), c = N_pad                 -> dst (N_pad, K) kind (mvae_transpose_convert)
  *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)
  *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros

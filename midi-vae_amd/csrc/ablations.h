@@ -11,7 +11,7 @@
 //   GEMM_ABL_NOMFMA / NOLOAD / NOATOMIC                            the fast GEMM without its MFMAs / global loads / atomics
 //   WS_ABL_NOSTORE / NOLOAD / NOMFMA                               proj_ws_k without its epilogue stores / A requests / MFMAs
 #pragma once
-#define MVAE_ABL_LIST(X) X(ABL_NOL) X(ABL_NOTRG) X(ABL_NOSAVE) X(ABL_NOX) X(ABL_NOMATH) X(ABL_NOBAR) X(ABL_NOB) X(ABL_NOTRANS) X(ABL_FILL) \
+#define MVAE_ABL_LIST(X) X(ABL_NOL) X(ABL_NOTRG) X(ABL_NOSAVE) X(ABL_NOX) X(ABL_NOMATH) X(ABL_NOBAR) X(ABL_NOB) X(ABL_NOTRANS) X(ABL_FILL) X(ABL_NOBAR1) X(ABL_NOBAR2) \
     X(GEMM_ABL_NOMFMA) X(GEMM_ABL_NOLOAD) X(GEMM_ABL_NOATOMIC) X(WS_ABL_NOSTORE) X(WS_ABL_NOLOAD) X(WS_ABL_NOMFMA)
 #ifndef ABL_NOL
 #define ABL_NOL 0
@@ -36,6 +36,12 @@
 #endif
 #ifndef ABL_NOTRANS
 #define ABL_NOTRANS 0
+#endif
+#ifndef ABL_NOBAR1
+#define ABL_NOBAR1 0      /* LSTM BPTT: without the barrier between the gate phase and the MFMA phase */
+#endif
+#ifndef ABL_NOBAR2
+#define ABL_NOBAR2 0      /* ... without the barrier at the end of the step */
 #endif
 #ifndef ABL_FILL
 #define ABL_FILL 0

@@ -304,10 +304,17 @@ __device__ __forceinline__ void pack_recurrent_body(const float* __restrict__ U,
     }
 }
 template <typename D>
-__device__ __forceinline__ void make_table_body(const float* W, const float* bias, D* table, int K, int N, int bid, int nb) {
+__device__ __forceinline__ void make_table_body(const float* W, const float* bias, D* table, int K, int N, int bid, int nb,
+                                                int paired = 0) {
+    // paired (MVAE_TABLE_PAIRED; N % 32 == 0): inside every block of 32 columns the two 16-column tiles are interleaved per lane -
+    // column 16 h + 4 q + e sits at 8 q + 4 h + e - so that one lane's values of a tile PAIR are 16 contiguous bytes (bf16): the
+    // indexed-input LSTM kernel gathers 8 x 16 bytes per row and step instead of 16 x 8
     const size_t n = (size_t)K * N;
-    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x)
-        st<D>::store(table + e, W[e] + bias[e % N]);
+    for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
+        const int c = (int)(e % N);
+        const int cp = paired ? (c & ~31) + ((c & 15) >> 2) * 8 + ((c >> 4) & 1) * 4 + (c & 3) : c;
+        st<D>::store(table + (e - c) + cp, W[e] + bias[c]);
+    }
 }
 template <typename D>
 __device__ __forceinline__ void transpose_convert_body(const float* W, D* out, int K, int N, int NPAD, int bid, int nb) {

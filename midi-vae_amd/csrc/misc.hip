@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void prepare_batch_k(const prep_batch pb) {
             else pack_recurrent_body<float>(src, reinterpret_cast<float*>(job.dst), job.a, job.b, job.c, bid, nb);
             break;
         case MVAE_PREP_MAKE_TABLE:
-            if (bf) make_table_body<bf16_t>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, bid, nb);
-            else make_table_body<float>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<float*>(job.dst), job.a, job.b, bid, nb);
+            if (bf) make_table_body<bf16_t>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, bid, nb, job.c);
+            else make_table_body<float>(src, reinterpret_cast<const float*>(job.src2), reinterpret_cast<float*>(job.dst), job.a, job.b, bid, nb, job.c);
             break;
         case MVAE_PREP_TRANSPOSE_CONVERT:
             if (bf) transpose_convert_body<bf16_t>(src, reinterpret_cast<bf16_t*>(job.dst), job.a, job.b, job.c, bid, nb);

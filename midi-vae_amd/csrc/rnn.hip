@@ -529,6 +529,7 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
         if (rc != MVAE_E_UNSUPPORTED) return rc;
     }
     if (a->seq_layout != MVAE_ROWMAJOR) return MVAE_E_UNSUPPORTED;   // the generic kernels are row-major only
+    if (a->xmode == MVAE_X_INDEX && a->table_layout != MVAE_TABLE_ROWMAJOR) return MVAE_E_ARG;     // ... and so are their lookup tables
     if (a->dtype == MVAE_F32) return fwd_cell<float>(*a, s);
     if (a->dtype == MVAE_BF16) return fwd_cell<bf16_t>(*a, s);
     return MVAE_E_ARG;

@@ -282,6 +282,7 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
 #define RES_NOHOOK(gi)
 
 enum { SAVE_NONE = 0, SAVE_HS = 1, SAVE_ALL = 2 };
+__device__ __forceinline__ int t_next2(int t, int T) { return t + 2 < T ? t + 2 : T - 1; }
 // Wave skew (round 4): the four waves of a workgroup leave every barrier together and run the same instruction stream, so their
 // memory instructions reach the CU's one address unit (and their LDS accesses the LDS) in the same cycles and queue behind each
 // other.  Wave w idles RES_WSKEW x 16 x w cycles behind the barrier that opens a memory-heavy phase: the streams stay de-phased
@@ -747,7 +748,9 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
         xoff = lane8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w * RNT) * 512;
     } else if (XMODE == MVAE_X_INDEX) {
-        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
+        // MVAE_TABLE_PAIRED (round 4): the lane's values of tiles 2j and 2j+1 are 16 contiguous bytes of the row - 8 gathers per
+        // step instead of 16 (a gather touches 16 table rows whatever its width: it is the instruction count that costs)
+        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 16;
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
         i_q = a.idx[(size_t)(T > 1 ? 1 : 0) * B + b];
     } else {
@@ -761,10 +764,21 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
     if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready, wait_value, a.status);      // chunk 0 of xp
     constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;     // bytes between gates / tiles
     constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
+    if (XMODE == MVAE_X_INDEX) {
 #pragma unroll
-    for (int n = 0; n < RNT; ++n)
+        for (int j = 0; j < RNT / 2; ++j)
 #pragma unroll
-        for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+            for (int g = 0; g < G; ++g) {
+                const u16x8 t = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + j * 64 + xoff);
+                xq[2 * j][g] = __builtin_shufflevector(t, t, 0, 1, 2, 3);
+                xq[2 * j + 1][g] = __builtin_shufflevector(t, t, 4, 5, 6, 7);
+            }
+    } else {
+#pragma unroll
+        for (int n = 0; n < RNT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g) xq[n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+    }
 
     constexpr float K2 = 2.8853900817779268f;   // 2 / ln 2
     f32x4 accA[4], accB[4], hn = {0.f, 0.f, 0.f, 0.f};
@@ -814,12 +828,20 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
         // next step's x of (tile m, gate g), into the registers whose values were just consumed
         auto request_x = [&](auto mc, auto gc) __attribute__((always_inline)) {
             constexpr int m = decltype(mc)::value, g = decltype(gc)::value;
-            if (XMODE != MVAE_X_CONST && !ABL_NOX) {
-                if (XMODE == MVAE_X_INDEX && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 8;   // (tile 3 overwrites i_q last)
+            if (XMODE == MVAE_X_INDEX && !ABL_NOX) {
+                // tile PAIRS: (0, 1) in tile 0's turn (slots 19.. of tile 1: both tiles' x are consumed by then), (2, 3) in tile 3's
+                if constexpr (m == 0 || m == RNT - 1) {
+                    constexpr int j = m == 0 ? 0 : 1;
+                    if (g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 16;      // (tile 3 overwrites i_q last)
+                    pinu(xoff);
+                    const u16x8 pr = *reinterpret_cast<const g_u16x8*>(x_p[g] + j * 64 + xoff);
+                    xq[2 * j][g] = __builtin_shufflevector(pr, pr, 0, 1, 2, 3);
+                    xq[2 * j + 1][g] = __builtin_shufflevector(pr, pr, 4, 5, 6, 7);
+                    if (m == RNT - 1 && g == G - 1) i_q = a.idx[(size_t)(t_next2(t, T)) * B + b];
+                }
+            } else if (XMODE != MVAE_X_CONST && !ABL_NOX) {
                 pinu(xoff);
                 xq[m][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + m * XN + xoff);
-                if (XMODE == MVAE_X_INDEX && m == RNT - 1 && g == G - 1)
-                    i_q = a.idx[(size_t)(t + 2 < T ? t + 2 : T - 1) * B + b];
             }
         };
         u16x4 held[G + 1];
@@ -1698,7 +1720,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
         STAMP(2);
         vm_drain();                                   // the T fragments (L2 hits issued a whole E phase ago)
         pinq(lt[0]); pinq(lt[1]); pinq(lt[2]); pinq(lt[3]);
-        res_barrier();
+        if (ABL_NOBAR1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else res_barrier();
         res_skew(w);
         STAMP(3);
 
@@ -1769,7 +1791,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
         if (HAS_EXT) dx_p -= (t > 1 ? cs_step : 0);
         da_p -= da_step;
         STAMP(7);
-        res_barrier();
+        if (ABL_NOBAR2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else res_barrier();
         STAMP(8);
         // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
         wave_signal_done_if<false>(t, psig, a.signal_done + pk);
@@ -2219,6 +2241,10 @@ int launch_gru_il(const mvae_rnn_fwd_args& a, hipStream_t s) {
 }
 template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    // lookup-table layout: the slot-interleaved LSTM kernel gathers tile pairs (MVAE_TABLE_PAIRED), everything else row-major
+    if (XMODE == MVAE_X_INDEX &&
+        a.table_layout != ((CELL == MVAE_LSTM && a.seq_layout == MVAE_TILE16P) ? MVAE_TABLE_PAIRED : MVAE_TABLE_ROWMAJOR))
+        return MVAE_E_ARG;
     if (a.acts) {
         if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
         if constexpr (CELL == MVAE_LSTM && XMODE != MVAE_X_SCALAR)
@@ -2542,6 +2568,7 @@ extern "C" int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, 
             return MVAE_E_UNSUPPORTED;
         if ((a.xmode == MVAE_X_DENSE && !a.xp) || (a.xmode == MVAE_X_INDEX && !(a.idx && a.table)) || (a.xmode == MVAE_X_CONST && !a.xp0))
             return MVAE_E_ARG;
+        if (a.xmode == MVAE_X_INDEX && a.table_layout != (a.cell == MVAE_LSTM ? MVAE_TABLE_PAIRED : MVAE_TABLE_ROWMAJOR)) return MVAE_E_ARG;
         m.p[i] = a;
         m.base[n_xpand + i] = total;
         total += a.B / 16;

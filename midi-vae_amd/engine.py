@@ -250,6 +250,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             return hl.TILE16P
         return hl.TILE16
 
+    def _paired_table(self, r):
+        """the lookup table of a one-hot input layer in the column order the slot-interleaved LSTM kernel gathers (two unit tiles
+        per 16-byte access: 8 gathers per row and step instead of 16, include/midivae_hip.h mvae_rnn_fwd_args.table_layout)"""
+        return r.xmode == hl.X_INDEX and self.spec.cell == "LSTM" and self._seq_layout(r) == hl.TILE16P
+
     def _scalar_as_dense(self, r):
         """1-feature input layers (velocity roll) of an LSTM / GRU model: x*W + b is written out (T*B*G*H bf16, one streaming
         kernel, ~0.1 ms) so that the layer runs on the slot-interleaved dense-input kernels (2.1 instead of 3.9 us/step)."""
@@ -417,6 +422,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 pb.pack_recurrent(P[p + ".U"], self.store[p + ".u_pack"], 0)
                 if r.xmode == hl.X_INDEX:
                     pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
+                    if (p + ".table_p") in self.store:
+                        pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table_p", r.K, s.GH), paired=True)
                 elif r.xmode == X_GATHER2:
                     d0 = r.K - s.attach
                     pb.make_table(P[p + ".W"][:d0], P[p + ".b"], self._v(p + ".table", d0, s.GH))
@@ -476,7 +483,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if r.xmode == hl.X_INDEX and xp_external:       # (the table rows written out inside the phase launch: _index_as_dense)
             kw.update(xp=self._v(p + ".xp", T, B, GH)[t0:t0 + Tc])
         elif r.xmode == hl.X_INDEX:
-            kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
+            if self._paired_table(r):
+                kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table_p", r.K, GH), table_layout=hl.TABLE_PAIRED)
+            else:
+                kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
         elif r.xmode == X_GATHER2:       # table[pitch] + table2[instrument] written out, then the dense-input kernels
             xp = self._v(p + ".xp", T, B, GH)[t0:t0 + Tc]
             ops.gather2_tile16(idx[t0:t0 + Tc], self._v("in.xa_idx", T, B)[t0:t0 + Tc], self.store[p + ".table"],

@@ -19,6 +19,7 @@ F32, BF16, ONEHOT = 0, 1, 2
 X_DENSE, X_INDEX, X_SCALAR, X_CONST = 0, 1, 2, 3
 ACT_NONE, ACT_TANH = 0, 1
 ROWMAJOR, TILE16, TILE16P = 0, 1, 2
+TABLE_ROWMAJOR, TABLE_PAIRED = 0, 1
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
@@ -36,7 +37,7 @@ class RnnFwdArgs(C.Structure):
                 ("bias", _vp), ("xp0", _vp), ("h0", _vp), ("c0", _vp), ("hs", _vp), ("cs", _vp), ("acts", _vp),
                 ("h_last", _vp), ("c_last", _vp), ("h0_ld", _i32), ("h_last_ld", _i32),
                 ("chunk_steps", _i32), ("wait_ready", _vp), ("wait_value", C.c_uint32), ("signal_done", _vp), ("status", _vp),
-                ("seq_layout", _i32)]
+                ("seq_layout", _i32), ("table_layout", _i32)]
 
 
 class RnnBwdArgs(C.Structure):

@@ -93,7 +93,7 @@ def pack_recurrent(U, cell, dtype, direction, out=None):
 
 def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=None, w_row=None, bias=None, xp0=None,
             h0=None, c0=None, hs=None, cs=None, acts=None, h_last=None, c_last=None, h0_ld=0, h_last_ld=0, seq_layout=0,
-            chunk_steps=0, wait_ready=None, wait_value=0, signal_done=None, status=None, build_only=False):
+            chunk_steps=0, wait_ready=None, wait_value=0, signal_done=None, status=None, build_only=False, table_layout=0):
     if xp is not None:
         xmode = hl.X_DENSE
     elif idx is not None:
@@ -104,7 +104,7 @@ def rnn_fwd(cell, dtype, T, B, H, u_pack, *, xp=None, idx=None, table=None, xs=N
         xmode = hl.X_CONST
     a = hl.RnnFwdArgs(cell, dtype, xmode, T, B, H, _p(u_pack), _pv(xp), _pv(idx), _p(table), _pv(xs), _p(w_row),
                       _p(bias), _p(xp0), _pv(h0), _pv(c0), _pv(hs), _pv(cs), _pv(acts), _pv(h_last), _pv(c_last), h0_ld, h_last_ld,
-                      chunk_steps, _pv(wait_ready), int(wait_value), _pv(signal_done), _pv(status), seq_layout)
+                      chunk_steps, _pv(wait_ready), int(wait_value), _pv(signal_done), _pv(status), seq_layout, int(table_layout))
     _tag(a, "wait_value", wait_value)
     if build_only:          # (a problem of rnn_fwd_multi; the tensors must stay alive until that launch)
         return a
@@ -296,6 +296,13 @@ def convert(src, dst):
              "mvae_convert")
 
 
+def make_table_paired(W, bias, table):
+    """lookup table in MVAE_TABLE_PAIRED column order (a one-job mvae_prepare_batch)"""
+    pb = PrepBatch()
+    pb.make_table(W, bias, table, paired=True)
+    pb.run()
+
+
 def make_table(W, bias, table):
     K, N = W.shape
     hl.check(hl.load().mvae_make_table(_p(W), _p(bias), _p(table), K, N, kind_of(table), _stream()), "mvae_make_table")
@@ -325,8 +332,9 @@ class PrepBatch:
         H, GH = U.shape
         self._add(hl.PREP_PACK_RECURRENT, out, H, GH, direction, U)
 
-    def make_table(self, W, bias, table):
-        self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], 0, W, bias)
+    def make_table(self, W, bias, table, paired=False):
+        """table (K, N) = W + bias; ``paired``: the column order the slot-interleaved LSTM kernel gathers (hl.TABLE_PAIRED)"""
+        self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], int(bool(paired)), W, bias)
 
     def transpose_convert(self, W, out, n_pad=None):
         K, N = W.shape

@@ -67,6 +67,37 @@ def _rnn_problem(cellname, H, T, B, seed, K=7):
     return rng, G, U, W, b, h0, c0
 
 
+def _paired_columns(table):
+    """MVAE_TABLE_PAIRED: inside every block of 32 columns, column 16 h + 4 q + e moves to 8 q + 4 h + e"""
+    K, N = table.shape
+    c = np.arange(N)
+    dst = (c & ~31) + ((c & 15) >> 2) * 8 + ((c >> 4) & 1) * 4 + (c & 3)
+    out = np.empty_like(table)
+    out[:, dst] = table
+    return out
+
+
+def test_paired_lookup_table_layout_and_its_rejection():
+    """PrepBatch.make_table(paired=True) writes the NumPy permutation; mvae_rnn_fwd refuses a table in the wrong layout"""
+    rng = np.random.default_rng(3)
+    K, N = 7, 1024
+    W, b = rng.standard_normal((K, N)), rng.standard_normal(N)
+    plain = torch.zeros((K, N), dtype=torch.bfloat16, device=DEV)
+    paired = torch.zeros_like(plain)
+    ops.make_table(dev(W), dev(b), plain)
+    ops.make_table_paired(dev(W), dev(b), paired)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(paired), _paired_columns(host(plain)))
+    T, B, H = 4, 16, 256
+    up = ops.pack_recurrent(dev(rng.standard_normal((H, 4 * H)) * 0.05), hl.LSTM, hl.BF16, 0)
+    idx = dev(rng.integers(0, K, (T, B)), torch.uint8)
+    hs = torch.zeros((T + 1, B, H), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="MVAE_E_ARG"):         # the slot-interleaved LSTM kernel needs the paired table
+        ops.rnn_fwd(hl.LSTM, hl.BF16, T, B, H, up, idx=idx, table=plain, hs=hs, seq_layout=hl.TILE16P)
+    with pytest.raises(RuntimeError, match="MVAE_E_ARG"):         # ... and nothing else takes it
+        ops.rnn_fwd(hl.LSTM, hl.BF16, T, B, H, up, idx=idx, table=paired, hs=hs, seq_layout=hl.TILE16, table_layout=hl.TABLE_PAIRED)
+
+
 @pytest.mark.parametrize("cellname,cell", CELLS)
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("xmode", ["dense", "index", "scalar", "const"])
@@ -106,8 +137,13 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
         cs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if cellname == "LSTM" else None
         acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
         h_last = torch.zeros((B, H), device=DEV)
+        kwl = dict(kw)
+        if xmode == "index" and cellname == "LSTM" and lay == hl.TILE16P:
+            # the slot-interleaved LSTM kernel gathers tile pairs: MVAE_TABLE_PAIRED column order (include/midivae_hip.h), built
+            # here in NumPy - the device's own permutation (PrepBatch.make_table(paired=True)) is checked against it below
+            kwl["table"], kwl["table_layout"] = dev(_paired_columns(host(kw["table"])), td), hl.TABLE_PAIRED
         ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
-                    acts=acts, h_last=h_last, seq_layout=lay, **kw)
+                    acts=acts, h_last=h_last, seq_layout=lay, **kwl)
         torch.cuda.synchronize()
         if res:
             acts = tile16(acts, T * B, GH, False, paired=lay == hl.TILE16P)
