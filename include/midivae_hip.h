@@ -111,7 +111,7 @@ typedef struct {
                               (H=256, bf16): TILE16 the phased ones, TILE16P the slot-interleaved ones (LSTM, GRU; not
                               for MVAE_X_SCALAR inputs)                                                            */
     int32_t table_layout;  /* MVAE_X_INDEX: MVAE_TABLE_ROWMAJOR (0), or MVAE_TABLE_PAIRED (1: MVAE_PREP_MAKE_TABLE with c = 1) -
-                              what the slot-interleaved LSTM kernel (MVAE_LSTM, MVAE_TILE16P) REQUIRES: one lane's values of two
+                              what the slot-interleaved LSTM and GRU kernels (MVAE_TILE16P) REQUIRE: one lane's values of two
                               neighbouring unit tiles are 16 contiguous bytes, 8 gathers per row and step instead of 16
                               (a memory instruction costs the CU's address unit the same whatever its width); every other
                               kernel takes the row-major table                                                          */

@@ -308,7 +308,7 @@ __device__ __forceinline__ void make_table_body(const float* W, const float* bia
                                                 int paired = 0) {
     // paired (MVAE_TABLE_PAIRED; N % 32 == 0): inside every block of 32 columns the two 16-column tiles are interleaved per lane -
     // column 16 h + 4 q + e sits at 8 q + 4 h + e - so that one lane's values of a tile PAIR are 16 contiguous bytes (bf16): the
-    // indexed-input LSTM kernel gathers 8 x 16 bytes per row and step instead of 16 x 8
+    // indexed-input slot-interleaved kernels gather 8 x 16 bytes per row and step instead of 16 x 8
     const size_t n = (size_t)K * N;
     for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
         const int c = (int)(e % N);

@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void gru_fwd_il_body(const mvae_rnn_fwd_args& a, cons
         xoff = lane8;
         xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w * RNT) * 512;
     } else if (XMODE == MVAE_X_INDEX) {
-        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 8;
+        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 16;         // MVAE_TABLE_PAIRED: tiles 2j, 2j+1 of a lane in one 16-byte gather
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 128;
         i_q = a.idx[(size_t)(T > 2 ? 2 : T - 1) * B + b];
     } else {
@@ -1114,14 +1114,28 @@ __device__ __forceinline__ void gru_fwd_il_body(const mvae_rnn_fwd_args& a, cons
     constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;
     constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
     const size_t x_step1 = (XMODE == MVAE_X_DENSE && T > 1) ? tps * (GH / 16) * 512 : 0;       // step 1 (buffer 1)
-    const unsigned xoff1 = XMODE == MVAE_X_INDEX ? (unsigned)a.idx[(size_t)(T > 1 ? 1 : 0) * B + b] * (GH * 2) + q * 8 : xoff;
+    const unsigned xoff1 = XMODE == MVAE_X_INDEX ? (unsigned)a.idx[(size_t)(T > 1 ? 1 : 0) * B + b] * (GH * 2) + q * 16 : xoff;
+    if (XMODE == MVAE_X_INDEX) {
 #pragma unroll
-    for (int n = 0; n < RNT; ++n)
+        for (int j = 0; j < RNT / 2; ++j)
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            xq[0][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
-            if (XMODE != MVAE_X_CONST) xq[1][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + x_step1 + g * XG + n * XN + xoff1);
-        }
+            for (int g = 0; g < G; ++g) {
+                const u16x8 p0 = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + j * 64 + xoff);
+                const u16x8 p1 = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + j * 64 + xoff1);
+                xq[0][2 * j][g] = __builtin_shufflevector(p0, p0, 0, 1, 2, 3);
+                xq[0][2 * j + 1][g] = __builtin_shufflevector(p0, p0, 4, 5, 6, 7);
+                xq[1][2 * j][g] = __builtin_shufflevector(p1, p1, 0, 1, 2, 3);
+                xq[1][2 * j + 1][g] = __builtin_shufflevector(p1, p1, 4, 5, 6, 7);
+            }
+    } else {
+#pragma unroll
+        for (int n = 0; n < RNT; ++n)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                xq[0][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + g * XG + n * XN + xoff);
+                if (XMODE != MVAE_X_CONST) xq[1][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + x_step1 + g * XG + n * XN + xoff1);
+            }
+    }
 
     gbyte *acts_p[G], *hs_p, *hh_prev_p;          // step t: saved gates; h_{t-1} (slot t); the candidate tiles of step t-1
     gbyte* x_p[G];                                // step min(t+2, T-1): inputs
@@ -1163,8 +1177,14 @@ __device__ __forceinline__ void gru_fwd_il_body(const mvae_rnn_fwd_args& a, cons
             cp[1] = *reinterpret_cast<const frag*>(hcur + (tl0 ^ 1056u));
         }
         auto request_x = [&](int n, int g) __attribute__((always_inline)) {
-            if (XMODE != MVAE_X_CONST) {
-                if (XMODE == MVAE_X_INDEX && n == 0 && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 8;
+            if (XMODE == MVAE_X_INDEX) {        // tile pairs: the even tile's turn fetches both (half the gathers)
+                if (n & 1) return;
+                if (n == 0 && g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 16;
+                pinu(xoff);
+                const u16x8 pr = *reinterpret_cast<const g_u16x8*>(x_p[g] + (n >> 1) * 64 + xoff);
+                xq[XB][n][g] = __builtin_shufflevector(pr, pr, 0, 1, 2, 3);
+                xq[XB][n + 1][g] = __builtin_shufflevector(pr, pr, 4, 5, 6, 7);
+            } else if (XMODE != MVAE_X_CONST) {
                 pinu(xoff);
                 xq[XB][n][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + n * XN + xoff);
             }
@@ -2243,7 +2263,7 @@ template <int CELL, int XMODE>
 int fwd_res_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     // lookup-table layout: the slot-interleaved LSTM kernel gathers tile pairs (MVAE_TABLE_PAIRED), everything else row-major
     if (XMODE == MVAE_X_INDEX &&
-        a.table_layout != ((CELL == MVAE_LSTM && a.seq_layout == MVAE_TILE16P) ? MVAE_TABLE_PAIRED : MVAE_TABLE_ROWMAJOR))
+        a.table_layout != (((CELL == MVAE_LSTM || CELL == MVAE_GRU) && a.seq_layout == MVAE_TILE16P) ? MVAE_TABLE_PAIRED : MVAE_TABLE_ROWMAJOR))
         return MVAE_E_ARG;
     if (a.acts) {
         if (!a.hs || (CELL == MVAE_LSTM && !a.cs)) return MVAE_E_UNSUPPORTED;     // partial saves: generic kernel
@@ -2568,7 +2588,7 @@ extern "C" int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, 
             return MVAE_E_UNSUPPORTED;
         if ((a.xmode == MVAE_X_DENSE && !a.xp) || (a.xmode == MVAE_X_INDEX && !(a.idx && a.table)) || (a.xmode == MVAE_X_CONST && !a.xp0))
             return MVAE_E_ARG;
-        if (a.xmode == MVAE_X_INDEX && a.table_layout != (a.cell == MVAE_LSTM ? MVAE_TABLE_PAIRED : MVAE_TABLE_ROWMAJOR)) return MVAE_E_ARG;
+        if (a.xmode == MVAE_X_INDEX && a.table_layout != MVAE_TABLE_PAIRED) return MVAE_E_ARG;       // (the slot-interleaved kernels gather tile pairs)
         m.p[i] = a;
         m.base[n_xpand + i] = total;
         total += a.B / 16;

@@ -158,7 +158,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # and the per-queue launches (producers dispatched first) place them better than one launch's index order
         self.phase_max_B = int(os.environ.get("MVAE_PHASE_MAX_B", "256"))
         # (_index_as_dense; measured r03_r: GRU step -0.07 ms, LSTM +0.09 ms - there the bottom layer does not set the pace)
-        self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "1" if spec.cell == "GRU" else "0") == "1"
+        #  Round 4: the indexed kernels gather tile PAIRS from a paired-column table (8 x 16 bytes per row and step instead of 16 x 8:
+        #  LSTM 2.66 -> 2.17, GRU 2.06 -> 1.70 us per step alone - faster than a dense input) and the written-out rows lose on both
+        #  cells (GRU 5.71 vs 5.63 ms per step, LSTM 7.11 vs 6.91: profiles/r04_l_index_dense_ab.txt): off by default
+        self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "0") == "1"
         self.index_dense_blocks = int(os.environ.get("MVAE_INDEX_DENSE_BLOCKS", "16"))
         self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
         self.gate_side_heads = True      # (settled r03_z: -0.03 ms)   # (decoder_forward: counter instead of event)
@@ -251,9 +254,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         return hl.TILE16
 
     def _paired_table(self, r):
-        """the lookup table of a one-hot input layer in the column order the slot-interleaved LSTM kernel gathers (two unit tiles
+        """the lookup table of a one-hot input layer in the column order the slot-interleaved LSTM / GRU kernels gather (two unit tiles
         per 16-byte access: 8 gathers per row and step instead of 16, include/midivae_hip.h mvae_rnn_fwd_args.table_layout)"""
-        return r.xmode == hl.X_INDEX and self.spec.cell == "LSTM" and self._seq_layout(r) == hl.TILE16P
+        return r.xmode == hl.X_INDEX and self.spec.cell in ("LSTM", "GRU") and self._seq_layout(r) == hl.TILE16P
 
     def _scalar_as_dense(self, r):
         """1-feature input layers (velocity roll) of an LSTM / GRU model: x*W + b is written out (T*B*G*H bf16, one streaming

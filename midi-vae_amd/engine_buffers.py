@@ -153,7 +153,7 @@ class Buffers(object):
                     buf(p + ".rh", r.T * B * H, **esz)
             if r.xmode == hl.X_INDEX:
                 buf(p + ".table", r.K * GH, **esz)
-                if self._paired_table(r):       # (what the slot-interleaved LSTM kernel gathers: hl.TABLE_PAIRED)
+                if self._paired_table(r):       # (what the slot-interleaved LSTM / GRU kernels gather: hl.TABLE_PAIRED)
                     buf(p + ".table_p", r.K * GH, **esz)
                 if self._index_as_dense(r):
                     buf(p + ".xp", r.T * B * GH, **esz)

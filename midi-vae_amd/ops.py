@@ -333,7 +333,7 @@ class PrepBatch:
         self._add(hl.PREP_PACK_RECURRENT, out, H, GH, direction, U)
 
     def make_table(self, W, bias, table, paired=False):
-        """table (K, N) = W + bias; ``paired``: the column order the slot-interleaved LSTM kernel gathers (hl.TABLE_PAIRED)"""
+        """table (K, N) = W + bias; ``paired``: the column order the slot-interleaved LSTM / GRU kernels gather (hl.TABLE_PAIRED)"""
         self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], int(bool(paired)), W, bias)
 
     def transpose_convert(self, W, out, n_pad=None):

@@ -92,7 +92,7 @@ def test_paired_lookup_table_layout_and_its_rejection():
     up = ops.pack_recurrent(dev(rng.standard_normal((H, 4 * H)) * 0.05), hl.LSTM, hl.BF16, 0)
     idx = dev(rng.integers(0, K, (T, B)), torch.uint8)
     hs = torch.zeros((T + 1, B, H), dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(RuntimeError, match="MVAE_E_ARG"):         # the slot-interleaved LSTM kernel needs the paired table
+    with pytest.raises(RuntimeError, match="MVAE_E_ARG"):         # the slot-interleaved kernels need the paired table
         ops.rnn_fwd(hl.LSTM, hl.BF16, T, B, H, up, idx=idx, table=plain, hs=hs, seq_layout=hl.TILE16P)
     with pytest.raises(RuntimeError, match="MVAE_E_ARG"):         # ... and nothing else takes it
         ops.rnn_fwd(hl.LSTM, hl.BF16, T, B, H, up, idx=idx, table=paired, hs=hs, seq_layout=hl.TILE16, table_layout=hl.TABLE_PAIRED)
@@ -138,8 +138,8 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
         acts = torch.zeros((T, B, GH), dtype=td, device=DEV)
         h_last = torch.zeros((B, H), device=DEV)
         kwl = dict(kw)
-        if xmode == "index" and cellname == "LSTM" and lay == hl.TILE16P:
-            # the slot-interleaved LSTM kernel gathers tile pairs: MVAE_TABLE_PAIRED column order (include/midivae_hip.h), built
+        if xmode == "index" and cellname in ("LSTM", "GRU") and lay == hl.TILE16P:
+            # the slot-interleaved LSTM / GRU kernels gather tile pairs: MVAE_TABLE_PAIRED column order (include/midivae_hip.h), built
             # here in NumPy - the device's own permutation (PrepBatch.make_table(paired=True)) is checked against it below
             kwl["table"], kwl["table_layout"] = dev(_paired_columns(host(kw["table"])), td), hl.TABLE_PAIRED
         ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,

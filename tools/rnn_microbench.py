@@ -86,7 +86,7 @@ modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": di
 flop = 2.0 * B * H * GH * T
 for name, kw in modes.items():
     lay = hl.TILE16 if (name == "scalar" and LAY == hl.TILE16P) else LAY
-    if name == "index" and a.cell == "LSTM" and lay == hl.TILE16P:      # (random values: any column order times the same)
+    if name == "index" and a.cell in ("LSTM", "GRU") and lay == hl.TILE16P:      # (random values: any column order times the same)
         kw = dict(kw, table_layout=hl.TABLE_PAIRED)
     ms = timeit(conc(lambda c: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=c["hs"] if c else hs, cs=c["cs"] if c else cs,
                                            acts=c["acts"] if c else acts, h_last=hl_, seq_layout=lay,
