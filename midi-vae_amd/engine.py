@@ -176,6 +176,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.value_join = not serial and len(self.s_proj) > 0     # (no stacked layer: no probe was run)
         self._join_seq = {}
         self._diag_no_param_grads = os.environ.get("MVAE_DIAG_NO_PARAM_GRADS", "0") == "1"
+        # (_grad_portions) -1: by the rows of the sequence (4 portions from 2^20 rows, none below 2^19), 0: off, N: N portions
+        self.grad_portions = int(os.environ.get("MVAE_GRAD_PORTIONS", "-1"))
+        self._grad_portion_jobs = None
+        self._single_slot = 0
         self._hold_dec_grads = 1     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
@@ -878,7 +882,49 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None):
+    def _grad_portions(self, r, B, publishes):
+        """Time portions of a layer's parameter-gradient work (per-queue schedule, LONG sequences).  At T * B >= 2^19 rows the
+        gradient GEMMs of a phase are milliseconds of whole-chip work that used to start when the layer's BPTT ENDS - at BASELINE
+        configs[2]'s shape (T=2048, 512 windows) 4 ms of tail behind the last BPTT and a latent-chain kernel starved for 1.5 ms
+        between the two BPTT phases (profiles/r04_m_timeline_config2_lstm.txt).  A layer that publishes its da chunks
+        (``publishes`` = (counter array, target, chunk steps)) has them released in P portions of the time axis by the chunk that
+        completes each portion (hipStreamWaitValue32 on the gradient queues): each portion is a full-size GEMM here (>= 2^17 rows:
+        round 2 tried it at T=512 x 256 windows, where a portion was all atomic epilogue), and only the last one is left when the
+        recurrence ends.  Portions of all layers of a phase are enqueued portion-major (_flush_grad_portions): a queue parked on
+        one layer's last chunk must not hold another layer's first portions."""
+        if publishes is None or self._grad_portion_jobs is None:
+            return 1
+        return self._portion_count(r, B, publishes[2])
+
+    def _portion_count(self, r, B, cs):
+        if not self.grad_portions:
+            return 1
+        R = r.T * B
+        P = self.grad_portions if self.grad_portions > 0 else int(min(4, R // (1 << 18)))
+        while P > 1 and (r.T % P or (r.T // P) % cs):
+            P -= 1
+        return max(P, 1)
+
+    def _flush_grad_portions(self):
+        """launch the collected gradient portions of a phase, portion-major (first portions of every layer first)"""
+        jobs, self._grad_portion_jobs = self._grad_portion_jobs, None
+        for _, fn in sorted(jobs or [], key=lambda j: j[0]):
+            fn()
+
+    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, publishes=None, rows=None):
+        P = self._grad_portions(r, B, publishes) if rows is None else 1
+        if P > 1:
+            counters, target, cs = publishes
+            Tp = r.T // P
+            for pi in range(P):                      # BPTT order: the LAST steps first
+                t_lo = r.T - (pi + 1) * Tp
+                g = (counters[t_lo // cs:t_lo // cs + 1], target)
+                self._grad_portion_jobs.append((pi, lambda t_lo=t_lo, g=g, pi=pi: self._rec_param_grads_rows(
+                    r, B, idx=idx, xs=xs, start=start, skip_dU=skip_dU, gate=g, rows=(t_lo, t_lo + Tp), first=pi == 0)))
+            return
+        return self._rec_param_grads_rows(r, B, idx=idx, xs=xs, start=start, skip_dU=skip_dU, gate=gate, rows=rows)
+
+    def _rec_param_grads_rows(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, rows=None, first=True):
         """Parameter gradients of one layer from its da, accumulated into the f32 gradient buffer: off the critical path, on
         the two gradient streams, once per layer after its BPTT.  ``gate`` = (counter word, value): the layer's BPTT is a problem
         of a phase launch that is still RUNNING - the gradient queues wait, on the device, for the layer's last published chunk
@@ -888,9 +934,15 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             return
         s, G, p = self.spec, self.G, r.prefix
         H, GH, T = s.H, s.GH, r.T
-        R = T * B
-        da = self._v(p + ".da", T, B, GH)
-        da2, hprev = da.view(R, GH), self._v(p + ".hs", T + 1, B, H)[:T].reshape(R, H)
+        t_lo, t_hi = rows if rows is not None else (0, T)        # (a time portion: the same GEMMs over rows [t_lo * B, t_hi * B))
+        Tq = t_hi - t_lo
+        R = Tq * B
+        da = self._v(p + ".da", T, B, GH)[t_lo:t_hi]
+        da2, hprev = da.view(R, GH), self._v(p + ".hs", T + 1, B, H)[t_lo:t_hi].reshape(R, H)
+        if idx is not None:
+            idx = idx[t_lo:t_hi]
+        if xs is not None:
+            xs = xs[t_lo:t_hi]
         sk = self._split_k(R)
         sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
         if gate is None:
@@ -906,7 +958,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             if skip_dU:             # (with its bias gradient in a K-streaming launch)
                 pass
             elif s.cell == "GRU":
-                rh = self._v(p + ".rh", T, B, H)
+                rh = self._v(p + ".rh", T, B, H)[t_lo:t_hi]
                 ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk,
                          colsum_b=gb[:2 * H] if fuse_b else None)
                 ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
@@ -917,10 +969,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         with self._on(sg2):
             if r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
-                ops.sum_over_time(da, T, B * GH, dxp0, accumulate=self._dxp0_clean)
-                ops.colsum(dxp0, B, GH, G[p + ".b"])
-                if not self.start_zero.get(p, False):        # (dW = start^T dxp0 = 0 for an all-zero start)
-                    ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+                # (time portions: every portion adds its share to dxp0 - zeroed by the weight preparation; what is derived from the
+                #  complete sum follows the portion that ends at step 0)
+                ops.sum_over_time(da, Tq, B * GH, dxp0, accumulate=self._dxp0_clean or not first)
+                if t_lo == 0:
+                    ops.colsum(dxp0, B, GH, G[p + ".b"])
+                    if not self.start_zero.get(p, False):        # (dW = start^T dxp0 = 0 for an all-zero start)
+                        ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
             else:
                 if not fuse_b:
                     ops.colsum(da2, R, GH, G[p + ".b"])
@@ -931,12 +986,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 elif r.xmode == X_GATHER2:      # two-hot rows: the pitch rows and the attached instrument rows of W
                     d0 = r.K - s.attach
                     ops.gemm(idx.reshape(-1), da2, G[p + ".W"][:d0], d0, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
-                    ops.gemm(self._v("in.xa_idx", R), da2, G[p + ".W"][d0:], s.attach, GH, R, trans_a=True, a_kind=hl.ONEHOT,
-                             accumulate=True, split_k=sk)
+                    ops.gemm(self._v("in.xa_idx", T, B)[t_lo:t_hi].reshape(-1), da2, G[p + ".W"][d0:], s.attach, GH, R, trans_a=True,
+                             a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
                     ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"])
                 else:
-                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:1 + T].reshape(R, H)
+                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t_lo:1 + t_hi].reshape(R, H)
                     ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
 
     def _kstream_ok(self, layers, B):
@@ -1018,7 +1073,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._rec_bptt(r, B, 0, 1, dhs_ext=ext, dh_last=dh_last if top else None,
                                dh_last_ld=dh_last_ld if top else 0, pipe=pipe, **ds)
                 if not kstream:
-                    self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
+                    self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, publishes=(sync[li, 0], da_target, cs))
             if top:
                 run()
             else:
@@ -1070,6 +1125,19 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             ks = dict(counters=sync[0, 0], target=target, rows=cs * B, status=self.store["pipe_status"])
             kstream_extra.append((self._kstream_problems(r, B, idx, ks, only_dU=True), sync[0, 0][r.T // cs - 1:r.T // cs], target))
             self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, skip_dU=True)
+            return
+        if (len(layers) == 1 and nch == 1 and self._grad_portion_jobs is not None and self.pipeline and
+                self._seq_layout(layers[0]) == hl.TILE16P and layers[0].T % self.pipe_chunk == 0 and
+                self._portion_count(layers[0], B, self.pipe_chunk) > 1 and self._single_slot < 5):
+            # a full-length single-layer branch whose gradients go in time portions: ONE launch that publishes its da chunks
+            r, cs = layers[0], self.pipe_chunk
+            sync, target, _ = self._sync_region(11 + self._single_slot, 1, r.T // cs, 4 * (B // 16), 0)
+            self._single_slot += 1
+            self._pipe_used = True
+            self._rec_bptt(r, B, 0, 1, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
+                           pipe=dict(chunk_steps=cs, status=self.store["pipe_status"], signal_done=sync[0, 0]),
+                           **(dstates(r) if dstates else {}))
+            self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, publishes=(sync[0, 0], target, cs))
             return
         streams = [None] + self.s_layer[:len(layers) - 1]
         done = [[None] * nch for _ in order]
@@ -1165,6 +1233,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         for a in self.aux:
             self._aux_backward(a, B)
         notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
+        if not notes_multi and self.grad_portions:       # (per-queue schedule: long sequences release their gradient work in portions)
+            self._grad_portion_jobs, self._single_slot = [], 0
         self._after_chain = [] if (notes_multi and not self.enc_bi and len(self.enc_notes) > 1 and
                                    self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta])) else None
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
@@ -1180,6 +1250,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._head_stack_backward(h, B, dstates, slot=None)
         self._head_stack_backward(self.head["notes"], B, dstates, slot=2)
         self._prefork = None
+        self._flush_grad_portions()
         self._join(*[h.stream for h in side], word=0)
         self._mark("  decoder BPTT")
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
@@ -1206,6 +1277,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._cur_B, self._n_side = B, len(self.enc_meta)
         if not (enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads)):      # (one launch: engine_phases.py)
             assert not latent_grads
+            if self.grad_portions:
+                self._grad_portion_jobs, self._single_slot = [], 3
             ks_extra = None
             if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
                 self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
@@ -1225,6 +1298,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._stack_backward(self.enc_notes, B, dh_last=dcat[:, 0:H], dh_last_ld=ldc, idx=self._v("in.x_idx", T, B), slot=3)
             self._prefork = None
             self._grad_streams = None
+            self._flush_grad_portions()
         self._n_side = 0
         # the two gradient queues finish last and together: chained, they would put two cross-queue hops in series - the
         # early finishers are chained into one of them, the other is waited for directly

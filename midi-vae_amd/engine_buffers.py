@@ -130,7 +130,7 @@ class Buffers(object):
         esz = dict(dtype=dt, device=dev)
         # time-pipelined stacks: progress counters / ready flags (4 stack slots x 1024 words) and the time-out status word
         # slots 0-3: the pipelined stacks; 4: a single-layer branch followed by the K-streaming launch; 5: the expansion of a 1-feature roll
-        st["sync"] = torch.zeros(12 * 1024, dtype=torch.int32, device=dev)     # (6.. : single-layer problems of a phase launch)
+        st["sync"] = torch.zeros(16 * 1024, dtype=torch.int32, device=dev)     # (6.. : single-layer problems of a phase launch; 11..: single-layer branches whose gradients go in time portions)
         words = torch.zeros(2, dtype=torch.int32, device=dev)     # [live status of the running step, latched status since the last check]
         st["join_words"] = torch.zeros(8, dtype=torch.int32, device=dev)       # (Engine._join, MVAE_VALUE_JOIN)
         # z' of a fused history pre-pass lands here (a FIXED address: the step is then a replayable plan) and is copied to the

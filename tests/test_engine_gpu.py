@@ -771,3 +771,33 @@ def test_attach_instruments_two_hot_rows_match_oracle(cell, dtype, H, T):
             assert np.linalg.norm(g[k]) < 1e-6, k
         else:
             assert _rel_l2(g[k], g_o[k]) < tol_g, (k, _rel_l2(g[k], g_o[k]))
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_gradient_time_portions_equal_whole_sequence_gradients(cell):
+    """Per-queue schedule, long sequences: a layer's parameter-gradient GEMMs are released in portions of the time axis by the da
+    chunks its BPTT publishes (Engine._grad_portions; BASELINE configs[2]/[3]: T=2048 x 512 windows).  Forced to 4 portions at a
+    small shape: every gradient tensor equals the whole-sequence launch (to f32 summation order), the single-layer branches
+    (velocity encoder / decoder) publish and follow the same way, and eight optimizer steps - the last ones plan replays - keep the
+    counters in step (a mis-gated portion reads da before it is written: the gradients would show it)."""
+    B = 32
+    spec, params, _, raw = _problem(cell, B, seed=9, H=256, Z=32, T=128)
+    grads = {}
+    for portions in (0, 4):
+        eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+        eng.phase_multi, eng.grad_portions = False, portions        # (the schedule batches above 256 windows take)
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        grads[portions] = eng.get_grads()
+        eng.check_pipeline()
+        for _ in range(8):          # (steps 1-2 start from other engine states, 3-5 are recorded, 6-8 replayed)
+            eng.train_step(B)
+        eng.check_pipeline()
+        assert np.isfinite(eng.metrics(B)["loss"])
+        if portions:
+            assert eng.plan_stats["replayed"] >= 1, eng.plan_stats
+    for k in grads[0]:
+        ref = np.linalg.norm(grads[0][k])
+        if ref > 1e-8:
+            assert np.linalg.norm(grads[4][k] - grads[0][k]) <= 2e-3 * ref, (k, np.linalg.norm(grads[4][k] - grads[0][k]) / ref)
