@@ -27,6 +27,9 @@ for c in LSTM GRU; do
   cp $(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1) $O/bench_${c}_kernel_stats.csv
   python tools/timeline.py $(find /tmp/ks_$c -name "*kernel_trace.csv" | head -1) --min-us 20 > $O/timeline_${c}_step.txt
 done
+# ... and of one step at configs[2]'s shape (T=2048, 512 windows: gradient time portions)
+timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ks_c2 -- python bench.py --config 2 --no-cpu-baseline --no-other-configs --steps 4 --warmup 2 --prewarm-max 1 > /dev/null 2>&1
+python tools/timeline.py $(find /tmp/ks_c2 -name "*kernel_trace.csv" | head -1) --min-us 100 > $O/timeline_config2_LSTM_step.txt
 fi; if want 3; then
 # 3. HBM traffic of the dominant kernel: reads (FETCH_SIZE) and writes in SEPARATE passes.  Writes as TCC_EA0_WRREQ_sum x 64 B:
 #    a `--pmc WRITE_SIZE` pass hangs in rocprofv3's start-up on this image (it cost a whole gpurun limit once); the two were
