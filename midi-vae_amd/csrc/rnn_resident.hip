@@ -187,6 +187,9 @@ __device__ __forceinline__ f32x4 widen4(s16x4 ident, u16x4 packed, f32x4 plus) {
 #ifndef BWL_MFMA_FIRST
 #define BWL_MFMA_FIRST 0      /* C = 0 inline in the first MFMA of each chain instead of zeroed accumulators: 8 v_mov_b64 less, but 2.78 vs 2.71 us per step (profiles/r04_h_bptt_ab.txt) */
 #endif
+#ifndef RES_WGMAJOR
+#define RES_WGMAJOR 0
+#endif
 #ifndef BWL_E_TILE_FENCE
 #define BWL_E_TILE_FENCE 0
 #endif
@@ -736,7 +739,7 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
         *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(h0v);
         if (SAVE == SAVE_ALL)      // c_0 -> slot 0 of the (T+1, B, H) TILE16P array: 8 bytes of the lane's 16 per tile pair
             *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned char*>(a.cs) +
-                                      ((size_t)bx * (RH / 32) + w * 2 + (n >> 1)) * 1024 + (unsigned)l * 16u + (n & 1) * 8) = pack4(creg[n]);
+                                      ((size_t)bx * (RES_WGMAJOR ? (T + 1) : 1) * (RH / 32) + w * 2 + (n >> 1)) * 1024 + (unsigned)l * 16u + (n & 1) * 8) = pack4(creg[n]);
     }
 
     // ---- x queue (packed bf16x4 per tile and gate) for the step about to be computed --------------------------
@@ -794,13 +797,20 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
 
     gbyte *acts_p[G], *cs_p, *hs_p;              // step t:   saved gates (per gate), c_t (slot t+1), h_{t-1} (slot t)
     gbyte* x_p[G];                               // step t+1: inputs (per gate)
-    const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2;
+    const size_t x_step = tps * (GH / 16) * 512, hs_step = (size_t)B * RH * 2;
+#if RES_WGMAJOR     // (experiment: saved activations workgroup-major - a workgroup's steps contiguous - instead of time-major)
+    const size_t acts_step = (size_t)(GH / 32) * 1024, cs_step = (size_t)(RH / 32) * 1024;
+    const size_t acts_b0 = (size_t)bx * T * (GH / 32), cs_b0 = (size_t)bx * (T + 1) * (RH / 32);
+#else
+    const size_t acts_step = x_step, cs_step = tps * (RH / 16) * 512;
+    const size_t acts_b0 = (size_t)bx * (GH / 32), cs_b0 = (size_t)bx * (RH / 32);
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        acts_p[g] = to_global(a.acts) + ((size_t)bx * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
-        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? acts_step : 0);
+        acts_p[g] = to_global(a.acts) + (acts_b0 + g * (RH / 32) + w * 2) * 1024;
+        x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE && T > 1 ? x_step : 0);
     }
-    cs_p = to_global(a.cs) + ((tps + bx) * (RH / 32) + w * 2) * 1024;
+    cs_p = to_global(a.cs) + (cs_b0 + w * 2) * 1024 + cs_step;
     hs_p = to_global(a.hs) + (size_t)bx * 16 * (RH * 2);
 
     for (int t = 0; t < T; ++t) {
@@ -985,7 +995,7 @@ __device__ __forceinline__ void lstm_fwd_il_body(const mvae_rnn_fwd_args& a, con
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             acts_p[g] += acts_step;
-            if (XMODE == MVAE_X_DENSE && t + 2 < T) x_p[g] += acts_step;
+            if (XMODE == MVAE_X_DENSE && t + 2 < T) x_p[g] += x_step;
         }
         cs_p += cs_step;
         hs_p += hs_step;
@@ -1626,11 +1636,18 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
     }
     // wave-uniform running pointers for step t-1 (the step whose values are fetched during step t)
     gbyte *acts_p[G], *cs_p, *dx_p, *da_p;
-    const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, da_step = (size_t)B * GH * 2;
+    const size_t dx_step = tps * (RH / 16) * 512, da_step = (size_t)B * GH * 2;
+#if RES_WGMAJOR
+    const size_t acts_step = (size_t)(GH / 32) * 1024, cs_step = (size_t)(RH / 32) * 1024;
+    const size_t acts_bT = ((size_t)bx * T + (T - 1)) * (GH / 32), cs_bT = ((size_t)bx * (T + 1) + (T - 1)) * (RH / 32);
+#else
+    const size_t acts_step = tps * (GH / 16) * 512, cs_step = dx_step;
+    const size_t acts_bT = ((size_t)(T - 1) * tps + bx) * (GH / 32), cs_bT = ((size_t)(T - 1) * tps + bx) * (RH / 32);
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g)
-        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + bx) * (GH / 32) + g * (RH / 32) + w * 2) * 1024;
-    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + bx) * (RH / 32) + w * 2) * 1024;      // c_{t-1} of step T-1
+        acts_p[g] = to_global(a.acts) + (acts_bT + g * (RH / 32) + w * 2) * 1024;
+    cs_p = to_global(a.cs) + (cs_bT + w * 2) * 1024;      // c_{t-1} of step T-1
     dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + bx) * (RH / 16) + w * RNT) * 512;
     da_p = to_global(a.da) + ((size_t)(T - 1) * B + bx * 16) * (GH * 2) + (size_t)w * 4 * (GH * 2);
 
@@ -1660,7 +1677,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
 #pragma unroll
     for (int g = 0; g < G; ++g) acts_p[g] -= (T > 1 ? acts_step : 0);
     cs_p -= (T > 1 ? cs_step : 0);
-    dx_p -= (T > 1 ? cs_step : 0);
+    dx_p -= (T > 1 ? dx_step : 0);
 
     float fillr = 0.f; (void)fillr;      // (ABL_FILL probe)
     const s16x4 ident = identity_fragment(l);
@@ -1808,7 +1825,7 @@ __device__ __forceinline__ void lstm_bwd_il_body(const mvae_rnn_bwd_args& a, con
 #pragma unroll
         for (int g = 0; g < G; ++g) acts_p[g] -= (t > 1 ? acts_step : 0);
         cs_p -= (t > 1 ? cs_step : 0);
-        if (HAS_EXT) dx_p -= (t > 1 ? cs_step : 0);
+        if (HAS_EXT) dx_p -= (t > 1 ? dx_step : 0);
         da_p -= da_step;
         STAMP(7);
         if (ABL_NOBAR2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else res_barrier();
