@@ -20,6 +20,9 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-major sequences)")
 ap.add_argument("--signal", type=int, default=0, help="publish every N steps in a counter like a pipelined producer (nobody waits)")
 ap.add_argument("--concurrent", type=int, default=1, help="run k copies of every launch on k streams (own buffers): contention")
+ap.add_argument("--cu-mask", default="", help="streams restricted to a set of CUs (hipExtStreamCreateWithCUMask): 'even' / 'odd' = every "
+                "other CU of each shader engine, 'low' = the first half, 'single16' / 'pairs16' = 16 CUs as 16 different CU indices' "
+                "first / as 8 neighbouring pairs, or comma-separated hex words")
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
@@ -61,7 +64,29 @@ def timeit(fn):
 counters = torch.zeros(1024, dtype=torch.int32, device=dev)
 status = torch.zeros(1, dtype=torch.int32, device=dev)
 sig = dict(chunk_steps=a.signal, signal_done=counters, status=status) if a.signal else {}
-streams = [torch.cuda.Stream() for _ in range(a.concurrent)]
+
+
+def masked_stream(words):
+    """a HIP stream whose kernels run only on the CUs of the mask (bit b: XCD b % 8, then shader engine, then CU index - the order
+    the driver deals user mask bits out in), wrapped for torch"""
+    import ctypes
+    path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln)
+    hip = ctypes.CDLL(path)
+    st = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(st.value)
+
+
+PRESETS = {"even": [0xFFFFFFFF, 0] * 4, "odd": [0, 0xFFFFFFFF] * 4, "low": [0xFFFFFFFF] * 4 + [0] * 4, "all": [0xFFFFFFFF] * 8,
+           "single16": [0xFFFF] + [0] * 7, "pairs16": [0xFF, 0xFF] + [0] * 6, "single32": [0xFFFFFFFF] + [0] * 7,
+           "pairs32": [0xFFFF, 0xFFFF] + [0] * 6}
+if a.cu_mask:
+    words = PRESETS[a.cu_mask] if a.cu_mask in PRESETS else [int(w, 16) for w in a.cu_mask.split(",")]
+    streams = [masked_stream(words) for _ in range(a.concurrent)]
+else:
+    streams = [torch.cuda.Stream() for _ in range(a.concurrent)]
 copies = [dict(hs=torch.zeros_like(hs), cs=None if cs is None else torch.zeros_like(cs), acts=torch.zeros_like(acts),
                da=torch.zeros_like(da), rh=torch.zeros_like(rh)) for _ in range(a.concurrent - 1)]
 
@@ -69,7 +94,7 @@ copies = [dict(hs=torch.zeros_like(hs), cs=None if cs is None else torch.zeros_l
 def conc(fn):
     """fn(buffers) on every stream at once (copy 0 uses the shared buffers)"""
     def run():
-        if a.concurrent == 1:
+        if a.concurrent == 1 and not a.cu_mask:
             return fn(None)
         ev = torch.cuda.current_stream().record_event()
         for i, st in enumerate(streams):
@@ -81,6 +106,12 @@ def conc(fn):
     return run
 
 
+if a.concurrent > 1 or a.cu_mask:       # what the fork / join harness itself costs per round (a trivial kernel on every stream)
+    tiny = torch.zeros(64, device=dev)
+    for c in copies:
+        c["tiny"] = torch.zeros(64, device=dev)
+    HARNESS_MS = timeit(conc(lambda c: (tiny if c is None else c["tiny"]).add_(1.0)))
+    print("harness only (one tiny kernel per stream) %7.3f ms per round - included in every line below" % HARNESS_MS)
 modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": dict(xs=xs, w_row=w_row, bias=bias),
          "const": dict(xp0=xp0)}
 flop = 2.0 * B * H * GH * T
@@ -92,7 +123,7 @@ for name, kw in modes.items():
                                            acts=c["acts"] if c else acts, h_last=hl_, seq_layout=lay,
                                            **(sig if lay == hl.TILE16P else {}), **kw)))
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
-ms = timeit(lambda: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY))
+ms = timeit(conc(lambda c: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY)))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
 for ext in (True, False):
     ms = timeit(conc(lambda c: ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, c["da"] if c else da, dhs_ext=dext if ext else None,
