@@ -13,6 +13,7 @@ column blocks of ONE (2Z, nInit*H) matrix and evaluated by one GEMM; the per-Den
 from __future__ import annotations
 
 from collections import OrderedDict
+import dataclasses
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -448,13 +449,22 @@ def _glorot_uniform(rng, shape):
 
 def _orthogonal(rng, shape):
     a = rng.standard_normal(shape)
-    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    try:        # a 256 x 1024 SVD on a BLAS pool sized for a 256-thread host takes 0.16-0.3 s, on one thread 0.05 s
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            u, _, vt = np.linalg.svd(a, full_matrices=False)
+    except ImportError:
+        u, _, vt = np.linalg.svd(a, full_matrices=False)
     return u if u.shape == shape else vt
 
 
 def init_params(spec: ModelSpec, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     """Kernels glorot_uniform over the FULL concatenated width, recurrent kernels orthogonal, biases zero; the
     encoder's Keras LSTM layers get unit_forget_bias (b_f = 1), recurrentshop's decoder cells do not."""
+    key = (dataclasses.astuple(spec), int(seed))
+    hit = _INIT_CACHE.get(key)
+    if hit is not None:                 # (an Engine draws its initial parameters at creation: the same spec again and again in one process)
+        return OrderedDict((n, v.copy()) for n, v in hit.items())
     rng = np.random.default_rng(seed)
     L = ParamLayout.build(spec)
     H = spec.H
@@ -470,4 +480,10 @@ def init_params(spec: ModelSpec, seed: int = 0) -> "OrderedDict[str, np.ndarray]
             if spec.cell == "LSTM" and n.startswith(("enc.", "cnotes.", "cinstr.")) and (n[:-2] + ".U") in L.entries:
                 out[n][H:2 * H] = 1.0
         out[n] = out[n].astype(np.float32)
+    if len(_INIT_CACHE) >= 16:
+        _INIT_CACHE.pop(next(iter(_INIT_CACHE)))
+    _INIT_CACHE[key] = OrderedDict((n, v.copy()) for n, v in out.items())
     return out
+
+
+_INIT_CACHE = {}

@@ -596,7 +596,7 @@ def test_elbo_trajectory_fresh_epsilon_on_the_benched_schedule(cell):
         if np.linalg.norm(du_o) > 0:
             rel[k] = float(np.linalg.norm(du - du_o) / np.linalg.norm(du_o))
         assert np.max(np.abs(du - du_o)) <= 2 * steps * spec.lr + 1e-7, k
-    print("relative L2 error of the 10-step update, worst tensors:", sorted(rel.items(), key=lambda kv: -kv[1])[:5])
+    print("relative L2 error of the %d-step update, worst tensors:" % steps, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
     assert max(rel.values()) < 0.35, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
 
 
