@@ -17,6 +17,8 @@
 //     it is re-read from L2 every step here (the H=256 bf16 resident-U kernel lives in rnn_resident.hip).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,46 @@ template <typename WT>
 __global__ void pack_recurrent_k(const float* __restrict__ U, WT* __restrict__ out, int H, int GH, int direction) {
     pack_recurrent_body<WT>(U, out, H, GH, direction, blockIdx.x, gridDim.x);
 }
+
+// ----------------------------------------------------------------------------------------------------------
+// weight streaming
+// ----------------------------------------------------------------------------------------------------------
+// acc[j] += A(s, j) * B(s) for NS k-groups x NJ tiles, the A fragments (1 KiB per wave access) streamed from L2 through a ring
+// of D fragment registers: fragment i + D is requested when fragment i is consumed, so D loads are in flight per wave instead
+// of the one or two hipcc keeps ahead in a rolled loop (round 4: f32 LSTM H=256 forward 52 -> 19.4, BPTT 33 -> 21 us
+// per time step, profiles/r04_s_f32_generic.txt; the f32 MFMAs alone are 13.7).  Fully unrolled: every ring slot is a register.
+template <typename WT, int NS, int NJ, int D, typename ADDR, typename BFRAG>
+__device__ __forceinline__ void stream_mma(const void* wave_base, unsigned lane_off, ADDR addr, BFRAG bfrag, f32x4* acc) {
+    // addr(s, j): fragment index relative to wave_base (a compile-time constant once unrolled).  Buffer loads: ONE lane-offset
+    // register + a scalar offset per fragment - as global loads hipcc hoists the 256 loop-invariant 64-bit addresses of a step
+    // out of the time loop and spills ~1 KiB per lane.
+    typedef typename op<WT>::frag frag;
+    static_assert(sizeof(frag) == 16, "one 16-byte access per lane and fragment");
+    constexpr int F = NS * NJ, DD = D < F ? D : F;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wave_base), 0, -1, 0x00020000);
+    auto fetch = [&](int i) {
+        return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, addr(i / NJ, i % NJ) * 1024, 0));
+    };
+    frag ring[DD];
+#pragma unroll
+    for (int i = 0; i < DD; ++i) ring[i] = fetch(i);
+    frag bf, bnext = bfrag(0);
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        if (i % NJ == 0) {              // the B fragment of a k-group is read from LDS one group ahead
+            bf = bnext;
+            if (i / NJ + 1 < NS) bnext = bfrag(i / NJ + 1);
+        }
+        const frag a = ring[i % DD];
+        if (i + DD < F) ring[i % DD] = fetch(i + DD);
+        acc[i % NJ] = op<WT>::mma(a, bf, acc[i % NJ]);
+        __builtin_amdgcn_sched_barrier(0);      // keeps request i + D in iteration i (unfenced, hipcc sinks every load to its use: depth 2)
+    }
+}
+#ifndef MVAE_STREAM_DEPTH
+#define MVAE_STREAM_DEPTH 16
+#endif
+constexpr int STREAM_DEPTH = MVAE_STREAM_DEPTH;
 
 // ----------------------------------------------------------------------------------------------------------
 // forward
@@ -52,7 +94,8 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
     const int b = blockIdx.x * 16 + r;
     const bool valid = b < B;
     const int bb = valid ? b : B - 1;
-    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
+    // this wave's fragments of a gate: tiles [w NT, w NT + NT), 1 KiB each (the wave index as a scalar: a uniform base address)
+    const frag* wave_u = reinterpret_cast<const frag*>(a.u_pack) + (size_t)__builtin_amdgcn_readfirstlane(w) * NT * S * 64;
     WT* __restrict__ hs = reinterpret_cast<WT*>(a.hs);
     WT* __restrict__ cs = reinterpret_cast<WT*>(a.cs);
     WT* __restrict__ acts = reinterpret_cast<WT*>(a.acts);
@@ -126,17 +169,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         const WT* hrow = hbuf + cur * 16 * LDH + r * LDH + q * FE;
-#pragma unroll 2
-        for (int s = 0; s < S; ++s) {
-            const frag bf = *reinterpret_cast<const frag*>(hrow + s * KG);
-#pragma unroll
-            for (int g = 0; g < GA; ++g)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int mt = g * (H / 16) + w * NT + n;
-                    acc[g][n] = op<WT>::mma(up[((size_t)mt * S + s) * 64 + l], bf, acc[g][n]);
-                }
-        }
+        stream_mma<WT, S, GA * NT, STREAM_DEPTH>(
+            wave_u, l * 16u, [](int s, int j) { return ((j / NT) * (H / 16) + j % NT) * S + s; },
+            [&](int s) { return *reinterpret_cast<const frag*>(hrow + s * KG); }, &acc[0][0]);
 
         f32x4 hnew[NT];
         if (CELL == MVAE_GRU) {
@@ -152,15 +187,9 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
             }
             lds_barrier();
             const WT* rhrow = rhbuf + r * LDH + q * FE;
-#pragma unroll 2
-            for (int s = 0; s < S; ++s) {
-                const frag bf = *reinterpret_cast<const frag*>(rhrow + s * KG);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int mt = 2 * (H / 16) + w * NT + n;
-                    acc[2][n] = op<WT>::mma(up[((size_t)mt * S + s) * 64 + l], bf, acc[2][n]);
-                }
-            }
+            stream_mma<WT, S, NT, STREAM_DEPTH>(
+                wave_u, l * 16u, [](int s, int n) { return (2 * (H / 16) + n) * S + s; },
+                [&](int s) { return *reinterpret_cast<const frag*>(rhrow + s * KG); }, &acc[2][0]);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 hh;
@@ -248,7 +277,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
     const int b = blockIdx.x * 16 + r;
     const bool valid = b < B;
     const int bb = valid ? b : B - 1;
-    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    const frag* wave_u = reinterpret_cast<const frag*>(a.ut_pack) + (size_t)__builtin_amdgcn_readfirstlane(w) * NT * S2 * 64;
     const WT* __restrict__ hs = reinterpret_cast<const WT*>(a.hs);
     const WT* __restrict__ cs = reinterpret_cast<const WT*>(a.cs);
     const WT* __restrict__ acts = reinterpret_cast<const WT*>(a.acts);
@@ -283,6 +312,13 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // acc[n] += U^T fragments of k-groups [S0, S0 + NS) x the da tile in LDS
+        auto stream_dh = [&](auto s0, auto ns) {
+            constexpr int S0 = decltype(s0)::value, NS = decltype(ns)::value;
+            stream_mma<WT, NS, NT, STREAM_DEPTH>(
+                wave_u, l * 16u, [](int s, int n) { return n * S2 + S0 + s; },
+                [&](int s) { return *reinterpret_cast<const frag*>(brow + (S0 + s) * KG); }, acc);
+        };
 
         if (CELL == MVAE_LSTM) {
 #pragma unroll
@@ -315,13 +351,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                 }
             }
             lds_barrier();
-#pragma unroll 4
-            for (int s = 0; s < S2; ++s) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
-            }
+            stream_dh(std::integral_constant<int, 0>{}, std::integral_constant<int, S2>{});
 #pragma unroll
             for (int n = 0; n < NT; ++n) dh[n] = acc[n];
         } else if (CELL == MVAE_GRU) {
@@ -343,13 +373,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
             }
             lds_barrier();
             constexpr int SH = H / KG;
-#pragma unroll 4
-            for (int s = 2 * SH; s < 3 * SH; ++s) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
-            }
+            stream_dh(std::integral_constant<int, 2 * SH>{}, std::integral_constant<int, SH>{});
             f32x4 drh[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -370,13 +394,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                 }
             }
             lds_barrier();
-#pragma unroll 4
-            for (int s = 0; s < 2 * SH; ++s) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
-            }
+            stream_dh(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * SH>{});
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -392,13 +410,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
                 if (valid) st<WT>::store4(da + ((size_t)t * B + b) * GH + ub[n], dy);
             }
             lds_barrier();
-#pragma unroll 4
-            for (int s = 0; s < S2; ++s) {
-                const frag bf = *reinterpret_cast<const frag*>(brow + s * KG);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = op<WT>::mma(up[((size_t)(w * NT + n) * S2 + s) * 64 + l], bf, acc[n]);
-            }
+            stream_dh(std::integral_constant<int, 0>{}, std::integral_constant<int, S2>{});
 #pragma unroll
             for (int n = 0; n < NT; ++n) dh[n] = acc[n];
         }

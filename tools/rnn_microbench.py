@@ -18,6 +18,7 @@ ap.add_argument("--T", type=int, default=512)
 ap.add_argument("--B", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--rowmajor", action="store_true", help="generic kernels (row-major sequences)")
+ap.add_argument("--f32", action="store_true", help="the f32 parity mode: generic kernels, f32 sequences and f32 MFMA")
 ap.add_argument("--signal", type=int, default=0, help="publish every N steps in a counter like a pipelined producer (nobody waits)")
 ap.add_argument("--concurrent", type=int, default=1, help="run k copies of every launch on k streams (own buffers): contention")
 ap.add_argument("--cu-mask", default="", help="streams restricted to a set of CUs (hipExtStreamCreateWithCUMask): 'even' / 'odd' = every "
@@ -26,14 +27,16 @@ ap.add_argument("--cu-mask", default="", help="streams restricted to a set of CU
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
+a.rowmajor = a.rowmajor or a.f32
+DT = hl.F32 if a.f32 else hl.BF16
 LAY = hl.ROWMAJOR if a.rowmajor else (hl.TILE16 if (a.phased or a.cell not in ("LSTM", "GRU")) else hl.TILE16P)
 G, H, T, B = hl.GATES[cell], 256, a.T, a.B
 GH = G * H
 dev = "cuda:0"
-bf = torch.bfloat16
+bf = torch.float32 if a.f32 else torch.bfloat16
 rng = np.random.default_rng(0)
 U = torch.tensor(rng.standard_normal((H, GH)) * 0.03, dtype=torch.float32, device=dev)
-up, ut = ops.pack_recurrent(U, cell, hl.BF16, 0), ops.pack_recurrent(U, cell, hl.BF16, 1)
+up, ut = ops.pack_recurrent(U, cell, DT, 0), ops.pack_recurrent(U, cell, DT, 1)
 xp = torch.tensor(rng.standard_normal((T, B, GH)) * 0.5, device=dev).to(bf)
 idx = torch.tensor(rng.integers(0, 61, (T, B)), dtype=torch.uint8, device=dev)
 table = torch.tensor(rng.standard_normal((61, GH)) * 0.5, device=dev).to(bf)
@@ -119,13 +122,13 @@ for name, kw in modes.items():
     lay = hl.TILE16 if (name == "scalar" and LAY == hl.TILE16P) else LAY
     if name == "index" and a.cell in ("LSTM", "GRU") and lay == hl.TILE16P:      # (random values: any column order times the same)
         kw = dict(kw, table_layout=hl.TABLE_PAIRED)
-    ms = timeit(conc(lambda c: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, hs=c["hs"] if c else hs, cs=c["cs"] if c else cs,
+    ms = timeit(conc(lambda c: ops.rnn_fwd(cell, DT, T, B, H, up, hs=c["hs"] if c else hs, cs=c["cs"] if c else cs,
                                            acts=c["acts"] if c else acts, h_last=hl_, seq_layout=lay,
                                            **(sig if lay == hl.TILE16P else {}), **kw)))
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
-ms = timeit(conc(lambda c: ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY)))
+ms = timeit(conc(lambda c: ops.rnn_fwd(cell, DT, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY)))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
 for ext in (True, False):
-    ms = timeit(conc(lambda c: ops.rnn_bwd(cell, hl.BF16, T, B, H, ut, hs, cs, acts, c["da"] if c else da, dhs_ext=dext if ext else None,
+    ms = timeit(conc(lambda c: ops.rnn_bwd(cell, DT, T, B, H, ut, hs, cs, acts, c["da"] if c else da, dhs_ext=dext if ext else None,
                                            rh=c["rh"] if c else rh, dh0=hl_, seq_layout=LAY, **(sig if LAY == hl.TILE16P else {}))))
     print("bwd ext=%d  %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (ext, ms, ms * 1e3 / T, flop / ms / 1e9))
