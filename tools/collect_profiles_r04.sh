@@ -57,6 +57,8 @@ fi; if want 5; then
 python tools/gemm_microbench.py 2>&1 | grep -v amdgpu > $O/gemm_microbench.txt
 python tools/rnn_microbench.py --cell LSTM 2>&1 | grep -v amdgpu > $O/rnn_microbench.txt
 python tools/rnn_microbench.py --cell GRU 2>&1 | grep -v amdgpu >> $O/rnn_microbench.txt
+# ... the generic kernels of the f32 parity mode (weight fragments streamed through a ring of in-flight loads)
+for c in LSTM GRU; do echo "== $c --f32" >> $O/rnn_microbench_f32.txt; python tools/rnn_microbench.py --cell $c --f32 --reps 3 2>&1 | grep -v amdgpu >> $O/rnn_microbench_f32.txt; done
 for args in "" "--with-prepass" "--windows 256 --songs 8" "--windows 256 --songs 8 --with-prepass" "--with-prepass --lazy"; do
   echo "== tools/fit_e2e_bench.py $args" >> $O/fit_e2e.txt
   python tools/fit_e2e_bench.py $args 2>&1 | grep -v amdgpu >> $O/fit_e2e.txt
