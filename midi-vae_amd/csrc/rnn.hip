@@ -76,10 +76,13 @@ constexpr int STREAM_DEPTH = MVAE_STREAM_DEPTH;
 // ----------------------------------------------------------------------------------------------------------
 template <typename WT> struct lds_pad { static constexpr int value = 16 / sizeof(WT); };
 
-template <int CELL, typename WT, int XMODE, int NT>
-__global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
+// NW waves per workgroup, NT unit tiles per wave (H = 16 NT NW).  NW = 8 for the f32 H = 256 case: a wave cannot issue its next
+// MFMA while one of its 256 fragment loads per step sits in the memory pipe's issue stage (~64 cycles each); with two waves per
+// SIMD the other one's MFMAs fill the pipe meanwhile.
+template <int CELL, typename WT, int XMODE, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
     constexpr int G = mvae_gates(CELL);
-    constexpr int H = NT * 64, GH = G * H;
+    constexpr int H = NT * 16 * NW, GH = G * H;
     constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS, S = H / KG;
     constexpr int LDH = H + lds_pad<WT>::value;
     typedef typename op<WT>::frag frag;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
 
     int ub[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) ub[n] = w * (H / 4) + n * 16 + q * 4;
+    for (int n = 0; n < NT; ++n) ub[n] = w * (H / NW) + n * 16 + q * 4;
     const int ld0 = a.h0_ld ? a.h0_ld : H, ldl = a.h_last_ld ? a.h_last_ld : H;
 
     // ---- initial state -------------------------------------------------------------------------------
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
         }
     }
     if (XMODE == MVAE_X_SCALAR) {
-        for (int i = tid; i < GH; i += 256) {
+        for (int i = tid; i < GH; i += NW * 64) {
             wb[i] = a.w_row[i];
             wb[GH + i] = a.bias[i];
         }
@@ -261,10 +264,10 @@ __global__ __launch_bounds__(256) void rnn_fwd_k(const mvae_rnn_fwd_args a) {
 // ----------------------------------------------------------------------------------------------------------
 // backward through time
 // ----------------------------------------------------------------------------------------------------------
-template <int CELL, typename WT, int NT>
-__global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
+template <int CELL, typename WT, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
     constexpr int G = mvae_gates(CELL);
-    constexpr int H = NT * 64, GH = G * H;
+    constexpr int H = NT * 16 * NW, GH = G * H;
     constexpr int KG = op<WT>::KG, FE = op<WT>::FRAG_ELEMS, S2 = GH / KG;
     constexpr int LDA = GH + lds_pad<WT>::value;
     typedef typename op<WT>::frag frag;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
 
     int ub[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) ub[n] = w * (H / 4) + n * 16 + q * 4;
+    for (int n = 0; n < NT; ++n) ub[n] = w * (H / NW) + n * 16 + q * 4;
 
     f32x4 dh[NT], dc[NT];
 #pragma unroll
@@ -429,22 +432,22 @@ __global__ __launch_bounds__(256) void rnn_bwd_k(const mvae_rnn_bwd_args a) {
 // ----------------------------------------------------------------------------------------------------------
 // dispatch
 // ----------------------------------------------------------------------------------------------------------
-template <int CELL, typename WT, int XMODE, int NT>
+template <int CELL, typename WT, int XMODE, int NT, int NW = 4>
 int launch_fwd(const mvae_rnn_fwd_args& a, hipStream_t s) {
-    constexpr int G = mvae_gates(CELL), H = NT * 64;
+    constexpr int G = mvae_gates(CELL), H = NT * 16 * NW;
     constexpr int LDH = H + lds_pad<WT>::value;
     size_t lds = (size_t)(2 + (CELL == MVAE_GRU ? 1 : 0)) * 16 * LDH * sizeof(WT);
     if (XMODE == MVAE_X_SCALAR) lds += (size_t)2 * G * H * sizeof(float);
     if (lds > 64 * 1024) {
         static bool raised = false;   // gfx950 has 160 KiB of LDS per CU; anything above 64 KiB must be requested
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_k<CELL, WT, XMODE, NT>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_fwd_k<CELL, WT, XMODE, NT, NW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return MVAE_E_LAUNCH;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((rnn_fwd_k<CELL, WT, XMODE, NT>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rnn_fwd_k<CELL, WT, XMODE, NT, NW>), dim3((a.B + 15) / 16), dim3(NW * 64), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
@@ -453,7 +456,9 @@ int fwd_nt(const mvae_rnn_fwd_args& a, hipStream_t s) {
     switch (a.H) {
         case 64: return launch_fwd<CELL, WT, XMODE, 1>(a, s);
         case 128: return launch_fwd<CELL, WT, XMODE, 2>(a, s);
-        case 256: return launch_fwd<CELL, WT, XMODE, 4>(a, s);
+        case 256:
+            if constexpr (sizeof(WT) == 4) return launch_fwd<CELL, WT, XMODE, 2, 8>(a, s);
+            else return launch_fwd<CELL, WT, XMODE, 4>(a, s);
     }
     return MVAE_E_UNSUPPORTED;
 }
@@ -477,20 +482,20 @@ int fwd_cell(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return MVAE_E_ARG;
 }
 
-template <int CELL, typename WT, int NT>
+template <int CELL, typename WT, int NT, int NW = 4>
 int launch_bwd(const mvae_rnn_bwd_args& a, hipStream_t s) {
-    constexpr int GH = mvae_gates(CELL) * NT * 64;
+    constexpr int GH = mvae_gates(CELL) * NT * 16 * NW;
     const size_t lds = (size_t)16 * (GH + lds_pad<WT>::value) * sizeof(WT);
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_k<CELL, WT, NT>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_bwd_k<CELL, WT, NT, NW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return MVAE_E_LAUNCH;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((rnn_bwd_k<CELL, WT, NT>), dim3((a.B + 15) / 16), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((rnn_bwd_k<CELL, WT, NT, NW>), dim3((a.B + 15) / 16), dim3(NW * 64), lds, s, a);
     MVAE_CHECK_LAUNCH();
     return MVAE_OK;
 }
@@ -499,7 +504,9 @@ int bwd_nt(const mvae_rnn_bwd_args& a, hipStream_t s) {
     switch (a.H) {
         case 64: return launch_bwd<CELL, WT, 1>(a, s);
         case 128: return launch_bwd<CELL, WT, 2>(a, s);
-        case 256: return launch_bwd<CELL, WT, 4>(a, s);
+        case 256:
+            if constexpr (sizeof(WT) == 4) return launch_bwd<CELL, WT, 2, 8>(a, s);
+            else return launch_bwd<CELL, WT, 4>(a, s);
     }
     return MVAE_E_UNSUPPORTED;
 }
