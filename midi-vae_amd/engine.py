@@ -190,6 +190,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._views_cache = {}
         self._prep = None                # PrepBatch per (step count pending): prepare_weights
         self._zero_scal_job = None
+        self._zero_grads_job = None
         self._deferred_side = None       # (phase launches) side-queue work to be released by a device counter instead of an event
         self._xp0_bias = set()           # constant-input cells whose xp0 rows hold the bias (written by the last weight preparation)
         self.start_zero = {}             # layer prefix -> the staged start rows of its head are all zero (staging)
@@ -1417,8 +1418,16 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._zero_scal()
             self._dxp0_clean = False
         if not self._grads_clean:
-            self.grads.zero_()
+            self._zero_grads()
         self._grads_clean = False
+
+    def _zero_grads(self):
+        """the gradient buffer of a step that does not follow an optimizer step (which leaves it zeroed): a prepare-batch job like
+        _zero_scal, so that this state of a step replays as a plan too"""
+        if self._zero_grads_job is None:
+            self._zero_grads_job = ops.PrepBatch()
+            self._zero_grads_job.zero(self.grads)
+        self._zero_grads_job.run()
 
     def _zero_scal(self):
         """the loss / metric accumulators of a call that does not prepare weights (a one-job mvae_prepare_batch: part of a step

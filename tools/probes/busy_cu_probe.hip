@@ -18,13 +18,22 @@ __global__ __launch_bounds__(256) void probe_k(rec* out, int iters, float* sink)
     __syncthreads();
     unsigned long long c0 = clock64(), r0 = wall_clock64();
     float v = lane * 1e-3f;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     bf16x8 a, b;
     for (int k = 0; k < 8; ++k) { a[k] = (__bf16)(0.01f * (lane + k)); b[k] = (__bf16)(0.02f * (lane - k)); }
     for (int it = 0; it < iters; ++it) {
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 64; ++k) v = __builtin_fmaf(v, 0.999f, 0.001f);
+        } else if (MODE == 3) {      // f32 MFMA, one accumulator (dependent chain)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 1.0f, acc, 0, 0, 0);
+        } else if (MODE == 4) {      // f32 MFMA, two accumulators alternating
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 1.0f, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v, 2.0f, acc2, 0, 0, 0);
+            }
         } else if (MODE == 1) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(256) void probe_k(rec* out, int iters, float* sink)
     }
     unsigned long long c1 = clock64(), r1 = wall_clock64();
     if (lane == 0) out[blockIdx.x] = {c1 - c0, r1 - r0};
-    if (v + acc[0] + acc[1] == 123.456f) sink[0] = v;
+    if (v + acc[0] + acc[1] + acc2[0] == 123.456f) sink[0] = v;
 }
 
 template <int MODE>
@@ -70,5 +79,8 @@ int main(int argc, char** argv) {
     for (int g : grids) run<0>("valu", g, 40000, d, sink);
     for (int g : grids) run<1>("mfma", g, 40000, d, sink);
     for (int g : grids) run<2>("lds+mfma", g, 20000, d, sink);
+    // f32 MFMA issue rate (16 per iteration): cycles per MFMA = s_memtime cycles / (iters * 16)
+    run<3>("f32 chain", 16, 40000, d, sink);
+    run<4>("f32 2-acc", 16, 40000, d, sink);
     return 0;
 }
