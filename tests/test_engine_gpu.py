@@ -801,3 +801,35 @@ def test_gradient_time_portions_equal_whole_sequence_gradients(cell):
         ref = np.linalg.norm(grads[0][k])
         if ref > 1e-8:
             assert np.linalg.norm(grads[4][k] - grads[0][k]) <= 2e-3 * ref, (k, np.linalg.norm(grads[4][k] - grads[0][k]) / ref)
+
+
+def test_l2_touch_companion_changes_no_result_and_replays():
+    """Engine._l2_touch (include/midivae_hip.h mvae_l2_touch_bwd): beside the BPTT phase launches a one-wave-per-tile kernel on a
+    queue of its own walks ahead of every long recurrence and touches the saved values it is about to read.  It only READS, and only
+    what was complete before the launch (a lower layer's upstream gradient, written by the dX GEMM while the launch runs, is left
+    alone: a line touched before its chunk is written would be served stale): losses and every gradient are the same with
+    and without it (to the summation order of the split-K atomics), and eight optimizer steps - recorded, then replayed as plans with the companion's counter targets patched -
+    run without a time-out."""
+    B = 32
+    spec, params, _, raw = _problem("LSTM", B, seed=12, H=256, Z=32, T=128)
+    out = {}
+    for on in (False, True):
+        eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+        assert eng.l2_touch and eng.s_touch is not None         # (default for LSTM)
+        eng.l2_touch = on
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        out[on] = (eng.metrics(B), eng.get_grads())
+        eng.check_pipeline()
+        for _ in range(8):
+            eng.train_step(B)
+        eng.check_pipeline()
+        assert eng.plan_stats["replayed"] >= 1, eng.plan_stats
+        assert np.isfinite(eng.metrics(B)["loss"])
+    for k, v in out[False][0].items():
+        assert abs(out[True][0][k] - v) <= 1e-6 * (1 + abs(v)), k
+    for k, g in out[False][1].items():          # (split-K partial sums meet in atomics: equal to f32 summation order)
+        ref = np.linalg.norm(g)
+        if ref > 1e-8:
+            assert np.linalg.norm(out[True][1][k] - g) <= 2e-5 * ref, (k, np.linalg.norm(out[True][1][k] - g) / ref)
