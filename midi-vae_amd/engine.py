@@ -921,7 +921,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         for pr in probs:
             B = pr.B
             info = pr.__dict__.get("_touch")
-            if info is not None and pr.T >= 4 * info[4] and pr.T % info[4] == 0:
+            if info is not None and pr.T >= 16 * info[4] and pr.T % info[4] == 0:      # (short sequences lose: T=64 2.13 -> 2.40 ms per step)
                 r, ext, counters, target, cs = info
                 p = r.prefix
                 arrays = [(self._v(p + ".acts", r.T, B, GH), (GH // 32) * 1024)]

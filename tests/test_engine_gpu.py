@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import midi_vae_amd  # noqa: F401
+from midi_vae_amd import ops
 from midi_vae_amd.engine import Engine
 from midi_vae_amd.layout import ModelSpec, init_params
 from oracle.vae_oracle import OracleVAE, make_cfg
@@ -811,7 +812,7 @@ def test_l2_touch_companion_changes_no_result_and_replays():
     and without it (to the summation order of the split-K atomics), and eight optimizer steps - recorded, then replayed as plans with the companion's counter targets patched -
     run without a time-out."""
     B = 32
-    spec, params, _, raw = _problem("LSTM", B, seed=12, H=256, Z=32, T=128)
+    spec, params, _, raw = _problem("LSTM", B, seed=12, H=256, Z=32, T=256)       # (the companion goes with sequences of >= 16 chunks)
     out = {}
     for on in (False, True):
         eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
@@ -819,7 +820,13 @@ def test_l2_touch_companion_changes_no_result_and_replays():
         eng.l2_touch = on
         eng.set_params(params)
         _stage(eng, raw, B)
-        eng.forward_backward(B)
+        launched, real = [], ops.l2_touch_bwd
+        ops.l2_touch_bwd = lambda problems, stream=None: (launched.append(len(problems)), real(problems, stream=stream))[1]
+        try:
+            eng.forward_backward(B)
+        finally:
+            ops.l2_touch_bwd = real
+        assert (len(launched) == 2 and min(launched) >= 2) if on else not launched, launched     # (decoder phase, encoder phase: >= both layers of the notes stack)
         out[on] = (eng.metrics(B), eng.get_grads())
         eng.check_pipeline()
         for _ in range(8):
