@@ -146,7 +146,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.s_touch = None
         if share is not None:
             self.s_touch = share.s_touch
-        elif self.l2_touch and self.tile16:
+        elif self.l2_touch and self.tile16 and training:
             # its kernel runs for a whole BPTT phase and WAITS for that phase's progress: on a hardware queue shared with the
             # critical stream or with a dX GEMM's it would hold back what it waits for (until its time-out), on a gradient queue the
             # gradient work of the phase
