@@ -143,6 +143,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # steps ahead itself and loses with it (5.60 -> 6.09 ms per step)
         self.l2_touch = os.environ.get("MVAE_L2_TOUCH", "1" if spec.cell == "LSTM" else "0") == "1"       # (A/B: profiles/r04_x_l2_touch.txt)
         self.l2_touch_lead = int(os.environ.get("MVAE_L2_TOUCH_LEAD", "8"))
+        # ... beside the DECODER's BPTT only: the encoder phase runs beside the K-streaming gradient launch and the decoder's held
+        # gradient GEMMs, which stream through the same L2s - its companion costs the step 0.17 ms (profiles/r04_x_l2_touch.txt 9)
+        self.l2_touch_phases = tuple(os.environ.get("MVAE_L2_TOUCH_PHASES", "dec").split(","))
         self.s_touch = None
         if share is not None:
             self.s_touch = share.s_touch

@@ -165,7 +165,8 @@ class PhaseLaunches(object):
     def _launch_phase_backward(self, key, probs, gemms, steps=0):
         streams = [self.s_proj[li] for li, _ in gemms]
         ok = [True]
-        self._l2_touch(probs)
+        if key[1] in self.l2_touch_phases:
+            self._l2_touch(probs)
         self._timed(key, lambda: ok.__setitem__(0, ops.rnn_bwd_multi(probs)), steps=steps)
         assert ok[0], "mvae_rnn_bwd_multi refused a problem _phase_ok admitted"
         for (li, fn), st in zip(gemms, streams):
