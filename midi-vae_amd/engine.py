@@ -361,7 +361,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             for a, b in zip(streams, streams[1:]):
                 self._wait_stream(b, a)
             self._join_seq[word] = seq = self._join_seq.get(word, 0) + 1
-            if seq >= 1 << 30:
+            if seq >= self._REBASE:
                 torch.cuda.synchronize()
                 self.store["join_words"][word:word + 1].zero_()
                 self._join_seq[word] = seq = 1
@@ -628,7 +628,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         they count up monotonically and the thresholds move with them."""
         reg = self.store["sync"][slot * 1024: slot * 1024 + n_if * 2 * nchp].view(n_if, 2, nchp)
         cum = self._sync_cum.setdefault(slot, [0, 0])
-        if cum[0] + nwaves >= 1 << 31 or cum[1] + pwaves >= 1 << 31:      # (once in millions of steps)
+        if cum[0] + nwaves >= self._REBASE or cum[1] + pwaves >= self._REBASE:      # (once in millions of steps; the plans' threshold)
             torch.cuda.synchronize()
             reg.zero_()
             cum[0] = cum[1] = 0
@@ -1343,7 +1343,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                     self.s_comm = torch.cuda.Stream()
             self._join_into(self.s_comm)
             with torch.cuda.stream(self.s_comm):
-                hook.early(self.grads[self.layout.dec_begin:self.layout.total])
+                self._host_call("early", lambda: hook.early(self.grads[self.layout.dec_begin:self.layout.total]))
         # ---- encoder recurrences: the notes stack and the meta rolls, independent branches ---------------------------
         self._cur_B, self._n_side = B, len(self.enc_meta)
         if not (enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads)):      # (one launch: engine_phases.py)
@@ -1462,7 +1462,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # (data parallel: whenever the hook is set, whatever THIS rank's schedule - a rank that fell back to chunked launches
         #  must still take part in the collective the others issue)
         if self.status_allreduce is not None:
-            self.status_allreduce(self.store["pipe_status"])
+            self._host_call("status", lambda: self.status_allreduce(self.store["pipe_status"]))
         # (the gradients are zeroed as they are consumed: the next step starts without a 17 MB fill launch in front of it)
         if s.optimizer == "Adam":
             # the step count is bumped by the weight-preparation launch that follows anyway (one dependent launch less
@@ -1602,11 +1602,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._hist_fused = None
 
     def train_step_finish(self, B, allreduce=None):
-        """the rest of the step; without a gradient hook (single GPU) it is one replayable call (engine_plan.py)"""
+        """the rest of the step: one replayable call (engine_plan.py) - with a gradient hook (data parallel) its collectives are
+        host actions between the call ranges of the plan"""
         try:
-            if allreduce is None:
-                return self._planned(("train_finish", B), lambda: self._train_step_finish(B, None))
-            return self._train_step_finish(B, allreduce)
+            return self._planned(("train_finish", B) + self._hook_kind(allreduce), lambda: self._train_step_finish(B, allreduce),
+                                 host=self._hook_table(allreduce))
         finally:
             if self._fused_dst is not None:          # (behind a possible redo of the step: the rows are final here)
                 (z_dst, zbuf), self._fused_dst = self._fused_dst, None
@@ -1629,16 +1629,30 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._branches_stay_forked = False
             self._bucket_hook = None
         self._verify_pipeline(lambda: self._redo_step(B))
-        gs = allreduce(self.grads) if allreduce is not None else 1.0
+        gs = self._host_call("reduce", lambda: allreduce(self.grads)) if allreduce is not None else 1.0
         self.optimizer_step(gs if gs is not None else 1.0)
 
     def train_step(self, B, allreduce=None):
-        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.  Without a hook the
-        whole step is one replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run
-        (engine_plan.py; reference: ONE Keras train_function call per minibatch, vae_training.py:804-809)."""
-        if allreduce is None:
-            return self._planned(("train", B), lambda: self._train_step(B, None))
-        return self._train_step(B, allreduce)
+        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.  The whole step is one
+        replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run (engine_plan.py; reference: ONE
+        Keras train_function call per minibatch, vae_training.py:804-809); the hook's collectives are issued from Python between
+        the plan's call ranges (host marks)."""
+        return self._planned(("train", B) + self._hook_kind(allreduce), lambda: self._train_step(B, allreduce),
+                             host=self._hook_table(allreduce))
+
+    def _hook_kind(self, allreduce):
+        """what a gradient hook adds to the plan key of a train step: that there is one, and whether it takes an early bucket"""
+        return () if allreduce is None else ("hook", bool(getattr(allreduce, "overlap", False)))
+
+    def _hook_table(self, allreduce):
+        """the host actions of a data-parallel step by tag (engine_plan._host_call): what a replayed step calls between its ranges
+        of launches - Python then issues nothing but the collectives (reference: one train_function call per minibatch)"""
+        if allreduce is None and self.status_allreduce is None:
+            return None
+        L = self.layout
+        return {"early": lambda: allreduce.early(self.grads[L.dec_begin:L.total]),
+                "reduce": lambda: allreduce(self.grads),
+                "status": lambda: self.status_allreduce(self.store["pipe_status"])}
 
     def _train_step(self, B, allreduce):
         self._redo_hist = None
@@ -1649,7 +1663,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._bucket_hook = None
         gs = 1.0
         if allreduce is not None:
-            gs = allreduce(self.grads)
+            gs = self._host_call("reduce", lambda: allreduce(self.grads))
         self.optimizer_step(gs if gs is not None else 1.0)
 
     def train_step_empty(self, allreduce):

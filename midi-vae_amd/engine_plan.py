@@ -17,10 +17,10 @@ from . import plan as _plan
 
 class _PlanSlot(object):
     """recordings / the armed plan of one kind of call on one engine"""
-    __slots__ = ("recs", "plan", "dead", "post", "runs")
+    __slots__ = ("recs", "plan", "dead", "post", "runs", "host_results")
 
     def __init__(self):
-        self.recs, self.plan, self.dead, self.post, self.runs = [], None, None, None, 0
+        self.recs, self.plan, self.dead, self.post, self.runs, self.host_results = [], None, None, None, 0, {}
 
 
 class PlannedSteps(object):
@@ -28,11 +28,24 @@ class PlannedSteps(object):
     # after a replay to what the recorded calls left)
     _PLAN_STATE = ("_count_pending", "_grads_clean", "_dxp0_clean", "_have_targets", "_S_done", "_pipe_used", "pipeline",
                    "multi_stream", "norm_B", "_have_staged_targets", "lean_sync", "value_join", "phase_multi")
+    # schedule knobs a caller (a test, an A/B script) may change on a LIVE engine: part of the plan key, so that a change selects
+    # other plans instead of replaying the launch list recorded under the old value
+    _PLAN_CONFIG = ("l2_touch", "l2_touch_lead", "l2_touch_phases", "head_slices", "grad_portions", "index_dense",
+                    "index_dense_blocks", "xpand_blocks", "pipe_chunk", "phase_max_B", "kstream_grads", "kstream_wgs",
+                    "kstream_singles", "pipe_gemm_blocks", "pipe_proj_blocks", "time_chunks", "fuse_head_bwd", "fuse_bias_grad",
+                    "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans")
+    # ... and the spec's floats that reach kernel arguments as immediates of the recorded launches
+    _PLAN_SPEC = ("lr", "beta", "prior_mean", "prior_std", "epsilon_std", "w_instr", "w_vel", "w_style", "w_held", "w_next", "w_sig",
+                  "w_cnotes", "w_cinstr", "optimizer")
+
+    _EV_MAX = 8192
+    _REBASE = 1 << 30          # device counters are re-based (synchronize + zero) before they reach this (engine._sync_region, _join)
 
     def _plan_init(self):
         self.use_plans = os.environ.get("MVAE_PLANS", "1") == "1"
         self._plans = {}
         self._ev_pool, self._ev_i = [], 0
+        self._host_results, self._ext_streams, self._plan_depth = {}, {}, 0
         self.plan_stats = {"recorded": 0, "replayed": 0, "refused": {}}
 
     # ---- events / stream ordering through the C ABI ---------------------------------------------------------------------------
@@ -43,7 +56,12 @@ class PlannedSteps(object):
             hl.check(hl.load().mvae_event_create(C.byref(h)), "mvae_event_create")
             self._ev_pool.append(h.value)
         ev = self._ev_pool[self._ev_i]
-        self._ev_i = (self._ev_i + 1) % 512
+        # The ring restarts with every planned call (_planned: _ev_i = 0); inside ONE call it only grows - a handle re-recorded
+        # while an earlier wait on it is still to be enqueued would order that wait against the wrong point.  Callers
+        # outside _planned (data-parallel steps run from Python) restart it at a step boundary (_step_begin).
+        self._ev_i += 1
+        if self._ev_i >= self._EV_MAX:
+            raise RuntimeError("one call drew %d events: the schedule is not meant to (time chunks x layers out of hand?)" % self._ev_i)
         return ev
 
     def _ev_record(self, stream):
@@ -72,32 +90,70 @@ class PlannedSteps(object):
                 self._join_seq[k[1]] = v
 
     def _plan_state(self):
+        spec = self.spec
         return (tuple(getattr(self, n, None) for n in self._PLAN_STATE) +
+                tuple(getattr(self, n, None) for n in self._PLAN_CONFIG) +
+                tuple(getattr(spec, n, None) for n in self._PLAN_SPEC) +
                 (frozenset(self._xp0_bias), tuple(sorted(self.start_zero.items())), bool(self._weights_dirty),
-                 frozenset(self._pipe_verified), self._prep is None))
+                 frozenset(self._pipe_verified), self._prep is None, getattr(self, "status_allreduce", None) is not None))
 
     def _plan_post(self, before):
         """what a call left changed, as (attribute values, weight-version moves) relative to the state ``before`` it"""
         return (tuple(getattr(self, n, None) for n in self._PLAN_STATE), frozenset(self._xp0_bias),
                 self._pver[0] - before[0], self._prepared_ver - self._pver[0])
 
-    def _planned(self, kind, fn):
+    def _host_call(self, tag, fn):
+        """a host action inside a step (a data-parallel step's collectives): run ``fn`` - noted as a host mark when the step is
+        being recorded, so that a replay of the step runs the table entry ``tag`` of its caller at the same place"""
+        rec = _plan.active()
+        if rec is None:
+            return fn()
+        out = rec.host(tag, torch.cuda.current_stream().cuda_stream, fn)
+        self._host_results[tag] = out
+        return out
+
+    def _replay_host(self, host, want):
+        streams = self._ext_streams
+
+        def run(tag, handle):
+            st = streams.get(handle)
+            if st is None:
+                st = streams[handle] = torch.cuda.ExternalStream(handle, device=self.device)
+            with torch.cuda.stream(st):
+                out = host[tag]()
+            if out != want.get(tag):         # (e.g. the gradient scale a hook returns: a constant of the recorded optimizer launch)
+                raise RuntimeError("host action %r returned %r; the recorded step was built for %r" % (tag, out, want.get(tag)))
+        return run
+
+    def _planned(self, kind, fn, host=None):
         """run ``fn`` (the Python enqueue of one call of kind ``kind``, a hashable that names everything the launch list depends
-        on besides the engine's state) - or, once three recordings of it agreed, replay its plan"""
+        on besides the engine's state) - or, once three recordings of it agreed, replay its plan.  ``host``: tag -> callable of
+        the host actions ``fn`` performs through _host_call (replayed between the call ranges they were recorded between)"""
         profiling = self.prof is not None and (self.prof_kinds is None or len(self.prof_kinds) > 0)      # (launches get bracketed)
+        if self._plan_depth == 0:
+            self._ev_i = 0          # the event ring restarts with every outermost call (planned or not)
         if (not self.use_plans or profiling or getattr(self, "marks", None) is not None or
                 _plan.active() is not None or self._hist_fused is not None):
-            return fn()
-        self._ev_i = 0
+            self._plan_depth += 1
+            try:
+                return fn()
+            finally:
+                self._plan_depth -= 1
         key = (kind, torch.cuda.current_stream().cuda_stream, self._plan_state())
         slot = self._plans.get(key)
         if slot is None:
             slot = self._plans[key] = _PlanSlot()
         if slot.plan is not None:
-            # (a counter about to wrap is re-based by the Python path: _sync_region / _join)
+            # (a counter about to wrap is re-based by the Python path - _sync_region / _join, both at 2^30 - which then runs WITHOUT a
+            #  recorder: the armed plan stays, and replays again from the next call on)
             cnt = self._plan_counters()
-            if all(cnt.get(k, 0) + d < (1 << 30) for k, d in slot.plan.inc.items()):
-                self._plan_set_counters(slot.plan.run(cnt))
+            if not all(cnt.get(k, 0) + d < self._REBASE for k, d in slot.plan.inc.items()):
+                return fn()
+            if True:
+                if slot.plan.marks:
+                    self._plan_set_counters(slot.plan.run_ranges(cnt, self._replay_host(host or {}, slot.host_results)))
+                else:
+                    self._plan_set_counters(slot.plan.run(cnt))
                 vals, xp0, dver, dprep = slot.post
                 for n, v in zip(self._PLAN_STATE, vals):
                     setattr(self, n, v)
@@ -110,10 +166,11 @@ class PlannedSteps(object):
         if slot.dead is not None:
             return fn()
         pre, ver = self._plan_counters(), (self._pver[0], self._prepared_ver)
+        self._host_results = {}
         with _plan.Recorder() as rec:
             out = fn()
-        post_state = self._plan_post(ver)
-        slot.recs.append((rec.calls, rec.tags, pre, self._plan_counters(), post_state))
+        post_state = self._plan_post(ver) + (tuple(sorted(self._host_results.items(), key=repr)),)
+        slot.recs.append((rec.calls, rec.tags, pre, self._plan_counters(), post_state, rec.marks))
         self.plan_stats["recorded"] += 1
         if rec.tainted is not None:      # (a kernel torch itself launched would be missing from the replay)
             slot.dead = "the call runs the torch operation %r" % rec.tainted
@@ -125,7 +182,8 @@ class PlannedSteps(object):
                 slot.dead = "the call leaves the engine in different states"
             else:
                 try:
-                    slot.plan, slot.post = _plan.StepPlan([r[:4] for r in (a, b, c)]), c[4]
+                    slot.plan, slot.post = _plan.StepPlan([r[:4] for r in (a, b, c)], [r[5] for r in (a, b, c)]), c[4][:4]
+                    slot.host_results = dict(c[4][4])
                 except _plan.NotReplayable as e:
                     slot.dead = str(e)
             if slot.dead is not None:

@@ -83,6 +83,19 @@ class Recorder(object):
 
     def __init__(self):
         self.calls, self.tags, self._saved, self.tainted, self._mode, self._pending = [], {}, {}, None, None, []
+        self.marks = []         # host marks: (index of the next call, tag, stream handle current at the mark)
+
+    def host(self, tag, stream_handle, fn):
+        """a HOST action in the middle of the step that a replay must repeat at the same place - a data-parallel step's
+        ``dist.all_reduce`` calls (torch / RCCL enqueue them, not this library): noted as a mark between two calls, run now with
+        the taint mode suspended (what it enqueues is the host action's own business, on replay as now)"""
+        self.marks.append((len(self.calls), tag, int(stream_handle)))
+        self._mode.__exit__(None, None, None)
+        try:
+            return fn()
+        finally:
+            self._mode = _taint_mode(self)
+            self._mode.__enter__()
 
     def note_field(self, arg_index, offset, key):
         """the NEXT library call carries a value of the engine's counter ``key`` in argument ``arg_index`` (at byte ``offset`` of
@@ -131,9 +144,14 @@ class NotReplayable(Exception):
 class StepPlan(object):
     """the C-side plan of one kind of step + the counters it advances"""
 
-    def __init__(self, recordings):
-        """``recordings``: three (calls, tags, counters_before, counters_after) of the same kind of step"""
+    def __init__(self, recordings, marks=()):
+        """``recordings``: three (calls, tags, counters_before, counters_after) of the same kind of step; ``marks``: the host
+        marks of each recording (Recorder.marks) - a replay runs the call ranges between them (run_ranges)"""
         assert len(recordings) == 3
+        marks = [list(m) for m in marks] or [[], [], []]
+        if not (marks[0] == marks[1] == marks[2]):
+            raise NotReplayable("the host actions of the three recordings differ: %r / %r / %r" % tuple(marks))
+        self.marks = marks[0]
         (ca, ta, pa, qa), (cb, tb, pb, qb), (cc, tc, pc, qc) = recordings
         if not (len(ca) == len(cb) == len(cc)):
             raise NotReplayable("the three recordings hold %d / %d / %d calls" % (len(ca), len(cb), len(cc)))
@@ -210,6 +228,19 @@ class StepPlan(object):
         if rc != 0:
             raise RuntimeError("mvae_plan_run: call %d failed: %s" % (self._lib.mvae_plan_failed_call(self._h),
                                                                        hl.ERRORS.get(rc, rc)))
+        return {k: counters.get(k, 0) + d for k, d in self.inc.items()}
+
+    def run_ranges(self, counters, host):
+        """like run, with the host actions in between: ``host(tag, stream_handle)`` is called at every mark, between the two call
+        ranges it was recorded between (every patch takes the counter values from BEFORE the step, whatever the range)"""
+        first = 0
+        for idx, tag, st in self.marks:
+            if idx > first:
+                self.run(counters, first, idx)
+            host(tag, st)
+            first = idx
+        if first < self.n_calls or not self.marks:
+            return self.run(counters, first, -1)
         return {k: counters.get(k, 0) + d for k, d in self.inc.items()}
 
     def close(self):

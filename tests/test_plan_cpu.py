@@ -117,3 +117,33 @@ def test_counter_values_announce_the_fields_they_land_in():
         assert rec._pending == [(0, C.sizeof(hl.GemmArgs) + hl.GemmArgs.k_wait_value.offset, ("sync", 3, 1))]
         ops._note_scalar(2, v)
         assert rec._pending[-1] == (2, -1, ("sync", 3, 1))
+
+
+def test_host_marks_must_agree_and_split_the_replay_into_ranges():
+    """A data-parallel step's collectives are HOST actions between two launches (Recorder.host): the three recordings must hold them
+    at the same places, and a replay calls them between the call ranges (run_ranges) - checked here on ranges no call of which
+    can run without a device, so only the order of (range, host action) is observed."""
+    a, b, c = _recording(0, 0), _recording(64, 1), _recording(128, 2)
+    m = [(1, "early", 0x99), (3, "reduce", 0x77), (3, "status", 0x77)]
+    with pytest.raises(P.NotReplayable):
+        P.StepPlan([a, b, c], [m, m, m[:2]])
+    with pytest.raises(P.NotReplayable):
+        P.StepPlan([a, b, c], [m, m, [(2, "early", 0x99)] + m[1:]])
+    p = P.StepPlan([a, b, c], [m, m, m])
+    assert p.marks == m
+    seen = []
+    real_run = p.run
+    p.run = lambda counters, first=0, last=-1: seen.append(("calls", first, last)) or {}
+    p.run_ranges({("sync", 0, 0): 0, ("join", 2): 0}, lambda tag, st: seen.append((tag, st)))
+    assert seen == [("calls", 0, 1), ("early", 0x99), ("calls", 1, 3), ("reduce", 0x77), ("status", 0x77), ("calls", 3, -1)]
+    p.run = real_run
+    p.close()
+
+
+def test_recorder_host_runs_the_action_outside_the_taint_mode_and_notes_the_mark():
+    import torch
+    with P.Recorder() as rec:
+        out = rec.host("reduce", 0x55, lambda: float(torch.ones(3).sum()))        # a torch kernel inside a host action: no taint
+        assert out == 3.0 and rec.tainted is None
+        torch.ones(2) + 1                                                           # ... outside one: the step is not replayable
+    assert rec.tainted is not None and rec.marks == [(0, "reduce", 0x55)]
