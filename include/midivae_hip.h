@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 6
+#define MVAE_ABI_VERSION 7
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -259,31 +259,6 @@ typedef struct {
 } mvae_xpand_args;
 int mvae_rnn_fwd_multi(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand, void* stream);
 int mvae_rnn_bwd_multi(const mvae_rnn_bwd_args* problems, int32_t n, void* stream);
-
-/* L2 TOUCH (round 4).  A BPTT kernel requests a time step's saved values one matrix phase (~1 us) ahead and has no registers for
- * more; beside other kernels an HBM round trip takes longer than that.  This companion launch - ONE WAVE per 16-row tile, on
- * another stream - walks the time axis `lead` steps ahead of the running recurrence and touches one dword of every 128-byte line
- * the recurrence is about to read, so that the recurrence's own loads hit the L2 of its XCD (LSTM BPTT alone 2.68 -> 2.30 us
- * per time step, profiles/r04_x_l2_touch.txt).  Where the recurrence is: the chunk counters it publishes
- * (mvae_rnn_bwd_args.signal_done; chunk c of chunk_steps steps is done when counters[c] >= target), with the pace of the
- * previous chunk in between; it never runs more than one chunk + lead ahead.  Workgroup first_wg + b of this launch takes tile b
- * of the problem and lands on XCD (first_wg + b) % 8 - first_wg = the index of the recurrence's first workgroup in ITS launch
- * (0 for mvae_rnn_bwd; the sum of B/16 of the problems before it for mvae_rnn_bwd_multi), so that both share an L2.
- * Array k: element (time step s, tile b) = tile_bytes[k] contiguous bytes at base[k] + (s * tiles + b) * tile_bytes[k]  (the
- * TILE16 / TILE16P sequences and 16 rows of a row-major (T, B, 256) bf16 sequence all have this form); NULL = unused.
- * Reads only; ends when everything is touched, when *status becomes non-zero or after 4 s.  n <= 8. */
-typedef struct {
-    const void* base[3];
-    uint32_t tile_bytes[3];
-    int32_t T, tiles;            /* time steps (walked T-1 .. 0); 16-row tiles */
-    int32_t chunk_steps;         /* of the recurrence; divides T */
-    int32_t first_wg;
-    int32_t lead;                /* time steps ahead of the recurrence's estimated position */
-    uint32_t target;
-    const uint32_t* counters;    /* [T / chunk_steps] */
-    const uint32_t* status;      /* or NULL */
-} mvae_l2_touch_args;
-int mvae_l2_touch_bwd(const mvae_l2_touch_args* problems, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Output heads: Dense(H -> N) + activation + Keras weighted loss + metric + d(logits), fused, over all

@@ -139,25 +139,6 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # them are ONE launch (mvae_gemm_kstream_multi) on the second gradient queue - a queue each cost more than the tail saved -
         # and the other gradient work of that phase (velocity / instrument encoders) goes to the first one.
         # kstream_wgs workgroups per GEMM: they wait beside the recurrences, one per CU (_kstream_ok: residency).
-        # L2-touch companion of the BPTT phase launches (_l2_touch): LSTM only - the GRU BPTT kernel requests its saved values two
-        # steps ahead itself and loses with it (5.60 -> 6.09 ms per step)
-        self.l2_touch = os.environ.get("MVAE_L2_TOUCH", "1" if spec.cell == "LSTM" else "0") == "1"       # (A/B: profiles/r04_x_l2_touch.txt)
-        self.l2_touch_lead = int(os.environ.get("MVAE_L2_TOUCH_LEAD", "8"))
-        # ... beside the DECODER's BPTT only: the encoder phase runs beside the K-streaming gradient launch and the decoder's held
-        # gradient GEMMs, which stream through the same L2s - its companion costs the step 0.17 ms (profiles/r04_x_l2_touch.txt 9)
-        self.l2_touch_phases = tuple(os.environ.get("MVAE_L2_TOUCH_PHASES", "dec").split(","))
-        self.s_touch = None
-        if share is not None:
-            self.s_touch = share.s_touch
-        elif self.l2_touch and self.tile16 and training:
-            # its kernel runs for a whole BPTT phase and WAITS for that phase's progress: on a hardware queue shared with the
-            # critical stream or with a dX GEMM's it would hold back what it waits for (until its time-out), on a gradient queue the
-            # gradient work of the phase
-            with torch.cuda.device(self.device):
-                self.s_touch = self._stream_apart_from([torch.cuda.current_stream(), *self.s_proj, *self.s_layer, self.s_grad,
-                                                        self.s_grad2, self.s_vel, self.s_instr])
-            if self.s_touch is None:
-                self.l2_touch = False
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "0")) or (24 if spec.cell == "GRU" else 32)   # (GRU: 3 GEMMs per layer)
         self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
@@ -246,27 +227,6 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                       "stacks and phase launches are off (Engine.pipeline = False)")
         self._serial_queues = True
         return self._aliased.pop()
-
-    def _stream_apart_from(self, streams):
-        """a new stream that shares its hardware queue with none of ``streams`` (mvae_streams_alias, as _own_queue_stream); None
-        if eight candidates in a row do"""
-        scratch = torch.zeros(2, dtype=torch.int32, device=self.device)
-        self._aliased = getattr(self, "_aliased", [])
-        tag = 100
-        for _ in range(8):
-            st = torch.cuda.Stream()
-            clash = False
-            for o in streams:
-                tag += 1
-                rc = hl.load().mvae_streams_alias(o.cuda_stream, st.cuda_stream, scratch.data_ptr(), tag)
-                hl.check(min(rc, 0), "mvae_streams_alias")
-                if rc != 0:
-                    clash = True
-                    break
-            if not clash:
-                return st
-            self._aliased.append(st)
-        return None
 
     @property
     def _weights_dirty(self):
@@ -909,36 +869,6 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if build:
             return launch(build_only=True)
         self._timed(("rnn_bwd", p), launch, steps=Tc)
-
-    def _l2_touch(self, probs):
-        """The L2-touch companion of a BPTT launch over ``probs`` (problems built by _rec_bptt(build=True), tagged with what they
-        publish): one wave per 16-row tile on a queue of its own walks ``l2_touch_lead`` time steps ahead of every long recurrence
-        and touches the saved values it is about to read, so that the recurrence's own one-phase-ahead requests hit the L2 of
-        its XCD (include/midivae_hip.h mvae_l2_touch_bwd; alone: LSTM BPTT 2.68 -> 2.30 us per time step).  Nothing waits for
-        it: it only reads, runs ahead of its recurrence and ends before it."""
-        if not self.l2_touch or not self.multi_stream or self.s_touch is None:
-            return
-        s = self.spec
-        H, GH = s.H, s.GH
-        touch, first = [], 0
-        for pr in probs:
-            B = pr.B
-            info = pr.__dict__.get("_touch")
-            if info is not None and pr.T >= 16 * info[4] and pr.T % info[4] == 0:      # (short sequences lose: T=64 2.13 -> 2.40 ms per step)
-                r, ext, counters, target, cs = info
-                p = r.prefix
-                arrays = [(self._v(p + ".acts", r.T, B, GH), (GH // 32) * 1024)]
-                arrays.append((self._v(p + ".cs", r.T + 1, B, H), (H // 32) * 1024) if s.cell == "LSTM"
-                              else (self._v(p + ".hs", r.T + 1, B, H), 16 * H * 2))
-                if ext is not None:
-                    arrays.append((ext, (H // 16) * 512))
-                touch.append(ops.l2_touch_problem(arrays, r.T, B // 16, cs, counters, target, first_wg=first,
-                                                  lead=self.l2_touch_lead, status=self.store["pipe_status"]))
-            first += B // 16
-        if not touch:
-            return
-        self._wait_stream(self.s_touch, torch.cuda.current_stream())       # starts when the launch it accompanies can
-        ops.l2_touch_bwd(touch, stream=self.s_touch)
 
     def _rec_dx(self, r, B, k=0, nch=1, **chunked):
         """Gradient w.r.t. the input sequence of layer ``r`` (= what the layer below receives at its h_t), time chunk k.

@@ -152,10 +152,6 @@ class PhaseLaunches(object):
             ext = dhs_ext if top else self._v(order[li - 1].prefix + ".dx", r.T, B, self.spec.H)
             probs.append(self._rec_bptt(r, B, dhs_ext=ext, dh_last=dh_last if top else None, dh_last_ld=dh_last_ld if top else 0,
                                         pipe=pipe, build=True, **(dstates(r) if dstates else {})))
-            # (the L2-touch companion, _launch_phase_backward.  Only what was COMPLETE before this launch may be touched ahead: a
-            #  lower layer's upstream gradient is written by the dX GEMM while the launch runs - a line touched before its chunk
-            #  is written would sit stale in this XCD's L2 when the recurrence reads it)
-            probs[-1].__dict__["_touch"] = (r, ext if top else None, sync[li, 0], da_target, cs)
             if li < L - 1:
                 gemms.append((li, lambda li=li, r=r: self._rec_dx(
                     r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True, chunk_wait=sync[li, 0],
@@ -165,8 +161,6 @@ class PhaseLaunches(object):
     def _launch_phase_backward(self, key, probs, gemms, steps=0):
         streams = [self.s_proj[li] for li, _ in gemms]
         ok = [True]
-        if key[1] in self.l2_touch_phases:
-            self._l2_touch(probs)
         self._timed(key, lambda: ok.__setitem__(0, ops.rnn_bwd_multi(probs)), steps=steps)
         assert ok[0], "mvae_rnn_bwd_multi refused a problem _phase_ok admitted"
         for (li, fn), st in zip(gemms, streams):
@@ -213,7 +207,6 @@ class PhaseLaunches(object):
             sync1, target1, _ = self._sync_region(5 + k, 1, r.T // cs, 4 * (B // 16), 0)
             probs.append(self._rec_bptt(r, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc, build=True,
                                         pipe=dict(chunk_steps=cs, status=status, signal_done=sync1[0, 0])))
-            probs[-1].__dict__["_touch"] = (r, None, sync1[0, 0], target1, cs)
             single_gate[r.prefix] = (sync1[0, 0][0:1], target1)
             if (kstream and follow is None and self.kstream_singles and r.T == T and cs == self.pipe_chunk and
                     (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 8):

@@ -24,7 +24,7 @@ CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -46,11 +46,6 @@ class RnnBwdArgs(C.Structure):
                 ("dc_last", _vp), ("da", _vp), ("rh", _vp), ("dh0", _vp), ("dc0", _vp), ("dh_last_ld", _i32), ("dh0_ld", _i32),
                 ("chunk_steps", _i32), ("wait_ready", _vp), ("wait_value", C.c_uint32), ("signal_done", _vp), ("status", _vp),
                 ("seq_layout", _i32)]
-
-
-class L2TouchArgs(C.Structure):
-    _fields_ = [("base", _vp * 3), ("tile_bytes", C.c_uint32 * 3), ("T", _i32), ("tiles", _i32), ("chunk_steps", _i32),
-                ("first_wg", _i32), ("lead", _i32), ("target", C.c_uint32), ("counters", _vp), ("status", _vp)]
 
 
 class GemmArgs(C.Structure):
@@ -122,7 +117,6 @@ SIGNATURES = {
     "mvae_rnn_bwd": (_i32, [C.POINTER(RnnBwdArgs), _vp]),
     "mvae_rnn_fwd_multi": (_i32, [C.POINTER(RnnFwdArgs), _i32, C.POINTER(XpandArgs), _i32, _vp]),
     "mvae_rnn_bwd_multi": (_i32, [C.POINTER(RnnBwdArgs), _i32, _vp]),
-    "mvae_l2_touch_bwd": (_i32, [C.POINTER(L2TouchArgs), _i32, _vp]),
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_gemm_kstream_multi": (_i32, [C.POINTER(GemmArgs), _i32, _vp]),

@@ -155,26 +155,6 @@ def rnn_bwd_multi(problems):
     return True
 
 
-def l2_touch_problem(arrays, T, tiles, chunk_steps, counters, target, *, first_wg=0, lead=16, status=None):
-    """one problem of l2_touch_bwd: ``arrays`` = up to three (tensor, bytes per (time step, 16-row tile)) pairs the recurrence
-    reads per time step; ``counters`` / ``target``: what it publishes (mvae_rnn_bwd_args.signal_done) and when a chunk counts as done"""
-    a = hl.L2TouchArgs()
-    for k, (t, nbytes) in enumerate(arrays):
-        a.base[k], a.tile_bytes[k] = t.data_ptr(), int(nbytes)
-    a.T, a.tiles, a.chunk_steps, a.first_wg, a.lead = int(T), int(tiles), int(chunk_steps), int(first_wg), int(lead)
-    a.target, a.counters, a.status = int(target), _pv(counters), _pv(status)
-    _tag(a, "target", target)
-    a.__dict__["_keep"] = [t for t, _ in arrays] + [counters, status]
-    return a
-
-
-def l2_touch_bwd(problems, stream=None):
-    """the L2-touch companion of a BPTT launch (include/midivae_hip.h), on ``stream`` (default: the current one)"""
-    arr = (hl.L2TouchArgs * len(problems))(*problems)
-    _note_fields(0, problems)
-    hl.check(hl.load().mvae_l2_touch_bwd(arr, len(problems), _stream() if stream is None else stream.cuda_stream), "mvae_l2_touch_bwd")
-
-
 def gemm(A, B, C, M, N, K, *, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=hl.ACT_NONE,
          accumulate=False, split_k=1, alpha=1.0, a_kind=None, c_layout=0, max_blocks=0, sys_release=False, chunk_rows=0,
          chunk_reverse=False, chunk_wait=None, chunk_wait_value=0, chunk_done=None, chunk_status=None, colsum_b=None,

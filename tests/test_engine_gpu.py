@@ -601,6 +601,18 @@ def test_elbo_trajectory_fresh_epsilon_on_the_benched_schedule(cell):
     assert max(rel.values()) < 0.35, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
 
 
+def test_elbo_stays_in_the_band_over_forty_steps_at_the_reference_learning_rate():
+    """The long run of tests/studies/elbo_long.py (200 steps, profiles/r05_*_elbo_200.txt) at a reduced size: 40 Adam steps at the
+    reference's lr 2e-4 (settings.py:113), LSTM bf16 on the benched schedule, T=128 - the ELBO within 1e-3 of the oracle's at EVERY
+    step, and no drift: the last ten steps are no further from the oracle than 3x the first ten."""
+    from tests.studies.elbo_long import run
+    import io
+    worst, left, rows = run("LSTM", 2e-4, 40, T=128, out=io.StringIO())
+    assert left is None and worst <= 1e-3, (worst, left)
+    first, last = max(r[3]["loss"] for r in rows[:10]), max(r[3]["loss"] for r in rows[-10:])
+    assert last <= max(3 * first, 2e-4), (first, last)
+
+
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 @pytest.mark.parametrize("B", [32, 200])
 def test_phase_launches_equal_the_per_stream_schedule(cell, B):
@@ -802,41 +814,3 @@ def test_gradient_time_portions_equal_whole_sequence_gradients(cell):
         ref = np.linalg.norm(grads[0][k])
         if ref > 1e-8:
             assert np.linalg.norm(grads[4][k] - grads[0][k]) <= 2e-3 * ref, (k, np.linalg.norm(grads[4][k] - grads[0][k]) / ref)
-
-
-def test_l2_touch_companion_changes_no_result_and_replays():
-    """Engine._l2_touch (include/midivae_hip.h mvae_l2_touch_bwd): beside the BPTT phase launches a one-wave-per-tile kernel on a
-    queue of its own walks ahead of every long recurrence and touches the saved values it is about to read.  It only READS, and only
-    what was complete before the launch (a lower layer's upstream gradient, written by the dX GEMM while the launch runs, is left
-    alone: a line touched before its chunk is written would be served stale): losses and every gradient are the same with
-    and without it (to the summation order of the split-K atomics), and eight optimizer steps - recorded, then replayed as plans with the companion's counter targets patched -
-    run without a time-out."""
-    B = 32
-    spec, params, _, raw = _problem("LSTM", B, seed=12, H=256, Z=32, T=256)       # (the companion goes with sequences of >= 16 chunks)
-    out = {}
-    for on in (False, True):
-        eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
-        assert eng.l2_touch and eng.s_touch is not None         # (default for LSTM)
-        eng.l2_touch = on
-        eng.set_params(params)
-        _stage(eng, raw, B)
-        launched, real = [], ops.l2_touch_bwd
-        ops.l2_touch_bwd = lambda problems, stream=None: (launched.append(len(problems)), real(problems, stream=stream))[1]
-        try:
-            eng.forward_backward(B)
-        finally:
-            ops.l2_touch_bwd = real
-        assert (launched == [2]) if on else not launched, launched     # (the decoder phase: both layers of the notes stack)
-        out[on] = (eng.metrics(B), eng.get_grads())
-        eng.check_pipeline()
-        for _ in range(8):
-            eng.train_step(B)
-        eng.check_pipeline()
-        assert eng.plan_stats["replayed"] >= 1, eng.plan_stats
-        assert np.isfinite(eng.metrics(B)["loss"])
-    for k, v in out[False][0].items():
-        assert abs(out[True][0][k] - v) <= 1e-6 * (1 + abs(v)), k
-    for k, g in out[False][1].items():          # (split-K partial sums meet in atomics: equal to f32 summation order)
-        ref = np.linalg.norm(g)
-        if ref > 1e-8:
-            assert np.linalg.norm(out[True][1][k] - g) <= 2e-5 * ref, (k, np.linalg.norm(out[True][1][k] - g) / ref)

@@ -814,35 +814,3 @@ def test_head_fused_input_gradient(dtype, tol, kind, N):
     got = host(tile16(dhs, R, H, False))
     assert np.abs(want).max() > 0
     close(got, want, tol, "dhs")
-
-
-def test_l2_touch_walk_ends_by_itself_on_status_and_on_bad_arguments():
-    """mvae_l2_touch_bwd: with every chunk published it touches everything and ends; with nothing published it stops one chunk +
-    lead ahead and ends when the status word is set; problems of several recurrences in one launch (first_wg); argument checks."""
-    import ctypes as C
-    import time
-    T, B, H, GH, cs = 64, 32, 256, 1024, 16
-    acts = torch.zeros((T, B, GH), dtype=torch.bfloat16, device=DEV)
-    cst = torch.zeros((T + 1, B, H), dtype=torch.bfloat16, device=DEV)
-    dx = torch.zeros((T, B, H), dtype=torch.bfloat16, device=DEV)
-    done = torch.full((T // cs,), 7, dtype=torch.int32, device=DEV)
-    none = torch.zeros(T // cs, dtype=torch.int32, device=DEV)
-    status = torch.zeros(1, dtype=torch.int32, device=DEV)
-    arrays = [(acts, (GH // 32) * 1024), (cst, (H // 32) * 1024), (dx, (H // 16) * 512)]
-    p0 = ops.l2_touch_problem(arrays, T, B // 16, cs, done, 7, first_wg=0, lead=8, status=status)
-    p1 = ops.l2_touch_problem(arrays[:1], T, B // 16, cs, done, 7, first_wg=B // 16, lead=8, status=status)
-    ops.l2_touch_bwd([p0, p1])
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    waiting = ops.l2_touch_problem(arrays, T, B // 16, cs, none, 7, first_wg=0, lead=8, status=status)
-    ops.l2_touch_bwd([waiting], stream=side)
-    time.sleep(0.05)
-    assert not side.query()                  # nothing published: it waits (bounded: 4 s)
-    status.fill_(1)
-    t0 = time.time()
-    side.synchronize()
-    assert time.time() - t0 < 1.0
-    bad = ops.l2_touch_problem(arrays, T, B // 16, 24, done, 7)            # chunk_steps does not divide T
-    arr = (hl.L2TouchArgs * 1)(bad)
-    assert hl.load().mvae_l2_touch_bwd(arr, 1, torch.cuda.current_stream().cuda_stream) == hl.E_ARG
-    assert hl.load().mvae_l2_touch_bwd(arr, 9, torch.cuda.current_stream().cuda_stream) == hl.E_ARG

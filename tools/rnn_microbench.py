@@ -24,8 +24,6 @@ ap.add_argument("--concurrent", type=int, default=1, help="run k copies of every
 ap.add_argument("--cu-mask", default="", help="streams restricted to a set of CUs (hipExtStreamCreateWithCUMask): 'even' / 'odd' = every "
                 "other CU of each shader engine, 'low' = the first half, 'single16' / 'pairs16' = 16 CUs as 16 different CU indices' "
                 "first / as 8 neighbouring pairs, or comma-separated hex words")
-ap.add_argument("--prefetch", type=int, default=-1, help="BPTT lines (with --signal): beside every launch the L2-touch companion "
-                "(mvae_l2_touch_bwd) walks the saved activations this many steps ahead, into the L2 of the XCD that will read them")
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
@@ -130,38 +128,11 @@ for name, kw in modes.items():
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
 ms = timeit(conc(lambda c: ops.rnn_fwd(cell, DT, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY)))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
-touch = None
-if a.prefetch >= 0:
-    assert a.signal, "--prefetch follows the chunk counters the launch publishes: add --signal 16"
-    tstreams = [torch.cuda.Stream() for _ in range(a.concurrent)]
-
-    def touch(i, acts_t, cs_t, dext_t):
-        """the product's L2-touch companion (mvae_l2_touch_bwd) beside copy 0's launch (the copies share the counters)"""
-        if i != 0:
-            return None
-        if touch.base is None:       # (the forward launches above published in the same counters)
-            torch.cuda.synchronize()
-            touch.base = int(counters[0].item())
-        touch.launches += 1
-        arrays = [(acts_t, (GH // 32) * 1024), (cs_t, (H // 32) * 1024) if cs_t is not None else (hs, 16 * H * 2)]
-        if dext_t is not None:
-            arrays.append((dext_t, (H // 16) * 512))
-        pr = ops.l2_touch_problem(arrays, T, B // 16, a.signal, counters, touch.base + touch.launches * 4 * (B // 16), lead=a.prefetch,
-                                  status=status)
-        tstreams[i].wait_stream(torch.cuda.current_stream())
-        ops.l2_touch_bwd([pr], stream=tstreams[i])
-        return tstreams[i]
-    touch.launches, touch.base = 0, None
-
 
 def bwd_call(c, ext):
-    i = 0 if c is None else 1 + next(k for k, x in enumerate(copies) if x is c)
     acts_c, cs_c = (c["acts"], c["cs"]) if c else (acts, cs)
-    st = touch(i, acts_c, cs_c, dext if ext else None) if touch else None
     ops.rnn_bwd(cell, DT, T, B, H, ut, hs, cs_c, acts_c, c["da"] if c else da, dhs_ext=dext if ext else None,
                 rh=c["rh"] if c else rh, dh0=hl_, seq_layout=LAY, **(sig if LAY == hl.TILE16P else {}))
-    if st is not None:
-        torch.cuda.current_stream().wait_stream(st)
 
 
 for ext in (True, False):
