@@ -388,9 +388,12 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     timed_kinds, every = eng.prof_kinds, 4       # every 4th step carries the brackets (two packets on the critical queue each)
+    host_s = 0.0                # time the host spends enqueueing the steps (the step() calls themselves)
     for i in range(args.steps):
         eng.prof_kinds = timed_kinds if i % every == 0 else set()
+        th = time.perf_counter()
         step()
+        host_s += time.perf_counter() - th
         marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -424,7 +427,9 @@ def main():
                                      "what": "HIP-event time of the collectives on their streams, mean over the timed steps, max "
                                              "over ranks (early: the decoder-side bucket beside the encoder BPTT, null when the "
                                              "overlap is off; late: what is reduced after the backward pass)"},
-                    "overlap": bool(getattr(allreduce, "overlap", False))}
+                    "overlap": bool(getattr(allreduce, "overlap", False)),
+                    # (a data-parallel step replays as a plan too: Python issues the collectives between its call ranges)
+                    "host_ms_per_step": host_s / args.steps * 1e3, "plan": dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]))}
         tt = torch.tensor([elapsed, median_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
@@ -526,7 +531,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port",
                                    "sample": "not timed for the decode configuration: oracle/torch_cpu.py covers the train step (the "
                                              "default --config 1 run carries the CPU baseline)"}
-        out["plan"] = dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]),
+        out["plan"] = dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]), host_ms_per_step=host_s / args.steps * 1e3,
                            what="step plans (include/midivae_hip.h): steps of the timed region enqueued by ONE mvae_plan_run call "
                                 "('replayed') - every 4th step, whose dominant launches are bracketed with HIP events, by Python")
         if dp_stats is not None:

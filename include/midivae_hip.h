@@ -207,6 +207,12 @@ int mvae_gemm(const mvae_gemm_args* a, void* stream);
  * (MVAE_E_ARG beyond) - they all wait, resident, for their producers.  Replaces the reference's implicit "gradients of every
  * weight of the encoder stack" inside K.gradients (vae_definition.py:1016-1045 via Keras' train_function). */
 int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n, void* stream);
+/* n <= 16 ORDINARY weight-gradient GEMMs as one launch (round 5): every problem C (M,N) f32 row-major += A^T B with trans_a = 1,
+ * trans_b = 0, accumulate = 1, bf16 or MVAE_A_ONEHOT A, bf16 B, optional colsum_b and split_k - what mvae_gemm would run on its
+ * fast kernel, with none of the chunk_* / k_wait fields (those producers must be DONE: order the launch behind them).  For short
+ * sequences (reference settings.py:108-109: T = 64), where a dozen such launches of 20-120 us each were most of what follows the
+ * last recurrence.  MVAE_E_UNSUPPORTED: a problem is not of this form (run it through mvae_gemm). */
+int mvae_gemm_multi(const mvae_gemm_args* problems, int32_t n, void* stream);
 
 /* Stream-ordered synchronisation with RUNNING kernels (hipStreamWaitValue32 / hipStreamWriteValue32 on plain device
  * memory): `stream` proceeds once *addr >= value / writes value to *addr after everything enqueued before it on `stream`. */

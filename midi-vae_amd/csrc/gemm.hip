@@ -576,6 +576,31 @@ __global__ __launch_bounds__(256) void gemm_kstream_multi_k(const kstream_multi 
     else gemm_fast_body<true, true, false, false>(m.p[i], vb, nvb, smem);
 }
 
+// Up to GM_MAX ordinary (not K-streaming) weight-gradient GEMMs - C (M,N) f32 += A (K,M)^T B (K,N), split-K, bf16 or one-hot A - as
+// ONE launch (mvae_gemm_multi).  Short sequences (the reference's shipped T = 64: K = T*B = 16384 rows) make every such GEMM a
+// 20-120 us launch of which most is fill and drain; a dozen of them on two queues beside and behind the recurrences was two thirds
+// of the step's tail, and each one's workgroups kept the recurrent launches (one workgroup per EMPTY CU) from being placed.
+// Workgroups [base[i], base[i] + wgs[i]) run problem i; every base is a multiple of 8, so that a problem's virtual block b still
+// runs on XCD b % 8 (the split-K panel sharing of gemm_fast_body).
+constexpr int GM_MAX = 16;
+struct gemm_multi {
+    mvae_gemm_args p[GM_MAX];
+    int32_t base[GM_MAX + 1];
+    int32_t wgs[GM_MAX];
+    int32_t variant[GM_MAX];     // 0: dense A, 1: dense A + column sums of B, 2: one-hot A
+    int32_t n;
+};
+__global__ __launch_bounds__(256) void gemm_multi_k(const gemm_multi m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.base[i + 1]) ++i;
+    const int vb = (int)blockIdx.x - m.base[i], nvb = m.wgs[i];
+    if (vb >= nvb) return;                      // (padding up to the next multiple of 8)
+    if (m.variant[i] == 1) gemm_fast_body<true, true, false, true>(m.p[i], vb, nvb, smem);
+    else if (m.variant[i] == 2) gemm_fast_body<true, true, true, false>(m.p[i], vb, nvb, smem);
+    else gemm_fast_body<true, true, false, false>(m.p[i], vb, nvb, smem);
+}
+
 // ===========================================================================================================
 // Weights-stationary persistent projection: x*W + b of a stacked layer behind a time-pipelined lower layer, K = H = 256.
 // In the fast kernel above a 128x128 tile with K = 256 is four k-iterations: prologue latency, the reload of the same 64 KB weight
@@ -797,8 +822,7 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
 #undef WS_WAIT
 // the problems proj_ws_k takes: the forward projection of a pipelined stack (A (M,256) and B (N,256) k-contiguous bf16, bf16 output)
 bool ws_ok(const mvae_gemm_args& a) {
-    static const bool off = getenv("MVAE_NO_WS_GEMM") != nullptr;
-    if (off || !a.chunk_rows || a.trans_a || !a.trans_b || a.K != WS_K || a.c_kind != MVAE_BF16 || a.accumulate ||
+    if (!a.chunk_rows || a.trans_a || !a.trans_b || a.K != WS_K || a.c_kind != MVAE_BF16 || a.accumulate ||
         a.act != MVAE_ACT_NONE || a.split_k > 1)
         return false;
     const int tiles_n = a.N / FBN, tiles_mc = a.chunk_rows / FBM;
@@ -950,6 +974,47 @@ extern "C" int mvae_gemm_kstream_multi(const mvae_gemm_args* problems, int32_t n
     return MVAE_OK;
 }
 
+extern "C" int mvae_gemm_multi(const mvae_gemm_args* problems, int32_t n, void* stream) {
+    if (!problems || n <= 0 || n > GM_MAX) return MVAE_E_ARG;
+    static_assert(sizeof(gemm_multi) <= 4096, "kernel arguments");
+    gemm_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const mvae_gemm_args* a = problems + i;
+        if (!a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->bias || a->act != MVAE_ACT_NONE) return MVAE_E_ARG;
+        if (!a->trans_a || a->trans_b || !a->accumulate || a->c_kind != MVAE_F32 || a->c_layout != MVAE_ROWMAJOR || a->k_wait ||
+            a->chunk_rows || a->chunk_wait || a->chunk_done || a->max_blocks != 0 || a->sys_release)
+            return MVAE_E_UNSUPPORTED;
+        if (!fast_ok(*a)) return MVAE_E_UNSUPPORTED;
+        if (a->a_kind == MVAE_A_ONEHOT) m.variant[i] = 2;
+        else if (a->colsum_b) {
+            if ((a->N % FBN) || a->a_kind != MVAE_BF16) return MVAE_E_UNSUPPORTED;
+            m.variant[i] = 1;
+        } else m.variant[i] = 0;
+        const int sk = a->split_k > 1 ? a->split_k : 1;
+        const long long wgs = (long long)((a->N + FBN - 1) / FBN) * ((a->M + FBM - 1) / FBM) * (sk >= 8 ? (sk + 7) / 8 * 8 : sk);
+        if (wgs > (1 << 20)) return MVAE_E_ARG;
+        m.p[i] = *a;
+        m.base[i] = (int32_t)total;
+        m.wgs[i] = (int32_t)wgs;
+        total += (wgs + 7) / 8 * 8;
+    }
+    m.base[n] = (int32_t)total;
+    const size_t lds = (size_t)2 * (f_img<true>() + f_img<true>()) * sizeof(bf16_t);
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_multi_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL(gemm_multi_k, dim3((unsigned)total), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 extern "C" int mvae_occupancy(int32_t which) {
     int n = 0;
     hipError_t e;
@@ -997,8 +1062,7 @@ extern "C" int mvae_gemm(const mvae_gemm_args* a, void* stream) {
     // A handful of output tiles with a long K (the Dense layers around the latent: M = batch, K up to nInit*H = 2304) is
     // a few workgroups marching through K for 100+ us on an otherwise idle chip: zero C and split K over atomics.
     mvae_gemm_args split;
-    static const bool autosplit = !getenv("MVAE_NO_AUTOSPLIT");
-    if (autosplit && !a->accumulate && a->split_k <= 1 && a->c_kind == MVAE_F32 && a->c_layout == MVAE_ROWMAJOR &&
+    if (!a->accumulate && a->split_k <= 1 && a->c_kind == MVAE_F32 && a->c_layout == MVAE_ROWMAJOR &&
         a->act == MVAE_ACT_NONE && a->K >= 512 && (long long)((a->M + 63) / 64) * ((a->N + 63) / 64) <= 32 && a->ldc == a->N) {
         if (hipMemsetAsync(a->C, 0, (size_t)a->M * a->N * sizeof(float), s) != hipSuccess) return MVAE_E_LAUNCH;
         split = *a;

@@ -48,7 +48,7 @@ struct entry {
 // of a step)
 const entry k_entries[] = {
     MVAE_ENTRY(mvae_rnn_fwd), MVAE_ENTRY(mvae_rnn_bwd), MVAE_ENTRY(mvae_rnn_fwd_multi), MVAE_ENTRY(mvae_rnn_bwd_multi),
-    MVAE_ENTRY(mvae_pack_recurrent), MVAE_ENTRY(mvae_gemm), MVAE_ENTRY(mvae_gemm_kstream_multi), MVAE_ENTRY(mvae_colsum),
+    MVAE_ENTRY(mvae_pack_recurrent), MVAE_ENTRY(mvae_gemm), MVAE_ENTRY(mvae_gemm_kstream_multi), MVAE_ENTRY(mvae_gemm_multi), MVAE_ENTRY(mvae_colsum),
     MVAE_ENTRY(mvae_stream_wait_value32), MVAE_ENTRY(mvae_stream_write_value32), MVAE_ENTRY(mvae_prepare_batch),
     MVAE_ENTRY(mvae_outer_bias_tile16), MVAE_ENTRY(mvae_gather2_tile16), MVAE_ENTRY(mvae_colsum_weighted),
     MVAE_ENTRY(mvae_sum_over_time), MVAE_ENTRY(mvae_head), MVAE_ENTRY(mvae_latent_fwd), MVAE_ENTRY(mvae_latent_bwd),

@@ -558,15 +558,6 @@ int bwd_cell(const mvae_rnn_bwd_args& a, hipStream_t s) {
     return MVAE_E_ARG;
 }
 
-// MVAE_GENERIC_RNN=1 in the environment forces the generic (weights re-read from L2) kernels: A/B measurements
-bool use_resident() {
-    static const bool on = [] {
-        const char* e = getenv("MVAE_GENERIC_RNN");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
-
 }  // namespace
 
 // rnn_resident.hip: H = 256 / bf16 kernels with the recurrent weights resident in registers + LDS
@@ -581,7 +572,7 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
     if (a->wait_ready && a->xmode != MVAE_X_DENSE) return MVAE_E_ARG;
     if (a->signal_done && !a->hs) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN && use_resident()) {
+    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN) {
         const int rc = mvae_rnn_fwd_resident(*a, s);
         if (rc != MVAE_E_UNSUPPORTED) return rc;
     }
@@ -598,7 +589,7 @@ extern "C" int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream) {
     if ((a->wait_ready || a->signal_done) && a->seq_layout != MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
     if (a->wait_ready && !a->dhs_ext) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN && use_resident()) {
+    if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN) {
         const int rc = mvae_rnn_bwd_resident(*a, s);
         if (rc != MVAE_E_UNSUPPORTED) return rc;
     }

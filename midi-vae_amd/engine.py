@@ -43,6 +43,7 @@ class _NullCtx(object):
 
 
 class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, Results):
+    INDEX_DENSE = False      # the one-hot bottom layer's table rows written out inside the phase launch (_index_as_dense): measured, off
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
                  training: bool = True, share: "Engine | None" = None):
         """``share``: another Engine of the same spec on the same device whose PARAMETERS (the flat f32 buffer itself) and HIP
@@ -118,10 +119,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # time steps per hand-over: a hand-over costs every workgroup a drained vmcnt and a counter, the persistent GEMM a wait - the
         # bigger the batch, the more rows a chunk should carry (A/B r02: 256 windows 8 / 16 / 32 / 64 -> 8.18 / 8.08 / 8.13 / 8.31 ms;
         # 512 windows, T=2048: 35.7 / 34.5 / 35.4 at 16 / 32 / 64; decode of 1024 windows: 57.0 / 58.9 / 60.1 / 59.9 k at 16 / 32 / 64 / 128)
-        self.pipe_chunk = int(os.environ.get("MVAE_PIPE_CHUNK", "0")) or (16 if self.maxB <= 256 else 32 if self.maxB <= 512 else 64)
+        self.pipe_chunk = 16 if self.maxB <= 256 else 32 if self.maxB <= 512 else 64
         while self.pipe_chunk > 16 and spec.T % self.pipe_chunk:
             self.pipe_chunk //= 2
-        self.pipe_gemm_blocks = int(os.environ.get("MVAE_PIPE_GEMM_BLOCKS", "64"))       # persistent grid of the dX GEMM between two pipelined layers (backward)
+        self.gate_pipe_gemms = False      # (engine_phases._launch_pipe_gemms: measured, off)
+        self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
         # 8 XCDs x (G*H / 128) column tiles - one workgroup per (XCD, column tile) keeps its weight panel in LDS for the whole launch:
         # 64 for LSTM, 48 for GRU.  (Round 1's kernel reloaded the panel per tile; decoder inference at 1024 windows was bound by it:
@@ -139,8 +141,18 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # them are ONE launch (mvae_gemm_kstream_multi) on the second gradient queue - a queue each cost more than the tail saved -
         # and the other gradient work of that phase (velocity / instrument encoders) goes to the first one.
         # kstream_wgs workgroups per GEMM: they wait beside the recurrences, one per CU (_kstream_ok: residency).
+        # SHORT sequences (the reference's shipped T = 64, settings.py:108-109): every weight-gradient GEMM is a 20-120 us launch
+        # that is mostly fill and drain, a dozen of them beside and behind the recurrences were two thirds of what followed the last
+        # BPTT, and their workgroups kept the recurrent launches (one workgroup per EMPTY CU) waiting for a place.  Up to
+        # defer_grads_rows rows (T x padded batch) per sequence they are collected during the backward pass and leave as ONE launch
+        # (mvae_gemm_multi) on the critical queue behind the last recurrence (_wgemm / _flush_deferred_gemms); above that the
+        # GEMMs are long enough to be worth running beside the recurrences.  (profiles/r05_c_*; 0 = never)
+        # GRU only (the reference's shipped cell): measured on T = 64, 256 windows 2.33 -> 2.06 ms per step (64 windows 1.85 -> 1.73);
+        # LSTM 2.12 -> 2.30 - its K-streaming launch hides more than the batched launch saves
+        self.defer_grads_rows = int(os.environ.get("MVAE_DEFER_GRADS_ROWS", "32768" if spec.cell == "GRU" else "0"))
+        self._deferred_gemms, self._deferred_small = None, []
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
-        self.kstream_wgs = int(os.environ.get("MVAE_KSTREAM_WGS", "0")) or (24 if spec.cell == "GRU" else 32)   # (GRU: 3 GEMMs per layer)
+        self.kstream_wgs = 24 if spec.cell == "GRU" else 32   # (GRU: 3 GEMMs per layer)
         self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
@@ -156,19 +168,19 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # ... up to this many (padded) windows per call: measured (profiles/r03_j_*) 256 windows -6 % (LSTM) / -9 % (GRU) per train
         # step, but 512 windows at T=2048 +6.5 % and decoding 1024 windows +4 % - there the recurrences themselves fill the chip
         # and the per-queue launches (producers dispatched first) place them better than one launch's index order
-        self.phase_max_B = int(os.environ.get("MVAE_PHASE_MAX_B", "256"))
+        self.phase_max_B = 256
         # (_index_as_dense; measured r03_r: GRU step -0.07 ms, LSTM +0.09 ms - there the bottom layer does not set the pace)
         #  Round 4: the indexed kernels gather tile PAIRS from a paired-column table (8 x 16 bytes per row and step instead of 16 x 8:
         #  LSTM 2.66 -> 2.17, GRU 2.06 -> 1.70 us per step alone - faster than a dense input) and the written-out rows lose on both
         #  cells (GRU 5.71 vs 5.63 ms per step, LSTM 7.11 vs 6.91: profiles/r04_l_index_dense_ab.txt): off by default
-        self.index_dense = os.environ.get("MVAE_INDEX_DENSE", "0") == "1"
-        self.index_dense_blocks = int(os.environ.get("MVAE_INDEX_DENSE_BLOCKS", "16"))
-        self.xpand_blocks = int(os.environ.get("MVAE_XPAND_BLOCKS", "16"))
+        self.index_dense = type(self).INDEX_DENSE      # (a class attribute: the buffers it needs are allocated here)
+        self.index_dense_blocks = 16
+        self.xpand_blocks = 16
         self.gate_side_heads = True      # (settled r03_z: -0.03 ms)   # (decoder_forward: counter instead of event)
         self._last_stack_gate = None
         # (_head_forward: inference on per-queue pipelined stacks.  profiles/r03_zz_decode_head_slices.txt: decode configs[4] LSTM
         #  -3..5 % with 2 slices, -1..3 % with 4; GRU -3 % / -6..7 %: the slices take memory bandwidth from the recurrences they follow)
-        self.head_slices = int(os.environ.get("MVAE_HEAD_SLICES", "2" if spec.cell == "LSTM" else "4"))
+        self.head_slices = 2 if spec.cell == "LSTM" else 4
         self._top_publish = None
         # (_join; r03_z: -0.02 / -0.04 ms.  NOT when kernels are run one at a time - rocprofv3 counter collection: a critical queue parked
         #  in a value wait and a writer queue held back behind it never finish; event joins work there)
@@ -177,7 +189,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._join_seq = {}
         self._diag_no_param_grads = os.environ.get("MVAE_DIAG_NO_PARAM_GRADS", "0") == "1"
         # (_grad_portions) -1: by the rows of the sequence (4 portions from 2^20 rows, none below 2^19), 0: off, N: N portions
-        self.grad_portions = int(os.environ.get("MVAE_GRAD_PORTIONS", "-1"))
+        self.grad_portions = -1
         self._grad_portion_jobs = None
         self._single_slot = 0
         self._hold_dec_grads = 1     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
@@ -912,6 +924,35 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         for _, fn in sorted(jobs or [], key=lambda j: j[0]):
             fn()
 
+    def _wgemm(self, A, Bm, C, M, N, K, **kw):
+        """a weight-gradient GEMM C (M,N) f32 += A^T Bm (ops.gemm with trans_a, accumulate): launched now on the current stream -
+        or, on a step that defers them (defer_grads_rows), kept as a problem of the one mvae_gemm_multi launch behind the last
+        recurrence"""
+        if self._deferred_gemms is not None and self.tile16 and K % 64 == 0 and (N % 128 == 0 or N < 128):
+            self._deferred_gemms.append(ops.gemm(A, Bm, C, M, N, K, trans_a=True, accumulate=True, build_only=True, **kw))
+            return
+        ops.gemm(A, Bm, C, M, N, K, trans_a=True, accumulate=True, **kw)
+
+    def _small(self, fn):
+        """a small launch of the parameter-gradient work (a column sum, a sum over time): now on the current stream - or, on a
+        step that defers (defer_grads_rows), behind the batched GEMM launch on the critical queue (a gate + a launch on a gradient
+        queue costs the command processors more than these kernels run)"""
+        if self._deferred_gemms is not None:
+            self._deferred_small.append(fn)
+        else:
+            fn()
+
+    def _flush_deferred_gemms(self):
+        """the step's collected weight-gradient GEMMs as one launch (per 16) on the current - the critical - stream, the small
+        launches behind it: everything they read was produced on this queue or joined into it"""
+        probs, self._deferred_gemms = self._deferred_gemms, None
+        small, self._deferred_small = self._deferred_small, []
+        if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
+            for g in probs:
+                ops.gemm_args(g)
+        for fn in small:
+            fn()
+
     def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, publishes=None, rows=None):
         P = self._grad_portions(r, B, publishes) if rows is None else 1
         if P > 1:
@@ -946,54 +987,64 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             xs = xs[t_lo:t_hi]
         sk = self._split_k(R)
         sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
-        if gate is None:
-            self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
+        deferring = self._deferred_gemms is not None
+        if deferring:                       # (everything below is collected: nothing is enqueued on the gradient queues now)
+            on1 = on2 = _NullCtx()
         else:
-            for st in ((sg1,) if sg1 is sg2 else (sg1, sg2)):
-                ops.stream_wait_value32(gate[0], gate[1], stream=st)
-        # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path)
-        fuse_b = r.xmode != hl.X_CONST and self.tile16 and self.fuse_bias_grad
+            on1, on2 = self._on(sg1), self._on(sg2)
+            if gate is None:
+                self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
+            else:
+                for st in ((sg1,) if sg1 is sg2 else (sg1, sg2)):
+                    ops.stream_wait_value32(gate[0], gate[1], stream=st)
+        # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path) - also for
+        # the decoder cells on a constant input when that input is all zeros (what the reference's packers always pass,
+        # vae_definition.py:820,916: dW = start^T sum_t(da) = 0 then, and the sum over time is only needed for the bias)
+        const_fused = (r.xmode == hl.X_CONST and self.start_zero.get(p, False) and self.tile16 and self.fuse_bias_grad and
+                       not skip_dU)
+        fuse_b = (r.xmode != hl.X_CONST or const_fused) and self.tile16 and self.fuse_bias_grad
         gb = G[p + ".b"]
-        with self._on(sg1):
+        with on1:
             # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
             if skip_dU:             # (with its bias gradient in a K-streaming launch)
                 pass
             elif s.cell == "GRU":
                 rh = self._v(p + ".rh", T, B, H)[t_lo:t_hi]
-                ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, trans_a=True, ldb=GH, ldc=GH, accumulate=True, split_k=sk,
-                         colsum_b=gb[:2 * H] if fuse_b else None)
-                ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, trans_a=True, ldb=GH, ldc=GH,
-                         accumulate=True, split_k=sk, colsum_b=gb[2 * H:] if fuse_b else None)
+                self._wgemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=sk, colsum_b=gb[:2 * H] if fuse_b else None)
+                self._wgemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, ldb=GH, ldc=GH, split_k=sk,
+                            colsum_b=gb[2 * H:] if fuse_b else None)
             else:
-                ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, trans_a=True, accumulate=True, split_k=sk,
-                         colsum_b=gb if fuse_b else None)
-        with self._on(sg2):
-            if r.xmode == hl.X_CONST:
+                self._wgemm(hprev, da2, G[p + ".U"], H, GH, R, split_k=sk, colsum_b=gb if fuse_b else None)
+        with on2:
+            if const_fused:
+                pass
+            elif r.xmode == hl.X_CONST:
                 dxp0 = self._v(p + ".dxp0", B, GH)
+                acc = self._dxp0_clean or not first
                 # (time portions: every portion adds its share to dxp0 - zeroed by the weight preparation; what is derived from the
                 #  complete sum follows the portion that ends at step 0)
-                ops.sum_over_time(da, Tq, B * GH, dxp0, accumulate=self._dxp0_clean or not first)
+                self._small(lambda: ops.sum_over_time(da, Tq, B * GH, dxp0, accumulate=acc))
                 if t_lo == 0:
-                    ops.colsum(dxp0, B, GH, G[p + ".b"])
+                    self._small(lambda: ops.colsum(dxp0, B, GH, G[p + ".b"]))
                     if not self.start_zero.get(p, False):        # (dW = start^T dxp0 = 0 for an all-zero start)
-                        ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True)
+                        self._small(lambda: ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True))
             else:
                 if not fuse_b:
-                    ops.colsum(da2, R, GH, G[p + ".b"])
+                    self._small(lambda: ops.colsum(da2, R, GH, G[p + ".b"]))
                 if r.xmode == X_EXT:
                     pass                                # (input-kernel gradient by the caller: _aux_backward)
                 elif r.xmode == hl.X_INDEX:
-                    ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
+                    self._wgemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, a_kind=hl.ONEHOT, split_k=sk)
                 elif r.xmode == X_GATHER2:      # two-hot rows: the pitch rows and the attached instrument rows of W
                     d0 = r.K - s.attach
-                    ops.gemm(idx.reshape(-1), da2, G[p + ".W"][:d0], d0, GH, R, trans_a=True, a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
-                    ops.gemm(self._v("in.xa_idx", T, B)[t_lo:t_hi].reshape(-1), da2, G[p + ".W"][d0:], s.attach, GH, R, trans_a=True,
-                             a_kind=hl.ONEHOT, accumulate=True, split_k=sk)
+                    self._wgemm(idx.reshape(-1), da2, G[p + ".W"][:d0], d0, GH, R, a_kind=hl.ONEHOT, split_k=sk)
+                    self._wgemm(self._v("in.xa_idx", T, B)[t_lo:t_hi].reshape(-1), da2, G[p + ".W"][d0:], s.attach, GH, R,
+                                a_kind=hl.ONEHOT, split_k=sk)
                 elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
-                    ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"])
+                    self._small(lambda: ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"]))
                 else:
                     lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t_lo:1 + t_hi].reshape(R, H)
-                    ops.gemm(lower, da2, G[p + ".W"], H, GH, R, trans_a=True, accumulate=True, split_k=sk)
+                    self._wgemm(lower, da2, G[p + ".W"], H, GH, R, split_k=sk)
 
     def _kstream_ok(self, layers, B):
         """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
@@ -1004,7 +1055,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         that may start late; at 512 windows 96: ordinary GEMMs then, as measured, profiles/r02_q_pipe_chunk_by_batch.txt.)"""
         s = self.spec
         count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
-        if not (self.kstream_grads and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
+        if not (self.kstream_grads and self._deferred_gemms is None and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
                 self._pipelined(layers) and all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers)):
             return False
         free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
@@ -1205,10 +1256,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if not self._fused_head_bwd(name, True):
             ops.gemm(dl, self._v(name + ".wt", NP, H), dhs, R, H, NP, c_layout=self.lay)   # dl (R,NP) W^T (NP,H); pad rows zero
         def grads():
-            ops.gemm(top, dl, G[outW], H, N, R, trans_a=True, ldb=NP, accumulate=True, split_k=self._split_k(R))
-            ops.colsum(dl, R, N, G[outb], ldx=NP)
+            self._wgemm(top, dl, G[outW], H, N, R, ldb=NP, split_k=self._split_k(R))
+            self._small(lambda: ops.colsum(dl, R, N, G[outb], ldx=NP))
         if defer:
             return dhs, grads
+        if self._deferred_gemms is not None:        # (collected, not enqueued: no fork)
+            grads()
+            return dhs
         self._fork(self.s_grad)
         with self._on(self.s_grad):
             grads()
@@ -1231,6 +1285,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # (one event for the branches, the notes head's gradient GEMM and the notes stack's lower layers)
         side = [h for h in self.dec_heads if h.stream is not None]
         self._cur_B, self._n_side = B, len(side)
+        self._deferred_gemms = [] if self._defers_grads(B) else None
         for a in self.aux:
             self._aux_backward(a, B)
         notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
@@ -1311,6 +1366,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._tail_streams = []
         self._join(*tail, self.s_grad, word=1)
         self._join(self.s_grad2, word=2)
+        self._flush_deferred_gemms()
+
+    def _defers_grads(self, B):
+        """does a step of B (padded) windows collect its weight-gradient GEMMs for one launch behind the last recurrence?"""
+        return bool(self.training and self.tile16 and self.multi_stream and 0 < self.spec.T * B <= self.defer_grads_rows)
 
     def _latent_chain_backward(self, Breal, B):
         """The same as ONE launch (csrc/latent.hip) followed by the parameter-gradient GEMMs on the side streams; None if
@@ -1542,15 +1602,16 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 (z_dst, zbuf), self._fused_dst = self._fused_dst, None
                 z_dst.copy_(zbuf[:z_dst.shape[0]])
 
-    def _overlap_hook(self, allreduce):
+    def _overlap_hook(self, allreduce, B):
         """the hook whose decoder bucket is reduced beside the encoder BPTT - not on a step that may still be redone (the first
         pipelined train step of an engine, _verify_pipeline): the redo zeroes and recomputes the gradients, which must not race a
         collective already in flight on part of them; that one step reduces the whole buffer afterwards"""
         unverified = self.pipeline and "train" not in self._pipe_verified
-        return allreduce if (getattr(allreduce, "overlap", False) and not unverified) else None
+        # (... nor on a step that defers its weight-gradient GEMMs: the decoder bucket is complete only behind the last recurrence)
+        return allreduce if (getattr(allreduce, "overlap", False) and not unverified and not self._defers_grads(self.pad16(B))) else None
 
     def _train_step_finish(self, B, allreduce):
-        self._bucket_hook = self._overlap_hook(allreduce)
+        self._bucket_hook = self._overlap_hook(allreduce, B)
         self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
             self.decoder_forward(B)
@@ -1586,7 +1647,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def _train_step(self, B, allreduce):
         self._redo_hist = None
-        self._bucket_hook = self._overlap_hook(allreduce)
+        self._bucket_hook = self._overlap_hook(allreduce, B)
         try:
             self.forward_backward(B)
         finally:

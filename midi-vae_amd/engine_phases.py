@@ -81,7 +81,7 @@ class PhaseLaunches(object):
             if not top:
                 gemms.append((li, lambda li=li: self._rec_xp(
                     layers[li + 1], B, 0, 1, max_blocks=self.pipe_proj_blocks, chunk_rows=cs * B, chunk_wait=sync[li, 0],
-                    chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status)))
+                    chunk_wait_value=hs_target, chunk_done=sync[li, 1], chunk_status=status), (sync[li, 0][0:1], hs_target)))
         return probs, gemms
 
     def _launch_phase_forward(self, key, probs, gemms, xpands=(), steps=0):
@@ -89,11 +89,19 @@ class PhaseLaunches(object):
         a GEMM reads nothing before its producer (a problem of the launch, behind the weight preparation on this queue) has
         published a chunk, its queue orders it against the GEMMs of the other phases, and an event record would be one more packet
         (~30-50 us) on the critical queue per phase.  A GEMM that starts early polls."""
-        streams = [self.s_proj[li] for li, _ in gemms]
+        streams = [self.s_proj[li] for li, _, _ in gemms]
         ok = [True]
         self._timed(key, lambda: ok.__setitem__(0, ops.rnn_fwd_multi(probs, xpands)), steps=steps)
         assert ok[0], "mvae_rnn_fwd_multi refused a problem _phase_ok admitted"
-        for (li, fn), st in zip(gemms, streams):
+        self._launch_pipe_gemms(gemms, streams)
+
+    def _launch_pipe_gemms(self, gemms, streams):
+        """the persistent GEMMs between the layers of a phase launch, each on its queue.  (``gate``: a value wait for the first chunk
+        its producer publishes, so that the GEMM is not dispatched - resident and polling - a phase early; measured in round 5, no
+        gain: T = 64 2.045 -> 2.057 ms, T = 512 6.73 -> 6.81, profiles/r05_c_*; kept as an option for that measurement only)"""
+        for (li, fn, gate), st in zip(gemms, streams):
+            if self.gate_pipe_gemms:
+                ops.stream_wait_value32(gate[0], gate[1], stream=st)
             with torch.cuda.stream(st):
                 fn()
 
@@ -155,17 +163,15 @@ class PhaseLaunches(object):
             if li < L - 1:
                 gemms.append((li, lambda li=li, r=r: self._rec_dx(
                     r, B, 0, 1, max_blocks=self.pipe_gemm_blocks, chunk_rows=cs * B, chunk_reverse=True, chunk_wait=sync[li, 0],
-                    chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status)))
+                    chunk_wait_value=da_target, chunk_done=sync[li, 1], chunk_status=status), (sync[li, 0][nchp - 1:nchp], da_target)))
         return probs, gemms, (sync, da_target, nchp)
 
     def _launch_phase_backward(self, key, probs, gemms, steps=0):
-        streams = [self.s_proj[li] for li, _ in gemms]
+        streams = [self.s_proj[li] for li, _, _ in gemms]
         ok = [True]
         self._timed(key, lambda: ok.__setitem__(0, ops.rnn_bwd_multi(probs)), steps=steps)
         assert ok[0], "mvae_rnn_bwd_multi refused a problem _phase_ok admitted"
-        for (li, fn), st in zip(gemms, streams):
-            with torch.cuda.stream(st):
-                fn()
+        self._launch_pipe_gemms(gemms, streams)
 
     def _notes_backward_multi(self, h, B, dext, dstates, start, head_grads):
         """BPTT through the decoder notes stack as one launch; the output Dense's parameter gradients are released by the launch's
@@ -173,9 +179,12 @@ class PhaseLaunches(object):
         not by the end of the launch - all through device counters, no event on the critical queue"""
         probs, gemms, (sync, da_target, nchp) = self._stack_problems_backward(h.layers, B, 2, dhs_ext=dext, dstates=dstates)
         self._launch_phase_backward(("rnn_bwd_multi", "dec"), probs, gemms, steps=h.T * len(h.layers))
-        ops.stream_wait_value32(sync[0, 0][nchp - 1:nchp], da_target, stream=self.s_grad)
-        with torch.cuda.stream(self.s_grad):
+        if self._deferred_gemms is not None:        # (short sequences: collected for the launch behind the last recurrence)
             head_grads()
+        else:
+            ops.stream_wait_value32(sync[0, 0][nchp - 1:nchp], da_target, stream=self.s_grad)
+            with torch.cuda.stream(self.s_grad):
+                head_grads()
         L = len(h.layers)
         for li, r in enumerate(reversed(h.layers)):
             if (li == L - 1 or self._hold_dec_grads >= 2) and self._hold_dec_grads and self._after_chain is not None:

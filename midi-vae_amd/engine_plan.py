@@ -33,7 +33,7 @@ class PlannedSteps(object):
     _PLAN_CONFIG = ("head_slices", "grad_portions", "index_dense",
                     "index_dense_blocks", "xpand_blocks", "pipe_chunk", "phase_max_B", "kstream_grads", "kstream_wgs",
                     "kstream_singles", "pipe_gemm_blocks", "pipe_proj_blocks", "time_chunks", "fuse_head_bwd", "fuse_bias_grad",
-                    "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans")
+                    "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans", "defer_grads_rows", "gate_pipe_gemms")
     # ... and the spec's floats that reach kernel arguments as immediates of the recorded launches
     _PLAN_SPEC = ("lr", "beta", "prior_mean", "prior_std", "epsilon_std", "w_instr", "w_vel", "w_style", "w_held", "w_next", "w_sig",
                   "w_cnotes", "w_cinstr", "optimizer")
@@ -46,6 +46,8 @@ class PlannedSteps(object):
         self._plans = {}
         self._ev_pool, self._ev_i = [], 0
         self._host_results, self._ext_streams, self._plan_depth = {}, {}, 0
+        self.steps_in_flight = int(os.environ.get("MVAE_STEPS_IN_FLIGHT", "1"))      # (_planned; 0 = the host runs ahead freely)
+        self._flight, self._flight_pool = [], []
         self.plan_stats = {"recorded": 0, "replayed": 0, "refused": {}}
 
     # ---- events / stream ordering through the C ABI ---------------------------------------------------------------------------
@@ -113,19 +115,59 @@ class PlannedSteps(object):
         return out
 
     def _replay_host(self, host, want):
-        streams = self._ext_streams
-
+        """the callback StepPlan.run_ranges hands a mark to: run the caller's host action ``tag`` with the stream current that was
+        current when it was recorded.  The critical stream is simply still current (a replay runs where its recording ran: the
+        stream is part of the plan key); any other one is one of the engine's own torch streams (the communication stream of the
+        early bucket).  NOT torch.cuda.ExternalStream(handle): wrapped that way the default stream (handle 0) is another stream to
+        torch - a collective issued under it was not ordered against the launches around it (measured: two-rank fit 3e-4 off)."""
         def run(tag, handle):
-            st = streams.get(handle)
-            if st is None:
-                st = streams[handle] = torch.cuda.ExternalStream(handle, device=self.device)
-            with torch.cuda.stream(st):
+            cur = torch.cuda.current_stream()
+            if handle == cur.cuda_stream:
                 out = host[tag]()
+            else:
+                st = self._ext_streams.get(handle)
+                if st is None:
+                    own = [self.s_comm, self.s_grad, self.s_grad2, self.s_vel, self.s_instr, self.s_held, self.s_next, *self.s_layer, *self.s_proj]
+                    st = next((x for x in own if x is not None and x.cuda_stream == handle), None)
+                    if st is None:
+                        raise RuntimeError("host action %r was recorded on a stream the engine does not own" % tag)
+                    self._ext_streams[handle] = st
+                with torch.cuda.stream(st):
+                    out = host[tag]()
             if out != want.get(tag):         # (e.g. the gradient scale a hook returns: a constant of the recorded optimizer launch)
                 raise RuntimeError("host action %r returned %r; the recorded step was built for %r" % (tag, out, want.get(tag)))
         return run
 
+    # kinds of calls that START a unit of work the host should not run ahead of (steps_in_flight), and that END one
+    # (train steps only: decoding BASELINE configs[4] measured 11.07 ms per call unpaced, 11.14 paced)
+    _PACE_START = ("train", "train_begin", "train_begin_fused")
+    _PACE_END = ("train", "train_finish")
+
     def _planned(self, kind, fn, host=None):
+        """_planned_call, paced: with ``steps_in_flight`` = n > 0 the host enqueues a step only when at most n - 1 earlier ones are
+        still unfinished (it waits for the event behind the n-th last).  Round 5 measurement: a device that has the NEXT step's
+        packets in its queues - a dozen hardware queues holding value waits that will not be satisfied for milliseconds - runs the
+        CURRENT step slower than one whose host enqueues step i + 1 only after step i has ended, although the enqueue (0.2 ms of
+        plan replay) is then exposed: reference shape T = 64 2.05 -> 1.63-1.68 ms per step (GRU and LSTM), BASELINE configs[1]
+        6.73 -> 6.56 (LSTM), 5.67 -> 5.59 (GRU); two steps in flight already lose all of it (profiles/r05_c_steps_in_flight.txt)."""
+        outer = self._plan_depth == 0 and _plan.active() is None
+        n = self.steps_in_flight if outer else 0
+        if n and kind[0] in self._PACE_START:
+            while len(self._flight) >= n:
+                ev = self._flight.pop(0)
+                ev.synchronize()
+                self._flight_pool.append(ev)
+        try:
+            return self._planned_call(kind, fn, host)
+        finally:
+            if n and kind[0] in self._PACE_END:
+                ev = self._flight_pool.pop() if self._flight_pool else torch.cuda.Event()
+                ev.record()
+                self._flight.append(ev)
+                if len(self._flight) > 8:                      # (an unpaced caller in between: nothing to wait for)
+                    self._flight_pool.append(self._flight.pop(0))
+
+    def _planned_call(self, kind, fn, host=None):
         """run ``fn`` (the Python enqueue of one call of kind ``kind``, a hashable that names everything the launch list depends
         on besides the engine's state) - or, once three recordings of it agreed, replay its plan.  ``host``: tag -> callable of
         the host actions ``fn`` performs through _host_call (replayed between the call ranges they were recorded between)"""

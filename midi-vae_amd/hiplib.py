@@ -120,6 +120,7 @@ SIGNATURES = {
     "mvae_pack_recurrent": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_gemm": (_i32, [C.POINTER(GemmArgs), _vp]),
     "mvae_gemm_kstream_multi": (_i32, [C.POINTER(GemmArgs), _i32, _vp]),
+    "mvae_gemm_multi": (_i32, [C.POINTER(GemmArgs), _i32, _vp]),
     "mvae_colsum": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mvae_stream_wait_value32": (_i32, [_vp, _vp, C.c_uint32]),
     "mvae_stream_write_value32": (_i32, [_vp, _vp, C.c_uint32]),

@@ -188,6 +188,30 @@ def gemm_kstream_multi(problems):
     hl.check(hl.load().mvae_gemm_kstream_multi(arr, len(problems), _stream()), "mvae_gemm_kstream_multi")
 
 
+GEMM_MULTI_MAX = 16
+
+
+def gemm_args(g):
+    """launch a problem built with ``gemm(..., build_only=True)``"""
+    _note_fields(0, [g])
+    hl.check(hl.load().mvae_gemm(g, _stream()), "mvae_gemm")
+
+
+def gemm_multi(problems, stream=None):
+    """ordinary split-K weight-gradient GEMMs (``gemm(..., trans_a=True, accumulate=True, build_only=True)``) as ONE launch per
+    GEMM_MULTI_MAX problems on the current (or given) stream; False if the library does not take one of them this way"""
+    st = _stream() if stream is None else stream.cuda_stream
+    for i in range(0, len(problems), GEMM_MULTI_MAX):
+        part = problems[i:i + GEMM_MULTI_MAX]
+        arr = (hl.GemmArgs * len(part))(*part)
+        _note_fields(0, part)
+        rc = hl.load().mvae_gemm_multi(arr, len(part), st)
+        if rc == hl.E_UNSUPPORTED:
+            return False
+        hl.check(rc, "mvae_gemm_multi")
+    return True
+
+
 def stream_wait_value32(word, value, stream=None):
     """the current (or given) stream proceeds once the 32-bit device word ``word`` (a 1-element view) is >= value"""
     _note_scalar(2, value)

@@ -27,7 +27,7 @@ from . import hiplib as hl
 # entry points a plan may hold (csrc/plan.cpp k_entries): everything that takes a stream
 RECORDABLE = (
     "mvae_rnn_fwd", "mvae_rnn_bwd", "mvae_rnn_fwd_multi", "mvae_rnn_bwd_multi", "mvae_pack_recurrent", "mvae_gemm",
-    "mvae_gemm_kstream_multi", "mvae_colsum", "mvae_stream_wait_value32", "mvae_stream_write_value32", "mvae_prepare_batch",
+    "mvae_gemm_kstream_multi", "mvae_gemm_multi", "mvae_colsum", "mvae_stream_wait_value32", "mvae_stream_write_value32", "mvae_prepare_batch",
     "mvae_outer_bias_tile16", "mvae_gather2_tile16", "mvae_colsum_weighted", "mvae_sum_over_time", "mvae_head", "mvae_latent_fwd",
     "mvae_latent_bwd", "mvae_latent_chain_fwd", "mvae_latent_chain_bwd", "mvae_relayout", "mvae_tanh_bwd", "mvae_convert",
     "mvae_make_table", "mvae_transpose_convert", "mvae_adam_step", "mvae_adam_step_dev", "mvae_rmsprop_step",

@@ -39,6 +39,7 @@ def test_bucketed_allreduce_beside_the_encoder_bptt(one_rank_rccl, cell):
     losses = {}
     for mode in ("none", "bucketed", "single"):
         eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.defer_grads_rows = 0        # (T = 64 would collect the weight-gradient GEMMs behind the last recurrence: no early bucket then)
         eng.set_params(params)
         _stage(eng, raw, B)
         hook = None if mode == "none" else make_allreduce(eng, dist, 1, overlap=(mode == "bucketed"))
@@ -86,5 +87,42 @@ def test_bench_dp_code_path_on_two_ranks_keeps_the_replicas_identical(overlap, t
     assert dp["replicas_max_abs_diff"] == 0.0, dp
     assert dp["rank_median_ms_per_step"]["min"] <= dp["rank_median_ms_per_step"]["max"]
     assert dp["allreduce_ms"]["late"] is not None and (dp["allreduce_ms"]["early_decoder_bucket"] is not None) == bool(overlap)
+    assert dp["host_ms_per_step"] > 0 and "replayed" in dp["plan"]
     import math
     assert math.isfinite(line["elbo"]["loss_final"])
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_steps_replay_as_plans_with_the_collectives_between_their_ranges(one_rank_rccl, overlap):
+    """a train step with a gradient hook is recorded like any other; its collectives are HOST actions between
+    the call ranges of the plan (engine_plan._host_call / plan.StepPlan.run_ranges).  Twelve steps with the bucketed hook on the
+    pipelined bf16 schedule: steps replay (plan_stats), every collective is issued every step (the hook's timing list counts them),
+    and losses and parameters equal those of an engine that enqueues every step from Python (use_plans off)."""
+    dist = one_rank_rccl
+    B, steps = 32, 12
+    spec, params, batch, raw = _problem("LSTM", B, seed=47, H=256, Z=64, T=64)
+    res = {}
+    for plans in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16")
+        eng.use_plans = plans
+        eng.defer_grads_rows = 0        # (the early bucket needs the decoder's gradients complete before the encoder BPTT)
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        hook = make_allreduce(eng, dist, 1, overlap=overlap)
+        hook.timing = []
+        losses = []
+        for _ in range(steps):
+            eng.train_step(B, allreduce=hook)
+            losses.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        tags = [t for t, _, _ in hook.timing]
+        assert tags.count("late") == steps and tags.count("early") == (steps - 1 if overlap else 0), tags   # (no early bucket on the unverified first step)
+        res[plans] = (losses, eng.get_params(), dict(eng.plan_stats))
+    assert res[True][2]["replayed"] >= steps - 8, res[True][2]       # (the first, unverified steps read the status word: never armed)
+    assert res[False][2]["replayed"] == 0
+    # (the same launch list; the split-K gradient sums are f32 atomics, so two runs agree to their order of summation, not bit for bit)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-4 * (1 + abs(b)), (res[True][0], res[False][0])
+    import numpy as np
+    for k, v in res[False][1].items():
+        assert np.linalg.norm(res[True][1][k] - v) <= 2e-3 * (np.linalg.norm(v) + 1e-6) + 1e-6, k

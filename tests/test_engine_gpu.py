@@ -661,7 +661,7 @@ def test_one_hot_bottom_layer_written_out_equals_the_indexed_kernel(cell, monkey
     spec, params, batch, raw = _problem(cell, B, seed=61, H=256, Z=64, T=64)
     res = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("MVAE_INDEX_DENSE", flag)
+        monkeypatch.setattr(Engine, "INDEX_DENSE", flag == "1")
         eng = Engine(spec, max_batch=B, dtype="bf16")
         assert eng.index_dense == (flag == "1")
         eng.set_params(params)

@@ -781,6 +781,54 @@ def test_gemm_k_streaming_multi_launch():
 
 
 @pytest.mark.gpu
+def test_gemm_multi_equals_the_single_launches():
+    """mvae_gemm_multi: the weight-gradient GEMMs of a short-sequence step as ONE launch - dense A with and without fused column
+    sums, a column block of a wider gradient (ldb / ldc), a narrow output (a head's Dense, N = 61 of 64 padded columns), a one-hot
+    A (table gradient), different split-K counts (bases padded to multiples of 8) - against float64 on the bf16-rounded operands
+    and against the same problems launched one by one; 20 problems = two launches; a problem the batched launch does not take
+    is reported, not computed."""
+    rng = np.random.default_rng(29)
+    K, GH = 4096, 768
+    bf = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV).to(torch.bfloat16)
+    A1, A2 = bf(rng.standard_normal((K, 256)) * 0.5), bf(rng.standard_normal((K, 256)) * 0.5)
+    Bf = bf(rng.standard_normal((K, GH)) * 0.5)
+    Bn = bf(rng.standard_normal((K, 64)) * 0.5)
+    idx = torch.tensor(rng.integers(0, 61, (K,)), dtype=torch.uint8, device=DEV)
+    def fresh():
+        return dict(C1=torch.zeros((256, GH), device=DEV), C2=torch.zeros((256, GH), device=DEV), C3=torch.zeros((256, 61), device=DEV),
+                    C4=torch.zeros((61, GH), device=DEV), cs=torch.zeros((GH,), device=DEV))
+    def problems(o, build):
+        kw = dict(trans_a=True, accumulate=True, build_only=build)
+        return [ops.gemm(A1, Bf, o["C1"], 256, 512, K, ldb=GH, ldc=GH, split_k=16, colsum_b=o["cs"][:512], **kw),
+                ops.gemm(A2, Bf[:, 512:], o["C1"][:, 512:], 256, 256, K, ldb=GH, ldc=GH, split_k=16, colsum_b=o["cs"][512:], **kw),
+                ops.gemm(A2, Bf, o["C2"], 256, GH, K, split_k=4, **kw),
+                ops.gemm(A1, Bn, o["C3"], 256, 61, K, ldb=64, split_k=16, **kw),
+                ops.gemm(idx, Bf, o["C4"], 61, GH, K, a_kind=hl.ONEHOT, split_k=3, **kw)]
+    multi, single = fresh(), fresh()
+    assert ops.gemm_multi(problems(multi, True))
+    problems(single, False)
+    torch.cuda.synchronize()
+    A164, A264, B64, Bn64 = (t.double().cpu().numpy() for t in (A1, A2, Bf, Bn))
+    A3 = np.zeros((K, 61))
+    A3[np.arange(K), idx.cpu().numpy()] = 1.0
+    want = dict(C1=np.concatenate([A164.T @ B64[:, :512], A264.T @ B64[:, 512:]], 1), C2=A264.T @ B64, C3=A164.T @ Bn64[:, :61],
+                C4=A3.T @ B64, cs=B64.sum(0))
+    for k, w in want.items():
+        np.testing.assert_allclose(multi[k].cpu().numpy(), w, rtol=2e-3, atol=2e-3 * np.sqrt(K), err_msg=k)
+        np.testing.assert_allclose(multi[k].cpu().numpy(), single[k].cpu().numpy(), rtol=1e-4, atol=1e-3, err_msg=k)
+    # more than 16 problems: two launches; every one accumulates into the same C
+    C = torch.zeros((256, GH), device=DEV)
+    assert ops.gemm_multi([ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, split_k=2, build_only=True) for _ in range(20)])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), 20 * want["C2"], rtol=2e-3, atol=20 * 2e-3 * np.sqrt(K))
+    # not of the batched form (no accumulate / a transposed B): refused as a whole, nothing launched
+    assert not ops.gemm_multi([ops.gemm(A1, Bf, torch.zeros((256, GH), device=DEV), 256, GH, K, trans_a=True, build_only=True)])
+    arr = (hl.GemmArgs * 1)(ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, build_only=True))
+    assert hl.load().mvae_gemm_multi(arr, 17, torch.cuda.current_stream().cuda_stream) == hl.E_ARG
+    assert hl.load().mvae_gemm_multi(None, 1, torch.cuda.current_stream().cuda_stream) == hl.E_ARG
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(hl.F32, 2e-5), (hl.BF16, 2e-2)])
 @pytest.mark.parametrize("kind,N", [(0, 61), (0, 16), (1, 1)])
 def test_head_fused_input_gradient(dtype, tol, kind, N):
