@@ -122,6 +122,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self.pipe_chunk = 16 if self.maxB <= 256 else 32 if self.maxB <= 512 else 64
         while self.pipe_chunk > 16 and spec.T % self.pipe_chunk:
             self.pipe_chunk //= 2
+        # the HOST is held at these points of a train step until the device has reached them (_pace: bit 2 in front of the backward
+        # pass, 4 in front of the encoder BPTT; 1 in front of the decoder forward): a device whose queues already hold the packets of
+        # the later phases - value waits on a dozen queues - runs the current phase slower.  T = 64: 1.71 -> 1.45 ms per step with
+        # 6, configs[1] 6.65 -> 6.57 (profiles/r05_c_steps_in_flight.txt); a replayed step is split into call ranges there
+        self.pace_mask = 6
         self.gate_pipe_gemms = False      # (engine_phases._launch_pipe_gemms: measured, off)
         self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
@@ -147,9 +152,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # defer_grads_rows rows (T x padded batch) per sequence they are collected during the backward pass and leave as ONE launch
         # (mvae_gemm_multi) on the critical queue behind the last recurrence (_wgemm / _flush_deferred_gemms); above that the
         # GEMMs are long enough to be worth running beside the recurrences.  (profiles/r05_c_*; 0 = never)
-        # GRU only (the reference's shipped cell): measured on T = 64, 256 windows 2.33 -> 2.06 ms per step (64 windows 1.85 -> 1.73);
-        # LSTM 2.12 -> 2.30 - its K-streaming launch hides more than the batched launch saves
-        self.defer_grads_rows = int(os.environ.get("MVAE_DEFER_GRADS_ROWS", "32768" if spec.cell == "GRU" else "0"))
+        # Measured on T = 64 with the host paced (steps_in_flight / pace_mask below): 256 windows GRU 2.07 -> 1.47 ms per step, LSTM
+        # 1.72 -> 1.69; 64 windows GRU 1.46 -> 1.18
+        self.defer_grads_rows = int(os.environ.get("MVAE_DEFER_GRADS_ROWS", "32768"))
         self._deferred_gemms, self._deferred_small = None, []
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = 24 if spec.cell == "GRU" else 32   # (GRU: 3 GEMMs per layer)
@@ -164,7 +169,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._redo_hist = None           # ... kept until the step is verified (_redo_step)
         self._fused_dst = None           # (caller's rows, engine buffer) of a fused pre-pass whose z' is still to be handed over
         # the recurrences of a phase as ONE launch on the critical queue instead of one launch per queue (engine_phases.py)
-        self.phase_multi = os.environ.get("MVAE_PHASE_MULTI", "1") == "1"
+        self.phase_multi = True
         # ... up to this many (padded) windows per call: measured (profiles/r03_j_*) 256 windows -6 % (LSTM) / -9 % (GRU) per train
         # step, but 512 windows at T=2048 +6.5 % and decoding 1024 windows +4 % - there the recurrences themselves fill the chip
         # and the per-queue launches (producers dispatched first) place them better than one launch's index order
@@ -1317,6 +1322,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if dcat is None:
             dcat = self._latent_backward_unfused(Breal, B)
         latent_grads, self._deferred_side = self._deferred_side, None
+        self._pace(4)
         ldc = self.ncat * H
         self._mark("  latent block backward")
         hook = self._bucket_hook
@@ -1523,8 +1529,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # critical queue); they are joined where the decoder BPTT ends.
         self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
+            self._pace(1)
             self.decoder_forward(B)
             self._mark("decoder forward + heads")
+            self._pace(2)
             self.backward(B)
         finally:
             self._branches_stay_forked = False
@@ -1615,6 +1623,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
         try:
             self.decoder_forward(B)
+            self._pace(2)
             self.backward(B)
         finally:
             self._branches_stay_forked = False
@@ -1638,12 +1647,22 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
     def _hook_table(self, allreduce):
         """the host actions of a data-parallel step by tag (engine_plan._host_call): what a replayed step calls between its ranges
         of launches - Python then issues nothing but the collectives (reference: one train_function call per minibatch)"""
-        if allreduce is None and self.status_allreduce is None:
-            return None
         L = self.layout
         return {"early": lambda: allreduce.early(self.grads[L.dec_begin:L.total]),
                 "reduce": lambda: allreduce(self.grads),
-                "status": lambda: self.status_allreduce(self.store["pipe_status"])}
+                "status": lambda: self.status_allreduce(self.store["pipe_status"]),
+                "pace1": self._pace_now, "pace2": self._pace_now, "pace4": self._pace_now}
+
+    def _pace(self, bit):
+        """hold the HOST here until the device has reached this point of the step (pace_mask: bit 1 before the decoder forward, 2
+        before the backward pass, 4 before the encoder BPTT) - a host action of the step, so a replayed step pauses there too"""
+        if self.pace_mask & bit:
+            self._host_call("pace%d" % bit, self._pace_now)
+
+    def _pace_now(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
 
     def _train_step(self, B, allreduce):
         self._redo_hist = None

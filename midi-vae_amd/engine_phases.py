@@ -13,7 +13,7 @@ expansion of the 1-feature velocity roll is a chunk-publishing producer INSIDE t
 velocity / instrument heads keep their own queues: they leave the critical queue with one event after the latent chain and are
 waited for where the decoder BPTT ends - long after they finished.
 Shapes the slot-interleaved kernels do not take (f32 parity mode, H != 256, the bidirectional encoder), stacks whose kernels
-cannot all be resident, and MVAE_PHASE_MULTI=0 run the per-stream schedule of engine.py.
+cannot all be resident, and Engine.phase_multi = False run the per-stream schedule of engine.py.
 """
 from __future__ import annotations
 

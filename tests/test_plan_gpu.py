@@ -212,7 +212,7 @@ def test_short_sequences_defer_their_weight_gradient_gemms_into_one_launch(cell)
     B = 48
     spec, params, batch, raw = _problem(cell, B, seed=61, H=256, Z=64, T=64)
     res = {}
-    for rows in (32768, 0):         # (the default is per cell: GRU defers, LSTM does not - both are checked both ways)
+    for rows in (32768, 0):
         eng = Engine(spec, max_batch=B, dtype="bf16")
         eng.defer_grads_rows = rows
         eng.set_params(params)
