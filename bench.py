@@ -204,7 +204,7 @@ def side_workload(config, cell, dtype, device, steps, warmup):
     prof = {}
     t0 = time.perf_counter()
     for i in range(steps):
-        eng.prof = prof if i % 4 == 0 else None        # (a bracketed step is enqueued from Python, the others are plan replays)
+        eng.prof = prof if i % 4 == 0 else None        # (every 4th step is bracketed)
         h0 = time.perf_counter()
         step()
         host += time.perf_counter() - h0
@@ -381,15 +381,19 @@ def main():
     fwd_prof = {k: v for k, v in (eng.prof_summary_last if hasattr(eng, "prof_summary_last") else {}).items() if k[0].startswith("rnn_fwd")}
     eng.prof_kinds = KINDS if decode else {k for k in KINDS if k[0].startswith("rnn_bwd")}
     eng.prof = {}               # HIP events on the launch streams
+    # (the brackets are C-ABI events from a pool - Engine._timed - so a bracketed step replays as a plan like any other once its
+    #  kind of call has been recorded three times: untimed, here)
+    for _ in range(3 if args.warmup else 0):
+        step()
+    torch.cuda.synchronize()
+    eng.prof = {}
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
-    # every 5th step carries the brackets (two packets on the critical queue each, and such a step is enqueued from Python - with
-    # one step in flight, Engine.steps_in_flight, its 2 ms of enqueue are not hidden behind the previous step)
-    timed_kinds, every = eng.prof_kinds, 5
+    timed_kinds, every = eng.prof_kinds, 4       # every 4th step carries the brackets (two packets on the critical queue each)
     host_s = 0.0                # time the host spends enqueueing the steps (the step() calls themselves)
     for i in range(args.steps):
         eng.prof_kinds = timed_kinds if i % every == 0 else set()
@@ -468,7 +472,7 @@ def main():
         # THIS command (tools/collect_profiles_r04.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, FETCH_SIZE
         # doubled as MI355X_MICROARCH.md prescribes for gfx950) is committed as profiles/<round>_bench_traffic.json and embedded
         traffic, traffic_src = None, None
-        for tf in ("r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"):
+        for tf in ("r05_bench_traffic.json", "r04_bench_traffic.json", "r03_bench_traffic.json", "r02_bench_traffic.json"):
             tf = os.path.join(ROOT, "profiles", tf)
             if traffic is None and os.path.exists(tf) and not decode:
                 try:
@@ -535,7 +539,7 @@ def main():
                                              "default --config 1 run carries the CPU baseline)"}
         out["plan"] = dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]), host_ms_per_step=host_s / args.steps * 1e3,
                            what="step plans (include/midivae_hip.h): steps of the timed region enqueued by ONE mvae_plan_run call "
-                                "('replayed') - every 5th step, whose dominant launches are bracketed with HIP events, by Python")
+                                "('replayed'), the bracketed ones (every 4th: HIP events around the dominant launches, Engine._timed) included")
         if dp_stats is not None:
             out["dp"] = dp_stats
         if world == 1 and not args.no_other_configs and args.config == 1 and args.dtype == "bf16" and not (args.batch or args.seq_len

@@ -503,6 +503,8 @@ int mvae_add_time_reversed(void* dst, const void* a, const void* b, int32_t kind
  * Events for cross-queue ordering inside a plan are plain entry points too (mvae_event_record / mvae_stream_wait_event).
  * --------------------------------------------------------------------------------------------------------- */
 int mvae_event_create(void** event);                 /* hipEventCreateWithFlags(hipEventDisableTiming) */
+int mvae_event_create_timed(void** event);           /* hipEventCreate: a pair of them brackets a launch INSIDE a plan (bench.py's roofline leg) */
+int mvae_event_elapsed_ms(void* first, void* second, float* ms);     /* waits for ``second``, then the time between the two records */
 int mvae_event_destroy(void* event);
 int mvae_event_record(void* event, void* stream);
 int mvae_stream_wait_event(void* stream, void* event);

@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256) void gemm_k(const mvae_gemm_args a) {
 //     transposes with eight 2-byte LDS stores per 16 bytes loaded.
 // ===========================================================================================================
 #include "ablations.h"      // GEMM_ABL_* timing switches: all 0 in the product build
+// s_sleep argument of the persistent GEMMs' chunk polls (x 64 clocks between two system-scope loads of the counter): a chunk arrives
+// every ~40 us; 256 waves of such a launch polling every 0.2 us (8) is traffic on one memory channel that buys nothing
+#ifndef GEMM_POLL_SLEEP
+#define GEMM_POLL_SLEEP 32
+#endif
 constexpr int FBM = 128, FBN = 128, FBK = 64;
 // k-contiguous image: [row][FBK + 8] (144-byte rows).  NOT conflict-free for ds_read_b128 - its four lane groups are non-contiguous
 // ({0-3, 12-15, 20-27}, ...: rows {0-3, 12-15} of one k chunk and rows {4-11} of the next share a group; PMC: SQ_LDS_BANK_CONFLICT 32-40 %
@@ -335,7 +340,7 @@ __device__ __forceinline__ void gemm_fast_body(const mvae_gemm_args a, const int
     const bool wt = a.chunk_done && a.c_layout == MVAE_TILE16 && a.c_kind != MVAE_F32 && !a.accumulate && (N % FBN) == 0;
     for (int ci = 0; ci < nchunks; ++ci) {
     const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
-    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
+    if (a.chunk_wait) wave_wait_ge<GEMM_POLL_SLEEP>(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
     for (int tile = vb; tile < total_tiles; tile += nvb) {
         int bx = tile % tiles_n, by = chunk * tiles_mc + (tile / tiles_n) % tiles_mc, bz = tile / (tiles_n * tiles_mc);
         if (xcd_rows) {
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     // The first chunk is waited for BEFORE anything is read: the launch may sit on its queue ahead of the weight preparation of
     // its step (no event orders it - one packet less on the critical queue per phase); the producer it polls runs behind that
     // preparation, so a published chunk says the weights are in place.
-    if (a.chunk_wait) wave_wait_ge(a.chunk_wait + (a.chunk_reverse ? nchunks - 1 : 0), a.chunk_wait_value, a.chunk_status, 3u);
+    if (a.chunk_wait) wave_wait_ge<GEMM_POLL_SLEEP>(a.chunk_wait + (a.chunk_reverse ? nchunks - 1 : 0), a.chunk_wait_value, a.chunk_status, 3u);
     u16x8 fb[4][8];                      // this wave's weights: column tile jj, k-group ks (32 k) - accumulator registers
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(256) void proj_ws_k(const mvae_gemm_args a) {
     const size_t row_bytes = (size_t)a.lda * 2;
     for (int ci = 0; ci < nchunks; ++ci) {
         const int chunk = a.chunk_reverse ? nchunks - 1 - ci : ci;
-        if (a.chunk_wait) wave_wait_ge(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
+        if (a.chunk_wait) wave_wait_ge<GEMM_POLL_SLEEP>(a.chunk_wait + chunk, a.chunk_wait_value, a.chunk_status, 3u);
         const int nloc = tiles_mc >> 3;                            // row blocks of this chunk on this XCD
         const int nt = g < nloc ? (nloc - g + G - 1) / G : 0;      // ... of this workgroup
         auto block_row = [&](const int t) { return (chunk * tiles_mc + x + 8 * (g + t * G)) * FBM; };

@@ -93,6 +93,20 @@ extern "C" int mvae_event_create(void** event) {
     *event = e;
     return MVAE_OK;
 }
+extern "C" int mvae_event_create_timed(void** event) {
+    if (!event) return MVAE_E_ARG;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return MVAE_E_LAUNCH;
+    *event = e;
+    return MVAE_OK;
+}
+extern "C" int mvae_event_elapsed_ms(void* first, void* second, float* ms) {
+    if (!first || !second || !ms) return MVAE_E_ARG;
+    if (hipEventSynchronize(reinterpret_cast<hipEvent_t>(second)) != hipSuccess) return MVAE_E_LAUNCH;
+    return hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(first), reinterpret_cast<hipEvent_t>(second)) == hipSuccess
+               ? MVAE_OK
+               : MVAE_E_LAUNCH;
+}
 extern "C" int mvae_event_destroy(void* event) {
     if (!event) return MVAE_E_ARG;
     return hipEventDestroy(reinterpret_cast<hipEvent_t>(event)) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from collections import OrderedDict
 
+import ctypes as C
 import numpy as np
 import os
 
@@ -29,6 +30,8 @@ from .engine_io import ArrayStaging, Results
 from .engine_optional import OptionalGraph
 from .engine_phases import PhaseLaunches
 from .engine_plan import PlannedSteps
+from .engine_grads import ParamGradients
+from .engine_steps import TrainSteps
 from .engine_buffers import Buffers, _Rec, _Head, _Aux        # noqa: F401  (the records of the layer description)
 from .slots import *        # noqa: F401,F403  (scalar slots S_*, N_SCALARS, X_EXT)
 from .slots import N_SCALARS, X_EXT, X_GATHER2
@@ -42,7 +45,7 @@ class _NullCtx(object):
         return False
 
 
-class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, Results):
+class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, ParamGradients, TrainSteps, Results):
     INDEX_DENSE = False      # the one-hot bottom layer's table rows written out inside the phase launch (_index_as_dense): measured, off
     def __init__(self, spec: ModelSpec, max_batch: int, dtype: str = "bf16", device: str = "cuda:0", seed: int = 0,
                  training: bool = True, share: "Engine | None" = None):
@@ -196,7 +199,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # (_grad_portions) -1: by the rows of the sequence (4 portions from 2^20 rows, none below 2^19), 0: off, N: N portions
         self.grad_portions = -1
         self._grad_portion_jobs = None
-        self._single_slot = 0
+        self._single_slot, self._single_slot_end = 0, 3
         self._hold_dec_grads = 1     # (engine_phases._notes_backward_multi; A/B r03_j: LSTM -0.06 ms, GRU neutral)
         self._after_chain = None
         self._tail_streams = []          # queues besides the two gradient queues that carry gradient work of the running step
@@ -394,11 +397,26 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if self.prof is None or (self.prof_kinds is not None and key[0] not in self.prof_kinds and key not in self.prof_kinds):
             fn()
             return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        # The pair comes from a pool indexed by the bracket's position in the call (C-ABI events, recorded through entry points a
+        # step plan holds): a bracketed step records the same launch list with the same handles every time - and REPLAYS.  A pair's
+        # previous measurement is read before it is recorded again (engine_plan._prof_harvest).
+        i = self._prof_i
+        self._prof_i += 1
+        while len(self._prof_pool) <= i:
+            pair = []
+            for _ in range(2):
+                h = C.c_void_p()
+                hl.check(hl.load().mvae_event_create_timed(C.byref(h)), "mvae_event_create_timed")
+                pair.append(h.value)
+            self._prof_pool.append(pair)
+        self._prof_harvest(i)
+        e0, e1 = self._prof_pool[i]
+        st = torch.cuda.current_stream().cuda_stream
+        hl.check(hl.load().mvae_event_record(e0, st), "mvae_event_record")
         fn()
-        e1.record()
-        self.prof.setdefault(key, []).append((e0, e1, steps))
+        hl.check(hl.load().mvae_event_record(e1, st), "mvae_event_record")
+        self._prof_pending[i] = (key, steps)
+        self._prof_call.append((i, key, steps))
 
     # ------------------------------------------------------------------------------------------------------
     # parameters
@@ -900,206 +918,6 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         ops.gemm(da.view(Tc * B, GH), self._v(p + ".wc", H, GH), dx, Tc * B, H, GH, trans_b=True, c_layout=self.lay,
                  **chunked)
 
-    def _grad_portions(self, r, B, publishes):
-        """Time portions of a layer's parameter-gradient work (per-queue schedule, LONG sequences).  At T * B >= 2^19 rows the
-        gradient GEMMs of a phase are milliseconds of whole-chip work that used to start when the layer's BPTT ENDS - at BASELINE
-        configs[2]'s shape (T=2048, 512 windows) 4 ms of tail behind the last BPTT and a latent-chain kernel starved for 1.5 ms
-        between the two BPTT phases (profiles/r04_m_timeline_config2_lstm.txt).  A layer that publishes its da chunks
-        (``publishes`` = (counter array, target, chunk steps)) has them released in P portions of the time axis by the chunk that
-        completes each portion (hipStreamWaitValue32 on the gradient queues): each portion is a full-size GEMM here (>= 2^17 rows:
-        round 2 tried it at T=512 x 256 windows, where a portion was all atomic epilogue), and only the last one is left when the
-        recurrence ends.  Portions of all layers of a phase are enqueued portion-major (_flush_grad_portions): a queue parked on
-        one layer's last chunk must not hold another layer's first portions."""
-        if publishes is None or self._grad_portion_jobs is None:
-            return 1
-        return self._portion_count(r, B, publishes[2])
-
-    def _portion_count(self, r, B, cs):
-        if not self.grad_portions:
-            return 1
-        R = r.T * B
-        P = self.grad_portions if self.grad_portions > 0 else int(min(4, R // (1 << 18)))
-        while P > 1 and (r.T % P or (r.T // P) % cs):
-            P -= 1
-        return max(P, 1)
-
-    def _flush_grad_portions(self):
-        """launch the collected gradient portions of a phase, portion-major (first portions of every layer first)"""
-        jobs, self._grad_portion_jobs = self._grad_portion_jobs, None
-        for _, fn in sorted(jobs or [], key=lambda j: j[0]):
-            fn()
-
-    def _wgemm(self, A, Bm, C, M, N, K, **kw):
-        """a weight-gradient GEMM C (M,N) f32 += A^T Bm (ops.gemm with trans_a, accumulate): launched now on the current stream -
-        or, on a step that defers them (defer_grads_rows), kept as a problem of the one mvae_gemm_multi launch behind the last
-        recurrence"""
-        if self._deferred_gemms is not None and self.tile16 and K % 64 == 0 and (N % 128 == 0 or N < 128):
-            self._deferred_gemms.append(ops.gemm(A, Bm, C, M, N, K, trans_a=True, accumulate=True, build_only=True, **kw))
-            return
-        ops.gemm(A, Bm, C, M, N, K, trans_a=True, accumulate=True, **kw)
-
-    def _small(self, fn):
-        """a small launch of the parameter-gradient work (a column sum, a sum over time): now on the current stream - or, on a
-        step that defers (defer_grads_rows), behind the batched GEMM launch on the critical queue (a gate + a launch on a gradient
-        queue costs the command processors more than these kernels run)"""
-        if self._deferred_gemms is not None:
-            self._deferred_small.append(fn)
-        else:
-            fn()
-
-    def _flush_deferred_gemms(self):
-        """the step's collected weight-gradient GEMMs as one launch (per 16) on the current - the critical - stream, the small
-        launches behind it: everything they read was produced on this queue or joined into it"""
-        probs, self._deferred_gemms = self._deferred_gemms, None
-        small, self._deferred_small = self._deferred_small, []
-        if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
-            for g in probs:
-                ops.gemm_args(g)
-        for fn in small:
-            fn()
-
-    def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, publishes=None, rows=None):
-        P = self._grad_portions(r, B, publishes) if rows is None else 1
-        if P > 1:
-            counters, target, cs = publishes
-            Tp = r.T // P
-            for pi in range(P):                      # BPTT order: the LAST steps first
-                t_lo = r.T - (pi + 1) * Tp
-                g = (counters[t_lo // cs:t_lo // cs + 1], target)
-                self._grad_portion_jobs.append((pi, lambda t_lo=t_lo, g=g, pi=pi: self._rec_param_grads_rows(
-                    r, B, idx=idx, xs=xs, start=start, skip_dU=skip_dU, gate=g, rows=(t_lo, t_lo + Tp), first=pi == 0)))
-            return
-        return self._rec_param_grads_rows(r, B, idx=idx, xs=xs, start=start, skip_dU=skip_dU, gate=gate, rows=rows)
-
-    def _rec_param_grads_rows(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, rows=None, first=True):
-        """Parameter gradients of one layer from its da, accumulated into the f32 gradient buffer: off the critical path, on
-        the two gradient streams, once per layer after its BPTT.  ``gate`` = (counter word, value): the layer's BPTT is a problem
-        of a phase launch that is still RUNNING - the gradient queues wait, on the device, for the layer's last published chunk
-        of da instead of for the whole launch.  (No event: the launch sits on the critical queue behind everything the gradient
-        work reads, so its first published chunk implies all of that; an event record would be one more packet there.)"""
-        if self._diag_no_param_grads:       # (MVAE_DIAG_NO_PARAM_GRADS=1, timing experiments only: the gradients are WRONG)
-            return
-        s, G, p = self.spec, self.G, r.prefix
-        H, GH, T = s.H, s.GH, r.T
-        t_lo, t_hi = rows if rows is not None else (0, T)        # (a time portion: the same GEMMs over rows [t_lo * B, t_hi * B))
-        Tq = t_hi - t_lo
-        R = Tq * B
-        da = self._v(p + ".da", T, B, GH)[t_lo:t_hi]
-        da2, hprev = da.view(R, GH), self._v(p + ".hs", T + 1, B, H)[t_lo:t_hi].reshape(R, H)
-        if idx is not None:
-            idx = idx[t_lo:t_hi]
-        if xs is not None:
-            xs = xs[t_lo:t_hi]
-        sk = self._split_k(R)
-        sg1, sg2 = self._grad_streams or (self.s_grad, self.s_grad2)
-        deferring = self._deferred_gemms is not None
-        if deferring:                       # (everything below is collected: nothing is enqueued on the gradient queues now)
-            on1 = on2 = _NullCtx()
-        else:
-            on1, on2 = self._on(sg1), self._on(sg2)
-            if gate is None:
-                self._fork(*((sg1,) if sg1 is sg2 else (sg1, sg2)))
-            else:
-                for st in ((sg1,) if sg1 is sg2 else (sg1, sg2)):
-                    ops.stream_wait_value32(gate[0], gate[1], stream=st)
-        # bias gradient = column sums of da: from the recurrent-kernel gradient GEMM's own pass over da (fast bf16 path) - also for
-        # the decoder cells on a constant input when that input is all zeros (what the reference's packers always pass,
-        # vae_definition.py:820,916: dW = start^T sum_t(da) = 0 then, and the sum over time is only needed for the bias)
-        const_fused = (r.xmode == hl.X_CONST and self.start_zero.get(p, False) and self.tile16 and self.fuse_bias_grad and
-                       not skip_dU)
-        fuse_b = (r.xmode != hl.X_CONST or const_fused) and self.tile16 and self.fuse_bias_grad
-        gb = G[p + ".b"]
-        with on1:
-            # recurrent kernel: dU = sum_t h_{t-1}^T da_t   (GRU candidate block uses r*h_{t-1})
-            if skip_dU:             # (with its bias gradient in a K-streaming launch)
-                pass
-            elif s.cell == "GRU":
-                rh = self._v(p + ".rh", T, B, H)[t_lo:t_hi]
-                self._wgemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=sk, colsum_b=gb[:2 * H] if fuse_b else None)
-                self._wgemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, ldb=GH, ldc=GH, split_k=sk,
-                            colsum_b=gb[2 * H:] if fuse_b else None)
-            else:
-                self._wgemm(hprev, da2, G[p + ".U"], H, GH, R, split_k=sk, colsum_b=gb if fuse_b else None)
-        with on2:
-            if const_fused:
-                pass
-            elif r.xmode == hl.X_CONST:
-                dxp0 = self._v(p + ".dxp0", B, GH)
-                acc = self._dxp0_clean or not first
-                # (time portions: every portion adds its share to dxp0 - zeroed by the weight preparation; what is derived from the
-                #  complete sum follows the portion that ends at step 0)
-                self._small(lambda: ops.sum_over_time(da, Tq, B * GH, dxp0, accumulate=acc))
-                if t_lo == 0:
-                    self._small(lambda: ops.colsum(dxp0, B, GH, G[p + ".b"]))
-                    if not self.start_zero.get(p, False):        # (dW = start^T dxp0 = 0 for an all-zero start)
-                        self._small(lambda: ops.gemm(start, dxp0, G[p + ".W"], r.K, GH, B, trans_a=True, accumulate=True))
-            else:
-                if not fuse_b:
-                    self._small(lambda: ops.colsum(da2, R, GH, G[p + ".b"]))
-                if r.xmode == X_EXT:
-                    pass                                # (input-kernel gradient by the caller: _aux_backward)
-                elif r.xmode == hl.X_INDEX:
-                    self._wgemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, a_kind=hl.ONEHOT, split_k=sk)
-                elif r.xmode == X_GATHER2:      # two-hot rows: the pitch rows and the attached instrument rows of W
-                    d0 = r.K - s.attach
-                    self._wgemm(idx.reshape(-1), da2, G[p + ".W"][:d0], d0, GH, R, a_kind=hl.ONEHOT, split_k=sk)
-                    self._wgemm(self._v("in.xa_idx", T, B)[t_lo:t_hi].reshape(-1), da2, G[p + ".W"][d0:], s.attach, GH, R,
-                                a_kind=hl.ONEHOT, split_k=sk)
-                elif r.xmode == hl.X_SCALAR:       # dW (1, GH) = xs^T da: a weighted column sum
-                    self._small(lambda: ops.colsum_weighted(da2, xs.reshape(-1), R, GH, G[p + ".W"]))
-                else:
-                    lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1 + t_lo:1 + t_hi].reshape(R, H)
-                    self._wgemm(lower, da2, G[p + ".W"], H, GH, R, split_k=sk)
-
-    def _kstream_ok(self, layers, B):
-        """K-streaming weight-gradient GEMMs behind the BPTT kernels of this stack?  Every layer's gradients must be GEMMs (index
-        or dense input, bias gradient fused), at most 8 of them - and their workgroups, which wait RESIDENT for the whole BPTT,
-        must find their CUs beside the stack's own kernels and the phase's other recurrences: a workgroup that only gets its CU
-        when another one retires does its whole share after the recurrence, which is the tail the launch exists to remove.
-        (At 256 windows: 256 - (32 + 32 + 32) = 160 free CUs for 128 workgroups - the single-layer branch's 32 on top are the ones
-        that may start late; at 512 windows 96: ordinary GEMMs then, as measured, profiles/r02_q_pipe_chunk_by_batch.txt.)"""
-        s = self.spec
-        count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
-        if not (self.kstream_grads and self._deferred_gemms is None and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
-                self._pipelined(layers) and all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers)):
-            return False
-        free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
-        return free >= self.kstream_wgs * count
-
-    def _kstream_problems(self, r, B, idx, ks, only_dU=False):
-        """the layer's weight-gradient GEMMs as K-streaming problems (mvae_gemm_args, not launched)"""
-        s, G, p = self.spec, self.G, r.prefix
-        H, GH, T = s.H, s.GH, r.T
-        R = T * B
-        hprev = self._v(p + ".hs", T + 1, B, H)[:T].reshape(R, H)
-        da2 = self._v(p + ".da", T, B, GH).view(R, GH)
-        kw = dict(k_wait=ks["counters"], k_wait_value=ks["target"], k_chunk_rows=ks["rows"], k_reverse=True, chunk_status=ks["status"],
-                  trans_a=True, accumulate=True, build_only=True)
-        def parts(M, N):        # K partitions per chunk: kstream_wgs workgroups per GEMM, whole 64-row k tiles each
-            tiles = -(-M // 128) * -(-N // 128)
-            P = 1
-            while P * 2 * tiles <= self.kstream_wgs and ks["rows"] % (P * 2 * 64) == 0:
-                P *= 2
-            return P
-        gb = G[p + ".b"]
-        out = []
-        if s.cell == "GRU":
-            rh = self._v(p + ".rh", T, B, H)
-            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, 2 * H, R, ldb=GH, ldc=GH, split_k=parts(H, 2 * H),
-                                colsum_b=gb[:2 * H], **kw))
-            out.append(ops.gemm(rh.view(R, H), da2[:, 2 * H:], G[p + ".U"][:, 2 * H:], H, H, R, ldb=GH, ldc=GH, split_k=parts(H, H),
-                                colsum_b=gb[2 * H:], **kw))
-        else:
-            out.append(ops.gemm(hprev, da2, G[p + ".U"], H, GH, R, split_k=parts(H, GH), colsum_b=gb, **kw))
-        if only_dU:
-            return out
-        if r.xmode == hl.X_INDEX:
-            out.append(ops.gemm(idx.reshape(-1), da2, G[p + ".W"], r.K, GH, R, a_kind=hl.ONEHOT, split_k=parts(r.K, GH), **kw))
-        else:
-            lower = self._v(r.lower.prefix + ".hs", T + 1, B, H)[1:1 + T].reshape(R, H)
-            out.append(ops.gemm(lower, da2, G[p + ".W"], H, GH, R, split_k=parts(H, GH), **kw))
-        return out
-
     def _stack_backward_pipe(self, layers, B, slot, *, dhs_ext=None, dh_last=None, dh_last_ld=0, dstates=None, idx=None,
                              xs=None, start=None):
         cs = self.pipe_chunk
@@ -1185,7 +1003,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             return
         if (len(layers) == 1 and nch == 1 and self._grad_portion_jobs is not None and self.pipeline and
                 self._seq_layout(layers[0]) == hl.TILE16P and layers[0].T % self.pipe_chunk == 0 and
-                self._portion_count(layers[0], B, self.pipe_chunk) > 1 and self._single_slot < 5):
+                self._portion_count(layers[0], B, self.pipe_chunk) > 1 and self._single_slot < self._single_slot_end):
             # a full-length single-layer branch whose gradients go in time portions: ONE launch that publishes its da chunks
             r, cs = layers[0], self.pipe_chunk
             sync, target, _ = self._sync_region(11 + self._single_slot, 1, r.T // cs, 4 * (B // 16), 0)
@@ -1295,7 +1113,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._aux_backward(a, B)
         notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
         if not notes_multi and self.grad_portions:       # (per-queue schedule: long sequences release their gradient work in portions)
-            self._grad_portion_jobs, self._single_slot = [], 0
+            self._grad_portion_jobs, self._single_slot, self._single_slot_end = [], 0, 3      # (decoder: sync slots 11..13)
         self._after_chain = [] if (notes_multi and not self.enc_bi and len(self.enc_notes) > 1 and
                                    self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta])) else None
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
@@ -1340,7 +1158,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if not (enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads)):      # (one launch: engine_phases.py)
             assert not latent_grads
             if self.grad_portions:
-                self._grad_portion_jobs, self._single_slot = [], 3
+                self._grad_portion_jobs, self._single_slot, self._single_slot_end = [], 3, 5      # (encoder: 14..15 - disjoint: the counters are cumulative per slot)
             ks_extra = None
             if not self.enc_bi and self._kstream_ok(self.enc_notes, B):
                 self._grad_streams = (self.s_grad, self.s_grad)     # the second gradient queue holds the notes stack's K-streaming launch
@@ -1472,223 +1290,6 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             ops.rmsprop_step(self.params, self.grads, self.opt_v, s.lr, grad_scale=grad_scale, zero_grad=True, guard=self._guard())
         self._grads_clean = True
         self._weights_dirty = True
-
-    def _step_begin(self):
-        """weight preparation (or, with unchanged weights, the zeroing it would have done) and clean gradient buffers"""
-        assert self.training
-        self._have_targets = True
-        if self._weights_dirty:
-            self.prepare_weights()          # (also zeroes the loss / metric accumulators and the constant-input cells' dxp0 sums)
-            self._dxp0_clean = True
-        else:
-            self._zero_scal()
-            self._dxp0_clean = False
-        if not self._grads_clean:
-            self._zero_grads()
-        self._grads_clean = False
-
-    def _zero_grads(self):
-        """the gradient buffer of a step that does not follow an optimizer step (which leaves it zeroed): a prepare-batch job like
-        _zero_scal, so that this state of a step replays as a plan too"""
-        if self._zero_grads_job is None:
-            self._zero_grads_job = ops.PrepBatch()
-            self._zero_grads_job.zero(self.grads)
-        self._zero_grads_job.run()
-
-    def _zero_scal(self):
-        """the loss / metric accumulators of a call that does not prepare weights (a one-job mvae_prepare_batch: part of a step
-        plan, which a torch fill would not be)"""
-        if self._zero_scal_job is None:
-            self._zero_scal_job = ops.PrepBatch()
-            self._zero_scal_job.zero(self.scal)
-        self._zero_scal_job.run()
-
-    def _redo_step(self, B):
-        """the forward + backward pass of a train step once more (first use of the pipelined kernels stalled: _verify_pipeline).
-        A fused history pre-pass is redone with it (the history rows came out of the timed-out forward); the gradient hook is
-        out of the way (_overlap_hook: no early bucket is in flight on an unverified step), so the buffer may be zeroed"""
-        self.scal.zero_()
-        self.grads.zero_()
-        self._hist_fused = self._redo_hist
-        try:
-            self.encoder_forward(B, with_init=True)
-        finally:
-            self._hist_fused = None
-        self.decoder_forward(B)
-        self.backward(B)
-
-    def forward_backward(self, B):
-        """One pass of forward + losses + backward on the staged batch (gradients left in self.grads)."""
-        self._mark("step start")
-        self._step_begin()
-        self._mark("weights prepared")
-        self.encoder_forward(B, with_init=True)
-        self._mark("encoder forward (incl. latent)")
-        # The velocity / instrument branches' backward depends on nothing the notes branch does in between: no join at
-        # the end of the decoder forward pass and no fork at the start of the backward pass (two packets less on the
-        # critical queue); they are joined where the decoder BPTT ends.
-        self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
-        try:
-            self._pace(1)
-            self.decoder_forward(B)
-            self._mark("decoder forward + heads")
-            self._pace(2)
-            self.backward(B)
-        finally:
-            self._branches_stay_forked = False
-        self._mark("backward")
-        self._verify_pipeline(lambda: self._redo_step(B))
-
-    def _verify_pipeline(self, redo, key="train"):
-        """First use of time-pipelined stacks by each kind of call (train step / encode / decode / predict): make sure no kernel
-        gave up waiting for its producer.  A first use can stall for seconds for reasons that do not repeat - first launches of the
-        kind's kernels (code-object loads, hipFuncSetAttribute) and first pinned / device allocations of the caller's staging beside
-        it, all of which hold new dispatches back while a WAITING kernel is resident - so the work is first redone as it is; if a
-        kernel gives up again (two of the engine's streams share a hardware queue, or kernels run one at a time under counter
-        collection) the engine falls back to one launch per chunk for good and redoes it once more."""
-        if not self.pipeline or key in self._pipe_verified or not self._pipe_used:
-            return                     # (a call whose batch did not run any stack pipelined verifies nothing)
-        self._pipe_verified.add(key)
-
-        def status():
-            # (data parallel: the decision stays rank-local - a rank whose shard is empty never gets here, so a collective in
-            #  this place could hang - and that is safe: a redo issues no collective (no early bucket on an unverified step,
-            #  _overlap_hook), recomputes the same gradients, and the per-step status all-reduce of optimizer_step is issued by
-            #  every rank whatever schedule it ended up with)
-            return int(self.store["pipe_status"].item())
-        if status() == 0:
-            return
-        self.store["pipe_status"].zero_()
-        self._dxp0_clean = False
-        redo()
-        if status() != 0:
-            import warnings
-            warnings.warn("time-pipelined recurrent kernels timed out waiting for their producers (status %d; call %r); falling "
-                          "back to chunked launches (Engine.pipeline = False)" % (int(self.store["pipe_status"].item()), key))
-            self.store["pipe_status"].zero_()
-            self.pipeline = False
-            self._dxp0_clean = False
-            redo()
-
-    def train_step_begin(self, B, hist_fused=None):
-        """First part of a train step - weight preparation and the encoder up to the sampled z - for callers that stage the
-        decoder heads' targets while it runs (Stager.stage(defer_targets=True) ... Stager.finish_targets()); the rest:
-        train_step_finish.
-
-        ``hist_fused`` = (eps2, z_out): the FUSED HISTORY PRE-PASS (reference vae_training.py:788-798 + :804-809 in one encoder
-        forward).  The reference runs ``encoder.predict`` over the song - with the weights this step starts from and a fresh
-        draw eps2 - to obtain the history input H[i] = z'[i-1] of ``fit``, then the step's own encoder forward with another
-        draw.  Same weights, same inputs, same mu / log sigma^2: here z' = mu + sigma * eps2 comes out of THIS step's encoder
-        forward (eps2: (Bp, Z) device view, already scaled; z_out: (>= B, Z) device rows that receive z'), is rolled into the
-        history columns of [z | history] (window 0: zeros) and the decoder's initial-state Denses follow as a separate GEMM.
-        Only for a minibatch that starts at window 0 of its song."""
-        if hist_fused is None:
-            return self._planned(("train_begin", B), lambda: self._train_step_begin(B, None))
-        # z' goes to a fixed engine buffer - the launch list then holds no per-song address and the step replays as a plan like
-        # any other - and to the caller's rows by one copy behind the step (train_step_finish)
-        eps2, z_dst = hist_fused
-        zbuf = self._v("hist_zout", self.pad16(B), self.spec.Z)
-        self._fused_dst = (z_dst, zbuf)
-        return self._planned(("train_begin_fused", B, eps2.data_ptr()), lambda: self._train_step_begin(B, (eps2, zbuf)))
-
-    def _train_step_begin(self, B, hist_fused):
-        self._step_begin()
-        self._hist_fused = self._redo_hist = hist_fused
-        try:
-            self.encoder_forward(B, with_init=True)
-        finally:
-            self._hist_fused = None
-
-    def train_step_finish(self, B, allreduce=None):
-        """the rest of the step: one replayable call (engine_plan.py) - with a gradient hook (data parallel) its collectives are
-        host actions between the call ranges of the plan"""
-        try:
-            return self._planned(("train_finish", B) + self._hook_kind(allreduce), lambda: self._train_step_finish(B, allreduce),
-                                 host=self._hook_table(allreduce))
-        finally:
-            if self._fused_dst is not None:          # (behind a possible redo of the step: the rows are final here)
-                (z_dst, zbuf), self._fused_dst = self._fused_dst, None
-                z_dst.copy_(zbuf[:z_dst.shape[0]])
-
-    def _overlap_hook(self, allreduce, B):
-        """the hook whose decoder bucket is reduced beside the encoder BPTT - not on a step that may still be redone (the first
-        pipelined train step of an engine, _verify_pipeline): the redo zeroes and recomputes the gradients, which must not race a
-        collective already in flight on part of them; that one step reduces the whole buffer afterwards"""
-        unverified = self.pipeline and "train" not in self._pipe_verified
-        # (... nor on a step that defers its weight-gradient GEMMs: the decoder bucket is complete only behind the last recurrence)
-        return allreduce if (getattr(allreduce, "overlap", False) and not unverified and not self._defers_grads(self.pad16(B))) else None
-
-    def _train_step_finish(self, B, allreduce):
-        self._bucket_hook = self._overlap_hook(allreduce, B)
-        self._branches_stay_forked = self.lean_sync and self.multi_stream and not self.aux
-        try:
-            self.decoder_forward(B)
-            self._pace(2)
-            self.backward(B)
-        finally:
-            self._branches_stay_forked = False
-            self._bucket_hook = None
-        self._verify_pipeline(lambda: self._redo_step(B))
-        gs = self._host_call("reduce", lambda: allreduce(self.grads)) if allreduce is not None else 1.0
-        self.optimizer_step(gs if gs is not None else 1.0)
-
-    def train_step(self, B, allreduce=None):
-        """forward + backward + (optional gradient all-reduce hook) + optimizer update on the staged batch.  The whole step is one
-        replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run (engine_plan.py; reference: ONE
-        Keras train_function call per minibatch, vae_training.py:804-809); the hook's collectives are issued from Python between
-        the plan's call ranges (host marks)."""
-        return self._planned(("train", B) + self._hook_kind(allreduce), lambda: self._train_step(B, allreduce),
-                             host=self._hook_table(allreduce))
-
-    def _hook_kind(self, allreduce):
-        """what a gradient hook adds to the plan key of a train step: that there is one, and whether it takes an early bucket"""
-        return () if allreduce is None else ("hook", bool(getattr(allreduce, "overlap", False)))
-
-    def _hook_table(self, allreduce):
-        """the host actions of a data-parallel step by tag (engine_plan._host_call): what a replayed step calls between its ranges
-        of launches - Python then issues nothing but the collectives (reference: one train_function call per minibatch)"""
-        L = self.layout
-        return {"early": lambda: allreduce.early(self.grads[L.dec_begin:L.total]),
-                "reduce": lambda: allreduce(self.grads),
-                "status": lambda: self.status_allreduce(self.store["pipe_status"]),
-                "pace1": self._pace_now, "pace2": self._pace_now, "pace4": self._pace_now}
-
-    def _pace(self, bit):
-        """hold the HOST here until the device has reached this point of the step (pace_mask: bit 1 before the decoder forward, 2
-        before the backward pass, 4 before the encoder BPTT) - a host action of the step, so a replayed step pauses there too"""
-        if self.pace_mask & bit:
-            self._host_call("pace%d" % bit, self._pace_now)
-
-    def _pace_now(self):
-        ev = torch.cuda.Event()
-        ev.record()
-        ev.synchronize()
-
-    def _train_step(self, B, allreduce):
-        self._redo_hist = None
-        self._bucket_hook = self._overlap_hook(allreduce, B)
-        try:
-            self.forward_backward(B)
-        finally:
-            self._bucket_hook = None
-        gs = 1.0
-        if allreduce is not None:
-            gs = self._host_call("reduce", lambda: allreduce(self.grads))
-        self.optimizer_step(gs if gs is not None else 1.0)
-
-    def train_step_empty(self, allreduce):
-        """Data parallel, ragged minibatch: this rank's shard is EMPTY (fewer windows than ranks) - contribute zero gradients to
-        the collective and apply the same update as everybody else."""
-        assert self.training and allreduce is not None
-        if self._weights_dirty:
-            self.prepare_weights()
-        else:
-            self.scal.zero_()
-        if not self._grads_clean:
-            self.grads.zero_()
-        self._grads_clean = False
-        gs = allreduce(self.grads)
-        self.optimizer_step(gs if gs is not None else 1.0)
 
     def stager(self):
         if self._stager is None:

@@ -253,8 +253,9 @@ class Results(object):
         """key -> (launches, mean ms, mean time steps per launch) for the event pairs collected since
         ``self.prof = {}`` (synchronises first)."""
         torch.cuda.synchronize()
-        return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b, _ in v])), float(np.mean([n for _, _, n in v])))
-                for k, v in (self.prof or {}).items()}
+        for i in list(self._prof_pending):
+            self._prof_harvest(i)
+        return {k: (len(v), float(np.mean([ms for ms, _ in v])), float(np.mean([n for _, n in v]))) for k, v in (self.prof or {}).items()}
 
     def bytes_resident(self):
         return (sum(t.numel() * t.element_size() for t in self.store.values()) +

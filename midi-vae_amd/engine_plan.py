@@ -17,10 +17,10 @@ from . import plan as _plan
 
 class _PlanSlot(object):
     """recordings / the armed plan of one kind of call on one engine"""
-    __slots__ = ("recs", "plan", "dead", "post", "runs", "host_results")
+    __slots__ = ("recs", "plan", "dead", "post", "runs", "host_results", "brackets")
 
     def __init__(self):
-        self.recs, self.plan, self.dead, self.post, self.runs, self.host_results = [], None, None, None, 0, {}
+        self.recs, self.plan, self.dead, self.post, self.runs, self.host_results, self.brackets = [], None, None, None, 0, {}, []
 
 
 class PlannedSteps(object):
@@ -46,6 +46,7 @@ class PlannedSteps(object):
         self._plans = {}
         self._ev_pool, self._ev_i = [], 0
         self._host_results, self._ext_streams, self._plan_depth = {}, {}, 0
+        self._prof_pool, self._prof_pending, self._prof_i, self._prof_call = [], {}, 0, []     # launch brackets (Engine._timed)
         self.steps_in_flight = int(os.environ.get("MVAE_STEPS_IN_FLIGHT", "1"))      # (_planned; 0 = the host runs ahead freely)
         self._flight, self._flight_pool = [], []
         self.plan_stats = {"recorded": 0, "replayed": 0, "refused": {}}
@@ -103,6 +104,15 @@ class PlannedSteps(object):
         """what a call left changed, as (attribute values, weight-version moves) relative to the state ``before`` it"""
         return (tuple(getattr(self, n, None) for n in self._PLAN_STATE), frozenset(self._xp0_bias),
                 self._pver[0] - before[0], self._prepared_ver - self._pver[0])
+
+    def _prof_harvest(self, i):
+        """read the measurement bracket pair ``i`` still holds (it is about to be recorded again, or the summary is due)"""
+        pend = self._prof_pending.pop(i, None)
+        if pend is not None and self.prof is not None:
+            ms = C.c_float()
+            e0, e1 = self._prof_pool[i]
+            hl.check(hl.load().mvae_event_elapsed_ms(e0, e1, C.byref(ms)), "mvae_event_elapsed_ms")
+            self.prof.setdefault(pend[0], []).append((float(ms.value), pend[1]))
 
     def _host_call(self, tag, fn):
         """a host action inside a step (a data-parallel step's collectives): run ``fn`` - noted as a host mark when the step is
@@ -174,14 +184,16 @@ class PlannedSteps(object):
         profiling = self.prof is not None and (self.prof_kinds is None or len(self.prof_kinds) > 0)      # (launches get bracketed)
         if self._plan_depth == 0:
             self._ev_i = 0          # the event ring restarts with every outermost call (planned or not)
-        if (not self.use_plans or profiling or getattr(self, "marks", None) is not None or
+            self._prof_i, self._prof_call = 0, []       # ... and so do the launch brackets
+        if (not self.use_plans or getattr(self, "marks", None) is not None or
                 _plan.active() is not None or self._hist_fused is not None):
             self._plan_depth += 1
             try:
                 return fn()
             finally:
                 self._plan_depth -= 1
-        key = (kind, torch.cuda.current_stream().cuda_stream, self._plan_state())
+        pkey = (None if not profiling else True if self.prof_kinds is None else frozenset(self.prof_kinds))      # which launches are bracketed
+        key = (kind, torch.cuda.current_stream().cuda_stream, self._plan_state(), pkey)
         slot = self._plans.get(key)
         if slot is None:
             slot = self._plans[key] = _PlanSlot()
@@ -192,6 +204,8 @@ class PlannedSteps(object):
             if not all(cnt.get(k, 0) + d < self._REBASE for k, d in slot.plan.inc.items()):
                 return fn()
             if True:
+                for i, _, _ in slot.brackets:            # (their pairs are recorded again by this replay)
+                    self._prof_harvest(i)
                 if slot.plan.marks:
                     self._plan_set_counters(slot.plan.run_ranges(cnt, self._replay_host(host or {}, slot.host_results)))
                 else:
@@ -202,6 +216,8 @@ class PlannedSteps(object):
                 self._xp0_bias = set(xp0)
                 self._pver[0] += dver
                 self._prepared_ver = self._pver[0] + dprep
+                for i, k, n in slot.brackets:
+                    self._prof_pending[i] = (k, n)
                 slot.runs += 1
                 self.plan_stats["replayed"] += 1
                 return None
@@ -213,6 +229,7 @@ class PlannedSteps(object):
             out = fn()
         post_state = self._plan_post(ver) + (tuple(sorted(self._host_results.items(), key=repr)),)
         slot.recs.append((rec.calls, rec.tags, pre, self._plan_counters(), post_state, rec.marks))
+        slot.brackets = list(self._prof_call)
         self.plan_stats["recorded"] += 1
         if rec.tainted is not None:      # (a kernel torch itself launched would be missing from the replay)
             slot.dead = "the call runs the torch operation %r" % rec.tainted

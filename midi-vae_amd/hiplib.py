@@ -154,6 +154,8 @@ SIGNATURES = {
     "mvae_bi_concat": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "mvae_add_time_reversed": (_i32, [_vp, _vp, _vp, _i32, _i32, _sz, _vp]),
     "mvae_event_create": (_i32, [C.POINTER(_vp)]),
+    "mvae_event_create_timed": (_i32, [C.POINTER(_vp)]),
+    "mvae_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(C.c_float)]),
     "mvae_event_destroy": (_i32, [_vp]),
     "mvae_event_record": (_i32, [_vp, _vp]),
     "mvae_stream_wait_event": (_i32, [_vp, _vp]),
