@@ -750,8 +750,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         H, Z = s.H, s.Z
         tg = s.style and self._have_targets
         ok = ops.latent_chain_fwd(
-            B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, self.n_init * H, s.split, s.beta, s.prior_mean,
-            s.prior_std, 1.0 / self.norm_B, cat=self._v("cat", B, self.ncat * H),
+            B, ops.ParamInt(Breal, ops.PARAM_B), H, Z, s.C if s.style else 0, self.ncat, s.zin, self.n_init * H, s.split, s.beta, s.prior_mean,
+            s.prior_std, ops.ParamFloat(1.0 / self.norm_B, ops.PARAM_INV_BATCH), cat=self._v("cat", B, self.ncat * H),
             w_pack=P["enc.pack.W"] if self.has_pack else None, b_pack=P["enc.pack.b"] if self.has_pack else None,
             w_extra=P["enc.extra.W"] if s.extra_layer else None, b_extra=P["enc.extra.b"] if s.extra_layer else None,
             w_mu=P["enc.zmean.W"], b_mu=P["enc.zmean.b"], w_lv=P["enc.zlogvar.W"], b_lv=P["enc.zlogvar.b"],
@@ -858,7 +858,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 def run():
                     ops.head(h.kind, self.kind, r1 - r0, H, h.N, top[i * Ts:(i + 1) * Ts], self._v(n + ".wt", h.NP, H), P[h.out + ".b"],
                              grad_scale=h.weight, probs=None, argmax=am[r0:r1], dlogits=None,
-                             scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=Breal)
+                             scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=ops.ParamInt(Breal, ops.PARAM_B))
                 if last:        # (behind the stack on this queue: complete by queue order)
                     run()
                 else:
@@ -871,7 +871,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         ops.head(h.kind, self.kind, R, H, h.N, top, self._v(n + ".wt", h.NP, H), P[h.out + ".b"], grad_scale=h.weight,
                  probs=self._v("out.%s_p" % n, R, h.N) if want_probs else None, argmax=self._v(n + ".argmax", R),
                  dlogits=self._v(n + ".dl", R, h.NP) if (self.training and tg) else None, **self._fused_head_bwd(n, tg),
-                 scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=Breal, **tgt)
+                 scalars=self.scal[h.slot:h.slot + 2], b_stride=B, b_valid=ops.ParamInt(Breal, ops.PARAM_B), **tgt)
 
     # ------------------------------------------------------------------------------------------------------
     # backward
@@ -1208,8 +1208,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         dcat = self._v("dcat", B, ldc)
         pk, ex, cat = self._v("pack", B, H), self._v("extra", B, H), self._v("cat", B, ldc)
         ok = ops.latent_chain_bwd(
-            B, Breal, H, Z, s.C if s.style else 0, self.ncat, s.zin, ldS, s.split, s.beta, s.prior_mean, s.prior_std, s.w_style,
-            1.0 / self.norm_B, wt_pack=self.store.get("lat.wt_pack"), wt_extra=self.store.get("lat.wt_extra"),
+            B, ops.ParamInt(Breal, ops.PARAM_B), H, Z, s.C if s.style else 0, self.ncat, s.zin, ldS, s.split, s.beta, s.prior_mean, s.prior_std, s.w_style,
+            ops.ParamFloat(1.0 / self.norm_B, ops.PARAM_INV_BATCH), wt_pack=self.store.get("lat.wt_pack"), wt_extra=self.store.get("lat.wt_extra"),
             wt_mu=self.store["lat.wt_mu"], wt_lv=self.store["lat.wt_lv"], wt_init=self.store["lat.wt_init"], S=S,
             pack=pk if self.has_pack else None,
             extra=ex if s.extra_layer else None, mu=self._v("mu", B, Z), logvar=self._v("lv", B, Z), eps=self._v("in.eps", B, Z),
@@ -1300,7 +1300,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def eval_step(self, B, want_probs=False):
         """Forward + losses only (``autoencoder.evaluate`` / ``autoencoder.predict``)."""
-        self._planned(("eval", B, bool(want_probs)), lambda: self._eval_step(B, want_probs))
+        self._planned(("eval", B, float(self.norm_B), bool(want_probs)), lambda: self._eval_step(B, want_probs), params=self._call_params(B))
 
     def _eval_step(self, B, want_probs):
         self._have_targets = True
@@ -1315,7 +1315,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def encode(self, B):
         """``encoder.predict``: z (B,Z) device view (left block of [z|history])."""
-        self._planned(("encode", B), lambda: self._encode(B))
+        self._planned(("encode", B, float(self.norm_B)), lambda: self._encode(B), params=self._call_params(B))
         return self._v("zh", self.pad16(B), self.spec.zin)[:B, :self.spec.Z]
 
     def _encode(self, B):
@@ -1329,7 +1329,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
 
     def decode(self, B, want_probs=True):
         """``decoder.predict`` on the staged [z|history]; argmax note indices are always produced on device."""
-        self._planned(("decode", B, bool(want_probs)), lambda: self._decode(B, want_probs))
+        self._planned(("decode", B, float(self.norm_B), bool(want_probs)), lambda: self._decode(B, want_probs), params=self._call_params(B))
 
     def _decode(self, B, want_probs):
         self._have_targets = False

@@ -27,7 +27,7 @@ class PlannedSteps(object):
     # attributes whose value decides which launches a call makes (part of the plan key) and which a call leaves changed (restored
     # after a replay to what the recorded calls left)
     _PLAN_STATE = ("_count_pending", "_grads_clean", "_dxp0_clean", "_have_targets", "_S_done", "_pipe_used", "pipeline",
-                   "multi_stream", "norm_B", "_have_staged_targets", "lean_sync", "value_join", "phase_multi")
+                   "multi_stream", "_have_staged_targets", "lean_sync", "value_join", "phase_multi")
     # schedule knobs a caller (a test, an A/B script) may change on a LIVE engine: part of the plan key, so that a change selects
     # other plans instead of replaying the launch list recorded under the old value
     _PLAN_CONFIG = ("head_slices", "grad_portions", "index_dense",
@@ -153,7 +153,7 @@ class PlannedSteps(object):
     _PACE_START = ("train", "train_begin", "train_begin_fused")
     _PACE_END = ("train", "train_finish")
 
-    def _planned(self, kind, fn, host=None):
+    def _planned(self, kind, fn, host=None, params=None):
         """_planned_call, paced: with ``steps_in_flight`` = n > 0 the host enqueues a step only when at most n - 1 earlier ones are
         still unfinished (it waits for the event behind the n-th last).  Round 5 measurement: a device that has the NEXT step's
         packets in its queues - a dozen hardware queues holding value waits that will not be satisfied for milliseconds - runs the
@@ -168,7 +168,7 @@ class PlannedSteps(object):
                 ev.synchronize()
                 self._flight_pool.append(ev)
         try:
-            return self._planned_call(kind, fn, host)
+            return self._planned_call(kind, fn, host, params)
         finally:
             if n and kind[0] in self._PACE_END:
                 ev = self._flight_pool.pop() if self._flight_pool else torch.cuda.Event()
@@ -177,7 +177,7 @@ class PlannedSteps(object):
                 if len(self._flight) > 8:                      # (an unpaced caller in between: nothing to wait for)
                     self._flight_pool.append(self._flight.pop(0))
 
-    def _planned_call(self, kind, fn, host=None):
+    def _planned_call(self, kind, fn, host=None, params=None):
         """run ``fn`` (the Python enqueue of one call of kind ``kind``, a hashable that names everything the launch list depends
         on besides the engine's state) - or, once three recordings of it agreed, replay its plan.  ``host``: tag -> callable of
         the host actions ``fn`` performs through _host_call (replayed between the call ranges they were recorded between)"""
@@ -203,6 +203,8 @@ class PlannedSteps(object):
             cnt = self._plan_counters()
             if not all(cnt.get(k, 0) + d < self._REBASE for k, d in slot.plan.inc.items()):
                 return fn()
+            if params:
+                cnt.update(params)          # (the call's parameters: the real number of windows, 1 / global minibatch size)
             if True:
                 for i, _, _ in slot.brackets:            # (their pairs are recorded again by this replay)
                     self._prof_harvest(i)
@@ -224,6 +226,8 @@ class PlannedSteps(object):
         if slot.dead is not None:
             return fn()
         pre, ver = self._plan_counters(), (self._pver[0], self._prepared_ver)
+        if params:
+            pre.update(params)
         self._host_results = {}
         with _plan.Recorder() as rec:
             out = fn()

@@ -119,13 +119,14 @@ class TrainSteps(object):
         history columns of [z | history] (window 0: zeros) and the decoder's initial-state Denses follow as a separate GEMM.
         Only for a minibatch that starts at window 0 of its song."""
         if hist_fused is None:
-            return self._planned(("train_begin", B), lambda: self._train_step_begin(B, None))
+            return self._planned(("train_begin",) + self._kind_B(B), lambda: self._train_step_begin(B, None), params=self._call_params(B))
         # z' goes to a fixed engine buffer - the launch list then holds no per-song address and the step replays as a plan like
         # any other - and to the caller's rows by one copy behind the step (train_step_finish)
         eps2, z_dst = hist_fused
         zbuf = self._v("hist_zout", self.pad16(B), self.spec.Z)
         self._fused_dst = (z_dst, zbuf)
-        return self._planned(("train_begin_fused", B, eps2.data_ptr()), lambda: self._train_step_begin(B, (eps2, zbuf)))
+        return self._planned(("train_begin_fused", B, self.norm_B, eps2.data_ptr()), lambda: self._train_step_begin(B, (eps2, zbuf)),
+                             params=self._call_params(B))
 
     def _train_step_begin(self, B, hist_fused):
         self._step_begin()
@@ -139,8 +140,8 @@ class TrainSteps(object):
         """the rest of the step: one replayable call (engine_plan.py) - with a gradient hook (data parallel) its collectives are
         host actions between the call ranges of the plan"""
         try:
-            return self._planned(("train_finish", B) + self._hook_kind(allreduce), lambda: self._train_step_finish(B, allreduce),
-                                 host=self._hook_table(allreduce))
+            return self._planned(("train_finish",) + self._kind_B(B) + self._hook_kind(allreduce),
+                                 lambda: self._train_step_finish(B, allreduce), host=self._hook_table(allreduce), params=self._call_params(B))
         finally:
             if self._fused_dst is not None:          # (behind a possible redo of the step: the rows are final here)
                 (z_dst, zbuf), self._fused_dst = self._fused_dst, None
@@ -173,8 +174,23 @@ class TrainSteps(object):
         replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run (engine_plan.py; reference: ONE
         Keras train_function call per minibatch, vae_training.py:804-809); the hook's collectives are issued from Python between
         the plan's call ranges (host marks)."""
-        return self._planned(("train", B) + self._hook_kind(allreduce), lambda: self._train_step(B, allreduce),
-                             host=self._hook_table(allreduce))
+        return self._planned(("train",) + self._kind_B(B) + self._hook_kind(allreduce), lambda: self._train_step(B, allreduce),
+                             host=self._hook_table(allreduce), params=self._call_params(B))
+
+    def _call_params(self, B):
+        """the parameters of a call on B windows (ops.PARAM_*): what a replayed plan patches into the launches that take them"""
+        return {ops.PARAM_B: int(B), ops.PARAM_INV_BATCH: ops.f32_bits(1.0 / self.norm_B)}
+
+    def _kind_B(self, B):
+        """what the number of windows contributes to the plan key of a train step.  On the default graph (fused latent chain, no
+        optional heads) a step's launch list depends on the PADDED batch only - the real count and the loss normaliser reach the
+        latent chain and the heads as tagged parameters (ops.ParamInt / ParamFloat) - so songs of 97 and 100 windows share a
+        plan: `python vae_training.py` on songs of 20-200 windows replays after three steps per 16-window bucket instead of three
+        per window count.  Any other graph: the real count and the normaliser are part of the key."""
+        s = self.spec
+        if self.fused_latent and self._chain_ok() and not s.signature and not self.aux:
+            return ("padded", self.pad16(B))
+        return (int(B), float(self.norm_B))
 
     def _hook_kind(self, allreduce):
         """what a gradient hook adds to the plan key of a train step: that there is one, and whether it takes an early bucket"""

@@ -41,6 +41,31 @@ class CounterValue(int):
         return self
 
 
+class ParamInt(int):
+    """a 32-bit integer argument that is a PARAMETER of the call (``key`` = ("param", name)) - the real number of windows of a
+    padded minibatch: every field it lands in is a patch of the step plan, field := the value the caller names at replay"""
+    def __new__(cls, value, key):
+        self = int.__new__(cls, int(value))
+        self.key = key
+        return self
+
+
+class ParamFloat(float):
+    """the same for a float argument (1 / global minibatch size); a plan carries it as its float32 bit pattern"""
+    def __new__(cls, value, key):
+        self = float.__new__(cls, float(value))
+        self.key = key
+        return self
+
+
+PARAM_B, PARAM_INV_BATCH = ("param", "windows"), ("param", "inv_batch")
+
+
+def f32_bits(v):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+
+
 def _tag(struct, field, value):
     """remember on an argument struct that ``field`` holds a counter value (consumed by _launch / the *_multi wrappers)"""
     key = getattr(value, "key", None)
@@ -263,6 +288,8 @@ def head(kind, dtype, R, H, N, hs, wt, bias, *, target_idx=None, target_val=None
     a = hl.HeadArgs(kind, dtype, R, H, N, int(dlogits is not None), hs.data_ptr(), _p(wt), _p(bias), _p(target_idx),
                     _p(target_val), _p(row_weight), float(grad_scale), _p(probs), _p(argmax), _p(dlogits), _p(scalars),
                     b_stride, b_valid, _p(wc), _p(dhs), _p(target_idx2))
+    _tag(a, "b_valid", b_valid)
+    _note_fields(0, [a])
     hl.check(hl.load().mvae_head(a, _stream()), "mvae_head")
 
 
@@ -286,6 +313,9 @@ def latent_chain_fwd(B, B_valid, H, Z, C, ncat, zin, n_init, split, beta, prior_
     a = hl.LatentChainFwdArgs(B, B_valid, H, Z, C, ncat, zin, n_init, int(bool(split)), beta, prior_mean, prior_std, inv_batch)
     for name, _ in hl.LatentChainFwdArgs._fields_[13:]:
         setattr(a, name, _p(t.get(name)))
+    _tag(a, "B_valid", B_valid)
+    _tag(a, "inv_batch", inv_batch)
+    _note_fields(0, [a])
     rc = hl.load().mvae_latent_chain_fwd(a, _stream())
     if rc == hl.E_UNSUPPORTED:
         return False
@@ -298,6 +328,9 @@ def latent_chain_bwd(B, B_valid, H, Z, C, ncat, zin, n_init, split, beta, prior_
                               style_weight, inv_batch)
     for name, _ in hl.LatentChainBwdArgs._fields_[14:]:
         setattr(a, name, _p(t.get(name)))
+    _tag(a, "B_valid", B_valid)
+    _tag(a, "inv_batch", inv_batch)
+    _note_fields(0, [a])
     rc = hl.load().mvae_latent_chain_bwd(a, _stream())
     if rc == hl.E_UNSUPPORTED:
         return False

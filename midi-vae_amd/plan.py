@@ -158,12 +158,21 @@ class StepPlan(object):
         keys = sorted(set(pa) | set(qa), key=repr)
         self.inc = {}
         for k in keys:
+            if k[0] == "param":          # (a call parameter, named by the caller at every replay: not a counter the step advances)
+                continue
             inc = [q.get(k, 0) - p.get(k, 0) for p, q in ((pa, qa), (pb, qb), (pc, qc))]
             if not inc[0] == inc[1] == inc[2]:
                 raise NotReplayable("counter %r advanced by %r in the three recordings" % (k, inc))
             if inc[0]:
                 self.inc[k] = inc[0]
-        self.keys = sorted(self.inc, key=repr)
+        # PARAMETERS of the call (ops.ParamInt / ParamFloat, key = ("param", name)): the caller names their values at every replay;
+        # every field tagged with one is a patch whether or not the three recordings differ in it
+        params = sorted({k for t in (ta, tb, tc) for k in t.values() if k[0] == "param"}, key=repr)
+        for k in params:
+            if not (k in pa and k in pb and k in pc):
+                raise NotReplayable("parameter %r was used by a call whose caller did not name its value" % (k,))
+        self.params = params
+        self.keys = sorted(set(self.inc) | set(params), key=repr)
         kidx = {k: i for i, k in enumerate(self.keys)}
         lib = hl.load()
         h = C.c_void_p()
@@ -211,6 +220,16 @@ class StepPlan(object):
                     for w in np.nonzero((wa != wb) | (wa != wc))[0]:
                         patches.append((slot, int(w) * 4) + patch_for("call %d (%s) argument %d byte %d" % (i, na, slot, int(w) * 4),
                                                                       (i, slot, int(w) * 4), int(wa[w]), int(wb[w]), int(wc[w])))
+                done = {(slot, off) for slot, off, _, _ in patches}
+                for (ci, slot, off), key in sorted(ta.items(), key=repr):         # parameter fields that happened to agree
+                    if ci != i or key[0] != "param" or (slot, off) in done:
+                        continue
+                    if off < 0:
+                        va, vb, vc = sa[slot], sb[slot], sc[slot]
+                    else:
+                        va, vb, vc = (int(np.frombuffer(b[slot], dtype="<u4", count=1, offset=off)[0]) for b in (ba, bb, bc))
+                    patches.append((slot, off) + patch_for("call %d (%s) argument %d byte %d" % (i, na, slot, off), (i, slot, off),
+                                                          va, vb, vc))
                 for slot, off, key, add in patches:
                     hl.check(lib.mvae_plan_add_patch(h, i, slot, off, key, add), "mvae_plan_add_patch")
                     self.n_patches += 1

@@ -147,3 +147,31 @@ def test_recorder_host_runs_the_action_outside_the_taint_mode_and_notes_the_mark
         assert out == 3.0 and rec.tainted is None
         torch.ones(2) + 1                                                           # ... outside one: the step is not replayable
     assert rec.tainted is not None and rec.marks == [(0, "reduce", 0x55)]
+
+
+def test_call_parameters_are_patched_whether_or_not_the_recordings_differ():
+    """ops.ParamInt / ParamFloat (key ("param", name)): the real number of windows of a padded minibatch and 1 / global minibatch
+    size reach a few launches as tagged values; the plan patches every such field with the value the caller names at replay - also
+    when the three recordings happened to carry the same value (songs of equal length) - so steps on 97 and 100 windows share one
+    plan.  A recording whose caller named no value for a parameter it used is refused."""
+    from midi_vae_amd import ops
+    recs = []
+    for base, seq, nwin in ((0, 0, 100), (64, 1, 100), (128, 2, 100)):
+        calls, tags, before, after = _recording(base, seq)
+        g = hl.GemmArgs(M=128, N=64, K=32, A=0x1000, B=0x2000, C=0x3000, chunk_wait=0x4000, chunk_wait_value=base + 64, alpha=1.0 / nwin)
+        calls[0] = ("mvae_gemm", [0, 0x77], {0: C.string_at(C.addressof(g), C.sizeof(g))})
+        calls[3][1][4] = nwin                                               # (an integer argument that carries the window count)
+        tags = dict(tags)
+        tags[(3, 4, -1)] = ops.PARAM_B
+        tags[(0, 0, hl.GemmArgs.alpha.offset)] = ops.PARAM_INV_BATCH
+        before = dict(before)
+        before[ops.PARAM_B], before[ops.PARAM_INV_BATCH] = nwin, ops.f32_bits(1.0 / nwin)
+        recs.append((calls, tags, before, after))
+    p = P.StepPlan(recs)
+    assert p.params == sorted([ops.PARAM_B, ops.PARAM_INV_BATCH], key=repr) and p.n_patches == 3 + 2
+    assert set(p.keys) == {("sync", 0, 0), ("join", 2), ops.PARAM_B, ops.PARAM_INV_BATCH} and set(p.inc) == {("sync", 0, 0), ("join", 2)}
+    p.close()
+    missing = [(c, t, {k: v for k, v in b.items() if k != ops.PARAM_B}, a) for c, t, b, a in recs]
+    with pytest.raises(P.NotReplayable):
+        P.StepPlan(missing)
+    assert ops.f32_bits(0.5) == 0x3F000000 and ops.ParamInt(7, ops.PARAM_B).key == ops.PARAM_B and float(ops.ParamFloat(0.25, ops.PARAM_INV_BATCH)) == 0.25

@@ -86,8 +86,10 @@ def test_the_plan_holds_what_python_would_enqueue_next():
     assert rec.tainted is None
     assert len(rec.calls) == plan.n_calls
     # the same step through the constructor's own comparison: recording it three times over must give the same patches
-    again = P.StepPlan([(rec.calls, rec.tags, before, eng._plan_counters())] * 3)
-    assert again.n_patches == 0 and again.n_calls == plan.n_calls       # (identical recordings: everything constant)
+    before.update(eng._call_params(B))        # (the call's parameters: real window count, 1 / global minibatch - always patches)
+    again = P.StepPlan([(rec.calls, rec.tags, before, eng._plan_counters())] * 3, [rec.marks] * 3)
+    n_param = sum(1 for k in rec.tags.values() if k[0] == "param")
+    assert again.n_patches == n_param > 0 and again.n_calls == plan.n_calls       # (identical recordings: everything else constant)
     again.close()
     eng.check_pipeline()
 
@@ -239,3 +241,33 @@ def test_short_sequences_defer_their_weight_gradient_gemms_into_one_launch(cell)
         assert np.linalg.norm(g1[k] - g0[k]) <= 1e-4 * (np.linalg.norm(g0[k]) + 1e-8) + 1e-7, k
     for a, b in zip(l1, l0):
         assert abs(a - b) <= 1e-4 * (1 + abs(b)), (l1, l0)
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM"])
+def test_ragged_minibatches_of_one_padded_size_share_a_plan(cell):
+    """Engine._kind_B (round 5): on the default graph a train step's launch list depends on the PADDED batch only; the real number
+    of windows and 1 / (global minibatch size) are call parameters (ops.ParamInt / ParamFloat) that a replayed plan patches into
+    the latent chain and the heads.  Songs of 100, 97, 104, 99 ... windows (all padded to 112) - what `python vae_training.py`
+    feeds at the reference's default settings - then replay one plan: per-step losses and the final parameters equal those of an
+    engine that enqueues every step from Python, and most steps are replays."""
+    sizes = [100, 97, 104, 99, 101, 98, 103, 112, 105, 97, 110, 100]
+    spec, params, batch, raw = _problem(cell, 112, seed=71, H=256, Z=64, T=64)
+    res = {}
+    for plans in (True, False):
+        eng = Engine(spec, max_batch=112, dtype="bf16")
+        eng.use_plans = plans
+        eng.set_params(params)
+        losses = []
+        for B in sizes:
+            sub = {k: (v[:B] if hasattr(v, "shape") and v.shape[:1] == (112,) else v) for k, v in raw.items()}
+            _stage(eng, sub, B)
+            eng.train_step(B)
+            losses.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        res[plans] = (losses, eng.get_params(), dict(eng.plan_stats))
+    assert res[True][2]["replayed"] >= len(sizes) - 6, res[True][2]
+    assert len(set(round(l, 4) for l in res[False][0])) > 6          # (the steps really differ)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-4 * (1 + abs(b)), (res[True][0], res[False][0])
+    for k, v in res[False][1].items():
+        assert np.linalg.norm(res[True][1][k] - v) <= 2e-3 * (np.linalg.norm(v) + 1e-6) + 1e-6, k
