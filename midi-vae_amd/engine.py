@@ -734,7 +734,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         if fused_hist is not None:
             eps2, z_out = fused_hist
             zh = self._v("zh", B, s.zin)
-            ops.history_from_latent(self._v("mu", B, Z), self._v("lv", B, Z), eps2, Breal, B, Z, zh[:, Z:2 * Z], z_out=z_out)
+            ops.history_from_latent(self._v("mu", B, Z), self._v("lv", B, Z), eps2, ops.ParamInt(Breal, ops.PARAM_B), B, Z, zh[:, Z:2 * Z],
+                                    z_out=z_out)
         self._signature_forward(Breal, B)
 
     def _chain_ok(self):

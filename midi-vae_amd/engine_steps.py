@@ -125,7 +125,7 @@ class TrainSteps(object):
         eps2, z_dst = hist_fused
         zbuf = self._v("hist_zout", self.pad16(B), self.spec.Z)
         self._fused_dst = (z_dst, zbuf)
-        return self._planned(("train_begin_fused", B, self.norm_B, eps2.data_ptr()), lambda: self._train_step_begin(B, (eps2, zbuf)),
+        return self._planned(("train_begin_fused",) + self._kind_B(B) + (eps2.data_ptr(),), lambda: self._train_step_begin(B, (eps2, zbuf)),
                              params=self._call_params(B))
 
     def _train_step_begin(self, B, hist_fused):

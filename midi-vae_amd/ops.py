@@ -485,6 +485,7 @@ def copy2d(dst, src, rows, cols, src_row0=0, zero_rows=0):
 def history_from_latent(mu, logvar, eps2, B, B_pad, Z, hist, z_out=None, prev=None):
     """the fused history pre-pass: z' = mu + exp(logvar / 2) * eps2 -> z_out rows [0, B); hist (a column-block view of
     [z | history]) row b = z'[b-1], row 0 = prev (or zeros), rows B.. zero"""
+    _note_scalar(3, B)          # (the real number of windows: a call parameter of a step plan, ParamInt)
     hl.check(hl.load().mvae_history_from_latent(_p(mu), _p(logvar), _pv(eps2), int(B), int(B_pad), int(Z), _pv(hist), hist.stride(0),
                                                 _pv(prev), _pv(z_out), z_out.stride(0) if z_out is not None else 0, _stream()),
              "mvae_history_from_latent")
