@@ -195,22 +195,26 @@ def side_workload(config, cell, dtype, device, steps, warmup):
             step()
         torch.cuda.synchronize()
     eng.prof_kinds = kinds
-    for i in range(warmup):
+    for i in range(max(warmup, 16)):       # (both kinds of step - bracketed, plain - recorded three times and replayed once)
         eng.prof = {} if i % 4 == 0 else None
         step()
     eng.prof = None
     torch.cuda.synchronize()
     host = 0.0
     prof = {}
+    per_step = []
     t0 = time.perf_counter()
     for i in range(steps):
         eng.prof = prof if i % 4 == 0 else None        # (every 4th step is bracketed)
         h0 = time.perf_counter()
         step()
         host += time.perf_counter() - h0
+        per_step.append(time.perf_counter() - h0)
     eng.prof = None
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+        sys.stderr.write("config %d host ms per step() call: %s\n" % (config, " ".join("%.2f" % (1e3 * v) for v in per_step)))
     eng.prof = prof
     summary = eng.prof_summary()
     eng.prof = None
@@ -262,7 +266,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo: two ranks on ONE GPU in tests/test_dp_gpu.py)")
     ap.add_argument("--hidden", type=int, default=256, help="(tests) cell width")
+    ap.add_argument("--side", default=None, help="(internal) 'config,cell,steps,warmup': measure ONE of the other workloads in this "
+                                                 "process and print its other_configs member")
     args = ap.parse_args()
+    if args.side:
+        cfg, cell_o, k, wu = args.side.split(",")
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps(side_workload(int(cfg), cell_o, args.dtype, torch.device("cuda", 0), int(k), int(wu))))
+        return
     if args.cell is None:
         args.cell = "GRU" if args.config == 0 else "LSTM"
 
@@ -364,29 +376,27 @@ def main():
     KINDS = ({("rnn_fwd", "dec.notes.1"), ("rnn_fwd_multi", "dec")} if decode else
              {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_fwd", "dec.notes.1"), ("rnn_bwd_multi", "dec"),
               ("rnn_fwd_multi", "dec")})
+    # The W warmup steps bracket forward AND BPTT launches (the forward figure of the critical-path bound comes from them).  Then
+    # ARM untimed steps of the two kinds the timed region runs - BPTT launches bracketed / plain - four of each: three recordings
+    # make a kind's enqueue a plan (engine_plan.py), the fourth replays it once.  (Round 5 found the first three plain steps of the
+    # timed region Python-enqueued at 8.8 instead of 6.5 ms: the pre-warm passes run no optimizer and so arm another kind of call.)
+    bwd_kinds = KINDS if decode else {k for k in KINDS if k[0].startswith("rnn_bwd")}
+    ARM = 8 if args.warmup else 0
     eng.prof_kinds = KINDS
-    if args.warmup:
-        eng.prof = {}
+    eng.prof = {} if args.warmup else None
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if eng.prof is not None:
-        eng.prof_summary_last = eng.prof_summary()
-        eng.prof = None
-    first_loss = eng.metrics(B)["loss"] if (args.warmup and not decode) else float("nan")
-
-    # One more event per step boundary on the critical stream gives the per-step times (median).  In the timed region only the
-    # DOMINANT kernel's launches are bracketed (a pair of events is two packets on the critical queue, ~30 us each: the forward
-    # figure of the critical-path bound comes from the warmup steps, which bracket both).
-    fwd_prof = {k: v for k, v in (eng.prof_summary_last if hasattr(eng, "prof_summary_last") else {}).items() if k[0].startswith("rnn_fwd")}
-    eng.prof_kinds = KINDS if decode else {k for k in KINDS if k[0].startswith("rnn_bwd")}
-    eng.prof = {}               # HIP events on the launch streams
-    # (the brackets are C-ABI events from a pool - Engine._timed - so a bracketed step replays as a plan like any other once its
-    #  kind of call has been recorded three times: untimed, here)
-    for _ in range(3 if args.warmup else 0):
+    fwd_prof = {k: v for k, v in eng.prof_summary().items() if k[0].startswith("rnn_fwd")} if args.warmup else {}
+    eng.prof = {} if args.warmup else None
+    for i in range(ARM):
+        eng.prof_kinds = bwd_kinds if i < ARM // 2 else set()
         step()
     torch.cuda.synchronize()
-    eng.prof = {}
+    eng.prof = None
+    first_loss = eng.metrics(B)["loss"] if (args.warmup and not decode) else float("nan")
+    eng.prof_kinds = bwd_kinds
+    eng.prof = {}               # HIP events on the launch streams (C-ABI events from a pool - Engine._timed - so a bracketed step
+    #                             replays as a plan like any other)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if dist is not None:
         dist.barrier()
@@ -401,12 +411,22 @@ def main():
         step()
         host_s += time.perf_counter() - th
         marks[i + 1].record()
+        if os.environ.get("MVAE_BENCH_STEP_TIMES") and i < 8:
+            sys.stderr.write("timed step %d: plans %s keys %d\n" % (i, {k: (v if k != "refused" else len(v)) for k, v in eng.plan_stats.items()}, len(eng._plans)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(raw_ms)
+    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+        sys.stderr.write("headline ms per step (events): %s\n" % " ".join("%.2f" % v for v in raw_ms))
+    _med = lambda v: (sorted(v)[len(v) // 2] if v else None)
+    step_split = {"plain_median": _med([m for i, m in enumerate(raw_ms) if i % every]),
+                  "bracketed_median": _med([m for i, m in enumerate(raw_ms) if i % every == 0]),
+                  "min": step_ms[0], "max": step_ms[-1], "bracketed_every": every,
+                  "slow_steps": [[i, round(m, 3)] for i, m in enumerate(raw_ms) if m > 1.05 * step_ms[len(step_ms) // 2]][:12]}
     median_ms = step_ms[len(step_ms) // 2] if args.steps % 2 else 0.5 * (step_ms[args.steps // 2 - 1] + step_ms[args.steps // 2])
     dp_stats = None
     if dist is not None:
@@ -490,7 +510,7 @@ def main():
         out = {
             "metric": "MIDI roll windows/sec (%s)" % ("decode" if decode else "train step"), "value": B * world * args.steps / elapsed,
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "median_ms_per_step": median_ms, "step_ms": step_split, "arming_steps": ARM, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": what, "baseline_config": args.config, "global_batch": B * world, "T": T, "cell": args.cell,
                        "parallelism": ("replicas%d" if decode else "dp%d") % world},
@@ -544,14 +564,25 @@ def main():
             out["dp"] = dp_stats
         if world == 1 and not args.no_other_configs and args.config == 1 and args.dtype == "bf16" and not (args.batch or args.seq_len
                                                                                                           or args.voices or args.latent):
-            # the other workloads, in this process, AFTER the headline region (which is exactly what it was without them)
+            # The other workloads, AFTER the headline region (which is exactly what it was without them), each in a process of its
+            # own started from here: an engine built in a process that has already driven another engine's hardware queues runs
+            # up to 14 % slower (measured at the reference's shape: 1.45 / 1.55 / 1.67 / 1.46 ms as the 1st .. 4th engine of one
+            # process under 16 hardware queues - profiles/r05_q_engines_per_process.txt); a user's process builds ONE model.
+            import subprocess
             del eng
             torch.cuda.empty_cache()
             others = []
-            for cfg, cell_o, k, wu in ((1, "GRU" if args.cell == "LSTM" else "LSTM", 20, 8), (2, args.cell, 10, 4),
-                                       (4, args.cell, 20, 4), (0, "GRU", 60, 12)):
+            for cfg, cell_o, k, wu in ((1, "GRU" if args.cell == "LSTM" else "LSTM", 20, 12), (2, args.cell, 10, 12),
+                                       (4, args.cell, 20, 12), (0, "GRU", 60, 12)):
                 try:
-                    others.append(side_workload(cfg, cell_o, args.dtype, device, k, wu))
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", args.dtype,
+                                        "--side", "%d,%s,%d,%d" % (cfg, cell_o, k, wu)],
+                                       capture_output=True, text=True, timeout=600)
+                    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+                        sys.stderr.write(r.stderr[-2000:])
+                    if r.returncode != 0:
+                        raise RuntimeError("exit %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1:] or ""))
+                    others.append(json.loads(r.stdout.strip().splitlines()[-1]))
                 except Exception as e:          # (a side measurement must never cost the headline line)
                     others.append({"baseline_config": cfg, "cell": cell_o, "error": "%s: %s" % (type(e).__name__, e)})
             out["other_configs"] = others

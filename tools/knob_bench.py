@@ -16,6 +16,9 @@ ap.add_argument("--cell", default=None)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--inflight", type=int, default=0, help="at most this many steps enqueued ahead of the device (0 = no limit)")
+ap.add_argument("--bracket", type=int, default=0, help="every Nth step carries HIP-event brackets around the BPTT launches (bench.py's measurement); "
+                "reports the bracketed and the plain steps apart (per-step synchronisation)")
+ap.add_argument("--skip-streams", type=int, default=0, help="take this many streams out of torch's pool before the engine is built")
 ap.add_argument("knobs", nargs="*")
 a = ap.parse_args()
 if a.shape == "bench":
@@ -25,6 +28,7 @@ else:
 B = a.batch
 spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
 w = make_windows(B, T, 61, V, 16, 2, Z, seed=1, epsilon_std=spec.epsilon_std)
+_skipped = [torch.cuda.Stream(device="cuda:0") for _ in range(a.skip_streams)]
 eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
 for kv in a.knobs:
     k, v = kv.split("=")
@@ -57,8 +61,30 @@ for rep in range(3):
     best.append((time.perf_counter() - t0) / a.steps * 1e3)
     host.append((t1 - t0) / a.steps * 1e3)
     dev.append(e0.elapsed_time(e1) / a.steps)
+if a.bracket:
+    kinds = {("rnn_bwd", "dec.notes.1"), ("rnn_bwd", "dec.notes.0"), ("rnn_bwd_multi", "dec")}
+    eng.prof_kinds = kinds
+    per = {True: [], False: []}
+    hostt = {True: [], False: []}
+    prof = {}
+    for i in range(a.steps + 16):
+        br = i % a.bracket == 0
+        eng.prof = prof if br else None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.train_step(B)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        if i >= 16:
+            per[br].append((time.perf_counter() - t0) * 1e3)
+            hostt[br].append((t1 - t0) * 1e3)
+    eng.prof = None
+    med = lambda v: sorted(v)[len(v) // 2] if v else float("nan")
+    print("bracket every %d: bracketed steps median %.3f ms (host %.3f, max %.3f, n %d) | plain steps median %.3f ms (host %.3f, max %.3f, n %d)" % (
+        a.bracket, med(per[True]), med(hostt[True]), max(per[True]), len(per[True]), med(per[False]), med(hostt[False]),
+        max(per[False] or [0]), len(per[False])))
 eng.check_pipeline()
 print("%-9s %s T=%d B=%d %-40s %.3f ms/step (3 x %d steps: %s; host enqueue %.3f, events %.3f)  [%d windows/s]  plans %s" % (
-    a.shape, cell, T, B, (" ".join(a.knobs) or "(defaults)") + (" inflight=%d" % a.inflight if a.inflight else ""), min(best), a.steps, " ".join("%.3f" % b for b in best), min(host), min(dev),
+    a.shape, cell, T, B, (" ".join(a.knobs) or "(defaults)") + (" skip=%d" % a.skip_streams if a.skip_streams else "") + (" inflight=%d" % a.inflight if a.inflight else ""), min(best), a.steps, " ".join("%.3f" % b for b in best), min(host), min(dev),
     B / min(best) * 1e3,
     {k: (v if k != "refused" else len(v)) for k, v in eng.plan_stats.items()}))
