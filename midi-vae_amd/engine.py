@@ -158,6 +158,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # Measured on T = 64 with the host paced (steps_in_flight / pace_mask below): 256 windows GRU 2.07 -> 1.47 ms per step, LSTM
         # 1.72 -> 1.69; 64 windows GRU 1.46 -> 1.18
         self.defer_grads_rows = int(os.environ.get("MVAE_DEFER_GRADS_ROWS", "32768"))
+        # ... the decoder side's (and the latent block's) BESIDE the encoder BPTT launch, on the gradient queue, released by that
+        # launch's first published chunk (_flush_deferred_gemms(early=...)): reference shape GRU 1.46 -> 1.39 ms, LSTM 1.705 -> 1.70;
+        # from defer_early_rows rows per sequence (192 windows x 64 steps: 1.525 -> 1.46; 128 windows 1.324 -> 1.327; 64: 1.17 -> 1.18)
+        self.defer_early, self.defer_early_rows = True, 12288
         self._deferred_gemms, self._deferred_small = None, []
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
         self.kstream_wgs = 24 if spec.cell == "GRU" else 32   # (GRU: 3 GEMMs per layer)

@@ -3,6 +3,8 @@
 hand: beside the recurrences for long sequences, as one batched launch behind the last recurrence for short ones)."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import hiplib as hl
@@ -66,16 +68,24 @@ class ParamGradients(object):
         else:
             fn()
 
-    def _flush_deferred_gemms(self):
+    def _flush_deferred_gemms(self, early=None):
         """the step's collected weight-gradient GEMMs as one launch (per 16) on the current - the critical - stream, the small
-        launches behind it: everything they read was produced on this queue or joined into it"""
-        probs, self._deferred_gemms = self._deferred_gemms, None
-        small, self._deferred_small = self._deferred_small, []
-        if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
-            for g in probs:
-                ops.gemm_args(g)
-        for fn in small:
-            fn()
+        launches behind it: everything they read was produced on this queue or joined into it.
+        ``early`` = (counter word, value): what has been collected SO FAR (the decoder side, the latent block) leaves now, on the
+        gradient queue, released on the device by the running encoder launch's first published chunk - its workgroups are
+        resident then, the GEMMs take the CUs it left empty - and the collection goes on for the encoder's own gradients."""
+        probs, small = self._deferred_gemms, self._deferred_small
+        self._deferred_gemms, self._deferred_small = ([] if early is not None else None), []
+        if early is not None:
+            if not probs and not small:
+                return
+            ops.stream_wait_value32(early[0], early[1], stream=self.s_grad)
+        with (torch.cuda.stream(self.s_grad) if early is not None else contextlib.nullcontext()):
+            if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
+                for g in probs:
+                    ops.gemm_args(g)
+            for fn in small:
+                fn()
 
     def _rec_param_grads(self, r, B, *, idx=None, xs=None, start=None, skip_dU=False, gate=None, publishes=None, rows=None):
         P = self._grad_portions(r, B, publishes) if rows is None else 1

@@ -237,6 +237,10 @@ class PhaseLaunches(object):
         for fn in held:         # (decoder gradient work held back behind the latent chain: _notes_backward_multi)
             kw = fn()
             self._rec_param_grads(kw["r"], kw["B"], start=kw["start"], gate=(sync[0, 0][nchp - 1:nchp], da_target))
+        if self._deferred_gemms is not None and self.defer_early and T * B >= self.defer_early_rows:
+            # short sequences: the decoder side's collected weight-gradient GEMMs run BESIDE this launch instead of behind it
+            L = len(self.enc_notes)
+            self._flush_deferred_gemms(early=(sync[L - 1, 0][nchp - 1:nchp], da_target))
         if kstream:
             cs = self.pipe_chunk
             problems = []

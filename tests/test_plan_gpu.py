@@ -207,16 +207,18 @@ def test_fused_history_prepass_steps_replay(monkeypatch):
 @pytest.mark.parametrize("cell", ["GRU", "LSTM"])
 def test_short_sequences_defer_their_weight_gradient_gemms_into_one_launch(cell):
     """Engine.defer_grads_rows (round 5): at the reference's shipped length (T = 64, settings.py:108-109) the weight-gradient GEMMs of
-    a step are collected during the backward pass and leave as ONE mvae_gemm_multi launch behind the last recurrence.  Same GEMM
-    bodies, same operands: losses identical, every gradient tensor equal to the order of the split-K atomics, against the
+    a step are collected during the backward pass and leave as mvae_gemm_multi launches: the decoder side's on the gradient queue
+    BESIDE the encoder BPTT launch (defer_early, released by that launch's first published chunk), the encoder's behind the last
+    recurrence - ONE launch behind it with defer_early off.  Same GEMM bodies, same operands: losses identical, every gradient tensor equal to the order of the split-K atomics, against the
     schedule that launches them one by one beside the recurrences (defer_grads_rows = 0) - and the deferred steps replay as plans."""
     from midi_vae_amd import ops
     B = 48
     spec, params, batch, raw = _problem(cell, B, seed=61, H=256, Z=64, T=64)
     res = {}
-    for rows in (32768, 0):
+    for rows in (32768, 32767, 0):
         eng = Engine(spec, max_batch=B, dtype="bf16")
         eng.defer_grads_rows = rows
+        eng.defer_early, eng.defer_early_rows = rows == 32768, 0
         eng.set_params(params)
         _stage(eng, raw, B)
         launched, real = [], ops.gemm_multi
@@ -225,7 +227,8 @@ def test_short_sequences_defer_their_weight_gradient_gemms_into_one_launch(cell)
             eng.forward_backward(B)
         finally:
             ops.gemm_multi = real
-        assert (len(launched) == 1 and launched[0] >= 8) if rows else not launched, launched
+        assert ((len(launched) == (2 if eng.defer_early else 1) and sum(launched) >= 8 and min(launched) >= 3) if rows
+                else not launched), launched
         m0, g0 = eng.metrics(B), eng.get_grads()
         losses = []
         for _ in range(8):
@@ -233,14 +236,16 @@ def test_short_sequences_defer_their_weight_gradient_gemms_into_one_launch(cell)
             losses.append(eng.metrics(B)["loss"])
         eng.check_pipeline()
         res[rows] = (m0, g0, losses, dict(eng.plan_stats))
-    (m1, g1, l1, st1), (m0, g0, l0, _) = res[32768], res[0]
-    assert st1["replayed"] >= 2, st1
-    for k in m0:
-        assert m1[k] == pytest.approx(m0[k], rel=1e-6, abs=1e-7), k
-    for k in g0:
-        assert np.linalg.norm(g1[k] - g0[k]) <= 1e-4 * (np.linalg.norm(g0[k]) + 1e-8) + 1e-7, k
-    for a, b in zip(l1, l0):
-        assert abs(a - b) <= 1e-4 * (1 + abs(b)), (l1, l0)
+    m0, g0, l0, _ = res[0]
+    for rows in (32768, 32767):
+        m1, g1, l1, st1 = res[rows]
+        assert st1["replayed"] >= 2, st1
+        for k in m0:
+            assert m1[k] == pytest.approx(m0[k], rel=1e-6, abs=1e-7), k
+        for k in g0:
+            assert np.linalg.norm(g1[k] - g0[k]) <= 1e-4 * (np.linalg.norm(g0[k]) + 1e-8) + 1e-7, k
+        for a, b in zip(l1, l0):
+            assert abs(a - b) <= 1e-4 * (1 + abs(b)), (l1, l0)
 
 
 @pytest.mark.parametrize("cell", ["GRU", "LSTM"])
