@@ -162,9 +162,18 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # launch's first published chunk (_flush_deferred_gemms(early=...)): reference shape GRU 1.46 -> 1.39 ms, LSTM 1.705 -> 1.70;
         # from defer_early_rows rows per sequence (192 windows x 64 steps: 1.525 -> 1.46; 128 windows 1.324 -> 1.327; 64: 1.17 -> 1.18)
         self.defer_early, self.defer_early_rows = True, 12288
+        # ... with K split further until a launch has about this many workgroups (_flush_deferred_gemms): at T*B = 16384 rows the
+        # usual split (2) makes ~150 workgroups of 128 k tiles each.  0 / 256 / 384 / 512 / 1024: GRU 1.405 / 1.39 / 1.40 / 1.338 / 1.383
+        # ms per step at the reference's shape, LSTM 1.70-1.71 throughout
+        self.defer_split_wgs = 512
         self._deferred_gemms, self._deferred_small = None, []
         self.kstream_grads = os.environ.get("MVAE_KSTREAM_GRADS", "1") == "1"
-        self.kstream_wgs = 24 if spec.cell == "GRU" else 32   # (GRU: 3 GEMMs per layer)
+        # (GRU: 3 GEMMs per layer -> 8 problems in the encoder launch.  Round 5, 256 windows T=512: 24 workgroups each = 192 resident
+        #  beside the 64 of the recurrences left the decoder side's held-back GEMMs no CU - 5.66 ms per step; 20 / 16 / 14 / 12:
+        #  5.42 / 5.43 / 5.36 / 5.34-5.39 (12-15 = one workgroup per output tile: under a tracer they fall 0.26 ms behind the BPTT);
+        #  <= 10: a workgroup owns two tiles and streams the second one after the BPTT: 6.13.  LSTM: 16 / 24 / 32 all 6.53, <= 12: 7.27)
+        self.kstream_wgs = 16 if spec.cell == "GRU" else 32
+        self.kstream_max_B = 256
         self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase

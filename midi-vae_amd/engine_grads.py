@@ -80,6 +80,19 @@ class ParamGradients(object):
             if not probs and not small:
                 return
             ops.stream_wait_value32(early[0], early[1], stream=self.s_grad)
+        if probs and self.defer_split_wgs:
+            # a short sequence's GEMMs are few workgroups with long k loops (T*B = 16384 rows: split_k 2, ~150 workgroups of 128 k
+            # tiles each for the whole launch): split K further until the launch has about defer_split_wgs workgroups
+            tiles = [(-(-g.M // 128)) * (-(-g.N // 128)) for g in probs]
+            total = sum(t * max(1, g.split_k) for t, g in zip(tiles, probs))
+            f = 1
+            while total * f * 2 <= self.defer_split_wgs and f < 8:
+                f *= 2
+            for g in probs:
+                sk = max(1, g.split_k) * f
+                while sk > 1 and g.K // sk < 512:
+                    sk //= 2
+                g.split_k = min(16, sk)
         with (torch.cuda.stream(self.s_grad) if early is not None else contextlib.nullcontext()):
             if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
                 for g in probs:
@@ -191,6 +204,8 @@ class ParamGradients(object):
         count = (3 if s.cell == "GRU" else 2) * len(layers)      # GEMMs per layer: dU (GRU: two launches) and dW
         if not (self.kstream_grads and self._deferred_gemms is None and self.multi_stream and self.fuse_bias_grad and self.tile16 and count <= 8 and
                 self._pipelined(layers) and all(r.xmode in (hl.X_INDEX, hl.X_DENSE) for r in layers)):
+            return False
+        if B > self.kstream_max_B:       # (a chunk's rows grow with the batch, the time the BPTT takes for it does not)
             return False
         free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
         return free >= self.kstream_wgs * count

@@ -1,6 +1,10 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_plan_gpu.py tests/test_baseline_configs_gpu.py -x -q -m gpu > gpurun_out/pytest_part.txt 2>&1; echo "pytest rc $?"; grep -E "passed|failed|rror" gpurun_out/pytest_part.txt | tail -5
-for k in "defer_portions=1" "defer_portions=2" "defer_portions=4"; do
-  timeout 300 python tools/knob_bench.py --shape reference --steps 200 $k 2>&1 | tail -1 | cut -c1-170
-  timeout 300 python tools/knob_bench.py --shape reference --cell LSTM --steps 200 $k 2>&1 | tail -1 | cut -c1-170
-done
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.txt 2>&1; echo "pytest rc $?"
+grep -E "passed|failed|rror" gpurun_out/pytest_gpu.txt | tail -3
+timeout 900 python bench.py > gpurun_out/bench_early.json 2> gpurun_out/bench_early.err
+python - <<'P'
+import json
+d=json.loads(open('gpurun_out/bench_early.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['median_ms_per_step'], d['step_ms'], d['plan']['recorded'], d['plan']['replayed'], d['roofline']['frac'])
+for o in d.get('other_configs',[]): print(o.get('baseline_config'), o.get('cell'), o.get('ms_per_step'), o.get('error'))
+P
