@@ -174,6 +174,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         #  <= 10: a workgroup owns two tiles and streams the second one after the BPTT: 6.13.  LSTM: 16 / 24 / 32 all 6.53, <= 12: 7.27)
         self.kstream_wgs = 16 if spec.cell == "GRU" else 32
         self.kstream_max_B = 256
+        self.dec_kstream = True           # the decoder notes stack's too (engine_phases._notes_backward_multi, _dec_kstream_ok)
+        self.hold_side_heads, self._hold_side = True, False
         self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
         self._kstream_extra = None
         self._grad_streams = None        # (s_grad, s_grad2) unless overridden for a phase
@@ -1047,7 +1049,12 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                     if nch > 1:
                         done[li][k] = self._ev_record(torch.cuda.current_stream())
                     if k == 0:
-                        self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
+                        if self._hold_side and self._after_chain is not None and idx is None and xs is None:
+                            # (a decoder side head beside a K-streaming notes stack: its gradient GEMMs would start at the end of
+                            #  the phase and run across the latent chain - they wait for the encoder launch's first chunk instead)
+                            self._after_chain.append(lambda r=r: dict(r=r, B=B, start=start))
+                        else:
+                            self._rec_param_grads(r, B, idx=idx, xs=xs, start=start)
                 if li > 0 and nch > 1:
                     with torch.cuda.stream(streams[li]):
                         run()
@@ -1128,7 +1135,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         notes_multi = len(self.dec_notes) > 1 and self._phase_ok(self.dec_notes, ())     # (one launch, gradient work by counters)
         if not notes_multi and self.grad_portions:       # (per-queue schedule: long sequences release their gradient work in portions)
             self._grad_portion_jobs, self._single_slot, self._single_slot_end = [], 0, 3      # (decoder: sync slots 11..13)
-        self._after_chain = [] if (notes_multi and not self.enc_bi and len(self.enc_notes) > 1 and
+        # (data parallel with the early bucket - _bucket_hook - : every decoder-side gradient has to be QUEUED when the bucket's
+        #  collective is issued, in front of the encoder launch: nothing is held back behind it then -
+        #  test_nothing_is_added_to_the_decoder_bucket_after_its_collective_was_issued)
+        early_bucket = self._bucket_hook is not None and self.multi_stream and self.layout.dec_begin > 0
+        self._after_chain = [] if (notes_multi and not self.enc_bi and len(self.enc_notes) > 1 and not early_bucket and
                                    self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta])) else None
         if self._branches_stay_forked:      # (train step: the side heads' queues go straight on with their own backward)
             if not notes_multi:
@@ -1138,17 +1149,22 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._fork(*[h.stream for h in side])
         else:
             self._fork_with_stack(self.dec_notes, *[h.stream for h in side], also=(self.s_grad,))
+        if notes_multi and self._dec_kstream_ok(self.dec_notes, B):
+            self._grad_streams = (self.s_grad, self.s_grad)      # the second gradient queue holds the notes stack's K-streaming launch
+            self._hold_side = self.hold_side_heads
         for h in side:
             with self._on(h.stream):
                 self._head_stack_backward(h, B, dstates, slot=None)
+        self._hold_side = False
         self._head_stack_backward(self.head["notes"], B, dstates, slot=2)
+        self._grad_streams = None
         self._prefork = None
         self._flush_grad_portions()
         self._join(*[h.stream for h in side], word=0)
         self._mark("  decoder BPTT")
         # (the signature head adds to d(z) between the initial-state Denses and the latent block: separate launches then)
         enc_multi = not self.enc_bi and self._phase_ok(self.enc_notes, [r for r, _, _ in self.enc_meta]) and len(self.enc_notes) > 1
-        self._deferred_side = [] if enc_multi else None       # (released by the encoder launch's first published chunk)
+        self._deferred_side = [] if (enc_multi and not early_bucket) else None       # (released by the encoder launch's first published chunk)
         dcat = (self._latent_chain_backward(Breal, B)
                 if (self.fused_latent and self._chain_ok() and not s.signature) else None)
         if dcat is None:

@@ -210,6 +210,24 @@ class ParamGradients(object):
         free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
         return free >= self.kstream_wgs * count
 
+    def _dec_kstream_ok(self, layers, B):
+        """the decoder notes stack's weight gradients as a K-streaming launch behind its BPTT launch?  As _kstream_ok, for a stack
+        whose bottom cell steps on a constant ALL-ZERO start row (what the reference's packers pass, vae_definition.py:820,916: its
+        input-kernel gradient is zero and its bias gradient the column sums of da, fused into the dU GEMM)."""
+        s = self.spec
+        if not (self.dec_kstream and self.kstream_grads and self._deferred_gemms is None and self.multi_stream and
+                self.fuse_bias_grad and self.tile16 and self._pipelined(layers) and B <= self.kstream_max_B and not self._diag_no_param_grads):
+            return False
+        bottom, rest = layers[0], layers[1:]
+        if not (bottom.xmode == hl.X_CONST and self.start_zero.get(bottom.prefix, False) and all(r.xmode == hl.X_DENSE for r in rest)):
+            return False
+        per = 2 if s.cell == "GRU" else 1
+        count = per * len(layers) + len(rest)
+        if count > 8:
+            return False
+        free = (self.num_cus - self._resident_cus(layers, B, backward=True, side=True)) * self._occ["kstream"]
+        return free >= self.kstream_wgs * count
+
     def _kstream_problems(self, r, B, idx, ks, only_dU=False):
         """the layer's weight-gradient GEMMs as K-streaming problems (mvae_gemm_args, not launched)"""
         s, G, p = self.spec, self.G, r.prefix

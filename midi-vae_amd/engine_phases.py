@@ -186,6 +186,20 @@ class PhaseLaunches(object):
             with torch.cuda.stream(self.s_grad):
                 head_grads()
         L = len(h.layers)
+        if self._dec_kstream_ok(h.layers, B):
+            # The stack's weight-gradient GEMMs as ONE K-streaming launch that FOLLOWS this launch chunk by chunk (as the encoder
+            # stack's do, _encoder_backward_multi): they end with the BPTT instead of starting at its end, i.e. they no longer run
+            # across the latent chain - a latency-bound kernel on the critical queue that takes 2-3 times as long beside them
+            # (timeline r05_p: 156 us against 55-77 alone) - nor beside the encoder launch.
+            cs, status = self.pipe_chunk, self.store["pipe_status"]
+            problems = []
+            for li, r in enumerate(reversed(h.layers)):
+                problems += self._kstream_problems(r, B, None, dict(counters=sync[li, 0], target=da_target, rows=cs * B, status=status),
+                                                   only_dU=r.xmode == hl.X_CONST)
+            ops.stream_wait_value32(sync[L - 1, 0][nchp - 1:nchp], da_target, stream=self.s_grad2)
+            with torch.cuda.stream(self.s_grad2):
+                ops.gemm_kstream_multi(problems)
+            return True
         for li, r in enumerate(reversed(h.layers)):
             if (li == L - 1 or self._hold_dec_grads >= 2) and self._hold_dec_grads and self._after_chain is not None:
                 # the bottom layer's da is complete when the launch ends - exactly when the latent chain (a latency-bound kernel

@@ -57,6 +57,62 @@ def test_bucketed_allreduce_beside_the_encoder_bptt(one_rank_rccl, cell):
     assert losses["bucketed"][2] < losses["bucketed"][0]
 
 
+class _ZeroingDist(object):
+    """stands in for torch.distributed: its 'all-reduce' ZEROES the tensor, in stream order.  Whatever is added to a bucket after
+    its collective was issued survives in the gradient buffer - and moves the parameters."""
+    class ReduceOp(object):
+        SUM = "sum"
+
+    class _Work(object):
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def __init__(self):
+        self.calls = []
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        self.calls.append(int(t.numel()))
+        t.zero_()
+        ev = torch.cuda.Event()
+        ev.record()
+        return self._Work(ev) if async_op else None
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_nothing_is_added_to_the_decoder_bucket_after_its_collective_was_issued(cell):
+    """dp.BucketedAllReduce.early reduces [dec_begin, total) beside the encoder BPTT: EVERY decoder-side gradient must have been
+    queued in front of it.  (Round 5 found that the schedule held the bottom decoder layer's - and now the side heads' - gradient
+    GEMMs back behind the latent chain, i.e. behind the early collective: invisible with one rank, where a sum over ranks changes
+    nothing.)  Here the 'collective' zeroes its bucket: with all gradients zero Adam's first moment must come out of the step as
+    exactly beta_1 times what it was."""
+    from midi_vae_amd.dp import BucketedAllReduce
+    B = 32
+    spec, params, batch, raw = _problem(cell, B, seed=53, H=256, Z=64, T=64)
+    eng = Engine(spec, max_batch=B, dtype="bf16")
+    eng.defer_grads_rows = 0
+    eng.set_params(params)
+    _stage(eng, raw, B)
+    for _ in range(2):                  # (the first pipelined step of an engine is verified, and takes no early bucket)
+        eng.train_step(B)
+    eng.check_pipeline()
+    before = eng.opt_m.clone()
+    fake = _ZeroingDist()
+    hook = BucketedAllReduce(fake, 2, eng.layout.dec_begin, overlap=True, scale=1.0)
+    eng.train_step(B, allreduce=hook)
+    eng.check_pipeline()
+    torch.cuda.synchronize()
+    assert fake.calls == [eng.layout.total - eng.layout.dec_begin, eng.layout.dec_begin], fake.calls
+    want = before * 0.9              # (Keras Adam, beta_1 = 0.9: m <- beta_1 m + (1 - beta_1) g with g = 0)
+    moved = ((eng.opt_m - want).abs() > 1e-5 * want.abs() + 1e-12).nonzero().flatten()
+    import numpy as np
+    names = sorted({n for n, e in eng.layout.entries.items() for i in moved[::max(1, len(moved) // 64)].tolist()
+                    if e.offset <= i < e.offset + int(np.prod(e.shape))})
+    assert len(moved) == 0, (len(moved), names)
+
+
 @pytest.mark.parametrize("overlap", [0, 1])
 def test_bench_dp_code_path_on_two_ranks_keeps_the_replicas_identical(overlap, tmp_path):
     """bench.py's own data-parallel path - make_allreduce / BucketedAllReduce with and without the early decoder bucket, the
