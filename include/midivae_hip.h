@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 7
+#define MVAE_ABI_VERSION 8
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -507,6 +507,7 @@ int mvae_event_create_timed(void** event);           /* hipEventCreate: a pair o
 int mvae_event_elapsed_ms(void* first, void* second, float* ms);     /* waits for ``second``, then the time between the two records */
 int mvae_event_destroy(void* event);
 int mvae_event_record(void* event, void* stream);
+int mvae_event_synchronize(void* event);             /* ABI 8: the HOST waits for the event's latest record (Engine._pace: a paced host) */
 int mvae_stream_wait_event(void* stream, void* event);
 
 typedef struct mvae_plan mvae_plan;

@@ -116,6 +116,10 @@ extern "C" int mvae_event_record(void* event, void* stream) {
     return hipEventRecord(reinterpret_cast<hipEvent_t>(event), reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? MVAE_OK
                                                                                                                   : MVAE_E_LAUNCH;
 }
+extern "C" int mvae_event_synchronize(void* event) {
+    if (!event) return MVAE_E_ARG;
+    return hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)) == hipSuccess ? MVAE_OK : MVAE_E_LAUNCH;
+}
 extern "C" int mvae_stream_wait_event(void* stream, void* event) {
     if (!event) return MVAE_E_ARG;
     return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(event), 0) == hipSuccess

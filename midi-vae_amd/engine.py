@@ -130,6 +130,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # the later phases - value waits on a dozen queues - runs the current phase slower.  T = 64: 1.71 -> 1.45 ms per step with
         # 6, configs[1] 6.65 -> 6.57 (profiles/r05_c_steps_in_flight.txt); a replayed step is split into call ranges there
         self.pace_mask = 6
+        self.pace_early = True            # (engine_steps._pace_point: the pauses end when the device reaches an EARLIER point of the queue)
+        self._pace_events, self._pace_recorded = {}, set()
         self.gate_pipe_gemms = False      # (engine_phases._launch_pipe_gemms: measured, off)
         self.pipe_gemm_blocks = 64       # persistent grid of the dX GEMM between two pipelined layers (backward)
         # ... and of the forward projection x*W + b: the weights-stationary kernel (csrc/gemm.hip proj_ws_k) wants a multiple of
@@ -842,7 +844,10 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         start = self._v("in.start_" + n, B, h.layers[0].K)
         self._top_publish = None
         if len(h.layers) > 1 and slot is not None:
-            if not self._notes_forward_multi(h, B, states, start):      # (both layers as one launch: engine_phases.py)
+            multi = self._notes_forward_multi(h, B, states, start)      # (both layers as one launch: engine_phases.py)
+            if multi and self.training:
+                self._pace_point(2)          # (the backward pass may be enqueued while the notes head runs)
+            if not multi:
                 # Inference on the per-queue pipelined schedule (a decode of 1024 windows x 4096 steps: the head's pass over 2 GB
                 # of h is 1.06 ms behind a 10.3 ms stack): the top layer publishes its chunks too and the head runs slice by
                 # slice on the (idle) gradient queue, each slice released by the chunk that completes it - only the last slice
@@ -1157,6 +1162,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._head_stack_backward(h, B, dstates, slot=None)
         self._hold_side = False
         self._head_stack_backward(self.head["notes"], B, dstates, slot=2)
+        if notes_multi:
+            self._pace_point(4)              # (the encoder phase may be enqueued while the latent chain runs)
         self._grad_streams = None
         self._prefork = None
         self._flush_grad_portions()

@@ -3,8 +3,11 @@ train_function call per minibatch, vae_training.py:804-809), their replay as pla
 parallelism."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
+from . import hiplib as hl
 from . import ops
 
 
@@ -203,18 +206,36 @@ class TrainSteps(object):
         return {"early": lambda: allreduce.early(self.grads[L.dec_begin:L.total]),
                 "reduce": lambda: allreduce(self.grads),
                 "status": lambda: self.status_allreduce(self.store["pipe_status"]),
-                "pace1": self._pace_now, "pace2": self._pace_now, "pace4": self._pace_now}
+                "pace1": lambda: self._pace_now(1), "pace2": lambda: self._pace_now(2), "pace4": lambda: self._pace_now(4)}
 
     def _pace(self, bit):
-        """hold the HOST here until the device has reached this point of the step (pace_mask: bit 1 before the decoder forward, 2
-        before the backward pass, 4 before the encoder BPTT) - a host action of the step, so a replayed step pauses there too"""
+        """hold the HOST here until the device has reached the pause's point of the step (pace_mask: bit 1 before the decoder forward,
+        2 before the backward pass, 4 before the encoder BPTT) - a host action of the step, so a replayed step pauses there too.
+        The point is an event of the pause's own: recorded further up the queue by _pace_point (pace_early), else here."""
         if self.pace_mask & bit:
-            self._host_call("pace%d" % bit, self._pace_now)
+            if bit not in self._pace_recorded:
+                self._pace_record(bit)
+            self._pace_recorded.discard(bit)
+            self._host_call("pace%d" % bit, lambda: self._pace_now(bit))
 
-    def _pace_now(self):
-        ev = torch.cuda.Event()
-        ev.record()
-        ev.synchronize()
+    def _pace_record(self, bit):
+        if bit not in self._pace_events:
+            h = C.c_void_p()
+            hl.check(hl.load().mvae_event_create(C.byref(h)), "mvae_event_create")
+            self._pace_events[bit] = h.value
+        hl.check(hl.load().mvae_event_record(self._pace_events[bit], torch.cuda.current_stream().cuda_stream), "mvae_event_record")
+        self._pace_recorded.add(bit)
+
+    def _pace_point(self, bit):
+        """the point of the step the host pause ``bit`` waits for, when it lies BEFORE the pause (pace_early): the pause further down
+        the same queue then ends when the device gets HERE, and the host's wake-up and the first launches of the next call range
+        hide behind the kernels in between (the notes head in front of the backward pass, the latent chain in front of the encoder
+        BPTT: 35-40 us of idle critical queue each, timeline r05_p)"""
+        if self.pace_mask & bit and self.pace_early:
+            self._pace_record(bit)
+
+    def _pace_now(self, bit):
+        hl.check(hl.load().mvae_event_synchronize(self._pace_events[bit]), "mvae_event_synchronize")
 
     def _train_step(self, B, allreduce):
         self._redo_hist = None

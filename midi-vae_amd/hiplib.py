@@ -24,7 +24,7 @@ CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -158,6 +158,7 @@ SIGNATURES = {
     "mvae_event_elapsed_ms": (_i32, [_vp, _vp, C.POINTER(C.c_float)]),
     "mvae_event_destroy": (_i32, [_vp]),
     "mvae_event_record": (_i32, [_vp, _vp]),
+    "mvae_event_synchronize": (_i32, [_vp]),
     "mvae_stream_wait_event": (_i32, [_vp, _vp]),
     "mvae_plan_create": (_i32, [C.POINTER(_vp)]),
     "mvae_plan_destroy": (_i32, [_vp]),

@@ -11,7 +11,7 @@ from midi_vae_amd.engine import Engine
 from midi_vae_amd.layout import ModelSpec
 from midi_vae_amd.synth import make_windows
 ap = argparse.ArgumentParser()
-ap.add_argument("--shape", default="reference", choices=["bench", "reference"])
+ap.add_argument("--shape", default="reference", choices=["bench", "reference", "config2"])
 ap.add_argument("--cell", default=None)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=200)
@@ -21,13 +21,18 @@ ap.add_argument("--bracket", type=int, default=0, help="every Nth step carries H
 ap.add_argument("--skip-streams", type=int, default=0, help="take this many streams out of torch's pool before the engine is built")
 ap.add_argument("knobs", nargs="*")
 a = ap.parse_args()
+C = 2
 if a.shape == "bench":
     cell, T, Z, V = a.cell or "LSTM", 512, 64, 4
+elif a.shape == "config2":            # BASELINE configs[2] / [3] per-GPU shape: seq 256 x 8 voices, z=128, 4 styles, 512 windows
+    cell, T, Z, V, C = a.cell or "LSTM", 2048, 128, 8, 4
+    if a.batch == 256:
+        a.batch = 512
 else:
     cell, T, Z, V = a.cell or "GRU", 64, 256, 4
 B = a.batch
-spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=2, Le=2, Ld=2)
-w = make_windows(B, T, 61, V, 16, 2, Z, seed=1, epsilon_std=spec.epsilon_std)
+spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=2, Ld=2)
+w = make_windows(B, T, 61, V, 16, C, Z, seed=1, epsilon_std=spec.epsilon_std)
 _skipped = [torch.cuda.Stream(device="cuda:0") for _ in range(a.skip_streams)]
 eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
 for kv in a.knobs:

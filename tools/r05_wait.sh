@@ -1,2 +1,6 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_dp_gpu.py -x -q -m gpu -k "nothing_is_added" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+for k in "pace_early=1" "pace_early=0"; do
+  timeout 300 python tools/knob_bench.py --shape bench --steps 60 $k 2>&1 | tail -1 | cut -c1-150
+  timeout 300 python tools/knob_bench.py --shape bench --cell GRU --steps 60 $k 2>&1 | tail -1 | cut -c1-150
+  timeout 300 python tools/knob_bench.py --shape reference --steps 200 $k 2>&1 | tail -1 | cut -c1-150
+done
