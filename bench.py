@@ -163,7 +163,7 @@ def workload_name(config, C, seq, voices, T, latent, B, named_batch, named_gpus,
                    "notes+instrument+velocity+style heads, Keras-Adam")
 
 
-def side_workload(config, cell, dtype, device, steps, warmup):
+def side_workload(config, cell, dtype, device, steps, warmup, step_times=False):
     """One of the OTHER workloads, measured in this process after the headline region (the driver then
     observes them): K steps bracketed by synchronize, the dominant kernel's launches of every 4th step bracketed with HIP events
     on their stream - the same measurement as the headline, shorter.  Returns the member of the line's ``other_configs`` array."""
@@ -213,7 +213,7 @@ def side_workload(config, cell, dtype, device, steps, warmup):
     eng.prof = None
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+    if step_times:
         sys.stderr.write("config %d host ms per step() call: %s\n" % (config, " ".join("%.2f" % (1e3 * v) for v in per_step)))
     eng.prof = prof
     summary = eng.prof_summary()
@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL over xGMI; gloo: two ranks on ONE GPU in tests/test_dp_gpu.py)")
     ap.add_argument("--hidden", type=int, default=256, help="(tests) cell width")
+    ap.add_argument("--step-times", action="store_true", help="(diagnostic) write every timed step's duration to stderr")
     ap.add_argument("--side", default=None, help="(internal) 'config,cell,steps,warmup': measure ONE of the other workloads in this "
                                                  "process and print its other_configs member")
     args = ap.parse_args()
@@ -273,7 +274,7 @@ def main():
         cfg, cell_o, k, wu = args.side.split(",")
         import torch
         torch.cuda.set_device(0)
-        print(json.dumps(side_workload(int(cfg), cell_o, args.dtype, torch.device("cuda", 0), int(k), int(wu))))
+        print(json.dumps(side_workload(int(cfg), cell_o, args.dtype, torch.device("cuda", 0), int(k), int(wu), step_times=args.step_times)))
         return
     if args.cell is None:
         args.cell = "GRU" if args.config == 0 else "LSTM"
@@ -411,8 +412,6 @@ def main():
         step()
         host_s += time.perf_counter() - th
         marks[i + 1].record()
-        if os.environ.get("MVAE_BENCH_STEP_TIMES") and i < 8:
-            sys.stderr.write("timed step %d: plans %s keys %d\n" % (i, {k: (v if k != "refused" else len(v)) for k, v in eng.plan_stats.items()}, len(eng._plans)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -420,7 +419,7 @@ def main():
     elapsed = time.perf_counter() - t0
     raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(raw_ms)
-    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+    if args.step_times:
         sys.stderr.write("headline ms per step (events): %s\n" % " ".join("%.2f" % v for v in raw_ms))
     _med = lambda v: (sorted(v)[len(v) // 2] if v else None)
     step_split = {"plain_median": _med([m for i, m in enumerate(raw_ms) if i % every]),
@@ -576,9 +575,9 @@ def main():
                                        (4, args.cell, 20, 12), (0, "GRU", 60, 12)):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", args.dtype,
-                                        "--side", "%d,%s,%d,%d" % (cfg, cell_o, k, wu)],
+                                        "--side", "%d,%s,%d,%d" % (cfg, cell_o, k, wu)] + (["--step-times"] if args.step_times else []),
                                        capture_output=True, text=True, timeout=600)
-                    if os.environ.get("MVAE_BENCH_STEP_TIMES"):
+                    if args.step_times:
                         sys.stderr.write(r.stderr[-2000:])
                     if r.returncode != 0:
                         raise RuntimeError("exit %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1:] or ""))
