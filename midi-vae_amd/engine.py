@@ -130,6 +130,13 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # the later phases - value waits on a dozen queues - runs the current phase slower.  T = 64: 1.71 -> 1.45 ms per step with
         # 6, configs[1] 6.65 -> 6.57 (profiles/r05_c_steps_in_flight.txt); a replayed step is split into call ranges there
         self.pace_mask = 6
+        # ... of a step enqueued in TWO calls (train_step_begin / train_step_finish: model.Autoencoder.fit, whose host converts the
+        # next minibatch - or the caller's next song - between two steps): only the pause in front of the backward pass.  A host that
+        # is held until the encoder BPTT starts comes back too late for that work: `python vae_training.py` at default settings
+        # 58 k -> 71 k windows/s end to end (no pause at all: 75 k, but configs[1] GRU fit 5.8 -> 7.6 ms per step); fit at configs[1]
+        # LSTM 7.9-8.1 -> 7.2-7.7 ms per 256-window step, GRU 5.64 -> 5.80 (profiles/r05_t_pace_mask_by_caller.txt)
+        self.pace_mask_split = 2
+        self._pace_mask_now = self.pace_mask
         self.pace_early = True            # (engine_steps._pace_point: the pauses end when the device reaches an EARLIER point of the queue)
         self._pace_events, self._pace_recorded = {}, set()
         self.gate_pipe_gemms = False      # (engine_phases._launch_pipe_gemms: measured, off)

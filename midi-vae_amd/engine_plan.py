@@ -33,7 +33,7 @@ class PlannedSteps(object):
     _PLAN_CONFIG = ("head_slices", "grad_portions", "index_dense",
                     "index_dense_blocks", "xpand_blocks", "pipe_chunk", "phase_max_B", "kstream_grads", "kstream_wgs", "kstream_max_B", "dec_kstream", "hold_side_heads",
                     "kstream_singles", "pipe_gemm_blocks", "pipe_proj_blocks", "time_chunks", "fuse_head_bwd", "fuse_bias_grad",
-                    "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans", "defer_grads_rows", "defer_early", "defer_early_rows", "defer_split_wgs", "gate_pipe_gemms", "pace_mask", "pace_early")
+                    "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans", "defer_grads_rows", "defer_early", "defer_early_rows", "defer_split_wgs", "gate_pipe_gemms", "pace_mask", "pace_mask_split", "_pace_mask_now", "pace_early")
     # ... and the spec's floats that reach kernel arguments as immediates of the recorded launches
     _PLAN_SPEC = ("lr", "beta", "prior_mean", "prior_std", "epsilon_std", "w_instr", "w_vel", "w_style", "w_held", "w_next", "w_sig",
                   "w_cnotes", "w_cinstr", "optimizer")

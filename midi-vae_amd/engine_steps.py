@@ -142,10 +142,12 @@ class TrainSteps(object):
     def train_step_finish(self, B, allreduce=None):
         """the rest of the step: one replayable call (engine_plan.py) - with a gradient hook (data parallel) its collectives are
         host actions between the call ranges of the plan"""
+        self._pace_mask_now = self.pace_mask_split
         try:
             return self._planned(("train_finish",) + self._kind_B(B) + self._hook_kind(allreduce),
                                  lambda: self._train_step_finish(B, allreduce), host=self._hook_table(allreduce), params=self._call_params(B))
         finally:
+            self._pace_mask_now = self.pace_mask
             if self._fused_dst is not None:          # (behind a possible redo of the step: the rows are final here)
                 (z_dst, zbuf), self._fused_dst = self._fused_dst, None
                 z_dst.copy_(zbuf[:z_dst.shape[0]])
@@ -177,6 +179,7 @@ class TrainSteps(object):
         replayable call: after three recorded steps its ~70 launches are enqueued by mvae_plan_run (engine_plan.py; reference: ONE
         Keras train_function call per minibatch, vae_training.py:804-809); the hook's collectives are issued from Python between
         the plan's call ranges (host marks)."""
+        self._pace_mask_now = self.pace_mask
         return self._planned(("train",) + self._kind_B(B) + self._hook_kind(allreduce), lambda: self._train_step(B, allreduce),
                              host=self._hook_table(allreduce), params=self._call_params(B))
 
@@ -212,7 +215,7 @@ class TrainSteps(object):
         """hold the HOST here until the device has reached the pause's point of the step (pace_mask: bit 1 before the decoder forward,
         2 before the backward pass, 4 before the encoder BPTT) - a host action of the step, so a replayed step pauses there too.
         The point is an event of the pause's own: recorded further up the queue by _pace_point (pace_early), else here."""
-        if self.pace_mask & bit:
+        if self._pace_mask_now & bit:
             if bit not in self._pace_recorded:
                 self._pace_record(bit)
             self._pace_recorded.discard(bit)
@@ -231,7 +234,7 @@ class TrainSteps(object):
         the same queue then ends when the device gets HERE, and the host's wake-up and the first launches of the next call range
         hide behind the kernels in between (the notes head in front of the backward pass, the latent chain in front of the encoder
         BPTT: 35-40 us of idle critical queue each, timeline r05_p)"""
-        if self.pace_mask & bit and self.pace_early:
+        if self._pace_mask_now & bit and self.pace_early:
             self._pace_record(bit)
 
     def _pace_now(self, bit):

@@ -433,6 +433,7 @@ class Decoder(_ModelView):
 
 class Autoencoder(_ModelView):
     name = "autoencoder"
+    prefetch = True          # fit: the next minibatch's host conversion runs on a worker thread beside the step being enqueued
 
     def __init__(self, shared, encoder: Encoder):
         super().__init__(shared)
@@ -589,26 +590,50 @@ class Autoencoder(_ModelView):
             a["hist"], a["hist_dev"] = self._history_source(a.get("hist"))
         keys = self._history_keys()
         pending = []
-        for e in range(epochs):
-            acc = eng.reset_accumulated()
-            for lo in range(0, n, batch_size):
-                hi = min(n, lo + batch_size)
-                eps = self._s.epsilon(hi - lo)               # one draw per GLOBAL minibatch: every rank holds the same stream
-                a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
-                if b0 > a0:
-                    norm = Norm.of(lo, hi, sp.T, **ws)
-                    first = fused is not None and lo == 0
-                    # the encoder's inputs first; the heads' targets are converted while the encoder already runs on the device
-                    B = st.stage(lo + a0, lo + b0, eps=eps[a0:b0], norm=norm, defer_targets=True,
-                                 eps2=fused._root().eps[:hi] if first else None, **a)
-                    eng.train_step_begin(B, hist_fused=(eng._v("in.eps2", eng.pad16(B), sp.Z), fused._root()._z[:hi]) if first else None)
-                    st.finish_targets()
-                    eng.train_step_finish(B, allreduce=dp.hook(eng) if dp is not None else allreduce)
-                    eng.accumulate_metrics(hi - lo)
-                    if first:
-                        fused.mark_valid()
-                else:
-                    eng.train_step_empty(dp.hook(eng))
+        # Minibatch i+1 is CONVERTED (the host packers: 2-6 ms per 256 windows of float64 one-hot rows) on a worker thread while the
+        # host enqueues step i - a call in which the paced host mostly waits for the device (Stager.prefetch).  One draw of epsilon
+        # per GLOBAL minibatch, in minibatch order as before: the next minibatch's draw just happens one step early.
+        order = [(e, lo) for e in range(epochs) for lo in range(0, n, batch_size)]
+
+        def plan(i):
+            e, lo = order[i]
+            hi = min(n, lo + batch_size)
+            eps = self._s.epsilon(hi - lo)               # one draw per GLOBAL minibatch: every rank holds the same stream
+            a0, b0 = (0, hi - lo) if dp is None else shard_bounds(hi - lo, dp.world, dp.rank)
+            first = fused is not None and lo == 0
+            kw = None
+            if b0 > a0:
+                kw = dict(eps=eps[a0:b0], norm=Norm.of(lo, hi, sp.T, **ws), defer_targets=True,
+                          eps2=fused._root().eps[:hi] if first else None, **a)
+            return dict(e=e, lo=lo, hi=hi, a0=a0, b0=b0, first=first, kw=kw, prefetched=False)
+
+        cur = plan(0) if order else None
+        acc = None
+        for i in range(len(order)):
+            b, cur = cur, None
+            lo, hi, a0, b0, first = b["lo"], b["hi"], b["a0"], b["b0"], b["first"]
+            if lo == 0:
+                acc = eng.reset_accumulated()
+            if b["kw"] is not None:
+                # the encoder's inputs first; the heads' targets are converted while the encoder already runs on the device
+                B = st.stage(lo + a0, lo + b0, prefetched=b["prefetched"], **b["kw"])
+                eng.train_step_begin(B, hist_fused=(eng._v("in.eps2", eng.pad16(B), sp.Z), fused._root()._z[:hi]) if first else None)
+                st.finish_targets()
+                if i + 1 < len(order):
+                    cur = plan(i + 1)
+                    if cur["kw"] is not None and not cur["first"] and self.prefetch:
+                        st.prefetch(cur["lo"] + cur["a0"], cur["lo"] + cur["b0"], **cur["kw"])
+                        cur["prefetched"] = True
+                eng.train_step_finish(B, allreduce=dp.hook(eng) if dp is not None else allreduce)
+                eng.accumulate_metrics(hi - lo)
+                if first:
+                    fused.mark_valid()
+            else:
+                eng.train_step_empty(dp.hook(eng))
+            if cur is None and i + 1 < len(order):
+                cur = plan(i + 1)
+            if hi < n:
+                continue
             if dp is not None:          # every rank, every fit call, here - not when (and if) a rank reads the History
                 dp.allreduce_sum(acc)
             pending.append(acc)

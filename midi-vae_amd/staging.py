@@ -17,6 +17,8 @@ shards included ("sum, then divide by the global count").
 from __future__ import annotations
 
 import ctypes as C
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -119,6 +121,9 @@ class Stager(object):
         self.done = [None, None]                     # event after the last upload from each mirror
         self.k = 0
         self._late = None
+        self._pf = None                              # a minibatch being converted ahead on the worker thread (prefetch)
+        self._worker, self._jobs = None, None
+        self._notes = []                             # (name, rows) of the start rows a conversion wrote: Engine._note_start at commit
 
     def _view(self, k, name, dtype, n):
         off, length, _ = self.regions[name]
@@ -198,13 +203,14 @@ class Stager(object):
             out[:B] = np.asarray(arr).reshape(-1, width)[lo:hi]
             out[B:] = 0.0
         if name.startswith("in.start_"):
-            self.eng._note_start(name, None if arr is None else out[:B])
+            self._notes.append((name, None if arr is None else out[:B]))
 
     # ---- one minibatch ------------------------------------------------------------------------------------------
     def stage(self, lo, hi, *, X, I=None, Vel=None, eps=None, hist=None, hist_dev=None, z=None, Y=None, C_=None,
               start_notes=None, start_instr=None, start_vel=None, w_notes=None, w_instr=None, w_vel=None, w_style=None,
               norm=None, batch_local=False, Held=None, Next=None, start_held=None, start_next=None, w_held=None, w_next=None,
-              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False, eps2=None, X_tm=None):
+              Add=None, S=None, w_sig=None, w_cnotes=None, w_cinstr=None, defer_targets=False, eps2=None, X_tm=None,
+              prefetched=False, _prefetch=False):
         """Windows [lo, hi) of a song -> the engine's input block (asynchronous).  Arrays are whole-song arrays indexed by
         window unless ``batch_local`` (then they hold exactly the hi-lo windows of this batch and lo is an offset of 0).
         ``eps`` is always batch-local (B, Z), already scaled by epsilon_std.  ``hist``: host (n, Z) history rows; ``hist_dev``:
@@ -216,7 +222,10 @@ class Stager(object):
 
         ``defer_targets``: convert and upload everything the ENCODER needs now and leave the decoder heads' targets and row weights
         (the second 64 MB float64 tensor of a minibatch) to ``finish_targets()`` - called after the encoder's launches are
-        enqueued, so that conversion runs on the host while the encoder recurrences run on the device."""
+        enqueued, so that conversion runs on the host while the encoder recurrences run on the device.
+
+        ``prefetched``: this minibatch was handed to ``prefetch()`` (same arguments) while the previous step was being enqueued:
+        its conversion - both halves - ran on a worker thread beside the paced host's waits; only the uploads are left."""
         eng, s = self.eng, self.eng.spec
         if batch_local:
             lo, hi = 0, hi - lo
@@ -226,85 +235,115 @@ class Stager(object):
         Bp = eng.pad16(B)
         T, V = s.T, s.V
         k = self.k
+        have_targets = Y is not None
+        nm = (norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next, w_sig, w_cnotes,
+                                                    w_cinstr)) if have_targets else None
+
+        def convert(late_now):
+            """everything that is HOST work: the caller's arrays -> mirror k.  Returns (start rows written, the deferred half of the
+            conversion - the decoder heads' targets - or None when it ran too)"""
+            if self.done[k] is not None:
+                self.done[k].synchronize()              # the upload that last read this mirror has completed
+            self._notes = []
+            if s.attach:
+                self._rows_twohot(k, "in.x_idx", "in.xa_idx", X, lo, hi, T, s.Din, s.attach, Bp, 0, "notes input", False)
+            elif X_tm is not None and not batch_local and X_tm[1] <= lo and hi <= X_tm[1] + X_tm[0].shape[1]:
+                out = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)
+                out[:, :B] = X_tm[0][:, lo - X_tm[1]:hi - X_tm[1]]
+                out[:, B:] = 0
+            else:
+                self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
+            if eng.enc_bi:          # the backward RNNs of a bidirectional encoder read the roll reversed in time
+                self._view(k, "in.x_idx_rev", np.uint8, T * Bp).reshape(T, Bp)[:] = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)[::-1]
+            if s.meta_instrument:
+                self._rows_u8(k, "in.i_idx", I, lo, hi, V, s.ID, Bp, 0, "instrument input")
+            if s.meta_velocity:
+                self._rows_f32(k, "in.vel", Vel, lo, hi, T, Bp)
+            if s.meta_held:
+                self._rows_u8(k, "in.d_idx", Held, lo, hi, T, 2, Bp, 0, "held-notes input")
+                self._rows_bm(k, "in.start_held", start_held, lo, hi, 2, Bp)
+            if s.meta_next:
+                self._rows_bm(k, "in.start_next", start_next, lo, hi, s.Dout, Bp)
+            self._rows_bm(k, "in.eps", eps, 0, B, s.Z, Bp)
+            if eps2 is not None:
+                self._rows_bm(k, "in.eps2", eps2, 0, B, s.Z, Bp)
+            self._rows_bm(k, "in.start_notes", start_notes, lo, hi, s.Dout, Bp)
+            if s.meta_instrument:
+                self._rows_bm(k, "in.start_instr", start_instr, lo, hi, s.ID, Bp)
+            if s.meta_velocity:
+                self._rows_bm(k, "in.start_vel", start_vel, lo, hi, 1, Bp)
+            if s.history and hist_dev is None and eps2 is None:
+                self._rows_bm(k, "in.hist", hist, lo, hi, s.Z, Bp)
+            if z is not None:
+                self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
+            if s.add_dim:
+                self._rows_bm(k, "in.add", Add, lo, hi, s.add_dim, Bp)
+            late = None
+            if have_targets:
+                def late():
+                    if s.attach:
+                        self._rows_twohot(k, "in.y_idx", "in.ya_idx", Y, lo, hi, T, s.Dout, s.attach, Bp, 255, "notes target", True)
+                    else:
+                        self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
+                    if w_notes is None:
+                        out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
+                        out[:, :B] = 1.0 / nm.nz_notes
+                        out[:, B:] = 0.0
+                    else:
+                        self._rows_f32(k, "in.rw_notes", w_notes, lo, hi, T, Bp, scale=1.0 / nm.nz_notes)
+                    if s.meta_instrument:
+                        self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
+                    if s.meta_velocity:
+                        self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
+                    if s.meta_held:
+                        self._per_window(k, "in.rw_held", w_held, lo, hi, T, Bp, 1.0 / (nm.nz_held * T))
+                    if s.meta_next:
+                        self._per_window(k, "in.rw_next", w_next, lo, hi, T, Bp, 1.0 / (nm.nz_next * T))
+                        self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
+
+                if late_now:
+                    late()
+                    late = None
+                if s.style:
+                    self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
+                if s.style or s.comp_notes or s.comp_instr:
+                    self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 255, "style target")
+                if s.signature:
+                    self._rows_bm(k, "in.sig", S, lo, hi, s.SD, Bp)
+                    self._per_window(k, "in.rw_sig", w_sig, lo, hi, 1, Bp, 1.0 / nm.nz_sig)
+                if s.comp_notes:
+                    self._per_window(k, "in.rw_cnotes", w_cnotes, lo, hi, 1, Bp, 1.0 / nm.nz_cnotes)
+                if s.comp_instr:
+                    self._per_window(k, "in.rw_cinstr", w_cinstr, lo, hi, 1, Bp, 1.0 / nm.nz_cinstr)
+            return self._notes, late
+
+        if _prefetch:               # (prefetch(): both halves on the worker thread, nothing of the engine touched)
+            box = {"done": threading.Event()}
+
+            def work():
+                try:
+                    box["out"] = convert(True)
+                except BaseException as e:      # (raised by the stage() call that takes the minibatch)
+                    box["err"] = e
+                box["done"].set()
+            self._pf = (box["done"], k, (lo, hi), box)
+            self._worker_submit(work)
+            return B
         self.k ^= 1
         self._late = None
-        if self.done[k] is not None:
-            self.done[k].synchronize()              # the upload that last read this mirror has completed
-        if s.attach:
-            self._rows_twohot(k, "in.x_idx", "in.xa_idx", X, lo, hi, T, s.Din, s.attach, Bp, 0, "notes input", False)
-        elif X_tm is not None and not batch_local and X_tm[1] <= lo and hi <= X_tm[1] + X_tm[0].shape[1]:
-            out = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)
-            out[:, :B] = X_tm[0][:, lo - X_tm[1]:hi - X_tm[1]]
-            out[:, B:] = 0
+        pf, self._pf = self._pf, None
+        if pf is not None:
+            pf[0].wait()
+            if "err" in pf[3] and prefetched and pf[2] == (lo, hi):
+                raise pf[3]["err"]
+        if prefetched and pf is not None and pf[1] == k and pf[2] == (lo, hi) and "out" in pf[3]:
+            notes, late = pf[3]["out"]
         else:
-            self._rows_u8(k, "in.x_idx", X, lo, hi, T, s.Din, Bp, 0, "notes input")
-        if eng.enc_bi:          # the backward RNNs of a bidirectional encoder read the roll reversed in time
-            self._view(k, "in.x_idx_rev", np.uint8, T * Bp).reshape(T, Bp)[:] = self._view(k, "in.x_idx", np.uint8, T * Bp).reshape(T, Bp)[::-1]
-        if s.meta_instrument:
-            self._rows_u8(k, "in.i_idx", I, lo, hi, V, s.ID, Bp, 0, "instrument input")
-        if s.meta_velocity:
-            self._rows_f32(k, "in.vel", Vel, lo, hi, T, Bp)
-        if s.meta_held:
-            self._rows_u8(k, "in.d_idx", Held, lo, hi, T, 2, Bp, 0, "held-notes input")
-            self._rows_bm(k, "in.start_held", start_held, lo, hi, 2, Bp)
-        if s.meta_next:
-            self._rows_bm(k, "in.start_next", start_next, lo, hi, s.Dout, Bp)
-        self._rows_bm(k, "in.eps", eps, 0, B, s.Z, Bp)
-        if eps2 is not None:
-            self._rows_bm(k, "in.eps2", eps2, 0, B, s.Z, Bp)
-        self._rows_bm(k, "in.start_notes", start_notes, lo, hi, s.Dout, Bp)
-        if s.meta_instrument:
-            self._rows_bm(k, "in.start_instr", start_instr, lo, hi, s.ID, Bp)
-        if s.meta_velocity:
-            self._rows_bm(k, "in.start_vel", start_vel, lo, hi, 1, Bp)
-        if s.history and hist_dev is None and eps2 is None:
-            self._rows_bm(k, "in.hist", hist, lo, hi, s.Z, Bp)
-        if z is not None:
-            self._rows_bm(k, "in.z", z, lo, hi, s.Z, Bp)
-        if s.add_dim:
-            self._rows_bm(k, "in.add", Add, lo, hi, s.add_dim, Bp)
-        have_targets = Y is not None
-        if have_targets:
-            nm = norm if norm is not None else Norm.of(lo, hi, T, w_notes, w_instr, w_vel, w_style, w_held, w_next, w_sig, w_cnotes,
-                                                       w_cinstr)
-            def late():
-                if s.attach:
-                    self._rows_twohot(k, "in.y_idx", "in.ya_idx", Y, lo, hi, T, s.Dout, s.attach, Bp, 255, "notes target", True)
-                else:
-                    self._rows_u8(k, "in.y_idx", Y, lo, hi, T, s.Dout, Bp, 255, "notes target")
-                if w_notes is None:
-                    out = self._view(k, "in.rw_notes", np.float32, T * Bp).reshape(T, Bp)
-                    out[:, :B] = 1.0 / nm.nz_notes
-                    out[:, B:] = 0.0
-                else:
-                    self._rows_f32(k, "in.rw_notes", w_notes, lo, hi, T, Bp, scale=1.0 / nm.nz_notes)
-                if s.meta_instrument:
-                    self._per_window(k, "in.rw_instr", w_instr, lo, hi, V, Bp, 1.0 / (nm.nz_instr * V))
-                if s.meta_velocity:
-                    self._per_window(k, "in.rw_vel", w_vel, lo, hi, T, Bp, 1.0 / (nm.nz_vel * T))
-                if s.meta_held:
-                    self._per_window(k, "in.rw_held", w_held, lo, hi, T, Bp, 1.0 / (nm.nz_held * T))
-                if s.meta_next:
-                    self._per_window(k, "in.rw_next", w_next, lo, hi, T, Bp, 1.0 / (nm.nz_next * T))
-                    self._rows_u8(k, "in.n_idx", Next, lo, hi, T, s.Dout, Bp, 255, "next-notes target")
-
-            self._late = (k, late) if defer_targets else None
-            if not defer_targets:
-                late()
-            if s.style:
-                self._per_window(k, "in.rw_style", w_style, lo, hi, 1, Bp, 1.0 / nm.nz_style)
-            if s.style or s.comp_notes or s.comp_instr:
-                self._rows_u8(k, "in.c_idx", C_, lo, hi, 1, s.C, Bp, 255, "style target")
-            if s.signature:
-                self._rows_bm(k, "in.sig", S, lo, hi, s.SD, Bp)
-                self._per_window(k, "in.rw_sig", w_sig, lo, hi, 1, Bp, 1.0 / nm.nz_sig)
-            if s.comp_notes:
-                self._per_window(k, "in.rw_cnotes", w_cnotes, lo, hi, 1, Bp, 1.0 / nm.nz_cnotes)
-            if s.comp_instr:
-                self._per_window(k, "in.rw_cinstr", w_cinstr, lo, hi, 1, Bp, 1.0 / nm.nz_cinstr)
-            eng.norm_B = float(nm.B)
-        else:
-            eng.norm_B = float(B)
+            notes, late = convert(not defer_targets)
+        for name, val in notes:
+            eng._note_start(name, val)
+        self._late = (k, late) if (late is not None) else ((k, None) if (have_targets and defer_targets) else None)
+        eng.norm_B = float(nm.B) if have_targets else float(B)
         # ---- ONE upload, ordered on the current stream behind whatever still reads the block -------------------------------
         cut = eng._in_late_off if (have_targets and defer_targets) else None
         if cut is None:
@@ -334,6 +373,31 @@ class Stager(object):
         eng._have_staged_targets = have_targets
         return B
 
+    def _worker_submit(self, fn):
+        """run ``fn`` on the stager's worker thread (started on first use; it has made the engine's device current once)"""
+        if self._worker is None:
+            self._jobs = queue.Queue()
+
+            def loop():
+                torch.cuda.set_device(self.eng.device)
+                while True:
+                    job = self._jobs.get()
+                    if job is None:
+                        return
+                    job()
+            self._worker = threading.Thread(target=loop, name="mvae-stage-prefetch", daemon=True)
+            self._worker.start()
+        self._jobs.put(fn)
+
+    def prefetch(self, lo, hi, **kw):
+        """Start converting minibatch [lo, hi) - both halves - on a worker thread into the mirror the NEXT ``stage`` call uses; that
+        call must pass the same arguments and ``prefetched=True``.  For the caller that is about to enqueue a train step: the paced
+        host spends most of that call waiting for the device, and the host packers (native, multi-threaded, the GIL
+        released) need 2-6 ms per 256-window minibatch of float64 one-hot rows depending on where the caller's arrays live
+        (two NUMA nodes on the benchmark host: fit at configs[1] was 5.7 or 7.3 ms per step by the luck of the process)."""
+        kw.pop("prefetched", None)
+        return self.stage(lo, hi, _prefetch=True, **kw)
+
     def finish_targets(self):
         """second half of ``stage(defer_targets=True)``: the decoder heads' targets and row weights, converted now (the encoder is
         already enqueued) and uploaded behind it on the same stream"""
@@ -341,7 +405,8 @@ class Stager(object):
             return
         k, late = self._late
         self._late = None
-        late()
+        if late is not None:
+            late()
         cut = self.eng._in_late_off
         self.eng._in_block[cut:].copy_(self.host[k][cut:], non_blocking=True)
         ev = torch.cuda.Event()

@@ -22,6 +22,8 @@ ap.add_argument("--with-prepass", action="store_true", help="history pre-pass (e
 ap.add_argument("--host-history", action="store_true", help="... through host arrays, as the reference does")
 ap.add_argument("--lazy", action="store_true", help="read the History objects after the epoch's last song instead of after every fit "
                 "(History is filled on first access: the reference-style immediate read waits for the device once per song)")
+ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 = as shipped)")
+ap.add_argument("--threads", type=int, default=-1, help="host packer threads (mvae_host_threads; -1 = default)")
 a = ap.parse_args()
 import torch
 s = build_settings(cell_type=a.cell, input_length=128, output_length=128, latent_dim=64, batch_size=a.batch)
@@ -32,12 +34,24 @@ for i in range(a.songs):
     w = make_windows(n, s["output_length"], s["output_dim"], s["max_voices"], 16, s["num_classes"], s["latent_dim"], seed=10 + i)
     X, Y, C, I, V, D = to_reference_format(w)
     songs.append((X, Y, C, I, V, D, np.zeros((n, s["signature_vector_length"]))))
+if a.threads >= 0:
+    hl.load().mvae_host_threads(a.threads)
 print("host packer threads: %d; one song = %d windows = %.0f MB of float64 one-hot rows (X) + as much again (Y)" % (
     hl.load().mvae_host_threads(-1), n, songs[0][0].nbytes / 1e6))
 
 
 # host-side wall time inside fit, by part (the device runs asynchronously beside all of it)
 from midi_vae_amd import staging as _st, engine as _en
+_init = _en.Engine.__init__
+
+
+def _init_with_knobs(self, *args, **kw):        # (the model builds its engines on first use)
+    _init(self, *args, **kw)
+    if a.pace_mask >= 0:
+        self.pace_mask = self.pace_mask_split = a.pace_mask
+
+
+_en.Engine.__init__ = _init_with_knobs
 HOST = {"stage": 0.0, "stage targets": 0.0, "train_step enqueue": 0.0, "read-back": 0.0}
 
 

@@ -20,9 +20,23 @@ ap.add_argument("--songs", type=int, default=64)
 ap.add_argument("--epochs", type=int, default=4)
 ap.add_argument("--min-windows", type=int, default=20)
 ap.add_argument("--max-windows", type=int, default=200)
+ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 = as shipped)")
+ap.add_argument("--in-flight", type=int, default=-1, help="Engine.steps_in_flight (-1 = as shipped)")
 a = ap.parse_args()
 s = build_settings()
 m = VAE().create(compute_dtype="bf16", seed=0, **create_kwargs(s))
+_init = _en.Engine.__init__
+
+
+def _init_with_knobs(self, *args, **kw):        # (the model builds its engines on first use)
+    _init(self, *args, **kw)
+    if a.pace_mask >= 0:
+        self.pace_mask = self.pace_mask_split = a.pace_mask
+    if a.in_flight >= 0:
+        self.steps_in_flight = a.in_flight
+
+
+_en.Engine.__init__ = _init_with_knobs
 rng = np.random.default_rng(7)
 songs = []
 for i in range(a.songs):
@@ -72,5 +86,6 @@ for ep in range(a.epochs):
           % (ep, "no pre-pass" if ep == 0 else "history pre-pass on the device", nw, dt, nw / dt, dt / steps * 1e3, t1 - t0, out["loss"]))
     print("         host time inside fit per optimizer step: %s" % ", ".join("%s %.2f ms" % (k, v / steps * 1e3) for k, v in HOST.items()))
 eng = m._shared.engine
+print("pace_mask %d, steps_in_flight %d" % (eng.pace_mask, eng.steps_in_flight))
 eng.check_pipeline()
 print("plans:", {k: (v if k != "refused" else len(v)) for k, v in eng.plan_stats.items()})
