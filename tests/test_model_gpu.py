@@ -231,6 +231,33 @@ def test_device_history_equals_host_history():
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("prepass", [False, True])
+def test_fit_with_the_next_minibatch_converted_ahead_equals_serial_staging(prepass):
+    """Autoencoder.prefetch (round 5): minibatch i+1 is converted by the host packers on a worker thread while step i is enqueued
+    (Stager.prefetch; reference counterpart: Keras slices the next batch inside fit, vae_training.py:804-809).  Same epsilon
+    stream (one draw per minibatch, in minibatch order), same mirrors, same uploads: two epochs over ragged minibatches
+    (21 = 8 + 8 + 5) give the losses and the parameters of a fit that converts every minibatch on the caller's thread."""
+    res = {}
+    for ahead in (True, False):
+        s, m, (X, Y, C, I, V, D) = _setup("GRU", n=21, seed=4)
+        m.autoencoder.prefetch = ahead
+        n = X.shape[0]
+        S = np.zeros((n, s["signature_vector_length"]))
+        m._shared.rng = np.random.default_rng(7)
+        H = (m.encoder.predict(pk.prepare_encoder_input_list(s, X, I, V, D), batch_size=s["batch_size"], verbose=False, device=True)
+             if prepass else np.zeros((n, s["latent_dim"])))
+        x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+        hist = m.autoencoder.fit(x, y, epochs=2, batch_size=s["batch_size"], shuffle=False, sample_weight=sw, verbose=False)
+        st = m._shared.engine.stager()
+        assert (st._worker is not None) == ahead
+        res[ahead] = ({k: list(v) for k, v in hist.history.items()}, m.autoencoder.get_weights())
+    (h1, w1), (h0, w0) = res[True], res[False]
+    for k in h0:
+        np.testing.assert_allclose(h1[k], h0[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    for a, b in zip(w1, w0):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+
+
 def test_history_is_filled_on_first_access_and_survives_later_fit_calls():
     """History.history is read from the device on first access (model.History): histories of several fit calls read AFTER the
     last call hold the same values as histories read immediately after each call."""
