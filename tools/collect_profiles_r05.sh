@@ -45,7 +45,7 @@ fi; if want 5; then
 python tools/gemm_microbench.py 2>&1 | grep -v amdgpu > $O/gemm_microbench.txt
 python tools/rnn_microbench.py --cell LSTM 2>&1 | grep -v amdgpu > $O/rnn_microbench.txt
 python tools/rnn_microbench.py --cell GRU 2>&1 | grep -v amdgpu >> $O/rnn_microbench.txt
-for args in "" "--with-prepass" "--windows 256 --songs 8 --with-prepass"; do
+for args in "" "--with-prepass" "--windows 256 --songs 8 --with-prepass" "--cell GRU"; do
   echo "== tools/fit_e2e_bench.py $args" >> $O/fit_e2e.txt
   python tools/fit_e2e_bench.py $args 2>&1 | grep -v amdgpu >> $O/fit_e2e.txt
 done
