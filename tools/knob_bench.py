@@ -18,6 +18,8 @@ ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--inflight", type=int, default=0, help="at most this many steps enqueued ahead of the device (0 = no limit)")
 ap.add_argument("--bracket", type=int, default=0, help="every Nth step carries HIP-event brackets around the BPTT launches (bench.py's measurement); "
                 "reports the bracketed and the plain steps apart (per-step synchronisation)")
+ap.add_argument("--no-meta", action="store_true", help="no velocity / instrument branches (encoder rolls and decoder heads)")
+ap.add_argument("--layers", type=int, default=2, help="cells per stack (encoder and decoder)")
 ap.add_argument("--skip-streams", type=int, default=0, help="take this many streams out of torch's pool before the engine is built")
 ap.add_argument("knobs", nargs="*")
 a = ap.parse_args()
@@ -31,7 +33,8 @@ elif a.shape == "config2":            # BASELINE configs[2] / [3] per-GPU shape:
 else:
     cell, T, Z, V = a.cell or "GRU", 64, 256, 4
 B = a.batch
-spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=2, Ld=2)
+spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=C, Le=a.layers, Ld=a.layers,
+                 **(dict(meta_velocity=False, meta_instrument=False) if a.no_meta else {}))
 w = make_windows(B, T, 61, V, 16, C, Z, seed=1, epsilon_std=spec.epsilon_std)
 _skipped = [torch.cuda.Stream(device="cuda:0") for _ in range(a.skip_streams)]
 eng = Engine(spec, max_batch=B, dtype="bf16", device="cuda:0", seed=1)
@@ -90,6 +93,6 @@ if a.bracket:
         max(per[False] or [0]), len(per[False])))
 eng.check_pipeline()
 print("%-9s %s T=%d B=%d %-40s %.3f ms/step (3 x %d steps: %s; host enqueue %.3f, events %.3f)  [%d windows/s]  plans %s" % (
-    a.shape, cell, T, B, (" ".join(a.knobs) or "(defaults)") + (" skip=%d" % a.skip_streams if a.skip_streams else "") + (" inflight=%d" % a.inflight if a.inflight else ""), min(best), a.steps, " ".join("%.3f" % b for b in best), min(host), min(dev),
+    a.shape, cell, T, B, (" ".join(a.knobs) or "(defaults)") + (" no-meta" if a.no_meta else "") + (" layers=%d" % a.layers if a.layers != 2 else "") + (" skip=%d" % a.skip_streams if a.skip_streams else "") + (" inflight=%d" % a.inflight if a.inflight else ""), min(best), a.steps, " ".join("%.3f" % b for b in best), min(host), min(dev),
     B / min(best) * 1e3,
     {k: (v if k != "refused" else len(v)) for k, v in eng.plan_stats.items()}))
