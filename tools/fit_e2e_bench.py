@@ -23,6 +23,7 @@ ap.add_argument("--host-history", action="store_true", help="... through host ar
 ap.add_argument("--lazy", action="store_true", help="read the History objects after the epoch's last song instead of after every fit "
                 "(History is filled on first access: the reference-style immediate read waits for the device once per song)")
 ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 = as shipped)")
+ap.add_argument("--pace-split", type=int, default=-1, help="Engine.pace_mask_split only (-1 = as shipped)")
 ap.add_argument("--threads", type=int, default=-1, help="host packer threads (mvae_host_threads; -1 = default)")
 a = ap.parse_args()
 import torch
@@ -49,6 +50,8 @@ def _init_with_knobs(self, *args, **kw):        # (the model builds its engines 
     _init(self, *args, **kw)
     if a.pace_mask >= 0:
         self.pace_mask = self.pace_mask_split = a.pace_mask
+    if a.pace_split >= 0:
+        self.pace_mask_split = a.pace_split
 
 
 _en.Engine.__init__ = _init_with_knobs

@@ -21,6 +21,7 @@ ap.add_argument("--epochs", type=int, default=4)
 ap.add_argument("--min-windows", type=int, default=20)
 ap.add_argument("--max-windows", type=int, default=200)
 ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 = as shipped)")
+ap.add_argument("--pace-split", type=int, default=-1, help="Engine.pace_mask_split only (-1 = as shipped)")
 ap.add_argument("--in-flight", type=int, default=-1, help="Engine.steps_in_flight (-1 = as shipped)")
 a = ap.parse_args()
 s = build_settings()
@@ -32,6 +33,8 @@ def _init_with_knobs(self, *args, **kw):        # (the model builds its engines 
     _init(self, *args, **kw)
     if a.pace_mask >= 0:
         self.pace_mask = self.pace_mask_split = a.pace_mask
+    if a.pace_split >= 0:
+        self.pace_mask_split = a.pace_split
     if a.in_flight >= 0:
         self.steps_in_flight = a.in_flight
 
