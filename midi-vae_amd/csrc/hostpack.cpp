@@ -116,13 +116,12 @@ int default_threads() {
         if (v > 1) local = v;
     }
     const int share = hw / local > 1 ? hw / local : 1;
-    // memory-bound: a quarter of the hardware threads saturates what the sockets deliver to one process (measured on the 256-thread
-    // host of an MI355X box: 16 threads convert a 256 x 512 x 61 float64 minibatch in ~4 ms, a train step takes 8.9); at least 4
-    // (or all of a smaller share), at most 64
-    int n;
-    if (local == 1) n = share > 16 ? (share / 4 > 16 ? share / 4 : 16) : share;        // alone on the host: round 2's measured optimum
-    else n = share / 4 > 4 ? share / 4 : (share < 4 ? share : 4);                     // max(4, threads / ranks / 4), within the share
-    return n > 64 ? 64 : n;
+    // Memory-bound, and called once per train step: FEW threads.  Round 5 on the 256-thread two-socket host of an MI355X box: warm, 8
+    // threads convert a 256 x 512 x 61 float64 minibatch (64 MB) in 0.71 ms = 90 GB/s, 64 threads in 0.5-0.8 ms - but a pool that has
+    // slept through a 6 ms train step wakes slowly and unevenly: inside fit the same conversion took 0.8-3.7 ms with 64 threads
+    // (5.85-9.09 ms per step over six processes), 0.5-1.1 ms with 8 (5.66-5.85 ms, all six).  At most 8, within the share.
+    const int n = share < 8 ? share : 8;
+    return n < 1 ? 1 : n;
 }
 
 Pool& pool() {

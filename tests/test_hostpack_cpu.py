@@ -117,7 +117,8 @@ def test_twohot_rows_to_two_index_rolls():
 
 def test_default_pool_is_a_share_of_the_cores_this_process_may_use():
     """one process per GPU under data parallelism: the packer pool is sized from the affinity mask divided by LOCAL_WORLD_SIZE
-    (8 ranks x 64 threads on a 256-thread host), never more than the share, never more than 64"""
+    (8 ranks x 64 threads on a 256-thread host), never more than the share, never more than 8 (round 5: a pool that
+    sleeps through a train step wakes slowly, and 8 warm threads already move 90 GB/s)"""
     import os
     import subprocess
     import sys
@@ -131,6 +132,6 @@ def test_default_pool_is_a_share_of_the_cores_this_process_may_use():
         e.update(env)
         return int(subprocess.check_output([sys.executable, "-c", code], env=e, cwd=root).decode().split()[-1])
     alone, eight = threads(), threads(LOCAL_WORLD_SIZE="8")
-    assert 1 <= alone <= min(cores, 64)
-    assert 1 <= eight <= max(cores // 8, 1) or eight == 4 and cores // 8 >= 4
+    assert 1 <= alone <= min(cores, 8)
+    assert 1 <= eight <= max(min(cores // 8, 8), 1)
     assert eight <= alone
