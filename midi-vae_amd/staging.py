@@ -392,9 +392,9 @@ class Stager(object):
     def prefetch(self, lo, hi, **kw):
         """Start converting minibatch [lo, hi) - both halves - on a worker thread into the mirror the NEXT ``stage`` call uses; that
         call must pass the same arguments and ``prefetched=True``.  For the caller that is about to enqueue a train step: the paced
-        host spends most of that call waiting for the device, and the host packers (native, multi-threaded, the GIL
-        released) need 2-6 ms per 256-window minibatch of float64 one-hot rows depending on where the caller's arrays live
-        (two NUMA nodes on the benchmark host: fit at configs[1] was 5.7 or 7.3 ms per step by the luck of the process)."""
+        host spends most of that call waiting for the device, and the conversion of a 256-window minibatch of float64
+        one-hot rows (native, the GIL released) takes 0.5-1 ms per half on a warm 8-thread pool - several ms when the pool is large
+        and has slept through the step (profiles/r05_t_pace_mask_by_caller.txt)."""
         kw.pop("prefetched", None)
         return self.stage(lo, hi, _prefetch=True, **kw)
 
