@@ -24,11 +24,14 @@ ap.add_argument("--lazy", action="store_true", help="read the History objects af
                 "(History is filled on first access: the reference-style immediate read waits for the device once per song)")
 ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 = as shipped)")
 ap.add_argument("--pace-split", type=int, default=-1, help="Engine.pace_mask_split only (-1 = as shipped)")
+ap.add_argument("--no-prefetch", action="store_true", help="convert every minibatch on the caller's thread (Autoencoder.prefetch = False)")
 ap.add_argument("--threads", type=int, default=-1, help="host packer threads (mvae_host_threads; -1 = default)")
 a = ap.parse_args()
 import torch
 s = build_settings(cell_type=a.cell, input_length=128, output_length=128, latent_dim=64, batch_size=a.batch)
 m = VAE().create(compute_dtype="bf16", seed=0, **create_kwargs(s))
+if a.no_prefetch:
+    m.autoencoder.prefetch = False
 n = a.windows
 songs = []
 for i in range(a.songs):
