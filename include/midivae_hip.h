@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MVAE_ABI_VERSION 8
+#define MVAE_ABI_VERSION 9
 
 enum { MVAE_OK = 0, MVAE_E_ARG = -1, MVAE_E_UNSUPPORTED = -2, MVAE_E_LAUNCH = -3,
        MVAE_E_FORMAT = -4 /* host packers: a row of the caller's array is not one-hot */ };
@@ -59,9 +59,19 @@ enum {
  *                   one lane's 8 values of a tile pair are 16 contiguous bytes: one memory instruction instead of two
  *                   (a VMEM instruction costs the CU's address unit the same 16 cycles whatever its width).
  *                   As a seq_layout it means: xp and dhs_ext TILE16, the saved activations (acts, cs) TILE16P - the
- *                   layout the slot-interleaved LSTM / GRU kernels use; forward and backward of a layer must agree. */
-enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1, MVAE_TILE16P = 2 };
-enum { MVAE_TABLE_ROWMAJOR = 0, MVAE_TABLE_PAIRED = 1 };       /* lookup tables of one-hot input layers (mvae_rnn_fwd_args.table_layout) */
+ *                   layout the slot-interleaved LSTM / GRU kernels use; forward and backward of a layer must agree.
+ *   MVAE_TILE16Q  : as TILE16P with the tiles j and j + 8 of every block of 256 columns interleaved (cols % 256 == 0):
+ *                       offset = ((m/16 * cols/32 + n/256 * 8 + (n/16)%8) * 64 + ((n%16)/4)*16 + m%16) * 8 + ((n/128)%2)*4 + n%4
+ *                   As a seq_layout (round 6) it selects the TWO-WAVES-PER-SIMD kernels (GRU, H = 256, bf16; rnn_w8.hip): a
+ *                   workgroup is 8 waves, wave w owns the unit tiles w and 8 + w of every gate - its pair; xp and dhs_ext
+ *                   are TILE16, a one-hot layer's table MVAE_TABLE_PAIRED8, and a chunk of a time-pipelined stack is
+ *                   published by 8 waves per workgroup (mvae_rnn_producer_waves). */
+enum { MVAE_ROWMAJOR = 0, MVAE_TILE16 = 1, MVAE_TILE16P = 2, MVAE_TILE16Q = 3 };
+/* lookup tables of one-hot input layers (mvae_rnn_fwd_args.table_layout).  PAIRED: tiles (2j, 2j+1) of a lane in 16 contiguous bytes;
+ * PAIRED8: tiles (j, j+8) of every block of 256 columns (column 128 h + 16 j + 4 q + e of the block sits at 32 j + 8 q + 4 h + e) */
+enum { MVAE_TABLE_ROWMAJOR = 0, MVAE_TABLE_PAIRED = 1, MVAE_TABLE_PAIRED8 = 2 };
+/* waves per workgroup that publish a chunk of a time-pipelined stack (signal_done += 1 each): 8 for MVAE_TILE16Q, else 4 */
+int mvae_rnn_producer_waves(int32_t seq_layout);
 
 int mvae_abi_version(void);
 /* human-readable build string (arch, compile date) */
@@ -381,7 +391,7 @@ int mvae_latent_chain_bwd(const mvae_latent_chain_bwd_args* a, void* stream);
  * latency per training step otherwise).  Each job is one of the single calls above:
  *   MVAE_PREP_PACK_RECURRENT   src = U (a=H, b=G*H) f32, c = direction        -> dst as mvae_pack_recurrent(kind)
  *   MVAE_PREP_MAKE_TABLE       src = W (a=K, b=N), src2 = bias (N), c = layout -> dst (K, N) kind    (mvae_make_table; c = 1:
- *                              MVAE_TABLE_PAIRED, see mvae_rnn_fwd_args.table_layout)
+ *                              MVAE_TABLE_PAIRED, c = 2: MVAE_TABLE_PAIRED8, see mvae_rnn_fwd_args.table_layout)
  *   MVAE_PREP_TRANSPOSE_CONVERT src = W (a=K, b=N), c = N_pad                 -> dst (N_pad, K) kind (mvae_transpose_convert)
  *   MVAE_PREP_CONVERT          src (a*b) f32                                  -> dst (a*b) kind      (mvae_convert)
  *   MVAE_PREP_ZERO             (no src)                                       -> dst (a*b) kind, a*b even for bf16: zeros
@@ -416,7 +426,8 @@ int mvae_outer_bias_tile16(const float* xs, const float* w, const float* bias, v
 int mvae_gather2_tile16(const uint8_t* idx, const uint8_t* idx2, const void* table, const void* table2, void* out, int32_t kind,
                         int32_t R, int32_t N, int32_t layout, void* stream);
 /* (rows, cols) row-major <-> tiled, same element kind on both sides.
- * to_tile16: 0 TILE16 -> row-major, 1 row-major -> TILE16, 2 TILE16P -> row-major, 3 row-major -> TILE16P */
+ * to_tile16: 0 TILE16 -> row-major, 1 row-major -> TILE16, 2 TILE16P -> row-major, 3 row-major -> TILE16P,
+ *            4 TILE16Q -> row-major, 5 row-major -> TILE16Q */
 int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16, void* stream);
 
 /* elementwise helpers */

@@ -312,7 +312,9 @@ __device__ __forceinline__ void make_table_body(const float* W, const float* bia
     const size_t n = (size_t)K * N;
     for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < n; e += (size_t)nb * blockDim.x) {
         const int c = (int)(e % N);
-        const int cp = paired ? (c & ~31) + ((c & 15) >> 2) * 8 + ((c >> 4) & 1) * 4 + (c & 3) : c;
+        // (paired == 2, MVAE_TABLE_PAIRED8; N % 256 == 0: the tiles j and j + 8 of every block of 256 columns)
+        const int cp = paired == 2 ? (c & ~255) + ((c >> 4) & 7) * 32 + ((c & 15) >> 2) * 8 + ((c >> 7) & 1) * 4 + (c & 3)
+                     : paired ? (c & ~31) + ((c & 15) >> 2) * 8 + ((c >> 4) & 1) * 4 + (c & 3) : c;
         st<D>::store(table + (e - c) + cp, W[e] + bias[c]);
     }
 }

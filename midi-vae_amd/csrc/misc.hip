@@ -194,7 +194,9 @@ __global__ void relayout_k(const D* src, D* dst, int rows, int cols, int to_tile
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(e / cols), c = (int)(e % cols);
         const size_t lane = (size_t)(((c & 15) >> 2) * 16 + (m & 15));
-        const size_t t = (to_tile & 2)
+        const size_t t = (to_tile & 4)
+            ? ((((size_t)(m >> 4) * (cols >> 5) + (c >> 8) * 8 + ((c >> 4) & 7)) * 64) + lane) * 8 + ((c >> 7) & 1) * 4 + (c & 3)
+            : (to_tile & 2)
             ? ((((size_t)(m >> 4) * (cols >> 5) + (c >> 5)) * 64) + lane) * 8 + ((c & 31) >> 4) * 4 + (c & 3)
             : ((((size_t)(m >> 4) * (cols >> 4) + (c >> 4)) * 64) + lane) * 4 + (c & 3);
         if (to_tile & 1) dst[t] = src[e]; else dst[e] = src[t];
@@ -395,6 +397,7 @@ inline int nblocks(size_t n, int per = 256, int cap = 2048) {
 }  // namespace
 
 extern "C" int mvae_abi_version(void) { return MVAE_ABI_VERSION; }
+extern "C" int mvae_rnn_producer_waves(int32_t seq_layout) { return seq_layout == MVAE_TILE16Q ? 8 : 4; }
 extern "C" const char* mvae_build_info(void) { return "libmidivae_hip gfx950 (CDNA4) built " __DATE__ " " __TIME__; }
 
 extern "C" int mvae_latent_fwd(const mvae_latent_fwd_args* a, void* stream) {
@@ -500,7 +503,7 @@ extern "C" int mvae_convert(const void* src, int32_t sk, void* dst, int32_t dk, 
 }
 extern "C" int mvae_relayout(const void* src, void* dst, int32_t kind, int32_t rows, int32_t cols, int32_t to_tile16,
                              void* stream) {
-    if (!src || !dst || rows <= 0 || cols <= 0 || (rows % 16) || (cols % ((to_tile16 & 2) ? 32 : 16)) || to_tile16 < 0 || to_tile16 > 3)
+    if (!src || !dst || rows <= 0 || cols <= 0 || (rows % 16) || (cols % ((to_tile16 & 4) ? 256 : (to_tile16 & 2) ? 32 : 16)) || to_tile16 < 0 || to_tile16 > 5)
         return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 g(nblocks((size_t)rows * cols)), b(256);
@@ -651,6 +654,7 @@ extern "C" int mvae_prepare_batch(const mvae_prep_job* jobs, int32_t n_jobs, voi
                 job.op > MVAE_PREP_BROADCAST_ROWS ||
                 (job.op == MVAE_PREP_CONVERT_PAD && job.c < job.b) ||
                 (job.kind != MVAE_F32 && job.kind != MVAE_BF16) || (job.op == MVAE_PREP_MAKE_TABLE && !job.src2) ||
+                (job.op == MVAE_PREP_MAKE_TABLE && (job.c < 0 || job.c > 2 || (job.c == 1 && (job.b % 32)) || (job.c == 2 && (job.b % 256)))) ||
                 (job.op == MVAE_PREP_ZERO && job.kind == MVAE_BF16 && (((size_t)job.a * job.b) & 1)))
                 return MVAE_E_ARG;
             if (job.op == MVAE_PREP_PACK_RECURRENT) {

@@ -2553,15 +2553,11 @@ int launch_bwd_multi(const rnn_bwd_multi& m, int total, hipStream_t s) {
 }  // namespace
 
 // Entry points used by rnn.hip's dispatch.  Return MVAE_E_UNSUPPORTED when the shape is not this file's.
-int mvae_rnn_fwd_w8(const mvae_rnn_fwd_args& a, hipStream_t s);      // rnn_w8.hip: two waves per SIMD
-static bool w8_enabled() {
-    static const bool on = [] { const char* e = getenv("MVAE_W8"); return e && atoi(e) != 0; }();
-    return on;
-}
+int mvae_rnn_fwd_w8(const mvae_rnn_fwd_args& a, hipStream_t s);      // rnn_w8.hip: two waves per SIMD (seq_layout MVAE_TILE16Q)
 int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s) {
+    if (a.seq_layout == MVAE_TILE16Q) return mvae_rnn_fwd_w8(a, s);
     if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || (a.seq_layout != MVAE_TILE16 && a.seq_layout != MVAE_TILE16P))
         return MVAE_E_UNSUPPORTED;
-    if (w8_enabled() && a.cell == MVAE_GRU && a.seq_layout == MVAE_TILE16P && a.xmode != MVAE_X_SCALAR) return mvae_rnn_fwd_w8(a, s);
     if (a.cell == MVAE_LSTM) return fwd_res_xmode<MVAE_LSTM>(a, s);
     if (a.cell == MVAE_GRU) return fwd_res_xmode<MVAE_GRU>(a, s);
     return MVAE_E_UNSUPPORTED;

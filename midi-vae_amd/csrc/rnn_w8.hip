@@ -36,6 +36,22 @@
 static_assert(!W8_ABL_NOBAR && !W8_ABL_NOMATH && !W8_ABL_NOL && !W8_ABL_NOB, "timing ablations: variant builds only");
 #endif
 
+// Phase stamps (build with -DW8_STAMPS): lane 0 of waves 0 and 4 of block 0 records s_memtime at marked points of steps
+// [64, 72); read back with mvae_debug_stamps_w8().  Development tooling only.
+#ifdef W8_STAMPS
+__device__ unsigned long long mvae_w8_stamps[2 * 8 * 16];
+#define W8_STAMP(k)                                                                                                   \
+    do {                                                                                                              \
+        if (bx == 0 && l == 0 && (w & 3) == 0 && t >= 64 && t < 72)                                                   \
+            mvae_w8_stamps[((w >> 2) * 8 + (t - 64)) * 16 + (k)] = __builtin_readcyclecounter();                      \
+    } while (0)
+extern "C" int mvae_debug_stamps_w8(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mvae_w8_stamps), sizeof(mvae_w8_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define W8_STAMP(k)
+#endif
+
 namespace {
 
 constexpr int RH = 256;
@@ -62,6 +78,22 @@ __device__ __forceinline__ void load1_agpr_nowait(frag& u, const frag* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&a"(u) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// un-tracked requests (the caller waits by count, then pins the destination): uniform base + 32-bit lane offset
+__device__ __forceinline__ void xload8(u16x4& d, const __attribute__((address_space(1))) unsigned char* base, unsigned off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void xload16(u16x8& d, const __attribute__((address_space(1))) unsigned char* base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void pin8(u16x8& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void iload1(int& d, const uint8_t* p) {
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
 __device__ __forceinline__ void pinu(unsigned& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pini(int& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin1(u16x4& a) { asm volatile("" : "+v"(a)); }
@@ -91,67 +123,84 @@ __device__ __forceinline__ float hsig(float x) { return __builtin_amdgcn_fmed3f(
 // ---------------------------------------------------------------------------------------------------------
 // GRU forward (Keras 2.0.x GRU: reset gate applied BEFORE the candidate matmul; gate order [z | r | candidate])
 // ---------------------------------------------------------------------------------------------------------
-// Step t, per wave (tiles n = 0, 1 of 16 units each):
-//   A  32 MFMA slots, B = h_{t-1} (all 8 k-groups read into registers behind the barrier): r over k-groups 0..3, then r
-//      and z over k-groups 4..7, then z over k-groups 0..3 - r is complete 8 slots before the phase ends and its
-//      arithmetic (hard_sigmoid, r*h -> rh tile) runs under the z slots of this wave and of its SIMD partner
-//   -  barrier (the candidate needs every wave's r*h)
-//   C  16 MFMA slots, B = r*h: tile 0 then tile 1; z's arithmetic and tile 0's tanh + h update run underneath
-//   -  tile 1's tanh + h update, h -> LDS, barrier
-// Phase-A slot s: gate, tile, k-group
-struct slot_a { int g, n, ks; };
-__host__ __device__ constexpr slot_a gru_slot_a(int s) {
+// Wave w owns the unit tiles a = w (units [16w, 16w+16)) and b = 8 + w: the a tiles of all waves are the k-groups 0..3 of
+// h, the b tiles the k-groups 4..7 - the two halves of h are exchanged at DIFFERENT points of the step, each behind
+// MFMAs that do not need it.  A step is 48 MFMA slots per wave; what the dependency chain
+//     candidate(tile) -> tanh, h update -> LDS -> barrier -> ds_read -> r = U_r h -> hard_sigmoid, r*h -> LDS -> barrier
+//     -> ds_read -> candidate
+// leaves idle (arithmetic, LDS round trips, barriers) is filled with the z MFMAs, which nothing waits for until the h update:
+//   slots  0.. 7  r, both tiles, k-groups 0..3 (h_a)        fillers: tanh + h update of tile b of the PREVIOUS step -> h_b
+//   -- barrier 2b; ds_read h_b (k-groups 4..7)
+//   slots  8..15  z, k-groups 0..3                           (cover the read)
+//   slots 16..23  r, tile a then tile b, k-groups 4..7       fillers: r_a -> r*h
+//   slots 24..27  z, tile a, k-groups 4..7                   fillers: r_b -> r*h
+//   -- barrier 1; ds_read r*h (all k-groups)
+//   slots 28..31  z, tile b, k-groups 4..7                   (cover)
+//   slots 32..39  candidate, tile a                          fillers: z
+//   slots 40..47  candidate, tile b                          fillers: tanh + h update of tile a -> h_a
+//   -- barrier 2a; ds_read h_a (k-groups 0..3) of the next step
+struct w8_slot { int kind, n, ks; };        // kind 0 = z, 1 = r, 2 = candidate (the gate index of the packed kernel)
+__host__ __device__ constexpr w8_slot gru_slot(int s) {
     if (s < 8) return {1, s & 1, s >> 1};
-    if (s < 24) return {((s - 8) >> 1) & 1 ? 0 : 1, s & 1, 4 + ((s - 8) >> 2)};
-    return {0, s & 1, (s - 24) >> 1};
+    if (s < 16) return {0, (s - 8) >> 2, (s - 8) & 3};
+    if (s < 24) return {1, (s - 16) >> 2, 4 + ((s - 16) & 3)};
+    if (s < 32) return {0, (s - 24) >> 2, 4 + ((s - 24) & 3)};
+    return {2, (s - 32) >> 3, (s - 32) & 7};
 }
-// NL of the 32 phase-A fragments live in LDS, spread evenly over the slots; the others in accumulator registers
-__host__ __device__ constexpr bool gru_a_is_l(int s, int NL) { return ((s + 1) * NL) / 32 != (s * NL) / 32; }
-__host__ __device__ constexpr int gru_a_lidx(int s, int NL) { return (s * NL) / 32; }
+// 16 of the 48 fragments of a wave live in LDS (every third slot), 32 in accumulator registers
+__host__ __device__ constexpr bool gru_is_l(int s) { return s % 3 == 2; }
+__host__ __device__ constexpr int gru_lidx(int s) { return s / 3; }
 
-template <int XMODE, int SAVE, int NLDS>
+template <int XMODE, int SAVE>
 __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, const unsigned bx) {
-    constexpr int G = 3, GH = G * RH, NAA = 32 - NLDS;
+    constexpr int G = 3, GH = G * RH, NLDS = 16;
     static_assert(XMODE != MVAE_X_SCALAR, "scalar inputs run on the phased kernel");
-    static_assert(NLDS >= 0 && NLDS <= 16, "LDS-resident fragments");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* hbuf = smem;                                             // [2][16][RH] bf16, swizzled
     unsigned char* rhbuf = smem + 2 * 16 * RH * 2;                          // [16][RH]
     frag* ulds = reinterpret_cast<frag*>(smem + 3 * 16 * RH * 2);           // [8][NLDS][64]
     const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                 // 0..7: units [32w, 32w + 32)
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                 // 0..7: unit tiles w and 8 + w
     const int T = a.T, B = a.B;
     const int b = bx * 16 + r;
     const size_t tps = (size_t)(B / 16);
     const frag* __restrict__ up = reinterpret_cast<const frag*>(a.u_pack);
     frag* myl = ulds + (size_t)w * NLDS * 64 + l;
     auto src_frag = [&](int g, int n, int ks) -> const frag* {
-        return up + (size_t)((g * (RH / 16) + w * 2 + n) * 8 + ks) * 64 + l;
+        return up + (size_t)((g * (RH / 16) + n * 8 + w) * 8 + ks) * 64 + l;
     };
-    frag ua[NAA > 0 ? NAA : 1], uc[16];
-    static_for<0, 32>(SF_LAMBDA(sc) {
+    // (the register-resident fragments first, un-waited; then the LDS-resident ones as plain loads - interleaved, every plain
+    //  load behind a volatile one would be waited for by itself: 16 round trips in a row)
+    frag ua[32];
+    static_for<0, 48>(SF_LAMBDA(sc) {
         constexpr int s = decltype(sc)::value;
-        constexpr slot_a sa = gru_slot_a(s);
-        if constexpr (gru_a_is_l(s, NLDS)) myl[(size_t)gru_a_lidx(s, NLDS) * 64] = *src_frag(sa.g, sa.n, sa.ks);
-        else load1_agpr_nowait(ua[s - gru_a_lidx(s, NLDS)], src_frag(sa.g, sa.n, sa.ks));
+        constexpr w8_slot sa = gru_slot(s);
+        if constexpr (!gru_is_l(s)) load1_agpr_nowait(ua[s - gru_lidx(s)], src_frag(sa.kind, sa.n, sa.ks));
     });
-    static_for<0, 16>(SF_LAMBDA(sc) {
-        constexpr int s = decltype(sc)::value;
-        load1_agpr_nowait(uc[s], src_frag(2, s >> 3, s & 7));
-    });
+    {
+        frag tmp[NLDS];
+        static_for<0, 48>(SF_LAMBDA(sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr w8_slot sa = gru_slot(s);
+            if constexpr (gru_is_l(s)) tmp[gru_lidx(s)] = *src_frag(sa.kind, sa.n, sa.ks);
+        });
+#pragma unroll
+        for (int i = 0; i < NLDS; ++i) myl[(size_t)i * 64] = tmp[i];
+    }
 
     const int ld0 = a.h0_ld ? a.h0_ld : RH, ldl = a.h_last_ld ? a.h_last_ld : RH;
-    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
-    const int ub0 = w * 32 + q * 4;
-    unsigned hw0 = (unsigned)r * 512u + ((((unsigned)w * 4u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned lane8 = (unsigned)l * 8u;
+    unsigned lane16 = (unsigned)l * 16u;                                  // TILE16Q: this wave's tiles w and 8 + w are pair w
+    const int ub0 = w * 16 + q * 4;
+    // h tile write position of tile a (tile b: + 256 bytes); B fragment k-group ks: bf4[ks & 3] + 256 * (ks >> 2)
+    unsigned hw0 = (unsigned)r * 512u + ((((unsigned)w * 2u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
     unsigned bf4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf4[j] = (unsigned)r * 512u + ((((unsigned)j * 4u + (unsigned)q) ^ (unsigned)r) << 4);
-    // row-major copy of h_{t-1} (hs slot t): waves 4..7 (one per SIMD), two 16-byte chunks per lane - and only they publish,
-    // so a consumer still counts 4 increments per workgroup and chunk
-    const bool copier = w >= 4;
-    const unsigned row0 = 4u * ((unsigned)w & 3u) + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    // row-major copy of h_{t-1} (hs slot t): one 16-byte chunk per lane, rows 2w and 2w + 1; every wave publishes its own
+    // stores: a consumer counts 8 increments per workgroup and chunk (mvae_rnn_waves())
+    const unsigned row0 = 2u * (unsigned)w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
     unsigned tl0 = row0 * 512u + ((ch0 ^ row0) << 4);
     unsigned tg0 = row0 * 512u + ch0 * 16u;
 
@@ -159,42 +208,51 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub0 + 16 * n) : z4;
-        *reinterpret_cast<u16x4*>(hbuf + (hw0 ^ (n << 5))) = pack4(hreg[n]);
+        hreg[n] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * ld0 + ub0 + 128 * n) : z4;
+        *reinterpret_cast<u16x4*>(hbuf + hw0 + 256 * n) = pack4(hreg[n]);
     }
-    // ---- x queue: requested TWO steps ahead into alternating buffers (the step loop is unrolled by two) ----------------
-    u16x4 xq[2][2][G];
+    // ---- x queue: requested TWO steps ahead into alternating buffers (the step loop is unrolled by two): beside other
+    // kernels an HBM round trip takes longer than the one step a single buffer gives it.  The requests are un-tracked asm loads
+    // and every wait is hand-counted (all waves issue the same memory instructions in the same order, vmcnt retires in issue
+    // order): hipcc's own bookkeeping loses count at the loop header and waits for all but the two youngest instructions there.
+    u16x4 xq[2][2][G];            // [buffer][tile][gate]
+    u16x8 xq8[2][G];              // X_INDEX: one 16-byte gather holds both tiles
+    auto xv = [&](int buf, int n, int g) __attribute__((always_inline)) -> u16x4 {
+        if (XMODE == MVAE_X_INDEX)
+            return n ? __builtin_shufflevector(xq8[buf][g], xq8[buf][g], 4, 5, 6, 7) : __builtin_shufflevector(xq8[buf][g], xq8[buf][g], 0, 1, 2, 3);
+        return xq[buf][n][g];
+    };
+    auto xpin = [&](int buf, int g) __attribute__((always_inline)) {
+        if (XMODE == MVAE_X_INDEX) pin8(xq8[buf][g]);
+        else { pin1(xq[buf][0][g]); pin1(xq[buf][1][g]); }
+    };
     unsigned xoff = 0;
     int i_q = 0;                                  // X_INDEX: the index of step min(t+2, T-1)
     const unsigned char* xbase0;
     if (XMODE == MVAE_X_DENSE) {
         xoff = lane8;
-        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w * 2) * 512;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp) + ((size_t)bx * (GH / 16) + w) * 512;
     } else if (XMODE == MVAE_X_INDEX) {
-        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 16;         // MVAE_TABLE_PAIRED: this wave's tile pair in one 16-byte gather
+        xoff = (unsigned)a.idx[b] * (GH * 2) + q * 16;         // MVAE_TABLE_PAIRED8: this wave's tiles w and 8 + w in one 16-byte gather
         xbase0 = reinterpret_cast<const unsigned char*>(a.table) + w * 64;
         i_q = a.idx[(size_t)(T > 2 ? 2 : T - 1) * B + b];
     } else {
         xoff = (unsigned)b * (GH * 2) + q * 8;
-        xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 64;
+        xbase0 = reinterpret_cast<const unsigned char*>(a.xp0) + w * 32;
     }
     const int cs_steps = a.chunk_steps;
     const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
     int pk = 0, phi = cs_steps;
     if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready, wait_value, a.status);
-    constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;
-    constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 512 : 32;
+    constexpr unsigned XG = XMODE == MVAE_X_DENSE ? (RH / 16) * 512 : RH * 2;      // gate stride
+    constexpr unsigned XN = XMODE == MVAE_X_DENSE ? 8 * 512 : 256;                  // tile a -> tile b
     const size_t x_step1 = (XMODE == MVAE_X_DENSE && T > 1) ? tps * (GH / 16) * 512 : 0;
     const unsigned xoff1 = XMODE == MVAE_X_INDEX ? (unsigned)a.idx[(size_t)(T > 1 ? 1 : 0) * B + b] * (GH * 2) + q * 16 : xoff;
     if (XMODE == MVAE_X_INDEX) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const u16x8 p0 = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + xoff);
-            const u16x8 p1 = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + xoff1);
-            xq[0][0][g] = __builtin_shufflevector(p0, p0, 0, 1, 2, 3);
-            xq[0][1][g] = __builtin_shufflevector(p0, p0, 4, 5, 6, 7);
-            xq[1][0][g] = __builtin_shufflevector(p1, p1, 0, 1, 2, 3);
-            xq[1][1][g] = __builtin_shufflevector(p1, p1, 4, 5, 6, 7);
+            xq8[0][g] = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + xoff);
+            xq8[1][g] = *reinterpret_cast<const u16x8*>(xbase0 + g * XG + xoff1);
         }
     } else {
 #pragma unroll
@@ -205,6 +263,10 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
                 if (XMODE != MVAE_X_CONST) xq[1][n][g] = *reinterpret_cast<const u16x4*>(xbase0 + x_step1 + g * XG + n * XN + xoff1);
             }
     }
+    // memory instructions per step, in issue order: [candidate save] r requests [h copy] z, candidate requests [index] [r save] [z save]
+    constexpr int V_SV = SAVE == SAVE_ALL ? 1 : 0, V_CP = SAVE >= SAVE_HS ? 1 : 0, V_IX = XMODE == MVAE_X_INDEX ? 1 : 0;
+    constexpr int V_RQ = XMODE == MVAE_X_CONST ? 0 : (XMODE == MVAE_X_INDEX ? 1 : 2);      // requests per gate
+    constexpr int V_STEP = 3 * V_SV + 3 * V_RQ + V_CP + V_IX;
 
     gbyte *acts_p[G], *hs_p, *hh_prev_p;          // step t: saved gates; h_{t-1} (slot t); the candidate tiles of step t-1
     gbyte* x_p[G];                                // step min(t+2, T-1): inputs
@@ -214,157 +276,202 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
         acts_p[g] = to_global(a.acts) + ((size_t)bx * (GH / 32) + g * (RH / 32) + w) * 1024;
         x_p[g] = to_global(xbase0) + g * XG + (XMODE == MVAE_X_DENSE ? (T > 2 ? 2 : T - 1) * acts_step : 0);
     }
-    hh_prev_p = acts_p[2];
+    hh_prev_p = acts_p[2];                        // (step 0 stores a placeholder where its own candidate goes one step later)
     hs_p = to_global(a.hs) + (size_t)bx * 16 * (RH * 2);
 
     constexpr float K2 = 2.8853900817779268f;
+    // step -1 of tile b: candidate 0 and z = 1 make the deferred h update reproduce h0 exactly (0 + 1 * (h0 - 0))
     f32x4 accR[2], accZ[2], accC[2];
-    u16x8 hh_pk = u16x8{0, 0, 0, 0, 0, 0, 0, 0};  // candidate of the previous step (this wave's tile pair), stored during phase A
-    frag bA[8], lt[2], cp[2];
+    accC[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accC[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accZ[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+    frag bh[8], lt[2], cp;     // B fragments: h k-groups 0..7, then (dead registers first) r*h: 0..3 behind barrier 1, 4..7 behind slot 31
     vm_drain();
     lds_barrier();
     if (W8_PRIO && w >= 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bh[ks] = *reinterpret_cast<const frag*>(hbuf + bf4[ks]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) accR[n] = unpack4(xv(0, n, 1));
+
+    // tanh + h update for one element of tile n (accC[n] = candidate pre-activation, accZ[n] = z); the candidate stays in accC
+    // in STAGES over the four elements of a tile (a stage per MFMA slot): one element's chain mul -> exp -> add -> rcp -> fma ->
+    // sub -> fma is seven dependent instructions; four chains side by side are four independent instructions per link
+    auto h_stage = [&](int n, int stage) __attribute__((always_inline)) {
+        if (W8_ABL_NOMATH) return;
+        // (element by element: arithmetic on the vector types becomes v_pk_*_f32, which costs a SIMD that also issues MFMAs
+        //  ~16 cycles per instruction - tools/probes/issue2_probe.hip - against ~4.4 for a plain VALU instruction)
+        f32x4& c = accC[n];
+        if (stage == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_exp2f(c[e] * K2);
+        } else if (stage == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_rcpf(c[e] + 1.0f);
+        } else if (stage == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c[e] = __builtin_fmaf(c[e], -2.0f, 1.0f);                          // the candidate (kept for the save)
+                hreg[n][e] = __builtin_fmaf(accZ[n][e], hreg[n][e] - c[e], c[e]);  // z*h + (1-z)*hh
+            }
+        }
+    };
+    auto mul4 = [&](const f32x4& x, const f32x4& y) __attribute__((always_inline)) {
+        return f32x4{x[0] * y[0], x[1] * y[1], x[2] * y[2], x[3] * y[3]};
+    };
 
     auto step = [&](const int t, auto parc) __attribute__((always_inline)) {
         constexpr int PAR = decltype(parc)::value;                     // t & 1: h_{t-1} sits in h buffer PAR
         constexpr int XB = XMODE == MVAE_X_CONST ? 0 : PAR;            // the buffer holding this step's inputs
+        constexpr int XNX = XMODE == MVAE_X_CONST ? 0 : 1 - PAR;       // ... the next step's
         unsigned char* hcur = hbuf + PAR * 8192;
         unsigned char* hnext = hbuf + (1 - PAR) * 8192;
         pinu(hw0); pinu(tl0);
+        // pipelined stack: x of step t+2 is requested during this step - its chunk must have been published
         if (XMODE == MVAE_X_DENSE && cs_steps && a.wait_ready && t + 2 < T && t + 2 == phi)
             wave_wait_ge(uniform_ptr(a.wait_ready + pk + 1), wait_value, a.status);
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(hh_prev_p);
         pins(x_p[0]); pins(x_p[1]); pins(x_p[2]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) { pin1(xq[XB][n][0]); pin1(xq[XB][n][1]); pin1(xq[XB][n][2]); }
-        if (XMODE == MVAE_X_INDEX) pini(i_q);
-        // ---- phase A ------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (!W8_ABL_NOB || t == 0) bA[ks] = *reinterpret_cast<const frag*>(hcur + bf4[ks & 3] + 256 * (ks >> 2));
-        if (NLDS > 0 && !W8_ABL_NOL) lt[0] = myl[0];
-        if (NLDS > 1 && !W8_ABL_NOL) lt[1] = myl[64];
-        if (SAVE >= SAVE_HS && copier) {
-            cp[0] = *reinterpret_cast<const frag*>(hcur + tl0);
-            cp[1] = *reinterpret_cast<const frag*>(hcur + (tl0 ^ 1056u));
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            accZ[n] = unpack4(xq[XB][n][0]);
-            accR[n] = unpack4(xq[XB][n][1]);
-        }
-        asm volatile("s_nop 1" : "+v"(accR[0]), "+v"(accR[1]), "+v"(accZ[0]), "+v"(accZ[1]));
+        // this step's z and candidate inputs were requested two steps ago: everything but the previous step's instructions has retired
+        if (XMODE != MVAE_X_CONST) vm_wait<V_STEP + V_IX + 2 * V_SV>();
+        xpin(XB, 0); xpin(XB, 2);
+        lt[0] = myl[0];
+        lt[1] = myl[64];
+        asm volatile("s_nop 1" : "+v"(accR[0]), "+v"(accR[1]));
         auto request_x = [&](int n, int g) __attribute__((always_inline)) {
-            if (XMODE == MVAE_X_INDEX) {
-                if (n & 1) return;
-                if (g == 0) xoff = (unsigned)i_q * (GH * 2) + q * 16;
+            if (XMODE == MVAE_X_CONST) return;
+            if (XMODE == MVAE_X_INDEX) {              // one gather per gate: both tiles of this wave
+                if (n) return;
+                if (g == 1) {                         // (the first request of a step) the index was loaded one step ago
+                    vm_wait<3 * V_SV>();
+                    pini(i_q);
+                    xoff = (unsigned)i_q * (GH * 2) + q * 16;
+                }
                 pinu(xoff);
-                const u16x8 pr = *reinterpret_cast<const g_u16x8*>(x_p[g] + xoff);
-                xq[XB][0][g] = __builtin_shufflevector(pr, pr, 0, 1, 2, 3);
-                xq[XB][1][g] = __builtin_shufflevector(pr, pr, 4, 5, 6, 7);
-            } else if (XMODE != MVAE_X_CONST) {
+                xload16(xq8[XB][g], x_p[g], xoff);
+            } else {
                 pinu(xoff);
-                xq[XB][n][g] = *reinterpret_cast<const g_u16x4*>(x_p[g] + n * XN + xoff);
+                xload8(xq[XB][n][g], x_p[g] + n * XN, xoff);
             }
         };
-        static_for<0, 32>(SF_LAMBDA(slc) {
+        static_for<0, 48>(SF_LAMBDA(slc) {
             constexpr int sl = decltype(slc)::value;
-            constexpr slot_a sa = gru_slot_a(sl);
-            constexpr bool isl = gru_a_is_l(sl, NLDS);
-            constexpr int li = gru_a_lidx(sl, NLDS);
-            f32x4& acc = sa.g == 1 ? accR[sa.n] : accZ[sa.n];
-            if constexpr (isl && W8_ABL_NOL) {
-                mfma1<true>(acc, uc[li], bA[sa.ks]);
-            } else if constexpr (isl) {
-                mfma1<false>(acc, lt[li & 1], bA[sa.ks]);
-                if constexpr (li + 2 < NLDS) lt[li & 1] = myl[(size_t)(li + 2) * 64];
+            constexpr w8_slot sa = gru_slot(sl);
+            constexpr int li = gru_lidx(sl);
+            f32x4& acc = sa.kind == 1 ? accR[sa.n] : (sa.kind == 0 ? accZ[sa.n] : accC[sa.n]);
+            const frag& bop = bh[sa.ks];
+            if constexpr (gru_is_l(sl) && W8_ABL_NOL) {
+                mfma1<true>(acc, ua[li], bop);
+            } else if constexpr (gru_is_l(sl)) {
+                mfma1<false>(acc, lt[li & 1], bop);
+                lt[li & 1] = myl[(size_t)((li + 2) & 15) * 64];
             } else {
-                mfma1<true>(acc, ua[NAA > 0 ? sl - li : 0], bA[sa.ks]);
+                mfma1<true>(acc, ua[sl - li], bop);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- fillers ----
-            if constexpr (sl == 1) {
-                if (SAVE == SAVE_ALL && t > 0) {
+            // ---- fillers ---------------------------------------------------------------------------------------------
+            if constexpr (sl == 0) { W8_STAMP(0); }
+            if constexpr (sl == 15) { W8_STAMP(4); }
+            if constexpr (sl == 23) { W8_STAMP(5); }
+            if constexpr (sl == 31) { W8_STAMP(8); }
+            if constexpr (sl == 39) { W8_STAMP(9); }
+            if constexpr (sl == 0) accZ[0] = unpack4(xv(XB, 0, 0));
+            if constexpr (sl >= 3 && sl < 6) h_stage(1, sl - 3);          // tile b of step t-1 (its last MFMA: slot 47)
+            if constexpr (sl == 6) *reinterpret_cast<u16x4*>(hcur + hw0 + 256) = pack4(hreg[1]);
+            if constexpr (sl == 7) {
+                W8_STAMP(2);
+                w8_barrier();                                             // ---- 2b: h_{t-1} is complete in hcur
+                W8_STAMP(3);
+#pragma unroll
+                for (int ks = 4; ks < 8; ++ks)
+                    if (!W8_ABL_NOB) bh[ks] = *reinterpret_cast<const frag*>(hcur + bf4[ks & 3] + 256);
+                if (SAVE >= SAVE_HS) cp = *reinterpret_cast<const frag*>(hcur + tl0);
+            }
+            if constexpr (sl == 8) {                                      // the candidate of step t-1 (both tiles), then its registers
+                if (SAVE == SAVE_ALL) {                                   // start the next accumulation
                     pinu(lane16);
-                    *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = hh_pk;
+                    *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = cat8(pack4(accC[0]), pack4(accC[1]));
                 }
+                accZ[1] = unpack4(xv(XB, 1, 0));
             }
-            if constexpr (sl == 3 || sl == 5) {
-                if (SAVE >= SAVE_HS && copier) {
+            if constexpr (sl == 9) {
+                accC[0] = unpack4(xv(XB, 0, 2));
+                accC[1] = unpack4(xv(XB, 1, 2));
+            }
+            if constexpr (sl == 13) {
+                if (SAVE >= SAVE_HS) {
                     pinu(tg0);
-                    store16_wt(hs_p, tg0 + (sl == 5 ? 1024u : 0u), cp[sl == 5 ? 1 : 0]);
+                    store16_wt(hs_p, tg0, cp);
                 }
             }
-            if constexpr (sl >= 8 && sl < 16 && (sl & 1) == 0) {       // the z / r inputs of step t+2
-                constexpr int k = (sl - 8) >> 1;
-                request_x(k >> 1, k & 1);
+            // the inputs of step t+2 (this step's are consumed: r at the end of the previous step, z and candidate above)
+            if constexpr (sl == 10) request_x(0, 1);
+            if constexpr (sl == 11) request_x(1, 1);
+            if constexpr (sl == 12) request_x(0, 0);
+            if constexpr (sl == 14) request_x(1, 0);
+            if constexpr (sl == 15) request_x(0, 2);
+            if constexpr (sl == 16) request_x(1, 2);
+            if constexpr (sl == 17) {
+                if (XMODE == MVAE_X_INDEX) iload1(i_q, a.idx + (size_t)(t + 3 < T ? t + 3 : T - 1) * B + b);
             }
-            // r of tiles 0, 1 (their last MFMA was slot 20 / 21): hard_sigmoid, r*h -> rh tile
-            if constexpr (sl == 24 || sl == 26) {
-                constexpr int n = (sl - 24) >> 1;
+            // r (tile a: last MFMA slot 19, tile b: 23): hard_sigmoid, r*h -> rh tile
+            if constexpr (sl == 22 || sl == 26) {
+                constexpr int n = sl == 26;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (!W8_ABL_NOMATH) accR[n][e] = hsig(accR[n][e]);
             }
-            if constexpr (sl == 25 || sl == 27) {
-                constexpr int n = (sl - 25) >> 1;
-                if (!W8_ABL_NOMATH) *reinterpret_cast<u16x4*>(rhbuf + (hw0 ^ (n << 5))) = pack4(accR[n] * hreg[n]);
+            if constexpr (sl == 23 || sl == 27) {
+                constexpr int n = sl == 27;
+                if (!W8_ABL_NOMATH) *reinterpret_cast<u16x4*>(rhbuf + hw0 + 256 * n) = pack4(mul4(accR[n], hreg[n]));
             }
-            if constexpr (sl == 28) {
+            if constexpr (sl == 27) {
+                W8_STAMP(6);
+                w8_barrier();                                             // ---- 1: r*h is complete
+                W8_STAMP(7);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    if (!W8_ABL_NOB) bh[ks] = *reinterpret_cast<const frag*>(rhbuf + bf4[ks]);
+            }
+            if constexpr (sl == 31) {
+#pragma unroll
+                for (int ks = 4; ks < 8; ++ks)
+                    if (!W8_ABL_NOB) bh[ks] = *reinterpret_cast<const frag*>(rhbuf + bf4[ks & 3] + 256);
+            }
+            if constexpr (sl == 29) {
                 if (SAVE == SAVE_ALL) {
                     pinu(lane16);
                     *reinterpret_cast<g_u16x8*>(acts_p[1] + lane16) = cat8(pack4(accR[0]), pack4(accR[1]));
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        w8_barrier();
-        // ---- phase C ------------------------------------------------------------------------------------------------
+            // z (tile a: last MFMA slot 27, tile b: 31)
+            if constexpr (sl == 33 || sl == 35) {
+                constexpr int n = sl == 35;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (!W8_ABL_NOB) bA[ks] = *reinterpret_cast<const frag*>(rhbuf + bf4[ks & 3] + 256 * (ks >> 2));
-#pragma unroll
-        for (int n = 0; n < 2; ++n) accC[n] = unpack4(xq[XB][n][2]);
-        asm volatile("s_nop 1" : "+v"(accC[0]), "+v"(accC[1]));
-        // candidate -> h for one element of tile n
-        auto h_math = [&](int n, int e) __attribute__((always_inline)) {
-            if (W8_ABL_NOMATH) return;
-            const float ex = __builtin_amdgcn_exp2f(accC[n][e] * K2);
-            const float hh = 1.0f - 2.0f * __builtin_amdgcn_rcpf(ex + 1.0f);
-            accC[n][e] = hh;                                       // kept for the save
-            hreg[n][e] = hh + accZ[n][e] * (hreg[n][e] - hh);      // z*h + (1-z)*hh
-        };
-        static_for<0, 16>(SF_LAMBDA(slc) {
-            constexpr int sl = decltype(slc)::value, n = sl >> 3, ks = sl & 7;
-            mfma1<true>(accC[n], uc[sl], bA[ks]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (sl == 3 || sl == 4) {                    // z (its last MFMA was phase A's slot 30 / 31)
-                constexpr int m = sl - 3;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (!W8_ABL_NOMATH) accZ[m][e] = hsig(accZ[m][e]);
+                for (int e = 0; e < 4; ++e) if (!W8_ABL_NOMATH) accZ[n][e] = hsig(accZ[n][e]);
             }
-            if constexpr (sl == 5) {
+            if constexpr (sl == 37) {
                 if (SAVE == SAVE_ALL) {
                     pinu(lane16);
                     *reinterpret_cast<g_u16x8*>(acts_p[0] + lane16) = cat8(pack4(accZ[0]), pack4(accZ[1]));
                 }
             }
-            if constexpr (sl == 6 || sl == 7) request_x(sl - 6, 2);        // the candidate inputs of step t+2
-            if constexpr (sl == 8) {
-                if (XMODE == MVAE_X_INDEX) i_q = a.idx[(size_t)(t + 3 < T ? t + 3 : T - 1) * B + b];
+            if constexpr (sl >= 43 && sl < 46) h_stage(0, sl - 43);        // tile a (its last MFMA: slot 39)
+            if constexpr (sl == 46) *reinterpret_cast<u16x4*>(hnext + hw0) = pack4(hreg[0]);
+            if constexpr (sl == 47) {
+                W8_STAMP(10);
+                w8_barrier();                                             // ---- 2a: the a half of h_t is complete in hnext
+                W8_STAMP(11);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    if (!W8_ABL_NOB) bh[ks] = *reinterpret_cast<const frag*>(hnext + bf4[ks]);
+                // the next step's r inputs: the first requests of the previous step
+                if (XMODE != MVAE_X_CONST) vm_wait<2 * V_STEP - V_SV - V_RQ>();
+                xpin(XNX, 1);
+                accR[0] = unpack4(xv(XNX, 0, 1));
+                accR[1] = unpack4(xv(XNX, 1, 1));
             }
-            if constexpr (sl >= 11 && sl < 15) h_math(0, sl - 11);        // tile 0 (its last MFMA was slot 7)
-            if constexpr (sl == 15) *reinterpret_cast<u16x4*>(hnext + hw0) = pack4(hreg[0]);
             __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_nop 9" : "+v"(accC[1]));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h_math(1, e);
-        *reinterpret_cast<u16x4*>(hnext + (hw0 ^ 32u)) = pack4(hreg[1]);
-        hh_pk = cat8(pack4(accC[0]), pack4(accC[1]));
-        if (t == T - 1 && a.h_last) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub0 + 16 * n) = hreg[n];
-        }
         hh_prev_p = acts_p[2];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -372,9 +479,8 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
             if (XMODE == MVAE_X_DENSE && t + 3 < T) x_p[g] += acts_step;
         }
         hs_p += hs_step;
-        w8_barrier();
         if (cs_steps && t == phi) {
-            if (SAVE >= SAVE_HS && a.signal_done && copier) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
+            if (SAVE >= SAVE_HS && a.signal_done) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
             ++pk;
             phi += cs_steps;
         }
@@ -385,22 +491,36 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
         step(t + 1, std::integral_constant<int, 1>{});
     }
     if (t < T) step(t, std::integral_constant<int, 0>{});
-    if (SAVE == SAVE_ALL) *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = hh_pk;
-    if (SAVE >= SAVE_HS && copier) {       // slot T = h_{T-1}
-        const unsigned char* hfin = hbuf + (T & 1) * 8192;
+    // ---- the deferred half of the last step ----------------------------------------------------------------------------
+    unsigned char* hfin = hbuf + (T & 1) * 8192;
+    asm volatile("s_nop 9" : "+v"(accC[1]));
+#pragma unroll
+    for (int st = 0; st < 3; ++st) h_stage(1, st);
+    *reinterpret_cast<u16x4*>(hfin + hw0 + 256) = pack4(hreg[1]);
+    if (SAVE == SAVE_ALL) *reinterpret_cast<g_u16x8*>(hh_prev_p + lane16) = cat8(pack4(accC[0]), pack4(accC[1]));
+    if (a.h_last) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x4*>(a.h_last + (size_t)b * ldl + ub0 + 128 * n) = hreg[n];
+    }
+    lds_barrier();
+    if (SAVE >= SAVE_HS) {       // slot T = h_{T-1}
         store16_wt(hs_p, tg0, *reinterpret_cast<const u16x8*>(hfin + tl0));
-        store16_wt(hs_p, tg0 + 1024u, *reinterpret_cast<const u16x8*>(hfin + (tl0 ^ 1056u)));
         if (cs_steps && a.signal_done) wave_signal_done<false>(uniform_ptr(a.signal_done + pk));
     }
     vm_drain();
+    // The last steps' requests are never consumed.  Their destination registers must stay allocated until the data has
+    // landed: a dead asm output is a free register to hipcc, and the load would arrive in whatever value was put there next.
+    if (XMODE != MVAE_X_CONST) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) { xpin(0, g); xpin(1, g); }
+        if (XMODE == MVAE_X_INDEX) pini(i_q);
+    }
 }
 
-#ifndef GRU_W8_NLDS
-#define GRU_W8_NLDS 16
-#endif
+constexpr int GRU_W8_NLDS = 16;
 template <int XMODE, int SAVE>
 __global__ __launch_bounds__(512, 1) void gru_fwd_w8_k(const mvae_rnn_fwd_args a) {
-    gru_fwd_w8_body<XMODE, SAVE, GRU_W8_NLDS>(a, blockIdx.x);
+    gru_fwd_w8_body<XMODE, SAVE>(a, blockIdx.x);
 }
 
 template <int XMODE, int SAVE>
@@ -419,7 +539,7 @@ int launch_gru_w8(const mvae_rnn_fwd_args& a, hipStream_t s) {
 }
 template <int XMODE>
 int gru_w8_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
-    if (XMODE == MVAE_X_INDEX && a.table_layout != MVAE_TABLE_PAIRED) return MVAE_E_ARG;
+    if (XMODE == MVAE_X_INDEX && a.table_layout != MVAE_TABLE_PAIRED8) return MVAE_E_ARG;
     if (a.acts) {
         if (!a.hs) return MVAE_E_UNSUPPORTED;
         return launch_gru_w8<XMODE, SAVE_ALL>(a, s);
@@ -432,7 +552,7 @@ int gru_w8_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
 
 // Entry point used by rnn_resident.hip's dispatch.  MVAE_E_UNSUPPORTED: not a shape of this file.
 int mvae_rnn_fwd_w8(const mvae_rnn_fwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16P || a.cell != MVAE_GRU)
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU)
         return MVAE_E_UNSUPPORTED;
     switch (a.xmode) {
         case MVAE_X_DENSE: return a.xp ? gru_w8_save<MVAE_X_DENSE>(a, s) : MVAE_E_ARG;

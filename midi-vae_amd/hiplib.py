@@ -18,13 +18,13 @@ GRU, LSTM, RNN = 0, 1, 2
 F32, BF16, ONEHOT = 0, 1, 2
 X_DENSE, X_INDEX, X_SCALAR, X_CONST = 0, 1, 2, 3
 ACT_NONE, ACT_TANH = 0, 1
-ROWMAJOR, TILE16, TILE16P = 0, 1, 2
-TABLE_ROWMAJOR, TABLE_PAIRED = 0, 1
+ROWMAJOR, TILE16, TILE16P, TILE16Q = 0, 1, 2, 3
+TABLE_ROWMAJOR, TABLE_PAIRED, TABLE_PAIRED8 = 0, 1, 2
 CELL_CODE = {"GRU": GRU, "LSTM": LSTM, "SimpleRNN": RNN}
 GATES = {GRU: 3, LSTM: 4, RNN: 1}
 E_ARG, E_UNSUPPORTED, E_LAUNCH, E_FORMAT = -1, -2, -3, -4
 HOST_F64, HOST_F32, HOST_U8 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERRORS = {-1: "MVAE_E_ARG (bad argument)", -2: "MVAE_E_UNSUPPORTED (shape/dtype not built)",
           -3: "MVAE_E_LAUNCH (HIP launch failed)", -4: "MVAE_E_FORMAT (a row is not one-hot)"}
 
@@ -112,6 +112,7 @@ class LatentChainBwdArgs(C.Structure):
 # name -> (restype, argtypes); every symbol include/midivae_hip.h declares
 SIGNATURES = {
     "mvae_abi_version": (_i32, []),
+    "mvae_rnn_producer_waves": (_i32, [_i32]),
     "mvae_build_info": (C.c_char_p, []),
     "mvae_rnn_fwd": (_i32, [C.POINTER(RnnFwdArgs), _vp]),
     "mvae_rnn_bwd": (_i32, [C.POINTER(RnnBwdArgs), _vp]),

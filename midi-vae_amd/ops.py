@@ -339,8 +339,9 @@ def latent_chain_bwd(B, B_valid, H, Z, C, ncat, zin, n_init, split, beta, prior_
 
 
 def relayout(src, dst, rows, cols, to_tile16, paired=False):
-    """row-major <-> TILE16 (or TILE16P with ``paired``); ``to_tile16`` True = row-major -> tiled"""
-    hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols, int(bool(to_tile16)) + (2 if paired else 0),
+    """row-major <-> TILE16 (TILE16P with ``paired`` True, TILE16Q with ``paired`` == "q"); ``to_tile16`` True = row-major -> tiled"""
+    hl.check(hl.load().mvae_relayout(_p(src), _p(dst), kind_of(src), rows, cols,
+                                     int(bool(to_tile16)) + (4 if paired == "q" else 2 if paired else 0),
                                      _stream()), "mvae_relayout")
 
 
@@ -391,7 +392,7 @@ class PrepBatch:
 
     def make_table(self, W, bias, table, paired=False):
         """table (K, N) = W + bias; ``paired``: the column order the slot-interleaved LSTM / GRU kernels gather (hl.TABLE_PAIRED)"""
-        self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], int(bool(paired)), W, bias)
+        self._add(hl.PREP_MAKE_TABLE, table, W.shape[0], W.shape[1], 2 if paired == 8 else int(bool(paired)), W, bias)
 
     def transpose_convert(self, W, out, n_pad=None):
         K, N = W.shape

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), "header declares %s but the library does not export it" % name
         assert name in hl.SIGNATURES, "binding misses %s" % name
     assert set(hl.SIGNATURES) == set(declared)
-    assert lib.mvae_abi_version() == 8
+    assert lib.mvae_abi_version() == 9
     assert b"gfx950" in lib.mvae_build_info()
 
 

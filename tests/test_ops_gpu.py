@@ -34,12 +34,24 @@ def tile16(t, rows, cols, to_tile, paired=False):
     return out
 
 
-def seq_layouts(res, cellname, xmode="dense"):
-    """sequence layouts (= kernel families) to exercise: generic row-major; resident phased (TILE16); and for LSTM
-    without a scalar input also the slot-interleaved kernels (TILE16P: saved activations in tile pairs)"""
+def seq_layouts(res, cellname, xmode="dense", forward=True):
+    """sequence layouts (= kernel families) to exercise: generic row-major; resident phased (TILE16); for LSTM / GRU
+    without a scalar input also the slot-interleaved kernels (TILE16P: saved activations in tile pairs); for GRU the
+    two-waves-per-SIMD kernels (TILE16Q: tiles j and j + 8 paired)"""
     if not res:
         return [hl.ROWMAJOR]
-    return [hl.TILE16, hl.TILE16P] if (cellname in ("LSTM", "GRU") and xmode != "scalar") else [hl.TILE16]
+    lays = [hl.TILE16, hl.TILE16P] if (cellname in ("LSTM", "GRU") and xmode != "scalar") else [hl.TILE16]
+    if cellname == "GRU" and xmode != "scalar" and (forward or W8_BACKWARD):
+        lays.append(hl.TILE16Q)
+    return lays
+
+
+W8_BACKWARD = False      # (the two-waves-per-SIMD BPTT kernel)
+
+
+def pairing(lay):
+    """the ``paired`` argument of tile16() / ops.relayout for a sequence layout's saved activations"""
+    return "q" if lay == hl.TILE16Q else lay == hl.TILE16P
 
 
 def resident(H, B, dtype, cell):
@@ -65,6 +77,16 @@ def _rnn_problem(cellname, H, T, B, seed, K=7):
     h0 = rng.standard_normal((B, H)) * 0.3
     c0 = rng.standard_normal((B, H)) * 0.3
     return rng, G, U, W, b, h0, c0
+
+
+def _paired8_columns(table):
+    """MVAE_TABLE_PAIRED8: inside every block of 256 columns, column 128 h + 16 j + 4 q + e moves to 32 j + 8 q + 4 h + e"""
+    K, N = table.shape
+    c = np.arange(N)
+    dst = (c & ~255) + ((c >> 4) & 7) * 32 + ((c & 15) >> 2) * 8 + ((c >> 7) & 1) * 4 + (c & 3)
+    out = np.empty_like(table)
+    out[:, dst] = table
+    return out
 
 
 def _paired_columns(table):
@@ -142,19 +164,82 @@ def test_rnn_forward(cellname, cell, dtype, tol, xmode, H, B):
             # the slot-interleaved LSTM / GRU kernels gather tile pairs: MVAE_TABLE_PAIRED column order (include/midivae_hip.h), built
             # here in NumPy - the device's own permutation (PrepBatch.make_table(paired=True)) is checked against it below
             kwl["table"], kwl["table_layout"] = dev(_paired_columns(host(kw["table"])), td), hl.TABLE_PAIRED
+        if xmode == "index" and lay == hl.TILE16Q:
+            kwl["table"], kwl["table_layout"] = dev(_paired8_columns(host(kw["table"])), td), hl.TABLE_PAIRED8
         ops.rnn_fwd(cell, dtype, T, B, H, up, h0=dev(h0), c0=dev(c0) if cellname == "LSTM" else None, hs=hs, cs=cs,
                     acts=acts, h_last=h_last, seq_layout=lay, **kwl)
         torch.cuda.synchronize()
         if res:
-            acts = tile16(acts, T * B, GH, False, paired=lay == hl.TILE16P)
+            acts = tile16(acts, T * B, GH, False, paired=pairing(lay))
             if cs is not None:
-                cs = tile16(cs, (T + 1) * B, H, False, paired=lay == hl.TILE16P)
+                cs = tile16(cs, (T + 1) * B, H, False, paired=pairing(lay))
         what = " (layout %d)" % lay
         close(host(hs), hs_o, tol, "hs" + what)
         close(host(acts), acts_o, tol, "acts" + what)
         close(host(h_last), hs_o[-1], tol, "h_last" + what)
         if cs is not None:
             close(host(cs), cs_o, tol, "cs" + what)
+
+
+@pytest.mark.parametrize("xmode", ["dense", "index", "const"])
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 7, 33])
+def test_gru_forward_two_waves_per_simd_short_odd_and_long(xmode, T):
+    """rnn_w8.hip (seq_layout TILE16Q): the step loop is unrolled by two with half of every step deferred into the next one and
+    hand-counted memory waits - lengths 1..7 and a longer odd one, every input mode, training / h-sequence-only / inference saves."""
+    H, B, cellname, cell = 256, 48, "GRU", hl.GRU
+    rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=100 + T)
+    GH, td = G * H, torch.bfloat16
+    kw = {}
+    if xmode == "dense":
+        xp = host(dev(rng.standard_normal((T, B, GH)) * 0.5, td))
+        kw["xp"] = tile16(dev(xp, td), T * B, GH, True)
+    elif xmode == "index":
+        idx = rng.integers(0, 61, (T, B))
+        table = host(dev(rng.standard_normal((61, GH)) * 0.5, td))
+        xp = table[idx]
+        kw.update(idx=dev(idx, torch.uint8), table=dev(_paired8_columns(table), td), table_layout=hl.TABLE_PAIRED8)
+    else:
+        xp0 = host(dev(rng.standard_normal((B, GH)) * 0.5, td))
+        xp = np.broadcast_to(xp0[None], (T, B, GH)).copy()
+        kw["xp0"] = dev(xp0, td)
+    hs_o, _, acts_o = vo.rnn_forward(cellname, xp, U, h0, None)
+    up = ops.pack_recurrent(dev(U), cell, hl.BF16, 0)
+    tol = dict(DTYPES)[hl.BF16]
+    for save in ("all", "hs", "none"):
+        hs = torch.zeros((T + 1, B, H), dtype=td, device=DEV) if save != "none" else None
+        acts = torch.zeros((T, B, GH), dtype=td, device=DEV) if save == "all" else None
+        h_last = torch.zeros((B, H), device=DEV)
+        ops.rnn_fwd(cell, hl.BF16, T, B, H, up, h0=dev(h0), hs=hs, acts=acts, h_last=h_last, seq_layout=hl.TILE16Q, **kw)
+        torch.cuda.synchronize()
+        close(host(h_last), hs_o[-1], tol, "h_last (%s)" % save)
+        if hs is not None:
+            close(host(hs), hs_o, tol, "hs (%s)" % save)
+        if acts is not None:
+            close(host(tile16(acts, T * B, GH, False, paired="q")), acts_o, tol, "acts")
+
+
+def test_paired8_table_and_tile16q_relayout():
+    """the device's MVAE_TABLE_PAIRED8 permutation and the TILE16Q relayout against their definitions in include/midivae_hip.h"""
+    rng = np.random.default_rng(5)
+    K, N = 61, 768
+    W, b = rng.standard_normal((K, N)), rng.standard_normal(N)
+    tab, plain = (torch.zeros((K, N), dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    pb = ops.PrepBatch()
+    pb.make_table(dev(W), dev(b), tab, paired=8)
+    pb.make_table(dev(W), dev(b), plain)
+    pb.run()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(host(tab), _paired8_columns(host(plain)))
+    rows, cols = 32, 768
+    a = rng.standard_normal((rows, cols))
+    m, c = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    off = (((m // 16) * (cols // 32) + (c // 256) * 8 + (c // 16) % 8) * 64 + ((c % 16) // 4) * 16 + m % 16) * 8 + ((c // 128) % 2) * 4 + c % 4
+    want = np.empty(rows * cols)
+    want[off.ravel()] = host(dev(a, torch.bfloat16)).ravel()
+    got = tile16(dev(a, torch.bfloat16), rows, cols, True, paired="q")
+    np.testing.assert_array_equal(host(got).ravel(), want)
+    back = tile16(got, rows, cols, False, paired="q")
+    np.testing.assert_array_equal(host(back), host(dev(a, torch.bfloat16)))
 
 
 def test_rnn_forward_zero_initial_state_and_inference_mode():
@@ -201,7 +286,7 @@ def _rnn_backward_case(cellname, cell, dtype, tol, H, B, ext, T):
 
     ut = ops.pack_recurrent(dev(U), cell, dtype, 1)
     res = resident(H, B, dtype, cell)
-    for lay in seq_layouts(res, cellname):
+    for lay in seq_layouts(res, cellname, forward=False):
         da = torch.zeros((T, B, GH), dtype=td, device=DEV)
         rh = torch.zeros((T, B, H), dtype=td, device=DEV)
         dh0 = torch.zeros((B, H), device=DEV)
@@ -209,7 +294,7 @@ def _rnn_backward_case(cellname, cell, dtype, tol, H, B, ext, T):
         acts_d, cs_d = dev(acts_o, td), dev(cs_o, td) if cs_o is not None else None
         dext_d = dev(dext, td) if ext else None
         if res:
-            pr = lay == hl.TILE16P
+            pr = pairing(lay)
             acts_d = tile16(acts_d, T * B, GH, True, paired=pr)
             cs_d = tile16(cs_d, (T + 1) * B, H, True, paired=pr) if cs_d is not None else None
             dext_d = tile16(dext_d, T * B, H, True) if ext else None

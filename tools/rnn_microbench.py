@@ -25,11 +25,14 @@ ap.add_argument("--cu-mask", default="", help="streams restricted to a set of CU
                 "other CU of each shader engine, 'low' = the first half, 'single16' / 'pairs16' = 16 CUs as 16 different CU indices' "
                 "first / as 8 neighbouring pairs, or comma-separated hex words")
 ap.add_argument("--phased", action="store_true", help="LSTM: phased resident kernels (TILE16) instead of the slot-interleaved ones")
+ap.add_argument("--w8", action="store_true", help="GRU: the two-waves-per-SIMD kernels (seq_layout TILE16Q); forward only until the BPTT exists")
 a = ap.parse_args()
 cell = hl.CELL_CODE[a.cell]
 a.rowmajor = a.rowmajor or a.f32
 DT = hl.F32 if a.f32 else hl.BF16
 LAY = hl.ROWMAJOR if a.rowmajor else (hl.TILE16 if (a.phased or a.cell not in ("LSTM", "GRU")) else hl.TILE16P)
+if a.w8:
+    LAY = hl.TILE16Q
 G, H, T, B = hl.GATES[cell], 256, a.T, a.B
 GH = G * H
 dev = "cuda:0"
@@ -119,12 +122,14 @@ modes = {"dense": dict(xp=xp), "index": dict(idx=idx, table=table), "scalar": di
          "const": dict(xp0=xp0)}
 flop = 2.0 * B * H * GH * T
 for name, kw in modes.items():
-    lay = hl.TILE16 if (name == "scalar" and LAY == hl.TILE16P) else LAY
+    lay = hl.TILE16 if (name == "scalar" and LAY in (hl.TILE16P, hl.TILE16Q)) else LAY
     if name == "index" and a.cell in ("LSTM", "GRU") and lay == hl.TILE16P:      # (random values: any column order times the same)
         kw = dict(kw, table_layout=hl.TABLE_PAIRED)
+    if name == "index" and lay == hl.TILE16Q:
+        kw = dict(kw, table_layout=hl.TABLE_PAIRED8)
     ms = timeit(conc(lambda c: ops.rnn_fwd(cell, DT, T, B, H, up, hs=c["hs"] if c else hs, cs=c["cs"] if c else cs,
                                            acts=c["acts"] if c else acts, h_last=hl_, seq_layout=lay,
-                                           **(sig if lay == hl.TILE16P else {}), **kw)))
+                                           **(sig if lay in (hl.TILE16P, hl.TILE16Q) else {}), **kw)))
     print("fwd %-6s %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (name, ms, ms * 1e3 / T, flop / ms / 1e9))
 ms = timeit(conc(lambda c: ops.rnn_fwd(cell, DT, T, B, H, up, h_last=hl_, xp0=xp0, seq_layout=LAY)))
 print("fwd const (inference, no saves) %7.3f ms  %6.2f us/step" % (ms, ms * 1e3 / T))
@@ -136,5 +141,7 @@ def bwd_call(c, ext):
 
 
 for ext in (True, False):
+    if a.w8 and not getattr(hl, "W8_BACKWARD", False):
+        break
     ms = timeit(conc(lambda c: bwd_call(c, ext)))
     print("bwd ext=%d  %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (ext, ms, ms * 1e3 / T, flop / ms / 1e9))
