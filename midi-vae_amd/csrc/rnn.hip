@@ -568,7 +568,7 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
     if (!a || !a->u_pack || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
     // time-pipelined stacks: only the slot-interleaved kernels (seq_layout TILE16P) poll / publish
     if (a->chunk_steps < 0 || ((a->wait_ready || a->signal_done) && a->chunk_steps == 0)) return MVAE_E_ARG;
-    if ((a->wait_ready || a->signal_done) && a->seq_layout != MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
+    if ((a->wait_ready || a->signal_done) && a->seq_layout != MVAE_TILE16P && a->seq_layout != MVAE_TILE16Q) return MVAE_E_UNSUPPORTED;
     if (a->wait_ready && a->xmode != MVAE_X_DENSE) return MVAE_E_ARG;
     if (a->signal_done && !a->hs) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -586,7 +586,7 @@ extern "C" int mvae_rnn_fwd(const mvae_rnn_fwd_args* a, void* stream) {
 extern "C" int mvae_rnn_bwd(const mvae_rnn_bwd_args* a, void* stream) {
     if (!a || !a->ut_pack || !a->hs || !a->acts || !a->da || a->T <= 0 || a->B <= 0) return MVAE_E_ARG;
     if (a->chunk_steps < 0 || ((a->wait_ready || a->signal_done) && a->chunk_steps == 0)) return MVAE_E_ARG;
-    if ((a->wait_ready || a->signal_done) && a->seq_layout != MVAE_TILE16P) return MVAE_E_UNSUPPORTED;
+    if ((a->wait_ready || a->signal_done) && a->seq_layout != MVAE_TILE16P && a->seq_layout != MVAE_TILE16Q) return MVAE_E_UNSUPPORTED;
     if (a->wait_ready && !a->dhs_ext) return MVAE_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (a->H == 256 && a->dtype == MVAE_BF16 && a->cell != MVAE_RNN) {

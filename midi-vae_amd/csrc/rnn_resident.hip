@@ -2562,7 +2562,9 @@ int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.cell == MVAE_GRU) return fwd_res_xmode<MVAE_GRU>(a, s);
     return MVAE_E_UNSUPPORTED;
 }
+int mvae_rnn_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s);
 int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    if (a.seq_layout == MVAE_TILE16Q) return mvae_rnn_bwd_w8(a, s);
     if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || (a.seq_layout != MVAE_TILE16 && a.seq_layout != MVAE_TILE16P))
         return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) {

@@ -517,6 +517,312 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// GRU backward through time, two waves per SIMD
+// ---------------------------------------------------------------------------------------------------------
+// Per step (t from T-1 down), per unit of this wave's tiles a = w and b = 8 + w, with d = dh_t + the upstream gradient:
+//     da_c = d (1-z)(1-hh^2)     da_z = d (h_{t-1} - hh) hs'(z)          -> da tile (LDS), exchange 1
+//     M1   drh = U_c^T da_c                      (16 MFMA slots, k-groups 16..23 of the packed transposed kernel)
+//     M2z  acc = U_z^T da_z                      (16 slots, k-groups 0..7: nothing of it waits for M1 - its slots carry E2)
+//     E2   da_r = drh h_{t-1} hs'(r) -> da tile, exchange 2;   part = d z + drh r
+//     M2r  acc += U_r^T da_r                     (16 slots, k-groups 8..15);   dh_{t-1} = acc + part
+// What does not depend on dh - unpacking the saved values, (1-z)(1-hh^2), (h_{t-1} - hh) hs'(z) of the NEXT step - runs in
+// the M2r slots; only d, two products per element and the exchange itself are exposed between two steps.
+// Outputs as the 4-wave kernel: da (T,B,3H) and rh = r h_{t-1} (T,B,H) row-major (operands of the parameter-gradient GEMMs):
+// assembled in LDS, one 16-byte chunk per lane, gate and step.
+__host__ __device__ constexpr bool gbw_is_l(int s) { return s % 3 == 2; }
+__host__ __device__ constexpr int gbw_lidx(int s) { return s / 3; }
+// slot s: unit tile n, k-group ks (of the 24 k-groups over the gate columns [z | r | candidate])
+struct gbw_slot { int n, ks; };
+__host__ __device__ constexpr gbw_slot gru_bslot(int s) {
+    if (s < 16) return {s & 1, 16 + (s >> 1)};            // M1
+    if (s < 32) return {s & 1, (s - 16) >> 1};            // M2z
+    return {s & 1, 8 + ((s - 32) >> 1)};                  // M2r
+}
+
+template <bool HAS_EXT>
+__device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, const unsigned bx) {
+    constexpr int G = 3, GH = G * RH, S2 = GH / 32, NLDS = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dabuf = smem;                                              // [16][GH] bf16, swizzled (24 KiB)
+    unsigned char* rhbuf = smem + 16 * GH * 2;                                // [16][RH]
+    frag* ulds = reinterpret_cast<frag*>(smem + 16 * GH * 2 + 16 * RH * 2);   // [8][NLDS][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = bx * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    frag* myl = ulds + (size_t)w * NLDS * 64 + l;
+    auto src_frag = [&](int n, int ks) -> const frag* { return up + (size_t)((n * 8 + w) * S2 + ks) * 64 + l; };
+    frag ua[32];
+    static_for<0, 48>(SF_LAMBDA(sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr gbw_slot sb = gru_bslot(s);
+        if constexpr (!gbw_is_l(s)) load1_agpr_nowait(ua[s - gbw_lidx(s)], src_frag(sb.n, sb.ks));
+    });
+    {
+        frag tmp[NLDS];
+        static_for<0, 48>(SF_LAMBDA(sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr gbw_slot sb = gru_bslot(s);
+            if constexpr (gbw_is_l(s)) tmp[gbw_lidx(s)] = *src_frag(sb.n, sb.ks);
+        });
+#pragma unroll
+        for (int i = 0; i < NLDS; ++i) myl[(size_t)i * 64] = tmp[i];
+    }
+
+    const int ub0 = w * 16 + q * 4;
+    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
+    // da tile (row stride 1536 B): this lane's 4 values of (gate g, tile n) at da_w0 + g * 512 + n * 256;  B fragment of
+    // k-group ks at b_row + (b_ch ^ (ks << 6))
+    unsigned da_w0 = (unsigned)r * (GH * 2) + ((((unsigned)w * 2u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned b_row = (unsigned)r * (GH * 2), b_ch = ((unsigned)q ^ (unsigned)r) << 4;
+    unsigned rw0 = (unsigned)r * 512u + ((((unsigned)w * 2u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    // row-major copies: one 16-byte chunk per lane and gate (row 2w + l/32, chunk l%32 of the gate's 32), one of the rh tile
+    const unsigned row0 = 2u * (unsigned)w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    unsigned cl0 = row0 * (GH * 2) + ((ch0 ^ row0) << 4);        // da tile, gate g: cl0 + g * 512
+    unsigned cg0 = row0 * (GH * 2) + ch0 * 16u;                  // global, gate g: + g * 512
+    unsigned tl0 = row0 * 512u + ((ch0 ^ row0) << 4), tg0 = row0 * 512u + ch0 * 16u;
+    unsigned hp_off = (unsigned)r * (RH * 2) + (unsigned)q * 8u;
+
+    f32x4 dh[2];
+    const int ldl = a.dh_last_ld ? a.dh_last_ld : RH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        dh[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * ldl + ub0 + 128 * n) : z4;
+    }
+    gbyte *acts_p[G], *hs_p, *dx_p, *da_p, *rh_p;
+    const size_t acts_step = tps * (GH / 32) * 1024, dx_step = tps * (RH / 16) * 512, hs_step = (size_t)B * RH * 2,
+                 da_step = (size_t)B * GH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + bx) * (GH / 32) + g * (RH / 32) + w) * 1024;
+    hs_p = to_global(a.hs) + ((size_t)(T - 1) * B + bx * 16) * (RH * 2) + w * 32;             // h_{t-1} = slot t
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + bx) * (RH / 16) + w) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + bx * 16) * (GH * 2);
+    rh_p = to_global(a.rh) + ((size_t)(T - 1) * B + bx * 16) * (RH * 2);
+
+    // pipelined stack bookkeeping, as the 4-wave kernels: chunk pk (first step plo) is the one being processed
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status, 2u);
+    int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;
+    int psig = (cs_steps && a.signal_done) ? plo : -1;
+
+    // saved values: z, r, hh as TILE16Q pairs (elements 0..3 tile a, 4..7 tile b); h_{t-1} (row-major) and the upstream gradient
+    // (TILE16) per tile.  All of a step's seven requests are un-tracked asm loads issued ONE step ahead in a fixed order
+    // [z hh h_a h_b r dx_a dx_b] behind the step's four copy stores; the waits are hand-counted (as in the forward kernel).
+    u16x8 qz, qh, qr;
+    u16x4 qp[2], qd[2];
+    constexpr int V_LD = HAS_EXT ? 7 : 5, V_ST_RH = 1;
+    auto issue_loads = [&]() __attribute__((always_inline)) {
+        pinu(lane16); pinu(hp_off); pinu(lane8);
+        xload16(qz, acts_p[0], lane16);
+        xload16(qh, acts_p[2], lane16);
+        xload8(qp[0], hs_p, hp_off);
+        xload8(qp[1], hs_p + 256, hp_off);
+        xload16(qr, acts_p[1], lane16);
+        if (HAS_EXT) {
+            xload8(qd[0], dx_p, lane8);
+            xload8(qd[1], dx_p + 8 * 512, lane8);
+        }
+    };
+    issue_loads();
+    vm_drain();
+    lds_barrier();
+
+    auto lo4 = [&](const u16x8& v) __attribute__((always_inline)) { return unpack4(__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
+    auto hi4 = [&](const u16x8& v) __attribute__((always_inline)) { return unpack4(__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+    // 0.2 [0 < y < 1] for a saved hard_sigmoid output
+    auto dhs = [&](float y) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f((y - y * y) * 0x1p100f, 0.0f, 0.2f); };
+    // per-step factors of the two products that wait for dh: w1 = (1-z)(1-hh^2), kz = (h_{t-1} - hh) hs'(z)
+    // (z, r and h_{t-1} are unpacked again from the request registers where the MFMA phases use them: the next requests leave late)
+    f32x4 w1[2], kz[2];
+    auto precompute = [&](int n) __attribute__((always_inline)) {
+        const f32x4 z = n ? hi4(qz) : lo4(qz), hh = n ? hi4(qh) : lo4(qh), hp = unpack4(qp[n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w1[n][e] = (1.0f - z[e]) * __builtin_fmaf(-hh[e], hh[e], 1.0f);
+            kz[n][e] = (hp[e] - hh[e]) * dhs(z[e]);
+        }
+    };
+    pin8(qz); pin8(qh); pin1(qp[0]); pin1(qp[1]);
+    precompute(0);
+    precompute(1);
+
+    frag bq[3], lt[2], cp;
+    f32x4 acc1[2], acc2[2], part[2], d[2];
+    auto step = [&](const int t) __attribute__((always_inline)) {
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(da_p);
+        if (HAS_EXT) pins(dx_p);
+        if (a.rh) pins(rh_p);
+        if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status, 2u);
+        // ---- E1 ---------------------------------------------------------------------------------------------------------
+        if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            d[n] = dh[n];
+            if (HAS_EXT) {
+                const f32x4 dx = unpack4(qd[n]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[n][e] += dx[e];
+            }
+            f32x4 dac, daz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dac[e] = d[n][e] * w1[n][e];
+                daz[e] = d[n][e] * kz[n][e];
+            }
+            *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (2 * 512 + n * 256))) = pack4(dac);
+            *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (0 * 512 + n * 256))) = pack4(daz);
+        }
+        w8_barrier();                                                     // ---- 1: da_c, da_z
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (16u << 6)));
+        bq[1] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (17u << 6)));
+        lt[0] = myl[0];
+        lt[1] = myl[64];
+        acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 1" : "+v"(acc1[0]), "+v"(acc1[1]));
+        static_for<0, 48>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value;
+            constexpr gbw_slot sb = gru_bslot(sl);
+            constexpr int li = gbw_lidx(sl), kq = sl >> 1;               // kq: running k-group count 0..23 in order of use
+            f32x4& acc = sl < 16 ? acc1[sb.n] : acc2[sb.n];
+            // B ring of 3: k-group kq + 2 is requested when kq starts (M2r's first two behind barrier 2)
+            if constexpr ((sl & 1) == 0 && kq + 2 < 16) {
+                constexpr int kn = kq + 2, ksn = kn < 8 ? 16 + kn : kn - 8;
+                bq[kn % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((unsigned)ksn << 6)));
+            }
+            if constexpr ((sl & 1) == 0 && kq >= 16 && kq + 2 < 24) {
+                constexpr int kn = kq + 2;
+                bq[kn % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((unsigned)(kn - 8) << 6)));
+            }
+            if constexpr (gbw_is_l(sl) && W8_ABL_NOL) {
+                mfma1<true>(acc, ua[li], bq[kq % 3]);
+            } else if constexpr (gbw_is_l(sl)) {
+                mfma1<false>(acc, lt[li & 1], bq[kq % 3]);
+                lt[li & 1] = myl[(size_t)((li + 2) & 15) * 64];
+            } else {
+                mfma1<true>(acc, ua[sl - li], bq[kq % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fillers ---------------------------------------------------------------------------------------------
+            // the next step's requests (this step's values were last used in slot 22): IN FRONT of this step's copy stores in
+            // issue order - vmcnt retires in order, a load behind a write-through store waits for that store's acknowledgement
+            // (unconditional - at t = 0 step 0's values once more: a request under a branch is an asm output merged with the old
+            //  value behind it, i.e. a register copy of data that has not landed)
+            if constexpr (sl == 23) issue_loads();                        // (acts_p / hs_p / dx_p were moved to step t-1 above)
+            // copies of the da tile's candidate and z columns (final since barrier 1)
+            if constexpr (sl == 24 || sl == 27) {
+                constexpr int g = sl == 24 ? 2 : 0;
+                cp = *reinterpret_cast<const frag*>(dabuf + (cl0 + g * 512));
+            }
+            if constexpr (sl == 26 || sl == 29) {
+                constexpr int g = sl == 26 ? 2 : 0;
+                pinu(cg0);
+                store16_wt(da_p, cg0 + g * 512, cp);
+            }
+            // M2's accumulators start at d z
+            if constexpr (sl == 10 || sl == 12) {
+                constexpr int n = sl == 12;
+                const f32x4 z = n ? hi4(qz) : lo4(qz);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[n][e] = d[n][e] * z[e];
+            }
+            // E2 (M1's last MFMAs: slots 14, 15): r, h_{t-1}: r h -> rh tile;  da_r = drh h hs'(r) -> da tile;  part = drh r
+            if constexpr (sl == 19 || sl == 22) {
+                constexpr int n = sl == 22;
+                const f32x4 rv = n ? hi4(qr) : lo4(qr), hpv = unpack4(qp[n]);
+                f32x4 dar, p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = rv[e] * hpv[e];
+                    dar[e] = acc1[n][e] * hpv[e] * dhs(rv[e]);
+                    part[n][e] = acc1[n][e] * rv[e];
+                }
+                if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + rw0 + 256 * n) = pack4(p);
+                *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (1 * 512 + n * 256))) = pack4(dar);
+            }
+            if constexpr (sl == 31) {
+                w8_barrier();                                             // ---- 2: da_r (and the rh tile)
+                bq[16 % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (8u << 6)));
+                bq[17 % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (9u << 6)));
+                cp = *reinterpret_cast<const frag*>(dabuf + (cl0 + 512u));
+            }
+            if constexpr (sl == 33) {
+                pinu(cg0);
+                store16_wt(da_p, cg0 + 512, cp);
+                if (a.rh) cp = *reinterpret_cast<const frag*>(rhbuf + tl0);
+            }
+            if constexpr (sl == 35) {
+                if (a.rh) {
+                    pinu(tg0);
+                    store16_wt(rh_p, tg0, cp);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(acc2[0]), "+v"(acc2[1]));
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dh[n][e] = acc2[n][e] + part[n][e];
+        da_p -= da_step;
+        if (a.rh) rh_p -= hs_step;
+        // the requests of slot 23 have retired when only the copy stores behind them are outstanding
+        if (a.rh) vm_wait<4>(); else vm_wait<3>();
+        pin8(qz); pin8(qh); pin8(qr); pin1(qp[0]); pin1(qp[1]);
+        precompute(0);
+        precompute(1);
+        // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
+        wave_signal_done_if<false>(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
+        {
+            const bool adv = cs_steps && t == plo;
+            pk -= adv ? 1 : 0;
+            plo -= adv ? cs_steps : 0;
+            pwait = (a.wait_ready && plo > 0) ? plo : -1;
+            psig = a.signal_done ? plo : -1;
+        }
+    };
+    for (int t = T - 1; t >= 0; --t) {
+        // pointers of the saved values move to step t-1 before step t's MFMA phases request them
+#pragma unroll
+        for (int g = 0; g < G; ++g) acts_p[g] -= (t > 0 ? acts_step : 0);
+        hs_p -= (t > 0 ? hs_step : 0);
+        if (HAS_EXT) dx_p -= (t > 0 ? dx_step : 0);
+        step(t);
+    }
+    const int ldd = a.dh0_ld ? a.dh0_ld : RH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 128 * n) = dh[n];
+    vm_drain();
+    pin8(qz); pin8(qh); pin8(qr); pin1(qp[0]); pin1(qp[1]);
+    if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
+}
+template <bool HAS_EXT>
+__global__ __launch_bounds__(512, 1) void gru_bwd_w8_k(const mvae_rnn_bwd_args a) {
+    gru_bwd_w8_body<HAS_EXT>(a, blockIdx.x);
+}
+template <bool HAS_EXT>
+int launch_gru_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    const size_t lds = (size_t)16 * 3 * RH * sizeof(bf16_t) + (size_t)16 * RH * sizeof(bf16_t) + (size_t)8 * 16 * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_w8_k<HAS_EXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((gru_bwd_w8_k<HAS_EXT>), dim3(a.B / 16), dim3(512), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 constexpr int GRU_W8_NLDS = 16;
 template <int XMODE, int SAVE>
 __global__ __launch_bounds__(512, 1) void gru_fwd_w8_k(const mvae_rnn_fwd_args a) {
@@ -550,7 +856,12 @@ int gru_w8_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
 
 }  // namespace
 
-// Entry point used by rnn_resident.hip's dispatch.  MVAE_E_UNSUPPORTED: not a shape of this file.
+int mvae_rnn_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU)
+        return MVAE_E_UNSUPPORTED;
+    return a.dhs_ext ? launch_gru_bwd_w8<true>(a, s) : launch_gru_bwd_w8<false>(a, s);
+}
+// Entry points used by rnn_resident.hip's dispatch.  MVAE_E_UNSUPPORTED: not a shape of this file.
 int mvae_rnn_fwd_w8(const mvae_rnn_fwd_args& a, hipStream_t s) {
     if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU)
         return MVAE_E_UNSUPPORTED;

@@ -46,7 +46,7 @@ def seq_layouts(res, cellname, xmode="dense", forward=True):
     return lays
 
 
-W8_BACKWARD = False      # (the two-waves-per-SIMD BPTT kernel)
+W8_BACKWARD = True       # (the two-waves-per-SIMD BPTT kernel)
 
 
 def pairing(lay):

@@ -141,7 +141,5 @@ def bwd_call(c, ext):
 
 
 for ext in (True, False):
-    if a.w8 and not getattr(hl, "W8_BACKWARD", False):
-        break
     ms = timeit(conc(lambda c: bwd_call(c, ext)))
     print("bwd ext=%d  %7.3f ms  %6.2f us/step  %6.1f TFLOP/s" % (ext, ms, ms * 1e3 / T, flop / ms / 1e9))
