@@ -613,24 +613,31 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
     int psig = (cs_steps && a.signal_done) ? plo : -1;
 
     // saved values: z, r, hh as TILE16Q pairs (elements 0..3 tile a, 4..7 tile b); h_{t-1} (row-major) and the upstream gradient
-    // (TILE16) per tile.  All of a step's seven requests are un-tracked asm loads issued ONE step ahead in a fixed order
-    // [z hh h_a h_b r dx_a dx_b] behind the step's four copy stores; the waits are hand-counted (as in the forward kernel).
+    // (TILE16) per tile.  Un-tracked asm loads, hand-counted waits (as in the forward kernel).  Per step, in issue order:
+    //   slot 0   [z hh h_a h_b] of step t-1: consumed from slot 36 on (factors of the two products that wait for dh).  (The
+    //            same arithmetic in the M1 slots of the next step, fed two steps ahead: 2.00 / 2.18 instead of 1.87 / 2.08 us.)
+    //   slot 23  [r dx_a dx_b] of step t-1: consumed at its E1 / E2
+    //   slots 26, 29, 33, 35  the copy stores (da tile by gate, rh tile) - BEHIND the requests: vmcnt retires in order, a load
+    //   behind a write-through store waits for that store's acknowledgement
     u16x8 qz, qh, qr;
-    u16x4 qp[2], qd[2];
-    constexpr int V_LD = HAS_EXT ? 7 : 5, V_ST_RH = 1;
-    auto issue_loads = [&]() __attribute__((always_inline)) {
-        pinu(lane16); pinu(hp_off); pinu(lane8);
-        xload16(qz, acts_p[0], lane16);
-        xload16(qh, acts_p[2], lane16);
-        xload8(qp[0], hs_p, hp_off);
-        xload8(qp[1], hs_p + 256, hp_off);
+    u16x4 qp[2], qd[2], hpk[2];
+    auto issue_early = [&](size_t back_a, size_t back_h) __attribute__((always_inline)) {
+        pinu(lane16); pinu(hp_off);
+        xload16(qz, acts_p[0] - back_a, lane16);
+        xload16(qh, acts_p[2] - back_a, lane16);
+        xload8(qp[0], hs_p - back_h, hp_off);
+        xload8(qp[1], hs_p - back_h + 256, hp_off);
+    };
+    auto issue_late = [&]() __attribute__((always_inline)) {
+        pinu(lane16); pinu(lane8);
         xload16(qr, acts_p[1], lane16);
         if (HAS_EXT) {
             xload8(qd[0], dx_p, lane8);
             xload8(qd[1], dx_p + 8 * 512, lane8);
         }
     };
-    issue_loads();
+    issue_early(0, 0);
+    issue_late();
     vm_drain();
     lds_barrier();
 
@@ -638,33 +645,52 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
     auto hi4 = [&](const u16x8& v) __attribute__((always_inline)) { return unpack4(__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
     // 0.2 [0 < y < 1] for a saved hard_sigmoid output
     auto dhs = [&](float y) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f((y - y * y) * 0x1p100f, 0.0f, 0.2f); };
-    // per-step factors of the two products that wait for dh: w1 = (1-z)(1-hh^2), kz = (h_{t-1} - hh) hs'(z)
-    // (z, r and h_{t-1} are unpacked again from the request registers where the MFMA phases use them: the next requests leave late)
-    f32x4 w1[2], kz[2];
-    auto precompute = [&](int n) __attribute__((always_inline)) {
-        const f32x4 z = n ? hi4(qz) : lo4(qz), hh = n ? hi4(qh) : lo4(qh), hp = unpack4(qp[n]);
+    // per-step factors of the products that wait for dh: w1 = (1-z)(1-hh^2), kz = (h_{t-1} - hh) hs'(z), z; in 5 pieces per tile
+    f32x4 w1[2], kz[2], zv[2], t_hh, t_hp;
+    auto precompute = [&](int n, int piece) __attribute__((always_inline)) {
+        if (piece == 0) {
+            zv[n] = n ? hi4(qz) : lo4(qz);
+            t_hh = n ? hi4(qh) : lo4(qh);
+        } else if (piece == 1) {
+            t_hp = unpack4(qp[n]);
+            hpk[n] = qp[n];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            w1[n][e] = (1.0f - z[e]) * __builtin_fmaf(-hh[e], hh[e], 1.0f);
-            kz[n][e] = (hp[e] - hh[e]) * dhs(z[e]);
+            for (int e = 0; e < 4; ++e) w1[n][e] = __builtin_fmaf(-t_hh[e], t_hh[e], 1.0f);
+        } else if (piece == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w1[n][e] *= 1.0f - zv[n][e];
+        } else if (piece == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kz[n][e] = (zv[n][e] - zv[n][e] * zv[n][e]) * 0x1p100f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kz[n][e] = (t_hp[e] - t_hh[e]) * __builtin_amdgcn_fmed3f(kz[n][e], 0.0f, 0.2f);
         }
     };
     pin8(qz); pin8(qh); pin1(qp[0]); pin1(qp[1]);
-    precompute(0);
-    precompute(1);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int pc = 0; pc < 5; ++pc) precompute(n, pc);
 
     frag bq[3], lt[2], cp;
-    f32x4 acc1[2], acc2[2], part[2], d[2];
+    f32x4 acc1[2], acc2[2], part[2], d[2], e_rv, e_hp;
+    constexpr int V_LATE = HAS_EXT ? 3 : 1;
+    acc2[0] = dh[0];
+    acc2[1] = dh[1];
     auto step = [&](const int t) __attribute__((always_inline)) {
         pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(hs_p); pins(da_p);
         if (HAS_EXT) pins(dx_p);
         if (a.rh) pins(rh_p);
         if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status, 2u);
-        // ---- E1 ---------------------------------------------------------------------------------------------------------
+        // ---- E1 (exposed): d = dh (+ the upstream gradient), da_c = d w1, da_z = d kz -----------------------------------
+        // r and the upstream gradient of this step: the requests of the previous step's slot 23, only its copy stores behind them
+        if (a.rh) vm_wait<4>(); else vm_wait<3>();
+        pin8(qr);
         if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            d[n] = dh[n];
+            d[n] = acc2[n];
             if (HAS_EXT) {
                 const f32x4 dx = unpack4(qd[n]);
 #pragma unroll
@@ -711,11 +737,40 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- fillers ---------------------------------------------------------------------------------------------
-            // the next step's requests (this step's values were last used in slot 22): IN FRONT of this step's copy stores in
-            // issue order - vmcnt retires in order, a load behind a write-through store waits for that store's acknowledgement
-            // (unconditional - at t = 0 step 0's values once more: a request under a branch is an asm output merged with the old
-            //  value behind it, i.e. a register copy of data that has not landed)
-            if constexpr (sl == 23) issue_loads();                        // (acts_p / hs_p / dx_p were moved to step t-1 above)
+            // (requests are unconditional - at t = 0 step 0's values once more: a request under a branch is an asm output merged
+            //  with the old value behind it, i.e. a register copy of data that has not landed)
+            if constexpr (sl == 0) issue_early(0, 0);                     // (acts_p / hs_p / dx_p were moved to step t-1 above)
+            // M2's accumulators start at d z
+            if constexpr (sl == 10 || sl == 12) {
+                constexpr int n = sl == 12;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[n][e] = d[n][e] * zv[n][e];
+            }
+            // E2 (M1's last MFMAs: slots 14, 15): r, h_{t-1}: r h -> rh tile;  da_r = drh h hs'(r) -> da tile;  part = drh r
+            if constexpr (sl == 16 || sl == 19) {
+                constexpr int n = sl == 19;
+                e_rv = n ? hi4(qr) : lo4(qr);
+                e_hp = unpack4(hpk[n]);
+                f32x4 p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = e_rv[e] * e_hp[e];
+                if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + rw0 + 256 * n) = pack4(p);
+            }
+            if constexpr (sl == 17 || sl == 20) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) e_hp[e] *= dhs(e_rv[e]);
+            }
+            if constexpr (sl == 18 || sl == 21) {
+                constexpr int n = sl == 21;
+                f32x4 dar;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dar[e] = acc1[n][e] * e_hp[e];
+                    part[n][e] = acc1[n][e] * e_rv[e];
+                }
+                *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (1 * 512 + n * 256))) = pack4(dar);
+            }
+            if constexpr (sl == 23) issue_late();
             // copies of the da tile's candidate and z columns (final since barrier 1)
             if constexpr (sl == 24 || sl == 27) {
                 constexpr int g = sl == 24 ? 2 : 0;
@@ -726,32 +781,18 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
                 pinu(cg0);
                 store16_wt(da_p, cg0 + g * 512, cp);
             }
-            // M2's accumulators start at d z
-            if constexpr (sl == 10 || sl == 12) {
-                constexpr int n = sl == 12;
-                const f32x4 z = n ? hi4(qz) : lo4(qz);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc2[n][e] = d[n][e] * z[e];
-            }
-            // E2 (M1's last MFMAs: slots 14, 15): r, h_{t-1}: r h -> rh tile;  da_r = drh h hs'(r) -> da tile;  part = drh r
-            if constexpr (sl == 19 || sl == 22) {
-                constexpr int n = sl == 22;
-                const f32x4 rv = n ? hi4(qr) : lo4(qr), hpv = unpack4(qp[n]);
-                f32x4 dar, p;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p[e] = rv[e] * hpv[e];
-                    dar[e] = acc1[n][e] * hpv[e] * dhs(rv[e]);
-                    part[n][e] = acc1[n][e] * rv[e];
-                }
-                if (a.rh) *reinterpret_cast<u16x4*>(rhbuf + rw0 + 256 * n) = pack4(p);
-                *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (1 * 512 + n * 256))) = pack4(dar);
-            }
             if constexpr (sl == 31) {
                 w8_barrier();                                             // ---- 2: da_r (and the rh tile)
                 bq[16 % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (8u << 6)));
                 bq[17 % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (9u << 6)));
                 cp = *reinterpret_cast<const frag*>(dabuf + (cl0 + 512u));
+                // drh r joins the accumulation here, where the wave has just waited anyway (M2z's last MFMA: slot 31)
+                asm volatile("s_nop 9" : "+v"(acc2[0]), "+v"(acc2[1]));
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[n][e] += part[n][e];
+                asm volatile("s_nop 1" : "+v"(acc2[0]), "+v"(acc2[1]));
             }
             if constexpr (sl == 33) {
                 pinu(cg0);
@@ -764,20 +805,17 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
                     store16_wt(rh_p, tg0, cp);
                 }
             }
+            // the next step's factors: its z, hh, h (slot 0) have retired when only what was issued behind them is outstanding
+            if constexpr (sl == 36) {
+                if (a.rh) vm_wait<V_LATE + 4>(); else vm_wait<V_LATE + 3>();
+                pin8(qz); pin8(qh); pin1(qp[0]); pin1(qp[1]);
+            }
+            if constexpr (sl >= 37 && sl < 47) precompute((sl - 37) / 5, (sl - 37) % 5);
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_nop 9" : "+v"(acc2[0]), "+v"(acc2[1]));
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dh[n][e] = acc2[n][e] + part[n][e];
         da_p -= da_step;
         if (a.rh) rh_p -= hs_step;
-        // the requests of slot 23 have retired when only the copy stores behind them are outstanding
-        if (a.rh) vm_wait<4>(); else vm_wait<3>();
-        pin8(qz); pin8(qh); pin8(qr); pin1(qp[0]); pin1(qp[1]);
-        precompute(0);
-        precompute(1);
         // pipelined stack: da of steps >= t is out; chunk t / cs is complete when t is its first step
         wave_signal_done_if<false>(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
         {
@@ -799,7 +837,7 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
     const int ldd = a.dh0_ld ? a.dh0_ld : RH;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
-        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 128 * n) = dh[n];
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 128 * n) = acc2[n];
     vm_drain();
     pin8(qz); pin8(qh); pin8(qr); pin1(qp[0]); pin1(qp[1]);
     if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
