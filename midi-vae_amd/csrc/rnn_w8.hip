@@ -120,6 +120,8 @@ __device__ __forceinline__ void w8_barrier() {
 }
 __device__ __forceinline__ float hsig(float x) { return __builtin_amdgcn_fmed3f(__builtin_fmaf(0.2f, x, 0.5f), 0.0f, 1.0f); }
 
+#include "rnn_multi.h"
+
 // ---------------------------------------------------------------------------------------------------------
 // GRU forward (Keras 2.0.x GRU: reset gate applied BEFORE the candidate matmul; gate order [z | r | candidate])
 // ---------------------------------------------------------------------------------------------------------
@@ -614,9 +616,10 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
 
     // saved values: z, r, hh as TILE16Q pairs (elements 0..3 tile a, 4..7 tile b); h_{t-1} (row-major) and the upstream gradient
     // (TILE16) per tile.  Un-tracked asm loads, hand-counted waits (as in the forward kernel).  Per step, in issue order:
-    //   slot 0   [z hh h_a h_b] of step t-1: consumed from slot 36 on (factors of the two products that wait for dh).  (The
-    //            same arithmetic in the M1 slots of the next step, fed two steps ahead: 2.00 / 2.18 instead of 1.87 / 2.08 us.)
-    //   slot 23  [r dx_a dx_b] of step t-1: consumed at its E1 / E2
+    //   slot 0   [z hh h_a h_b dx_a dx_b] of step t-1: z, hh, h consumed from slot 36 on (factors of the two products that wait
+    //            for dh; the same arithmetic in the M1 slots of the next step, fed two steps ahead: 2.00 / 2.18 instead of 1.87 /
+    //            2.08 us), the upstream gradient at the next E1 - a whole step after its request
+    //   slot 23  [r] of step t-1 (this step's is used until slot 21): consumed from the next step's slot 16 on
     //   slots 26, 29, 33, 35  the copy stores (da tile by gate, rh tile) - BEHIND the requests: vmcnt retires in order, a load
     //   behind a write-through store waits for that store's acknowledgement
     u16x8 qz, qh, qr;
@@ -627,14 +630,15 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
         xload16(qh, acts_p[2] - back_a, lane16);
         xload8(qp[0], hs_p - back_h, hp_off);
         xload8(qp[1], hs_p - back_h + 256, hp_off);
-    };
-    auto issue_late = [&]() __attribute__((always_inline)) {
-        pinu(lane16); pinu(lane8);
-        xload16(qr, acts_p[1], lane16);
         if (HAS_EXT) {
+            pinu(lane8);
             xload8(qd[0], dx_p, lane8);
             xload8(qd[1], dx_p + 8 * 512, lane8);
         }
+    };
+    auto issue_late = [&]() __attribute__((always_inline)) {
+        pinu(lane16);
+        xload16(qr, acts_p[1], lane16);
     };
     issue_early(0, 0);
     issue_late();
@@ -675,7 +679,7 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
 
     frag bq[3], lt[2], cp;
     f32x4 acc1[2], acc2[2], part[2], d[2], e_rv, e_hp;
-    constexpr int V_LATE = HAS_EXT ? 3 : 1;
+    constexpr int V_EARLY = HAS_EXT ? 6 : 4;
     acc2[0] = dh[0];
     acc2[1] = dh[1];
     auto step = [&](const int t) __attribute__((always_inline)) {
@@ -684,10 +688,11 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
         if (a.rh) pins(rh_p);
         if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status, 2u);
         // ---- E1 (exposed): d = dh (+ the upstream gradient), da_c = d w1, da_z = d kz -----------------------------------
-        // r and the upstream gradient of this step: the requests of the previous step's slot 23, only its copy stores behind them
-        if (a.rh) vm_wait<4>(); else vm_wait<3>();
-        pin8(qr);
-        if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
+        // the upstream gradient of this step: the previous step's slot 0; behind it the r request and the copy stores
+        if (HAS_EXT) {
+            if (a.rh) vm_wait<5>(); else vm_wait<4>();
+            pin1(qd[0]); pin1(qd[1]);
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             d[n] = acc2[n];
@@ -747,6 +752,10 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
                 for (int e = 0; e < 4; ++e) acc2[n][e] = d[n][e] * zv[n][e];
             }
             // E2 (M1's last MFMAs: slots 14, 15): r, h_{t-1}: r h -> rh tile;  da_r = drh h hs'(r) -> da tile;  part = drh r
+            if constexpr (sl == 16) {        // r: the previous step's slot 23; behind it its copy stores and this step's slot 0
+                if (a.rh) vm_wait<4 + V_EARLY>(); else vm_wait<3 + V_EARLY>();
+                pin8(qr);
+            }
             if constexpr (sl == 16 || sl == 19) {
                 constexpr int n = sl == 19;
                 e_rv = n ? hi4(qr) : lo4(qr);
@@ -807,7 +816,7 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
             }
             // the next step's factors: its z, hh, h (slot 0) have retired when only what was issued behind them is outstanding
             if constexpr (sl == 36) {
-                if (a.rh) vm_wait<V_LATE + 4>(); else vm_wait<V_LATE + 3>();
+                if (a.rh) vm_wait<1 + 4>(); else vm_wait<1 + 3>();
                 pin8(qz); pin8(qh); pin1(qp[0]); pin1(qp[1]);
             }
             if constexpr (sl >= 37 && sl < 47) precompute((sl - 37) / 5, (sl - 37) % 5);
@@ -892,6 +901,48 @@ int gru_w8_save(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return a.hs ? launch_gru_w8<XMODE, SAVE_HS>(a, s) : launch_gru_w8<XMODE, SAVE_NONE>(a, s);
 }
 
+// ---- phase launches (as rnn_resident.hip's: every recurrence of a phase as ONE launch), 8 waves per workgroup -------------
+template <int SAVE>
+__global__ __launch_bounds__(512, 1) void gru_fwd_multi_w8_k(const rnn_fwd_multi m) {
+    const int bid = (int)blockIdx.x, nx = m.nx;
+    int i = 0;
+    while (i + 1 < nx + m.n && bid >= m.base[i + 1]) ++i;
+    const unsigned bx = (unsigned)(bid - m.base[i]);
+    if (i < nx) {
+        xpand_body<8>(m.xp[i], (int)bx, m.base[i + 1] - m.base[i]);
+        return;
+    }
+    const mvae_rnn_fwd_args a = m.p[i - nx];       // (a copy: the fields then live in scalar registers for the whole launch)
+    const int xm = __builtin_amdgcn_readfirstlane(a.xmode);
+    if (xm == MVAE_X_DENSE) gru_fwd_w8_body<MVAE_X_DENSE, SAVE>(a, bx);
+    else if (xm == MVAE_X_INDEX) gru_fwd_w8_body<MVAE_X_INDEX, SAVE>(a, bx);
+    else gru_fwd_w8_body<MVAE_X_CONST, SAVE>(a, bx);
+}
+__global__ __launch_bounds__(512, 1) void gru_bwd_multi_w8_k(const rnn_bwd_multi m) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < m.n && bid >= m.base[i + 1]) ++i;
+    const unsigned bx = (unsigned)(bid - m.base[i]);
+    const mvae_rnn_bwd_args a = m.p[i];
+    const bool ext = __builtin_amdgcn_readfirstlane(a.dhs_ext != nullptr);
+    if (ext) gru_bwd_w8_body<true>(a, bx);
+    else gru_bwd_w8_body<false>(a, bx);
+}
+template <int SAVE>
+int launch_fwd_multi_w8(const rnn_fwd_multi& m, int total, hipStream_t s) {
+    const size_t lds = (size_t)3 * 16 * RH * sizeof(bf16_t) + (size_t)8 * GRU_W8_NLDS * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_multi_w8_k<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((gru_fwd_multi_w8_k<SAVE>), dim3(total), dim3(512), lds, s, m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 }  // namespace
 
 int mvae_rnn_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
@@ -909,4 +960,74 @@ int mvae_rnn_fwd_w8(const mvae_rnn_fwd_args& a, hipStream_t s) {
         case MVAE_X_CONST: return a.xp0 ? gru_w8_save<MVAE_X_CONST>(a, s) : MVAE_E_ARG;
     }
     return MVAE_E_UNSUPPORTED;
+}
+
+// (see rnn_resident.hip's mvae_rnn_fwd_multi / mvae_rnn_bwd_multi, which route seq_layout MVAE_TILE16Q here)
+int mvae_rnn_fwd_multi_w8(const mvae_rnn_fwd_args* problems, int32_t n, const mvae_xpand_args* xpand, int32_t n_xpand, void* stream) {
+    rnn_fwd_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    m.nx = n_xpand;
+    int total = 0;
+    for (int i = 0; i < n_xpand; ++i) {
+        const mvae_xpand_args& x = xpand[i];
+        if (!((x.xs && x.w && x.bias) || (x.idx && x.table)) || !x.out || !x.chunk_done || x.out_kind != MVAE_BF16 || x.R <= 0 || x.N != 3 * RH ||
+            x.chunk_rows <= 0 || (x.chunk_rows % 16) || (x.R % x.chunk_rows) || x.blocks <= 0 || x.blocks > 256 ||
+            (!x.idx && ((reinterpret_cast<uintptr_t>(x.w) & 15) || (reinterpret_cast<uintptr_t>(x.bias) & 15))) ||
+            (x.idx && ((reinterpret_cast<uintptr_t>(x.table) & 7) || (reinterpret_cast<uintptr_t>(x.idx) & 3))) ||
+            (size_t)x.chunk_rows * x.N * 2 > 0x7fffffffull)
+            return MVAE_E_ARG;
+        m.xp[i] = x;
+        m.base[i] = total;
+        total += x.blocks;
+    }
+    const mvae_rnn_fwd_args& f = problems[0];
+    for (int i = 0; i < n; ++i) {
+        const mvae_rnn_fwd_args& a = problems[i];
+        if (!a.u_pack || a.T <= 0 || a.B <= 0 || (a.B % 16) || a.chunk_steps < 0 ||
+            ((a.wait_ready || a.signal_done) && a.chunk_steps == 0) || (a.wait_ready && a.xmode != MVAE_X_DENSE) ||
+            (a.signal_done && !a.hs))
+            return MVAE_E_ARG;
+        if (a.H != RH || a.dtype != MVAE_BF16 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU || a.xmode == MVAE_X_SCALAR || !a.hs ||
+            (a.acts != nullptr) != (f.acts != nullptr) || a.cs)
+            return MVAE_E_UNSUPPORTED;
+        if ((a.xmode == MVAE_X_DENSE && !a.xp) || (a.xmode == MVAE_X_INDEX && !(a.idx && a.table)) || (a.xmode == MVAE_X_CONST && !a.xp0))
+            return MVAE_E_ARG;
+        if (a.xmode == MVAE_X_INDEX && a.table_layout != MVAE_TABLE_PAIRED8) return MVAE_E_ARG;
+        m.p[i] = a;
+        m.base[n_xpand + i] = total;
+        total += a.B / 16;
+    }
+    m.base[n_xpand + n] = total;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return f.acts ? launch_fwd_multi_w8<SAVE_ALL>(m, total, s) : launch_fwd_multi_w8<SAVE_HS>(m, total, s);
+}
+int mvae_rnn_bwd_multi_w8(const mvae_rnn_bwd_args* problems, int32_t n, void* stream) {
+    rnn_bwd_multi m;
+    memset(&m, 0, sizeof(m));
+    m.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const mvae_rnn_bwd_args& a = problems[i];
+        if (!a.ut_pack || !a.hs || !a.acts || !a.da || a.T <= 0 || a.B <= 0 || (a.B % 16) || a.chunk_steps < 0 ||
+            ((a.wait_ready || a.signal_done) && a.chunk_steps == 0) || (a.wait_ready && !a.dhs_ext))
+            return MVAE_E_ARG;
+        if (a.H != RH || a.dtype != MVAE_BF16 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU) return MVAE_E_UNSUPPORTED;
+        m.p[i] = a;
+        m.base[i] = total;
+        total += a.B / 16;
+    }
+    m.base[n] = total;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)16 * 3 * RH * sizeof(bf16_t) + (size_t)16 * RH * sizeof(bf16_t) + (size_t)8 * 16 * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_multi_w8_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL(gru_bwd_multi_w8_k, dim3(total), dim3(512), lds, s, m);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
 }

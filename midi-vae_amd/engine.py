@@ -63,6 +63,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # the resident-weights recurrent kernels (H=256, bf16, GRU/LSTM) stream TILE16 sequences; everything else is
         # row-major.  Batches are padded to a multiple of 16 rows (one workgroup = 16 rows) with zero-weight rows.
         self.tile16 = (spec.H == 256 and self.kind == hl.BF16 and spec.cell in ("GRU", "LSTM"))
+        #  Round 6: GRU layers on the two-waves-per-SIMD kernels (rnn_w8.hip, seq_layout TILE16Q): alone 1.23-1.54 us per time step
+        #  forward, 1.88-2.08 BPTT against 1.50-1.75 / 2.16-2.37 for the one-wave kernels.  MVAE_GRU_W8=0: the round-5 kernels.
+        self.gru_w8 = os.environ.get("MVAE_GRU_W8", "1") != "0"
         self.lay = hl.TILE16 if self.tile16 else hl.ROWMAJOR          # what the GEMM epilogues write (xp, dX)
         self.maxB = (int(max_batch) + 15) // 16 * 16
         self.layout = self._make_layout()
@@ -298,19 +301,29 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         ones."""
         if not self.tile16:
             return hl.ROWMAJOR
+        if self.spec.cell == "GRU" and self.gru_w8:      # (round 6) two waves per SIMD: rnn_w8.hip
+            return hl.TILE16Q
         if self.spec.cell in ("LSTM", "GRU"):   # (a 1-feature input is expanded to x*W + b first: _scalar_as_dense)
             return hl.TILE16P
         return hl.TILE16
 
+    def _il(self, r):
+        """does the layer run on the slot-interleaved kernel family (one wave per SIMD: TILE16P; two: TILE16Q)?"""
+        return self._seq_layout(r) in (hl.TILE16P, hl.TILE16Q)
+
+    def _rnn_waves(self, r):
+        """waves per workgroup of the layer's recurrent kernels that publish a chunk of a time-pipelined stack"""
+        return hl.load().mvae_rnn_producer_waves(self._seq_layout(r))
+
     def _paired_table(self, r):
         """the lookup table of a one-hot input layer in the column order the slot-interleaved LSTM / GRU kernels gather (two unit tiles
         per 16-byte access: 8 gathers per row and step instead of 16, include/midivae_hip.h mvae_rnn_fwd_args.table_layout)"""
-        return r.xmode == hl.X_INDEX and self.spec.cell in ("LSTM", "GRU") and self._seq_layout(r) == hl.TILE16P
+        return r.xmode == hl.X_INDEX and self.spec.cell in ("LSTM", "GRU") and self._il(r)
 
     def _scalar_as_dense(self, r):
         """1-feature input layers (velocity roll) of an LSTM / GRU model: x*W + b is written out (T*B*G*H bf16, one streaming
         kernel, ~0.1 ms) so that the layer runs on the slot-interleaved dense-input kernels (2.1 instead of 3.9 us/step)."""
-        return r.xmode == hl.X_SCALAR and self._seq_layout(r) == hl.TILE16P
+        return r.xmode == hl.X_SCALAR and self._il(r)
 
     def _index_as_dense(self, r):
         """the bottom layer of the encoder notes stack (one-hot pitch rows) sets the pace of the encoder-forward phase, and the
@@ -318,7 +331,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         a dense input: inside a phase launch the table rows are written out by a chunk-publishing producer (PhaseLaunches.
         _xpand_problem) and the layer reads them as a dense projection."""
         return (self.index_dense and self.training and r.xmode == hl.X_INDEX and self.enc_notes and r is self.enc_notes[0] and
-                self._seq_layout(r) == hl.TILE16P)
+                self._il(r))
 
     def _mark(self, name):
         """development: timestamp on the main stream at a section boundary (``self.marks = []`` to collect): (name, host time of
@@ -490,7 +503,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 if r.xmode == hl.X_INDEX:
                     pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table", r.K, s.GH))
                     if (p + ".table_p") in self.store:
-                        pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table_p", r.K, s.GH), paired=True)
+                        pb.make_table(P[p + ".W"], P[p + ".b"], self._v(p + ".table_p", r.K, s.GH),
+                                      paired=8 if self._seq_layout(r) == hl.TILE16Q else True)
                 elif r.xmode == X_GATHER2:
                     d0 = r.K - s.attach
                     pb.make_table(P[p + ".W"][:d0], P[p + ".b"], self._v(p + ".table", d0, s.GH))
@@ -551,7 +565,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             kw.update(xp=self._v(p + ".xp", T, B, GH)[t0:t0 + Tc])
         elif r.xmode == hl.X_INDEX:
             if self._paired_table(r):
-                kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table_p", r.K, GH), table_layout=hl.TABLE_PAIRED)
+                kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table_p", r.K, GH),
+                          table_layout=hl.TABLE_PAIRED8 if self._seq_layout(r) == hl.TILE16Q else hl.TABLE_PAIRED)
             else:
                 kw.update(idx=idx[t0:t0 + Tc], table=self._v(p + ".table", r.K, GH))
         elif r.xmode == X_GATHER2:       # table[pitch] + table2[instrument] written out, then the dense-input kernels
@@ -637,7 +652,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         T = layers[0].T
         return (self.pipeline and self.multi_stream and len(layers) - 1 <= len(self.s_layer) and T % self.pipe_chunk == 0 and
                 len(layers) * 2 * (T // self.pipe_chunk) <= 1024 and
-                all(self._seq_layout(r) == hl.TILE16P for r in layers) and
+                all(self._il(r) for r in layers) and
                 self._resident_cus(layers, self._cur_B) <= self.num_cus)
 
     def _sync_region(self, slot, n_if, nchp, nwaves, pwaves):
@@ -660,7 +675,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                             publish_top=False):
         cs = self.pipe_chunk
         T = layers[0].T
-        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
+        nchp, nwaves, pwaves = T // cs, self._rnn_waves(layers[0]) * (B // 16), 4 * self.pipe_proj_blocks
         L = len(layers)
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
@@ -950,7 +965,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                              xs=None, start=None):
         cs = self.pipe_chunk
         T = layers[0].T
-        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
+        nchp, nwaves, pwaves = T // cs, self._rnn_waves(layers[0]) * (B // 16), 4 * self.pipe_gemm_blocks
         order = list(reversed(layers))               # order[0] = top layer: runs on this stream, publishes da
         L = len(order)
         kstream = self._kstream_ok(layers, B)
@@ -1021,7 +1036,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             # a single-layer branch beside a K-streaming stack: ONE launch that publishes its da chunk by chunk (nobody waits inside
             # the stack), its dU GEMM joins the stack's K-streaming launch, the rest of its gradients follows its end as usual
             r, cs = layers[0], self.pipe_chunk
-            sync, target, _ = self._sync_region(4, 1, r.T // cs, 4 * (B // 16), 0)
+            sync, target, _ = self._sync_region(4, 1, r.T // cs, self._rnn_waves(r) * (B // 16), 0)
             self._rec_bptt(r, B, 0, 1, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
                            pipe=dict(chunk_steps=cs, status=self.store["pipe_status"], signal_done=sync[0, 0]),
                            **(dstates(r) if dstates else {}))
@@ -1030,11 +1045,11 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
             self._rec_param_grads(r, B, idx=idx, xs=xs, start=start, skip_dU=True)
             return
         if (len(layers) == 1 and nch == 1 and self._grad_portion_jobs is not None and self.pipeline and
-                self._seq_layout(layers[0]) == hl.TILE16P and layers[0].T % self.pipe_chunk == 0 and
+                self._il(layers[0]) and layers[0].T % self.pipe_chunk == 0 and
                 self._portion_count(layers[0], B, self.pipe_chunk) > 1 and self._single_slot < self._single_slot_end):
             # a full-length single-layer branch whose gradients go in time portions: ONE launch that publishes its da chunks
             r, cs = layers[0], self.pipe_chunk
-            sync, target, _ = self._sync_region(11 + self._single_slot, 1, r.T // cs, 4 * (B // 16), 0)
+            sync, target, _ = self._sync_region(11 + self._single_slot, 1, r.T // cs, self._rnn_waves(r) * (B // 16), 0)
             self._single_slot += 1
             self._pipe_used = True
             self._rec_bptt(r, B, 0, 1, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld,
@@ -1212,7 +1227,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 with self._on(st):
                     inp = (dict(xs=self._v(src, r.T, B)) if r.xmode == hl.X_SCALAR else dict(idx=self._v(src, r.T, B)))
                     follow = (ks_extra is not None and not ks_extra and self.kstream_singles and r.T == T and
-                              self._seq_layout(r) == hl.TILE16P and r.xmode != hl.X_CONST and
+                              self._il(r) and r.xmode != hl.X_CONST and
                               (2 if s.cell == "GRU" else 1) + (3 if s.cell == "GRU" else 2) * len(self.enc_notes) <= 8)
                     self._stack_backward([r], B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc,
                                          kstream_extra=ks_extra if follow else None, **inp)

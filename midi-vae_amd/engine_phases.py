@@ -28,7 +28,7 @@ class PhaseLaunches(object):
         """may ``stack`` (bottom -> top) and the single-layer recurrences ``singles`` run as one launch?"""
         recs = list(stack) + list(singles)
         return (self.phase_multi and self._cur_B <= self.phase_max_B and self.tile16 and self.multi_stream and 0 < len(recs) <= 8 and
-                all(self._seq_layout(r) == hl.TILE16P for r in recs) and (len(stack) < 2 or self._pipelined(stack)) and
+                all(self._il(r) for r in recs) and (len(stack) < 2 or self._pipelined(stack)) and
                 all(r.xmode != hl.X_SCALAR or self._scalar_as_dense(r) for r in recs))
 
     # ---- forward ----------------------------------------------------------------------------------------------------
@@ -40,7 +40,7 @@ class PhaseLaunches(object):
         while r.T % cs:
             cs //= 2
         blocks = self.xpand_blocks if idx is None else self.index_dense_blocks
-        sync, target, _ = self._sync_region(5 if idx is None else 9, 1, r.T // cs, 4 * blocks, 0)
+        sync, target, _ = self._sync_region(5 if idx is None else 9, 1, r.T // cs, self._rnn_waves(r) * blocks, 0)      # (the producer's blocks are blocks of the launch: as many waves each)
         xp = self._v(p + ".xp", r.T, B, s.GH)
         if idx is None:
             x = ops.xpand(xs, P[p + ".W"].view(-1), P[p + ".b"], xp, r.T * B, s.GH, cs * B, sync[0, 0], blocks)
@@ -58,7 +58,7 @@ class PhaseLaunches(object):
             return [self._rec_forward(r, B, idx=idx, start=start, h_last=h_last, h_last_ld=h_last_ld, build=True,
                                       pipe=bottom, xp_external=bottom is not None, **(states(r) if states else {}))], []
         cs, T = self.pipe_chunk, layers[0].T
-        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_proj_blocks
+        nchp, nwaves, pwaves = T // cs, self._rnn_waves(layers[0]) * (B // 16), 4 * self.pipe_proj_blocks
         sync, hs_target, xp_target = self._sync_region(slot, L - 1, nchp, nwaves, pwaves)
         self._last_stack_gate = (sync[0, 0][0:1], hs_target)       # the bottom layer's first published chunk of THIS call
         status = self.store["pipe_status"]
@@ -147,7 +147,7 @@ class PhaseLaunches(object):
             return [self._rec_bptt(r, B, dhs_ext=dhs_ext, dh_last=dh_last, dh_last_ld=dh_last_ld, build=True,
                                    **(dstates(r) if dstates else {}))], [], None
         cs, T = self.pipe_chunk, layers[0].T
-        nchp, nwaves, pwaves = T // cs, 4 * (B // 16), 4 * self.pipe_gemm_blocks
+        nchp, nwaves, pwaves = T // cs, self._rnn_waves(layers[0]) * (B // 16), 4 * self.pipe_gemm_blocks
         sync, da_target, dx_target = self._sync_region(slot, L, nchp, nwaves, pwaves)
         status = self.store["pipe_status"]
         self._pipe_used = True
@@ -227,7 +227,7 @@ class PhaseLaunches(object):
             # every single-layer branch publishes its da too: its gradient work is released by ITS last chunk (a 4-step instrument
             # roll is done 1.8 ms before the launch ends), and a full-length one's dU can join the K-streaming launch
             cs = self.pipe_chunk if r.T % self.pipe_chunk == 0 else r.T
-            sync1, target1, _ = self._sync_region(5 + k, 1, r.T // cs, 4 * (B // 16), 0)
+            sync1, target1, _ = self._sync_region(5 + k, 1, r.T // cs, self._rnn_waves(r) * (B // 16), 0)
             probs.append(self._rec_bptt(r, B, dh_last=dcat[:, k * H:(k + 1) * H], dh_last_ld=ldc, build=True,
                                         pipe=dict(chunk_steps=cs, status=status, signal_done=sync1[0, 0])))
             single_gate[r.prefix] = (sync1[0, 0][0:1], target1)
