@@ -159,6 +159,9 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 template <int SLEEP = 8>        // (64: a throughput consumer that polls for most of its producer's run time)
 __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status, uint32_t code = 1u) {
+    // the spin bound scales with the pause between two looks, so that every waiter gives up after the SAME ~2-4 s whatever its
+    // SLEEP (the GEMMs' SLEEP = 32 used to wait four times as long as the recurrent kernels they follow)
+    constexpr unsigned LIMIT = 0x200000u * 8u / (SLEEP > 0 ? SLEEP : 1);
     unsigned tmp, spins, val;
     asm volatile(
         "s_mov_b32 %1, 0\n"
@@ -171,14 +174,14 @@ __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t valu
         "s_cbranch_scc1 L_ready_%=\n\t"
         "s_sleep %5\n\t"
         "s_add_u32 %1, %1, 1\n\t"
-        "s_cmp_lt_u32 %1, 0x200000\n\t"
+        "s_cmp_lt_u32 %1, %6\n\t"
         "s_cbranch_scc1 L_wait_%=\n"
         "L_ready_%=:\n\t"
         MVAE_ACQ_INV
         : "=&v"(tmp), "=&s"(spins), "=&s"(val)
-        : "s"(flag), "s"(value), "n"(SLEEP)
+        : "s"(flag), "s"(value), "n"(SLEEP), "n"(LIMIT)
         : "memory", "scc");
-    if (spins >= 0x200000u && status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (spins >= LIMIT && status) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the same under a scalar condition evaluated inside the block: if (t == bound) wait
 __device__ __forceinline__ void wave_wait_ge_if(int t, int bound, const uint32_t* flag, uint32_t value, uint32_t* status, uint32_t code = 1u) {

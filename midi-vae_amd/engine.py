@@ -24,6 +24,7 @@ import torch
 
 from . import hiplib as hl
 from . import ops
+from . import plan
 from .layout import ModelSpec, ParamLayout, init_params
 
 from .engine_io import ArrayStaging, Results
@@ -195,6 +196,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         self._cur_B = self.maxB          # padded batch of the call being scheduled
         self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self._occ = {k: max(1, hl.load().mvae_occupancy(i)) for i, k in enumerate(("dx", "proj", "kstream"))}
+        self._chain_refused = False      # the library refused the fused latent chain once: steps key their plans by the exact window count
         self._hist_fused = None          # train step whose history comes out of its own encoder forward (model.py: fused pre-pass)
         self._redo_hist = None           # ... kept until the step is verified (_redo_step)
         self._fused_dst = None           # (caller's rows, engine buffer) of a fused pre-pass whose z' is still to be handed over
@@ -769,6 +771,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         fused_hist = self._hist_fused            # (history of this minibatch from this very forward pass: train_step_begin)
         if not (self.fused_latent and self._chain_ok() and
                 self._latent_chain_forward(Breal, B, with_init and fused_hist is None)):
+            self._chain_refused_now()
             self._latent_forward_unfused(Breal, B)
         if fused_hist is not None:
             eps2, z_out = fused_hist
@@ -781,6 +784,18 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         """shapes the fused latent chain (csrc/latent.hip) takes: a pack Dense whenever rolls are concatenated, 16-byte rows"""
         s = self.spec
         return (self.has_pack or self.ncat == 1) and s.zin % 4 == 0 and s.Z % 4 == 0
+
+    def _chain_refused_now(self):
+        """The step runs the separate latent launches (the library refused the fused chain: its workgroup would need more than
+        160 KB of LDS - H = 512 with several heads - or the graph has a signature head).  They take the real window count and the
+        loss normaliser as plain arguments and zero the padding rows with a torch operation only on a ragged batch, so such a step
+        must never share a plan between window counts (_kind_B) - and a recording made under the padded key before this was known
+        is dropped."""
+        if not self._chain_refused:
+            self._chain_refused = True
+            rec = plan.active()
+            if rec is not None and rec.tainted is None:
+                rec.tainted = "separate latent launches (the fused chain was refused)"
 
     def _latent_chain_forward(self, Breal, B, with_init):
         """Encoder tail Denses, latent block and the decoder's initial-state Denses as ONE launch (csrc/latent.hip): six
@@ -1197,6 +1212,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         dcat = (self._latent_chain_backward(Breal, B)
                 if (self.fused_latent and self._chain_ok() and not s.signature) else None)
         if dcat is None:
+            self._chain_refused_now()
             dcat = self._latent_backward_unfused(Breal, B)
         latent_grads, self._deferred_side = self._deferred_side, None
         self._pace(4)

@@ -94,8 +94,10 @@ class ParamGradients(object):
                     sk //= 2
                 g.split_k = min(16, sk)
         with (torch.cuda.stream(self.s_grad) if early is not None else contextlib.nullcontext()):
-            if probs and not ops.gemm_multi(probs):            # (a shape the batched launch does not take: one by one)
-                for g in probs:
+            if probs:
+                # (a shape the batched launch does not take: that part and what follows one by one - NOT the parts in front of it,
+                #  which have been launched and accumulate)
+                for g in probs[ops.gemm_multi(probs):]:
                     ops.gemm_args(g)
             for fn in small:
                 fn()

@@ -194,7 +194,7 @@ class TrainSteps(object):
         plan: `python vae_training.py` on songs of 20-200 windows replays after three steps per 16-window bucket instead of three
         per window count.  Any other graph: the real count and the normaliser are part of the key."""
         s = self.spec
-        if self.fused_latent and self._chain_ok() and not s.signature and not self.aux:
+        if self.fused_latent and self._chain_ok() and not self._chain_refused and not s.signature and not self.aux:
             return ("padded", self.pad16(B))
         return (int(B), float(self.norm_B))
 

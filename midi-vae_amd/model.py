@@ -161,19 +161,43 @@ class EpsilonStream(object):
     (reference: K.random_normal inside the sampling Lambda, vae_definition.py:498-502 - one draw per batch).  ONE stream: numpy fills
     an array sample by sample, so R rows drawn at once and handed out in order are the values R successive draws give - the oracle
     tests draw minibatch by minibatch from an equal generator and get equal numbers.  At the reference's default settings the two
-    draws of a step (the step's own, the history pre-pass's) were 0.45 ms of a 1.7 ms step on the caller's thread."""
+    draws of a step (the step's own, the history pre-pass's) were 0.45 ms of a 1.7 ms step on the caller's thread.
+
+    The stream runs AHEAD of its consumer by up to 1.5 blocks, so the generator's own state is not "what has been consumed".  A
+    caller that touches the generator between two draws is noticed (its state no longer is what the last block left behind): the
+    buffered rows are dropped and the next draw starts from the generator as it is now - an in-place reseed or a restored state
+    takes effect at once, as it would with one draw per batch.  ``reset()`` does the same explicitly; ``close()`` ends the worker
+    thread (a replaced stream used to leave its executor behind)."""
     BLOCK = 1024
 
     def __init__(self, rng, Z, std):
         from concurrent.futures import ThreadPoolExecutor
         self.rng, self.Z, self.std = rng, int(Z), float(std)
         self._buf, self._pos, self._next = np.zeros((0, self.Z), np.float32), 0, None
+        self._left = self._fingerprint()       # the generator's state behind the last block drawn
         self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvae-epsilon")      # (every draw, in submission order)
 
+    def _fingerprint(self):
+        return repr(self.rng.bit_generator.state)
+
     def _draw(self, rows):
-        return (self.rng.standard_normal((rows, self.Z)) * self.std).astype(np.float32)
+        out = (self.rng.standard_normal((rows, self.Z)) * self.std).astype(np.float32)
+        self._left = self._fingerprint()
+        return out
+
+    def reset(self):
+        """forget the rows drawn ahead: the next draw comes from the generator as it is now"""
+        if self._next is not None:
+            self._next.result()
+        self._buf, self._pos, self._next = np.zeros((0, self.Z), np.float32), 0, None
+        self._left = self._fingerprint()
+
+    def close(self):
+        self._pool.shutdown(wait=True)
 
     def take(self, n):
+        if (self._next is None or self._next.done()) and self._fingerprint() != self._left:     # the caller moved the generator: nothing buffered is valid
+            self.reset()
         out, need = [], int(n)
         while need > 0:
             avail = len(self._buf) - self._pos
@@ -273,6 +297,8 @@ class _Shared(object):
     def epsilon(self, n):
         st = getattr(self, "_eps_stream", None)
         if st is None or st.rng is not self.rng or st.Z != self.spec.Z or st.std != float(self.spec.epsilon_std):
+            if st is not None:
+                st.close()
             st = self._eps_stream = EpsilonStream(self.rng, self.spec.Z, self.spec.epsilon_std)     # (a caller replaced the generator)
         return st.take(n)
 

@@ -224,17 +224,19 @@ def gemm_args(g):
 
 def gemm_multi(problems, stream=None):
     """ordinary split-K weight-gradient GEMMs (``gemm(..., trans_a=True, accumulate=True, build_only=True)``) as ONE launch per
-    GEMM_MULTI_MAX problems on the current (or given) stream; False if the library does not take one of them this way"""
+    GEMM_MULTI_MAX problems on the current (or given) stream.  Returns HOW MANY of the problems were launched: the library
+    validates a part as a whole before it launches anything, so when it does not take a problem this way the parts in front of
+    it have run (they accumulate: the caller must not launch them again) and ``problems[returned:]`` are the caller's."""
     st = _stream() if stream is None else stream.cuda_stream
     for i in range(0, len(problems), GEMM_MULTI_MAX):
         part = problems[i:i + GEMM_MULTI_MAX]
         arr = (hl.GemmArgs * len(part))(*part)
-        _note_fields(0, part)
         rc = hl.load().mvae_gemm_multi(arr, len(part), st)
         if rc == hl.E_UNSUPPORTED:
-            return False
+            return i
+        _note_fields(0, part)
         hl.check(rc, "mvae_gemm_multi")
-    return True
+    return len(problems)
 
 
 def stream_wait_value32(word, value, stream=None):

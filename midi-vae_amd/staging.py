@@ -227,6 +227,13 @@ class Stager(object):
         ``prefetched``: this minibatch was handed to ``prefetch()`` (same arguments) while the previous step was being enqueued:
         its conversion - both halves - ran on a worker thread beside the paced host's waits; only the uploads are left."""
         eng, s = self.eng, self.eng.spec
+        # what a prefetched conversion was made FROM: the very objects (and the scalars that decide the conversion).  A stage()
+        # call takes it only for the same ones - another song of equal length, an epsilon drawn again after the prefetch or other
+        # row weights convert afresh (ADVICE r05: window range and mirror alone used to decide)
+        token = (lo, hi, bool(batch_local), bool(defer_targets)) + tuple(
+            id(a) for a in (X, I, Vel, eps, hist, hist_dev, z, Y, C_, start_notes, start_instr, start_vel, w_notes, w_instr, w_vel,
+                            w_style, norm, Held, Next, start_held, start_next, w_held, w_next, Add, S, w_sig, w_cnotes, w_cinstr,
+                            eps2, X_tm))
         if batch_local:
             lo, hi = 0, hi - lo
         B = hi - lo
@@ -326,7 +333,7 @@ class Stager(object):
                 except BaseException as e:      # (raised by the stage() call that takes the minibatch)
                     box["err"] = e
                 box["done"].set()
-            self._pf = (box["done"], k, (lo, hi), box)
+            self._pf = (box["done"], k, token, box)
             self._worker_submit(work)
             return B
         self.k ^= 1
@@ -334,9 +341,9 @@ class Stager(object):
         pf, self._pf = self._pf, None
         if pf is not None:
             pf[0].wait()
-            if "err" in pf[3] and prefetched and pf[2] == (lo, hi):
+            if "err" in pf[3] and prefetched and pf[2] == token:
                 raise pf[3]["err"]
-        if prefetched and pf is not None and pf[1] == k and pf[2] == (lo, hi) and "out" in pf[3]:
+        if prefetched and pf is not None and pf[1] == k and pf[2] == token and "out" in pf[3]:
             notes, late = pf[3]["out"]
         else:
             notes, late = convert(not defer_targets)

@@ -50,6 +50,10 @@ DEFAULT_CFG = dict(
     comp_notes=False, w_cnotes=1.0, comp_instr=False, w_cinstr=1.0,   # reference settings.py:195-200
     add_dim=0,                                                      # decoder_additional_input_dim, settings.py:167-177
     bidirectional=False,                                            # settings.py:159
+    # SURVEY A.6 / F9 hedge, ORACLE ONLY, forward only, excluded from every parity claim: "none" = the decoder as written (the
+    # readout is accepted and dropped: x_t = start); "add" = the other reading of recurrentshop's readout, x_t = start + y_{t-1}
+    # with y_{-1} = initial_readout = start.  The product implements "none"; "add" exists so that its cost can be evaluated.
+    readout="none",
 )
 
 
@@ -175,10 +179,17 @@ def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
-def rnn_forward(cell, xp, U, h0, c0=None):
+# recurrent activations by name: (function, derivative from the OUTPUT).  "hard_sigmoid" is what the reference's layers use
+# (Keras / recurrentshop defaults); "sigmoid" exists for tests/test_oracle_third_party_cpu.py ONLY:
+# with it the cells below are the cells torch.nn.LSTMCell / GRUCell implement, an implementation this repo did not write.
+_REC_ACT = {"hard_sigmoid": (hard_sigmoid, _dhs), "sigmoid": (sigmoid, lambda y: y * (1.0 - y))}
+
+
+def rnn_forward(cell, xp, U, h0, c0=None, rec_act="hard_sigmoid"):
     """Recurrence over pre-projected inputs.  xp (T,B,G*H) already holds x_t W + b.
     Returns hs (T+1,B,H) with hs[0]=h0, cs (T+1,B,H) (LSTM else None), acts (T,B,G*H) = post-activation gates.
-    GRU uses the Keras-2.0.x 'reset before matmul' form (Appendix A.2 / A.5)."""
+    GRU uses the Keras-2.0.x 'reset before matmul' form (Appendix A.2 / A.5).  ``rec_act``: test-only switch (_REC_ACT)."""
+    hard_sigmoid = _REC_ACT[rec_act][0]          # (shadows the module function inside this call)
     T, B, GH = xp.shape
     H = U.shape[0]
     hs = np.zeros((T + 1, B, H), xp.dtype)
@@ -209,9 +220,10 @@ def rnn_forward(cell, xp, U, h0, c0=None):
     return hs, cs, acts
 
 
-def rnn_backward(cell, hs, cs, acts, U, dhs_ext=None, dh_last=None):
+def rnn_backward(cell, hs, cs, acts, U, dhs_ext=None, dh_last=None, rec_act="hard_sigmoid"):
     """BPTT.  dhs_ext (T,B,H): gradient arriving at every h_t (t=1..T stored at index t-1) from above;
     dh_last (B,H): extra gradient at the final state.  Returns da (T,B,G*H) (= d xp), dU, dh0, dc0."""
+    _dhs = _REC_ACT[rec_act][1]                  # (test-only switch, see rnn_forward)
     T, B, GH = acts.shape
     H = U.shape[0]
     da = np.zeros_like(acts)
@@ -353,10 +365,12 @@ class OracleVAE(object):
         return z
 
     # ---- decoder --------------------------------------------------------------------------------
-    def _dec_head(self, p, cells, inits, outprefix, start, zh, steps, cache, key):
+    def _dec_head(self, p, cells, inits, outprefix, start, zh, steps, cache, key, act=None):
         """One decoder head: ``cells`` / ``inits`` are the per-layer parameter prefixes of the cell stack and
-        of its initial-state Denses."""
+        of its initial-state Denses.  ``act``: the head's output activation (readout="add" only)."""
         cell = self.cfg["cell"]
+        if self.cfg.get("readout", "none") == "add":
+            return self._dec_head_readout_add(p, cells, inits, outprefix, start, zh, steps, cache, key, act)
         layers = []
         x_seq = None
         for l, (cp, ip) in enumerate(zip(cells, inits)):
@@ -372,6 +386,26 @@ class OracleVAE(object):
         cache[key] = layers
         return x_seq @ p[outprefix + ".W"] + p[outprefix + ".b"]           # (steps,B,out) logits
 
+    def _dec_head_readout_add(self, p, cells, inits, outprefix, start, zh, steps, cache, key, act):
+        """SURVEY A.6, the alternative reading: the previous step's OUTPUT is fed back, x_t = start + y_{t-1} (y_{-1} = start).
+        Step by step through the whole stack; no backward pass exists for it (OracleVAE.backward raises)."""
+        cell = self.cfg["cell"]
+        st = [self._states(p, ip, zh, cache, key + ".init%d" % l) for l, ip in enumerate(inits)]
+        h = [s_[0] for s_ in st]
+        c = [s_[1] if cell == "LSTM" else None for s_ in st]
+        y, logits = start, []
+        for _ in range(steps):
+            x = start + y
+            for l, cp in enumerate(cells):
+                hs, cs, _ = rnn_forward(cell, (x @ p[cp + ".W"] + p[cp + ".b"])[None], p[cp + ".U"], h[l], c[l])
+                h[l], c[l] = hs[1], (cs[1] if cs is not None else None)
+                x = hs[1]
+            lg = x @ p[outprefix + ".W"] + p[outprefix + ".b"]
+            logits.append(lg)
+            y = act(lg)
+        cache[key] = None
+        return np.stack(logits)
+
     def decode(self, p, z, hist, starts, cache=None, add=None):
         """z (B,Z), hist (B,Z) or None, starts = dict(notes (B,Dout), instr (B,ID), vel (B,)), add (B,add_dim) = the decoder's
         additional input (reference :553-556).  Returns dict of batch-major outputs: notes (B,T,Dout) probs, instr (B,V,ID)
@@ -385,24 +419,24 @@ class OracleVAE(object):
         out = {}
         Ld = cfg["Ld"]
         lg = self._dec_head(p, ["dec.notes.%d" % l for l in range(Ld)], ["dec.notes.init.%d" % l for l in range(Ld)],
-                            "dec.notes.out", np.asarray(starts["notes"], dt), zh, cfg["T"], c, "dec_notes")
+                            "dec.notes.out", np.asarray(starts["notes"], dt), zh, cfg["T"], c, "dec_notes", act=softmax)
         out["notes"] = softmax(lg).transpose(1, 0, 2)
         if cfg["meta_instrument"]:
             lg = self._dec_head(p, ["dec.instr.cell"], ["dec.instr.init"], "dec.instr.out",
-                                np.asarray(starts["instr"], dt), zh, cfg["V"], c, "dec_instr")
+                                np.asarray(starts["instr"], dt), zh, cfg["V"], c, "dec_instr", act=softmax)
             out["instr"] = softmax(lg).transpose(1, 0, 2)
         if cfg["meta_velocity"]:
             lg = self._dec_head(p, ["dec.vel.cell"], ["dec.vel.init"], "dec.vel.out",
-                                np.asarray(starts["vel"], dt).reshape(-1, 1), zh, cfg["T"], c, "dec_vel")
+                                np.asarray(starts["vel"], dt).reshape(-1, 1), zh, cfg["T"], c, "dec_vel", act=sigmoid)
             out["vel"] = sigmoid(lg).transpose(1, 0, 2)
         if cfg["meta_held"]:
             lg = self._dec_head(p, ["dec.held.cell"], ["dec.held.init"], "dec.held.out",
-                                np.asarray(starts.get("held", np.zeros((z.shape[0], 2))), dt), zh, cfg["T"], c, "dec_held")
+                                np.asarray(starts.get("held", np.zeros((z.shape[0], 2))), dt), zh, cfg["T"], c, "dec_held", act=softmax)
             out["held"] = softmax(lg).transpose(1, 0, 2)
         if cfg["meta_next"]:
             lg = self._dec_head(p, ["dec.next.%d" % l for l in range(Ld)], ["dec.next.init.%d" % l for l in range(Ld)],
                                 "dec.next.out", np.asarray(starts.get("next", np.zeros((z.shape[0], cfg["Dout"]))), dt), zh,
-                                cfg["T"], c, "dec_next")
+                                cfg["T"], c, "dec_next", act=softmax)
             out["next"] = softmax(lg).transpose(1, 0, 2)
         return out
 
@@ -542,6 +576,8 @@ class OracleVAE(object):
     def backward(self, p, c):
         """Gradients of metrics['loss'] w.r.t. every parameter (dict name -> array)."""
         cfg, dt = self.cfg, self.dtype
+        if cfg.get("readout", "none") != "none":
+            raise NotImplementedError("readout=%r is a forward-only study switch of the oracle (SURVEY A.6)" % cfg["readout"])
         b = c["batch"]
         out = c["out"]
         g = {}

@@ -310,21 +310,11 @@ def _decisive(params, bias_std=0.5, out_gain=16.0, seed=5):
     return out
 
 
-@pytest.mark.parametrize("T,V", [(512, 4), (4096, 8)])
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-def test_decode_on_decisive_weights_equals_the_oracles_argmax(cell, dtype, T, V, capsys):
-    """north_star 'bit-exact for the argmax note-index decode', measured where it means something: decisive outputs (median top-2
-    gap of the oracle > 1e-3 asserted, 0.2-0.4 measured), T=512 (configs[1]) and T=4096 (configs[4]), the f32 parity mode AND the
-    benched bf16 path (reference vae_definition.py:1048-1095 'argmax' decode of decoder.predict).
-    f32 mode: every row whose oracle gap is >= 1e-5 decodes to the oracle's index.
-    bf16 mode: a row may differ only where the oracle's top-2 gap is within twice the largest probability error of the path - the
-    bound the CPU study derives (weights, h and x*W+b rounded to bf16 each move p by ~1e-3..1e-2, none dominates; DESIGN.md section 7)
-    - and every row with a gap >= 0.05 agrees.  The agreement by gap bucket is printed (profiles/r05_*_decode_agreement.txt)."""
+def _decisive_decode_case(cell, dtype, T, V, capsys, wseed=5, out_gain=16.0, zseed=3):
     B, Z = 16, 128
     spec = ModelSpec(cell=cell, H=256, Z=Z, Din=61, Dout=61, T=T, V=V, ID=16, C=4, Le=2, Ld=2)
-    params = _decisive(init_params(spec, 5))
-    z, hist = _decode_inputs(B, Z, 3)
+    params = _decisive(init_params(spec, wseed), out_gain=out_gain, seed=wseed)
+    z, hist = _decode_inputs(B, Z, zseed)
     orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
     p64 = {k: v.astype(np.float64) for k, v in params.items()}
     out_o = orc.decode(p64, z.astype(np.float64), hist.astype(np.float64),
@@ -346,9 +336,9 @@ def test_decode_on_decisive_weights_equals_the_oracles_argmax(cell, dtype, T, V,
     rep = ", ".join("gap >= %g: %.3f %% of %.1f %% rows" % (g, 100 * np.mean(~differ[gap >= g]) if np.any(gap >= g) else float("nan"),
                                                            100 * np.mean(gap >= g)) for g in (0.0, 1e-4, 1e-3, 1e-2, 1e-1))
     with capsys.disabled():
-        print("\ndecisive decode %s %s T=%d, %d rows: median oracle top-2 gap %.3f; argmax agreement by gap: %s; |p - p_oracle| mean %.2e "
+        print("\ndecisive decode %s %s T=%d weights %d gain %g, %d rows: median oracle top-2 gap %.3f; argmax agreement by gap: %s; |p - p_oracle| mean %.2e "
               "max %.2e; rows that differ: %d (largest gap among them %.2e)"
-              % (cell, dtype, T, idx.size, np.median(gap), rep, err.mean(), err.max(), int(differ.sum()),
+              % (cell, dtype, T, wseed, out_gain, idx.size, np.median(gap), rep, err.mean(), err.max(), int(differ.sum()),
                  float(gap[differ].max()) if differ.any() else 0.0))
     if dtype == "f32":
         assert np.all(gap[differ] < 1e-5), (int(differ.sum()), float(gap[differ].max()))
@@ -356,11 +346,38 @@ def test_decode_on_decisive_weights_equals_the_oracles_argmax(cell, dtype, T, V,
     else:
         assert np.all(gap[differ] <= 2.0 * err.max()), (float(gap[differ].max()), float(err.max()))
         assert not differ[gap >= 0.05].any()
-        assert differ.mean() < 5e-3 and err.mean() < 2e-3, (differ.mean(), err.mean())
+        assert err.mean() < 2e-3, err.mean()
+        if out_gain >= 16:
+            assert differ.mean() < 5e-3, differ.mean()
     eng.decode(B, want_probs=False)             # (the configs[4] path: one byte per row leaves the chip)
     assert np.array_equal(eng.note_indices(B), idx)
     del eng
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("T,V", [(512, 4), (4096, 8)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_decode_on_decisive_weights_equals_the_oracles_argmax(cell, dtype, T, V, capsys):
+    """north_star 'bit-exact for the argmax note-index decode', measured where it means something: decisive outputs (median top-2
+    gap of the oracle > 1e-3 asserted, 0.2-0.4 measured), T=512 (configs[1]) and T=4096 (configs[4]), the f32 parity mode AND the
+    benched bf16 path (reference vae_definition.py:1048-1095 'argmax' decode of decoder.predict).
+    f32 mode: every row whose oracle gap is >= 1e-5 decodes to the oracle's index.
+    bf16 mode: a row may differ only where the oracle's top-2 gap is within twice the largest probability error of the path - the
+    bound the CPU study derives (weights, h and x*W+b rounded to bf16 each move p by ~1e-3..1e-2, none dominates; DESIGN.md section 7)
+    - and every row with a gap >= 0.05 agrees.  The agreement by gap bucket is printed (profiles/r05_*_decode_agreement.txt)."""
+    _decisive_decode_case(cell, dtype, T, V, capsys)
+
+
+@pytest.mark.parametrize("out_gain", [4.0, 16.0])
+@pytest.mark.parametrize("wseed,zseed", [(1, 11), (2, 12), (3, 13)])
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_decisive_decode_over_weight_and_input_seeds(cell, wseed, zseed, out_gain, capsys):
+    """the decisive-weights agreement is not one draw - three weight / bias seeds with their own latent inputs and two
+    output gains (x4: smaller top-2 gaps, more rows near a tie; x16: the original) at T=512 on the benched bf16 path.  The guarantee
+    asserted is the documented one: a row may differ from the float64 oracle only where the oracle's top-2 gap is within twice the
+    path's largest probability error, and every row with a gap >= 0.05 agrees."""
+    _decisive_decode_case(cell, "bf16", 512, 4, capsys, wseed=wseed, out_gain=out_gain, zseed=zseed)
 
 
 def test_config4_decode_full_size_properties():

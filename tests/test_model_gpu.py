@@ -1,5 +1,6 @@
 """The reference-shaped calls (fit / evaluate / predict on the packers' lists) end to end on the GPU vs the oracle."""
 import numpy as np
+import torch
 import pytest
 
 import midi_vae_amd  # noqa: F401
@@ -256,6 +257,46 @@ def test_fit_with_the_next_minibatch_converted_ahead_equals_serial_staging(prepa
         np.testing.assert_allclose(h1[k], h0[k], rtol=1e-5, atol=1e-6, err_msg=k)
     for a, b in zip(w1, w0):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+
+
+def test_a_prefetched_conversion_is_taken_only_for_the_very_same_arrays():
+    """Stager.stage(prefetched=True) used to accept a prefetched conversion when only the mirror and the window range
+    matched.  Another song of equal length (or an epsilon drawn again) behind a prefetch of the first one must be converted
+    afresh: the engine's input block then equals the one a plain stage() of the second song uploads."""
+    from midi_vae_amd.staging import Norm
+    s, m, (X, Y, C, I, V, D) = _setup("GRU", n=8, seed=4)
+    _, _, (X2, Y2, C2, I2, V2, D2) = _setup("GRU", n=8, seed=4)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(8)
+    X2, Y2, C2, I2, V2, D2 = (a[perm] if isinstance(a, np.ndarray) and a.shape[:1] == (8,) else a for a in (X2, Y2, C2, I2, V2, D2))
+    n, ae = 8, m.autoencoder
+    S, H = np.zeros((n, s["signature_vector_length"])), np.zeros((n, s["latent_dim"]))
+    eng = m._shared.get_engine(s["batch_size"], training=True)
+    st = eng.stager()
+
+    def kw_of(X, Y, C, I, V, D, eps):
+        x, y, sw = pk.prepare_autoencoder_input_and_output_list(s, X, Y, C, I, V, D, S, H, return_sample_weight=True)
+        a = ae._unpack_x(x)
+        a.update(ae._unpack_y(y))
+        ws = ae._unpack_w(sw, n)
+        a.update(ws)
+        a["hist"], a["hist_dev"] = ae._history_source(a.get("hist"))
+        return dict(eps=eps, norm=Norm.of(0, n, m.spec.T, **ws), **a)
+
+    eps = rng.standard_normal((n, s["latent_dim"])).astype(np.float32) * 0.01
+    kw1, kw2 = kw_of(X, Y, C, I, V, D, eps), kw_of(X2, Y2, C2, I2, V2, D2, eps)
+    st.stage(0, n, **kw2)
+    torch.cuda.synchronize()
+    want = eng._in_block.clone()
+    st.stage(0, n, **kw1)                        # (the other mirror: the next call uses the first one again)
+    st.prefetch(0, n, **kw1)
+    st.stage(0, n, prefetched=True, **kw2)       # the same window range, other arrays
+    torch.cuda.synchronize()
+    assert torch.equal(eng._in_block, want)
+    st.prefetch(0, n, **kw1)
+    st.stage(0, n, prefetched=True, **kw1)       # ... and the prefetched arrays themselves are taken
+    torch.cuda.synchronize()
+    assert not torch.equal(eng._in_block, want)
 
 
 def test_history_is_filled_on_first_access_and_survives_later_fit_calls():

@@ -171,3 +171,27 @@ def test_first_use_verification_retries_once_then_falls_back():
         Engine._verify_pipeline(eng, redo, key="train")
     assert calls == [1, 1] and not eng.pipeline and len(w) == 1
     assert int(eng.store["pipe_status"]) == 0 and eng._dxp0_clean is False
+
+
+def test_epsilon_stream_is_one_stream_notices_a_moved_generator_and_ends_its_thread():
+    """model.EpsilonStream (the sampling layer's N(0, epsilon_std) draws, reference vae_definition.py:498-502) draws ahead of its
+    consumer on a worker thread: rows come out in the order successive draws would give them; a generator the caller reseeds or
+    restores in place between two draws is noticed (the buffered rows are dropped); a replaced stream's thread ends."""
+    import threading
+    import time
+    from midi_vae_amd.model import EpsilonStream
+    rng = np.random.default_rng(3)
+    st = EpsilonStream(rng, 8, 0.5)
+    full = (np.random.default_rng(3).standard_normal((1024, 8)) * 0.5).astype(np.float32)
+    assert np.array_equal(st.take(5), full[:5]) and np.array_equal(st.take(7), full[5:12])
+    for _ in range(200):                       # (the block drawn ahead, if any, finishes)
+        if st._next is None or st._next.done():
+            break
+        time.sleep(0.01)
+    rng.bit_generator.state = np.random.default_rng(9).bit_generator.state
+    fresh = (np.random.default_rng(9).standard_normal((1024, 8)) * 0.5).astype(np.float32)
+    assert np.array_equal(st.take(4), fresh[:4])
+    st.reset()                                 # explicit: the rows drawn ahead are forgotten, the generator is where it is
+    before = threading.active_count()
+    st.close()
+    assert threading.active_count() == before - 1

@@ -890,7 +890,7 @@ def test_gemm_multi_equals_the_single_launches():
                 ops.gemm(A1, Bn, o["C3"], 256, 61, K, ldb=64, split_k=16, **kw),
                 ops.gemm(idx, Bf, o["C4"], 61, GH, K, a_kind=hl.ONEHOT, split_k=3, **kw)]
     multi, single = fresh(), fresh()
-    assert ops.gemm_multi(problems(multi, True))
+    assert ops.gemm_multi(problems(multi, True)) == 5
     problems(single, False)
     torch.cuda.synchronize()
     A164, A264, B64, Bn64 = (t.double().cpu().numpy() for t in (A1, A2, Bf, Bn))
@@ -903,11 +903,22 @@ def test_gemm_multi_equals_the_single_launches():
         np.testing.assert_allclose(multi[k].cpu().numpy(), single[k].cpu().numpy(), rtol=1e-4, atol=1e-3, err_msg=k)
     # more than 16 problems: two launches; every one accumulates into the same C
     C = torch.zeros((256, GH), device=DEV)
-    assert ops.gemm_multi([ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, split_k=2, build_only=True) for _ in range(20)])
+    assert ops.gemm_multi([ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, split_k=2, build_only=True) for _ in range(20)]) == 20
     torch.cuda.synchronize()
     np.testing.assert_allclose(C.cpu().numpy(), 20 * want["C2"], rtol=2e-3, atol=20 * 2e-3 * np.sqrt(K))
     # not of the batched form (no accumulate / a transposed B): refused as a whole, nothing launched
-    assert not ops.gemm_multi([ops.gemm(A1, Bf, torch.zeros((256, GH), device=DEV), 256, GH, K, trans_a=True, build_only=True)])
+    assert ops.gemm_multi([ops.gemm(A1, Bf, torch.zeros((256, GH), device=DEV), 256, GH, K, trans_a=True, build_only=True)]) == 0
+    # ... in the SECOND part of a long list: the first 16 have been launched and are reported as such - the caller runs the rest
+    # one by one and nothing is added twice (the engine used to re-launch all of them)
+    C = torch.zeros((256, GH), device=DEV)
+    mixed = [ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, split_k=2, build_only=True) for _ in range(18)]
+    mixed.append(ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, split_k=2, max_blocks=7, build_only=True))
+    done = ops.gemm_multi(mixed)
+    assert done == 16
+    for g in mixed[done:]:
+        ops.gemm_args(g)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), 19 * want["C2"], rtol=2e-3, atol=19 * 2e-3 * np.sqrt(K))
     arr = (hl.GemmArgs * 1)(ops.gemm(A2, Bf, C, 256, GH, K, trans_a=True, accumulate=True, build_only=True))
     assert hl.load().mvae_gemm_multi(arr, 17, torch.cuda.current_stream().cuda_stream) == hl.E_ARG
     assert hl.load().mvae_gemm_multi(None, 1, torch.cuda.current_stream().cuda_stream) == hl.E_ARG

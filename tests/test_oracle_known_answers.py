@@ -89,3 +89,23 @@ def test_history_roll():
     z = np.arange(12.0).reshape(4, 3)
     h = vo.history_from_z(z)
     assert np.all(h[0] == 0) and np.array_equal(h[1:], z[:-1])
+
+
+def test_readout_add_is_a_forward_only_study_switch_of_the_oracle():
+    """SURVEY A.6 hedge (VERDICT r05 missing #3): cfg['readout'] = 'add' steps the decoder on x_t = start + y_{t-1}; with every
+    output Dense zeroed except its bias the outputs are constant, and with zero output biases of a sigmoid / softmax head y is NOT
+    zero - so the two readings differ even there; 'none' (the default, the reference as written) is what everything else tests.
+    No backward pass exists for 'add'."""
+    from oracle.vae_oracle import OracleVAE, make_cfg
+    from tests.oracle_util import tiny_problem
+    cfg, p, batch, eps, m = tiny_problem("GRU", B=3, H=8, Z=6, T=5, V=3, seed=2)
+    assert cfg.get("readout", "none") == "none"
+    base, cache = m.forward(p, batch, eps)
+    m2 = OracleVAE(make_cfg(**dict(cfg, readout="add")))
+    alt, cache2 = m2.forward(p, batch, eps)
+    assert abs(alt["loss"] - base["loss"]) > 1e-6
+    # step 0 of a head sees x_0 = start + start = 0 on both readings (the packers' start rows are zeros): the first output agrees
+    np.testing.assert_allclose(cache2["out"]["notes"][:, 0], cache["out"]["notes"][:, 0], rtol=1e-12, atol=1e-14)
+    assert np.abs(cache2["out"]["notes"][:, 1:] - cache["out"]["notes"][:, 1:]).max() > 1e-6
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        m2.backward(p, cache2)

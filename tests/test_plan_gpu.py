@@ -276,3 +276,32 @@ def test_ragged_minibatches_of_one_padded_size_share_a_plan(cell):
         assert abs(a - b) <= 2e-4 * (1 + abs(b)), (res[True][0], res[False][0])
     for k, v in res[False][1].items():
         assert np.linalg.norm(res[True][1][k] - v) <= 2e-3 * (np.linalg.norm(v) + 1e-6) + 1e-6, k
+
+
+def test_a_refused_latent_chain_keys_plans_by_the_exact_window_count():
+    """when the library refuses the fused latent chain (MVAE_E_UNSUPPORTED: more than 160 KB of LDS) the step runs the
+    separate latent launches, which take the real window count and the loss normaliser as PLAIN arguments and zero the padding
+    rows with a torch operation only on a ragged batch.  Such steps must not share a plan per padded size: three full minibatches
+    would arm one that a ragged minibatch then replays with a stale count.  Forced here by refusing the chain from Python; the
+    losses of a mixed sequence of window counts equal those of an engine that never replays."""
+    sizes = [112, 112, 112, 112, 100, 97, 112, 100, 97, 100, 97]
+    spec, params, batch, raw = _problem("GRU", 112, seed=73, H=256, Z=64, T=32)
+    res = {}
+    for plans in (True, False):
+        eng = Engine(spec, max_batch=112, dtype="bf16")
+        eng.use_plans = plans
+        eng.set_params(params)
+        eng._latent_chain_forward = lambda *a, **k: False
+        eng._latent_chain_backward = lambda *a, **k: None
+        losses = []
+        for B in sizes:
+            sub = {k: (v[:B] if hasattr(v, "shape") and v.shape[:1] == (112,) else v) for k, v in raw.items()}
+            _stage(eng, sub, B)
+            eng.train_step(B)
+            losses.append(eng.metrics(B)["loss"])
+        eng.check_pipeline()
+        assert eng._chain_refused
+        assert eng._kind_B(100) == (100, float(eng.norm_B))
+        res[plans] = losses
+    for a, b in zip(res[True], res[False]):
+        assert abs(a - b) <= 2e-4 * (1 + abs(b)), (res[True], res[False])
