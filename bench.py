@@ -15,10 +15,21 @@ velocity + style heads.  A train "step" = forward + all losses + backward + (gra
 minibatch of synthetic piano-roll windows already resident in HBM; a decode "step" = one batch of latents through the decoder,
 one byte per row (the argmax note index) written.  Weak scaling: the per-GPU batch is fixed.
 
+Multi-GPU driver commands (what the DP configs of BASELINE.json name):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --config 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --config 3
+    ... --gpus 8 --config 4        (decode: replicas, no collective)
+With N > 1 ranks and no --dp-overlap the step's gradient exchange is PROBED first, untimed: a short region with one all-reduce
+after the backward pass, then one with the decoder-side bucket reduced beside the encoder BPTT (dp.BucketedAllReduce).  The faster
+policy runs the timed K steps; a probe that raises or whose pipeline times out is recorded and loses.  Both figures are in ``dp``.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline     dominant kernel (the T-step recurrent kernels) measured live with HIP events on the launch stream
   cpu_baseline the same step as float32 torch-CPU tensor operations on the host cores (oracle/torch_cpu.py), rank 0 / N=1 only,
                bounded sample, timed BEFORE the GPU phase
+  fit_e2e      (N=1, the default run) the PRODUCT path a reference user calls: one 1024-window song per autoencoder.fit call on
+               float64 one-hot lists at configs[1] - ms per optimizer step and windows/s including host conversion and upload
+               (tools/fit_e2e_bench.py --json in a process of its own, after the headline region)
   elbo         (train configs, rank 0 / N=1) the ELBO after each of K_e optimizer steps with a fresh epsilon per step on the first
                16 windows of the bench's inputs: this engine (bf16, the timed schedule) beside float64 torch-CPU arithmetic
                (oracle/torch_cpu.py elbo_trajectory, in the CPU subprocess phase), and their largest difference
@@ -203,6 +214,7 @@ def side_workload(config, cell, dtype, device, steps, warmup, step_times=False):
     host = 0.0
     prof = {}
     per_step = []
+    paced0 = eng.pace_wait_s
     t0 = time.perf_counter()
     for i in range(steps):
         eng.prof = prof if i % 4 == 0 else None        # (every 4th step is bracketed)
@@ -213,6 +225,7 @@ def side_workload(config, cell, dtype, device, steps, warmup, step_times=False):
     eng.prof = None
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    paced = eng.pace_wait_s - paced0                     # host time spent WAITING for the device inside step() (Engine._pace_now)
     if step_times:
         sys.stderr.write("config %d host ms per step() call: %s\n" % (config, " ".join("%.2f" % (1e3 * v) for v in per_step)))
     eng.prof = prof
@@ -232,14 +245,25 @@ def side_workload(config, cell, dtype, device, steps, warmup, step_times=False):
     out = {"workload": workload_name(config, C, seq, voices, T, latent, B, named_batch, named_gpus, cell, decode),
            "baseline_config": config, "cell": cell, "mode": mode, "steps": steps, "ms_per_step": ms_step,
            "value": B * steps / elapsed, "unit": "windows/s", "host_ms_per_step": host / steps * 1e3,
-           "bound": "host" if host > 0.9 * elapsed else "device",
+           # the paced host spends part of every step() call waiting for the device: what it WORKS is the rest
+           "host_work_ms_per_step": (host - paced) / steps * 1e3, "host_paced_wait_ms_per_step": paced / steps * 1e3,
+           "bound": "host" if (host - paced) > 0.9 * elapsed else "device",
            "roofline": {"kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                         "us_per_time_step": tot_ms * 1e3 / tot_steps * lpl if tot_steps else float("nan")},
            "whole_step": {"tflops": flop / (ms_step * 1e-3) / 1e12, "frac_of_peak": flop / (ms_step * 1e-3) / 1e12 / peak},
-           "plan": dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]))}
+           "plan": _plan_block(eng)}
     del eng
     torch.cuda.empty_cache()
     return out
+
+
+def _plan_block(eng, **more):
+    """step-plan statistics of an engine for the line: ``refused`` = kinds of call the engine gave up making replayable, with the
+    reason of each (a torch operation inside the call - the prewarm's forward_backward passes -, three recordings that differ in
+    something that is not an announced counter ...); such calls are enqueued from Python every time"""
+    st = eng.plan_stats
+    return dict({k: v for k, v in st.items() if k != "refused"}, refused=len(st["refused"]),
+                refused_kinds={str(k)[:80]: str(v)[:120] for k, v in list(st["refused"].items())[:6]}, **more)
 
 
 def main():
@@ -332,10 +356,43 @@ def main():
         eng.stage_decoder_inputs(B, hist=w["hist"])
         eng.stage_targets(B, w["x_idx"], w["c_idx"])
 
-    allreduce = None
+    allreduce, probe_stats = None, None
     if use_dist and not decode:
         from midi_vae_amd.dp import make_allreduce
         overlap = (world > 1) if args.dp_overlap < 0 else bool(args.dp_overlap)
+        if args.dp_overlap < 0 and (world > 1 or os.environ.get("MVAE_BENCH_PROBE_DP") == "1"):
+            # The first run of this path on real ranks must not be losable: both policies of the gradient
+            # exchange run a short UNTIMED region each - one all-reduce behind the backward pass, then the decoder-side bucket
+            # beside the encoder BPTT (the path that has only ever run on one rank) - and the faster one runs the timed steps.
+            # A region that raises, or whose pipeline times out (check_pipeline: the status word is MAX-reduced over the ranks, so
+            # every rank sees it), loses and is recorded; ranks agree through MAX-reduced figures.
+            probe_stats, n_probe = {}, max(4, min(10, args.steps))
+            for name, ov in (("late", False), ("early_bucket", True)):
+                ms, err = None, None
+                try:
+                    if ov and os.environ.get("MVAE_BENCH_FAIL_OVERLAP") == "1":      # (tests: a forced failure still yields a line)
+                        raise RuntimeError("forced failure of the early-bucket region (MVAE_BENCH_FAIL_OVERLAP=1)")
+                    ar = make_allreduce(eng, dist, world, overlap=ov)
+                    for _ in range(6):                        # (three recordings arm the step plan of this kind of step)
+                        eng.train_step(B, allreduce=ar)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    tp0 = time.perf_counter()
+                    for _ in range(n_probe):
+                        eng.train_step(B, allreduce=ar)
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - tp0) / n_probe * 1e3
+                    eng.check_pipeline()
+                except Exception as e:                        # noqa: BLE001 (whatever it is, the other policy still runs)
+                    err = "%s: %s" % (type(e).__name__, str(e)[:200])
+                t = torch.tensor([ms if err is None else 1e9, 0.0 if err is None else 1.0], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                failed = float(t[1].item()) > 0
+                probe_stats[name] = {"ms_per_step": None if failed else float(t[0].item()), "steps": n_probe,
+                                     "error": err if err is not None else ("failed on another rank" if failed else None)}
+            lt, ea = probe_stats["late"]["ms_per_step"], probe_stats["early_bucket"]["ms_per_step"]
+            overlap = ea is not None and (lt is None or ea < lt)
+            probe_stats["chosen"] = "early_bucket" if overlap else "late"
         allreduce = make_allreduce(eng, dist, world, overlap=overlap)
         allreduce.timing = []          # (HIP-event pairs around the early and the late collective: dp.BucketedAllReduce)
 
@@ -454,7 +511,7 @@ def main():
                                              "overlap is off; late: what is reduced after the backward pass)"},
                     "overlap": bool(getattr(allreduce, "overlap", False)),
                     # (a data-parallel step replays as a plan too: Python issues the collectives between its call ranges)
-                    "host_ms_per_step": host_s / args.steps * 1e3, "plan": dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]))}
+                    "host_ms_per_step": host_s / args.steps * 1e3, "plan": _plan_block(eng), "policy_probe": probe_stats}
         tt = torch.tensor([elapsed, median_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, median_ms = float(tt[0].item()), float(tt[1].item())
@@ -516,7 +573,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "%s (%s, %s %s, resident recurrent weights)" % (
                              dom, "forward recurrence" if decode else "BPTT", args.cell, args.dtype),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         # `traffic` per the contract is what THIS run measured: bench.py cannot run a counter pass over itself, so
+                         # it is null; the committed PMC pass over the same kernel body is carried under its own name
+                         "traffic": None, "traffic_from_committed_profile": traffic, "traffic_source": traffic_src,
                          # per time step and row: LSTM BPTT reads gates 4H + cell state H + upstream gradient H, writes da 4H;
                          # GRU reads gates 3H + h H + upstream gradient H, writes da 3H + r*h H; the
                          # inference forward reads x*W + b (G*H) and writes h (H)
@@ -556,7 +615,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port",
                                    "sample": "not timed for the decode configuration: oracle/torch_cpu.py covers the train step (the "
                                              "default --config 1 run carries the CPU baseline)"}
-        out["plan"] = dict(eng.plan_stats, refused=len(eng.plan_stats["refused"]), host_ms_per_step=host_s / args.steps * 1e3,
+        out["plan"] = _plan_block(eng, host_ms_per_step=host_s / args.steps * 1e3,
                            what="step plans (include/midivae_hip.h): steps of the timed region enqueued by ONE mvae_plan_run call "
                                 "('replayed'), the bracketed ones (every 4th: HIP events around the dominant launches, Engine._timed) included")
         if dp_stats is not None:
@@ -585,6 +644,15 @@ def main():
                 except Exception as e:          # (a side measurement must never cost the headline line)
                     others.append({"baseline_config": cfg, "cell": cell_o, "error": "%s: %s" % (type(e).__name__, e)})
             out["other_configs"] = others
+            # the PRODUCT path: what a reference user calls, host conversion and upload included
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fit_e2e_bench.py"), "--json", "--songs", "2",
+                                    "--cell", args.cell], capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    raise RuntimeError("exit %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1:] or ""))
+                out["fit_e2e"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                out["fit_e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -6,6 +6,7 @@ Reference counterpart: one backend call per minibatch - Keras' compiled train / 
 """
 from __future__ import annotations
 
+import time
 import ctypes as C
 import os
 
@@ -47,6 +48,7 @@ class PlannedSteps(object):
         self._ev_pool, self._ev_i = [], 0
         self._host_results, self._ext_streams, self._plan_depth = {}, {}, 0
         self._prof_pool, self._prof_pending, self._prof_i, self._prof_call = [], {}, 0, []     # launch brackets (Engine._timed)
+        self.pace_wait_s = 0.0      # host seconds spent waiting for the device by design (steps_in_flight, pace_mask): not host WORK
         self.steps_in_flight = int(os.environ.get("MVAE_STEPS_IN_FLIGHT", "1"))      # (_planned; 0 = the host runs ahead freely)
         self._flight, self._flight_pool = [], []
         self.plan_stats = {"recorded": 0, "replayed": 0, "refused": {}}
@@ -165,7 +167,9 @@ class PlannedSteps(object):
         if n and kind[0] in self._PACE_START:
             while len(self._flight) >= n:
                 ev = self._flight.pop(0)
+                t0 = time.perf_counter()
                 ev.synchronize()
+                self.pace_wait_s += time.perf_counter() - t0
                 self._flight_pool.append(ev)
         try:
             return self._planned_call(kind, fn, host, params)

@@ -3,6 +3,7 @@ train_function call per minibatch, vae_training.py:804-809), their replay as pla
 parallelism."""
 from __future__ import annotations
 
+import time
 import ctypes as C
 
 import torch
@@ -238,7 +239,9 @@ class TrainSteps(object):
             self._pace_record(bit)
 
     def _pace_now(self, bit):
+        t0 = time.perf_counter()
         hl.check(hl.load().mvae_event_synchronize(self._pace_events[bit]), "mvae_event_synchronize")
+        self.pace_wait_s += time.perf_counter() - t0          # (bench.py: host time inside a step that is waiting, not work)
 
     def _train_step(self, B, allreduce):
         self._redo_hist = None

@@ -148,6 +148,41 @@ def test_bench_dp_code_path_on_two_ranks_keeps_the_replicas_identical(overlap, t
     assert math.isfinite(line["elbo"]["loss_final"])
 
 
+@pytest.mark.parametrize("fail_overlap", [False, True])
+def test_bench_probes_both_gradient_exchange_policies_and_survives_a_failing_one(fail_overlap):
+    """with N > 1 ranks and no --dp-overlap, bench.py runs a short untimed region per policy (one all-reduce behind
+    the backward pass / the decoder bucket beside the encoder BPTT), records both in dp.policy_probe and times the K steps with the
+    faster one; a region that raises (forced here) loses and the line is printed all the same.  Two gloo ranks on the one GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MVAE_PIPELINE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if fail_overlap:
+        env["MVAE_BENCH_FAIL_OVERLAP"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--hidden", "64", "--seq-len", "8", "--voices", "2", "--latent", "16", "--batch", "16", "--prewarm-max", "0",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    probe = line["dp"]["policy_probe"]
+    assert probe["late"]["ms_per_step"] > 0 and probe["late"]["error"] is None
+    if fail_overlap:
+        assert probe["early_bucket"]["ms_per_step"] is None and "forced failure" in probe["early_bucket"]["error"]
+        assert probe["chosen"] == "late" and line["dp"]["overlap"] is False
+    else:
+        assert probe["early_bucket"]["ms_per_step"] > 0
+        assert line["dp"]["overlap"] == (probe["chosen"] == "early_bucket")
+    assert line["dp"]["replicas_max_abs_diff"] == 0.0 and line["steps"] == 3
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_data_parallel_steps_replay_as_plans_with_the_collectives_between_their_ranges(one_rank_rccl, overlap):
     """a train step with a gradient hook is recorded like any other; its collectives are HOST actions between

@@ -26,6 +26,7 @@ ap.add_argument("--pace-mask", type=int, default=-1, help="Engine.pace_mask (-1 
 ap.add_argument("--pace-split", type=int, default=-1, help="Engine.pace_mask_split only (-1 = as shipped)")
 ap.add_argument("--no-prefetch", action="store_true", help="convert every minibatch on the caller's thread (Autoencoder.prefetch = False)")
 ap.add_argument("--threads", type=int, default=-1, help="host packer threads (mvae_host_threads; -1 = default)")
+ap.add_argument("--json", action="store_true", help="one JSON line at the end (the last epoch): what bench.py embeds as fit_e2e")
 a = ap.parse_args()
 import torch
 s = build_settings(cell_type=a.cell, input_length=128, output_length=128, latent_dim=64, batch_size=a.batch)
@@ -120,3 +121,11 @@ for ep in (1, 2, 3):
           "pre-pass %.3f s, python packers %.3f s, fit %.3f s | loss %.4f" % (ep, nw, dt, nw / dt, fit_note, tp, tk, tf, loss))
     print("         host time inside fit per %d-window step: %s" % (a.batch, ", ".join(
         "%s %.2f ms" % (k_, v_ / (nw / a.batch) * 1e3) for k_, v_ in HOST.items())))
+    last = dict(windows=nw, seconds=dt, windows_per_s=nw / dt, ms_per_optimizer_step=dt / (nw / a.batch) * 1e3,
+                fit_only_ms_per_optimizer_step=None if a.lazy else tf / (nw / a.batch) * 1e3, loss=float(loss),
+                host_ms_per_step={k_: v_ / (nw / a.batch) * 1e3 for k_, v_ in HOST.items()})
+if a.json:
+    import json
+    print(json.dumps(dict(last, cell=a.cell, batch=a.batch, windows_per_song=n, songs=len(songs), prepass=bool(a.with_prepass),
+                          what="autoencoder.fit on the reference's float64 one-hot lists (vae_training.py:802-809), one fit call per "
+                               "song: host conversion + upload + train steps + history read-back; third epoch over the songs")))
