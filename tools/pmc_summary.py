@@ -4,7 +4,6 @@ recurrent kernel: mean per launch, per-wave-per-step instruction counts, MFMA-bu
    python tools/pmc_summary.py gpurun_out/prof_c/pmc_*_counter_collection.csv > profiles/<round>_rnn_pmc_summary.txt"""
 import collections, csv, re, sys
 T, B = 512, 256
-waves = (B // 16) * 4
 agg = collections.defaultdict(list)
 for f in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
@@ -16,9 +15,11 @@ m = lambda k, c: (sum(agg[(k, c)]) / len(agg[(k, c)])) if (k, c) in agg else flo
 # writes: WRITE_SIZE (KiB) or - its pass hangs in rocprofv3's start-up on this image - TCC_EA0_WRREQ_sum x 64 B
 written_mb = lambda k: m(k, "WRITE_SIZE") * 1024 / 1e6 if (k, "WRITE_SIZE") in agg else m(k, "TCC_EA0_WRREQ_sum") * 64 / 1e6
 print("rocprofv3 --pmc, one pass per counter group; tools/rnn_microbench.py --cell LSTM / GRU (T=%d steps, B=%d rows, H=256, bf16)" % (T, B))
-print("per launch: %d workgroups x 4 waves; SQ_*_CYCLES counters are quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles)" % (B // 16))
+print("per launch: %d workgroups x 4 waves (x 8 for the two-waves-per-SIMD *_w8_k kernels); SQ_*_CYCLES counters are quad-cycles except "
+      "SQ_VALU_MFMA_BUSY_CYCLES (cycles)" % (B // 16))
 print("FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950\n")
 for k in kernels:
+    waves = (B // 16) * (8 if "_w8" in k else 4)
     wc, mf = m(k, "SQ_WAVE_CYCLES"), m(k, "SQ_VALU_MFMA_BUSY_CYCLES")
     print(k)
     print("  cycles per wave per time step      %8.0f   (= %.2f us at 2.4 GHz)" % (wc * 4 / waves / T, wc * 4 / waves / T / 2400))
@@ -29,5 +30,6 @@ for k in kernels:
     n_mfma, n_valu, n_lds, n_vmem = (m(k, c) / waves / T for c in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM"))
     print("  per wave per step: MFMA %.0f  other VALU %.0f (SQ_INSTS_VALU %.0f includes the MFMAs)  LDS %.0f  VMEM %.0f" % (
         n_mfma, n_valu - n_mfma, n_valu, n_lds, n_vmem))
-    print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (
-        2 * m(k, "FETCH_SIZE") * 1024 / 1e6, written_mb(k)))
+    if (k, "FETCH_SIZE") in agg or (k, "WRITE_SIZE") in agg or (k, "TCC_EA0_WRREQ_sum") in agg:     # (their own passes: tools/pmc_traffic.py)
+        print("  HBM per launch: read %.1f MB (2 x FETCH_SIZE)  written %.1f MB" % (
+            2 * m(k, "FETCH_SIZE") * 1024 / 1e6, written_mb(k)))
