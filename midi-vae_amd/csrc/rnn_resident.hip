@@ -2469,8 +2469,19 @@ int mvae_rnn_fwd_resident(const mvae_rnn_fwd_args& a, hipStream_t s) {
     return MVAE_E_UNSUPPORTED;
 }
 int mvae_rnn_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s);
+// MVAE_LSTM_BWD_W8=1 (default OFF; read at every call): the LSTM BPTT of seq_layout TILE16P on the two-waves-per-SIMD kernel of
+// rnn_w8.hip (same data, same results).  It LOSES - 3.7-3.9 us per time step against 2.5-2.7 - because a quarter of U^T has to be
+// streamed from L2 and gfx950 retires vector memory instructions in issue order: every streamed fragment waits behind the HBM-latency
+// requests of the next step's saved activations (profiles/r06_g_lstm_bptt_w8.txt).  Kept as the measured experiment.
+bool mvae_lstm_bwd_w8_enabled() {
+    const char* e = getenv("MVAE_LSTM_BWD_W8");
+    return e && atoi(e) != 0;
+}
 int mvae_rnn_bwd_resident(const mvae_rnn_bwd_args& a, hipStream_t s) {
     if (a.seq_layout == MVAE_TILE16Q) return mvae_rnn_bwd_w8(a, s);
+    if (a.cell == MVAE_LSTM && a.seq_layout == MVAE_TILE16P && a.H == RH && a.dtype == MVAE_BF16 && (a.B % 16) == 0 &&
+        mvae_lstm_bwd_w8_enabled())
+        return mvae_rnn_bwd_w8(a, s);
     if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || (a.seq_layout != MVAE_TILE16 && a.seq_layout != MVAE_TILE16P))
         return MVAE_E_UNSUPPORTED;
     if (a.cell == MVAE_LSTM) {

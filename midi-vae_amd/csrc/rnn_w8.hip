@@ -29,11 +29,29 @@
 #ifndef W8_ABL_NOB
 #define W8_ABL_NOB 0        /* B fragments read once per launch */
 #endif
+#ifndef W8_B2B
+#define W8_B2B 13           /* GRU forward: slot behind which barrier 2b stands (the h_b write is slot 6; h_b is needed from slot 16) */
+#endif
+#ifndef W8_B1
+#define W8_B1 30            /* ... barrier 1 (the last r*h write is slot 27; r*h is needed from slot 32) */
+#endif
+#ifndef W8_TA0
+#define W8_TA0 42           /* ... first slot of tile a's tanh + h update (3 slots, then the h_a write; its last MFMA is slot 39) */
+#endif
+#ifndef W8_BWD_Z_LATE
+#define W8_BWD_Z_LATE 0     /* GRU BPTT: da_z (only M2z waits for it, slot 16) computed behind barrier 1 and exchanged by a barrier of its own in slot 8 */
+#endif
+#ifndef W8_ABL_NOSTREAM
+#define W8_ABL_NOSTREAM 0   /* LSTM BPTT: the fragments streamed from L2 replaced by register ones (no requests) */
+#endif
+#ifndef W8_ABL_NOLOADS
+#define W8_ABL_NOLOADS 0    /* LSTM BPTT: no requests of the next step's saved values (the stream alone in the memory queue) */
+#endif
 #ifndef W8_PRIO
 #define W8_PRIO 0           /* s_setprio 1 for waves 4..7 (the second-dispatched wave of every SIMD) */
 #endif
 #ifndef MVAE_VARIANT_BUILD
-static_assert(!W8_ABL_NOBAR && !W8_ABL_NOMATH && !W8_ABL_NOL && !W8_ABL_NOB, "timing ablations: variant builds only");
+static_assert(!W8_ABL_NOBAR && !W8_ABL_NOMATH && !W8_ABL_NOL && !W8_ABL_NOB && !W8_ABL_NOSTREAM && !W8_ABL_NOLOADS, "timing ablations: variant builds only");
 #endif
 
 // Phase stamps (build with -DW8_STAMPS): lane 0 of waves 0 and 4 of block 0 records s_memtime at marked points of steps
@@ -380,7 +398,7 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
             if constexpr (sl == 0) accZ[0] = unpack4(xv(XB, 0, 0));
             if constexpr (sl >= 3 && sl < 6) h_stage(1, sl - 3);          // tile b of step t-1 (its last MFMA: slot 47)
             if constexpr (sl == 6) *reinterpret_cast<u16x4*>(hcur + hw0 + 256) = pack4(hreg[1]);
-            if constexpr (sl == 7) {
+            if constexpr (sl == W8_B2B) {
                 W8_STAMP(2);
                 w8_barrier();                                             // ---- 2b: h_{t-1} is complete in hcur
                 W8_STAMP(3);
@@ -426,7 +444,7 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
                 constexpr int n = sl == 27;
                 if (!W8_ABL_NOMATH) *reinterpret_cast<u16x4*>(rhbuf + hw0 + 256 * n) = pack4(mul4(accR[n], hreg[n]));
             }
-            if constexpr (sl == 27) {
+            if constexpr (sl == W8_B1) {
                 W8_STAMP(6);
                 w8_barrier();                                             // ---- 1: r*h is complete
                 W8_STAMP(7);
@@ -457,8 +475,8 @@ __device__ __forceinline__ void gru_fwd_w8_body(const mvae_rnn_fwd_args& a, cons
                     *reinterpret_cast<g_u16x8*>(acts_p[0] + lane16) = cat8(pack4(accZ[0]), pack4(accZ[1]));
                 }
             }
-            if constexpr (sl >= 43 && sl < 46) h_stage(0, sl - 43);        // tile a (its last MFMA: slot 39)
-            if constexpr (sl == 46) *reinterpret_cast<u16x4*>(hnext + hw0) = pack4(hreg[0]);
+            if constexpr (sl >= W8_TA0 && sl < W8_TA0 + 3) h_stage(0, sl - W8_TA0);        // tile a (its last MFMA: slot 39)
+            if constexpr (sl == W8_TA0 + 3) *reinterpret_cast<u16x4*>(hnext + hw0) = pack4(hreg[0]);
             if constexpr (sl == 47) {
                 W8_STAMP(10);
                 w8_barrier();                                             // ---- 2a: the a half of h_t is complete in hnext
@@ -705,10 +723,10 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 dac[e] = d[n][e] * w1[n][e];
-                daz[e] = d[n][e] * kz[n][e];
+                if (!W8_BWD_Z_LATE) daz[e] = d[n][e] * kz[n][e];
             }
             *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (2 * 512 + n * 256))) = pack4(dac);
-            *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (0 * 512 + n * 256))) = pack4(daz);
+            if (!W8_BWD_Z_LATE) *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (0 * 512 + n * 256))) = pack4(daz);
         }
         w8_barrier();                                                     // ---- 1: da_c, da_z
         bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (16u << 6)));
@@ -745,6 +763,14 @@ __device__ __forceinline__ void gru_bwd_w8_body(const mvae_rnn_bwd_args& a, cons
             // (requests are unconditional - at t = 0 step 0's values once more: a request under a branch is an asm output merged
             //  with the old value behind it, i.e. a register copy of data that has not landed)
             if constexpr (sl == 0) issue_early(0, 0);                     // (acts_p / hs_p / dx_p were moved to step t-1 above)
+            if constexpr (W8_BWD_Z_LATE && (sl == 2 || sl == 4)) {
+                constexpr int n = sl == 4;
+                f32x4 daz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) daz[e] = d[n][e] * kz[n][e];
+                *reinterpret_cast<u16x4*>(dabuf + (da_w0 + (0 * 512 + n * 256))) = pack4(daz);
+            }
+            if constexpr (W8_BWD_Z_LATE && sl == 9) w8_barrier();          // ---- 1b: da_z (its first B fragment is requested in slot 12)
             // M2's accumulators start at d z
             if constexpr (sl == 10 || sl == 12) {
                 constexpr int n = sl == 12;
@@ -870,6 +896,323 @@ int launch_gru_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
     return MVAE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LSTM backward through time, two waves per SIMD (the dominant kernel of a training step)
+// ---------------------------------------------------------------------------------------------------------
+// Same data as the 4-wave kernel lstm_bwd_il_k (seq_layout MVAE_TILE16P: a drop-in for it, the forward kernels stay as they are):
+// wave w owns the unit tiles 2w and 2w + 1 - pair w of every TILE16P array.  Per step (t from T-1 down), with d = dh_t + upstream:
+//     E   dO = d tanh(c_t) hs'(o);   dct = dc + d o (1 - tanh(c_t)^2);   di = dct g hs'(i);   df = dct c_{t-1} hs'(f);
+//         dg = dct i (1 - g^2);   dc_{t-1} = dct f                                          -> da tile (LDS), barrier
+//     M   dh_{t-1} = U^T-fragments x [di | df | dg | dO]: 64 MFMA slots per wave (32 k-groups x 2 unit tiles)
+// U^T is 512 KiB - a CU's whole register file: a wave keeps 32 of its 64 fragments in accumulator registers, 16 in LDS, and
+// STREAMS the other 16 from L2 every step through a ring of 4 (tools/probes/l2stream_probe.hip: 128 KiB per CU and step beside
+// 128 MFMAs per SIMD cost 0.10 us per step on 16 ... 128 CUs).  The factors of d that do not depend on the recurrence -
+// tanh(c_t) hs'(o) and o (1 - tanh(c_t)^2) of the NEXT step - are computed in the M slots; what E leaves exposed is the
+// arithmetic on dct.  All memory instructions of a step are issued in a fixed order (table below) and waited for by count.
+__host__ __device__ constexpr int lbw_class(int s) { return (s & 3) < 2 ? 0 : ((s & 3) == 2 ? 1 : 2); }      // 0 AGPR, 1 LDS, 2 streamed
+// Memory instructions issued in the fillers of M slot s (at most one KIND per slot; within slot 0 the four requests in order):
+//   streamed fragments, consumed in slots c = 4j + 3: an L2 round trip beside the LDS and store traffic of a step takes ~700 cycles =
+//   ~22 MFMA slots (a ring of 4, every request 16 slots ahead, ran 3.5 us per step against 2.07 without the stream), so
+//     c = 3 .. 15   are requested in slots 51 .. 63 of the PREVIOUS step (the E phase in between)  -> ring[0..3]
+//     c = 19 .. 31  together in slot 0, 18 .. 30 slots ahead                                       -> ring[4..7]
+//     c = 35 .. 47  in slots 3 .. 15, as ring[0..3] are consumed;  c = 51 .. 63 in slots 19 .. 31 as ring[4..7] are
+//   the next step's requests: i f g o c_{t-2} in slots 1 .. 17, the upstream tiles in 21, 25
+//   the 4 copy stores of the da tile in slots 4, 6, 8, 10 (their LDS reads two slots earlier, right behind the barrier: the next E
+//   phase of a faster wave must not find them unread); vmcnt retires in issue order and a write-through store is acknowledged
+//   after ~0.3 us, which every request behind them can afford: none is consumed less than 24 slots later
+__host__ __device__ constexpr int lbw_vm_ops(int s, bool ext) {
+    if (s == 0) return 4;
+    if ((s & 3) == 3 && (s <= 31 || s >= 51)) return 1;
+    if ((s & 3) == 1 && s < (ext ? 28 : 20)) return 1;
+    if (s >= 4 && s <= 10 && (s & 1) == 0) return 1;
+    return 0;
+}
+__host__ __device__ constexpr int lbw_vm_before(int s, bool ext) {      // issued in slots [0, s)
+    int n = 0;
+    for (int i = 0; i < s; ++i) n += lbw_vm_ops(i, ext);
+    return n;
+}
+// memory instructions younger than the request of the streamed fragment that slot c (c % 4 == 3) uses, when slot c starts
+__host__ __device__ constexpr int lbw_ring_younger(int c, bool ext) {
+    if (c < 16) return lbw_vm_before(64, ext) - lbw_vm_before(c + 49, ext) + lbw_vm_before(c, ext);
+    if (c < 32) return 3 - (c - 19) / 4 + lbw_vm_before(c, ext) - lbw_vm_before(1, ext);
+    return lbw_vm_before(c, ext) - lbw_vm_before(c - 31, ext);
+}
+// ring entry of the fragment consumed in slot c
+__host__ __device__ constexpr int lbw_ring_entry(int c) { return ((c >> 4) & 1) * 4 + ((c >> 2) & 3); }
+
+template <bool HAS_EXT>
+__device__ __forceinline__ void lstm_bwd_w8_body(const mvae_rnn_bwd_args& a, const unsigned bx) {
+    constexpr int G = 4, GH = G * RH, S2 = GH / 32, NLDS = 16, NSTR = 16;
+    constexpr int V_STEP = lbw_vm_before(64, HAS_EXT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dabuf = smem;                                              // [16][GH] bf16, swizzled (32 KiB)
+    frag* ulds = reinterpret_cast<frag*>(smem + 16 * GH * 2);                 // [8][NLDS][64]
+    const int tid = threadIdx.x, l = tid & 63, q = l >> 4, r = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B;
+    const int b = bx * 16 + r;
+    const size_t tps = (size_t)(B / 16);
+    const frag* __restrict__ up = reinterpret_cast<const frag*>(a.ut_pack);
+    frag* myl = ulds + (size_t)w * NLDS * 64 + l;
+    // slot s: k-group s / 2 (over the gate columns [i | f | g | o]), unit tile 2w + s % 2
+    auto src_frag = [&](int s) -> const frag* { return up + (size_t)((2 * w + (s & 1)) * S2 + (s >> 1)) * 64 + l; };
+    frag ua[32];
+    static_for<0, 64>(SF_LAMBDA(sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (lbw_class(s) == 0) load1_agpr_nowait(ua[(s >> 2) * 2 + (s & 1)], src_frag(s));
+    });
+    {
+        frag tmp[NLDS];
+        static_for<0, 64>(SF_LAMBDA(sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (lbw_class(s) == 1) tmp[s >> 2] = *src_frag(s);
+        });
+#pragma unroll
+        for (int i = 0; i < NLDS; ++i) myl[(size_t)i * 64] = tmp[i];
+    }
+    // the streamed fragments (slots 4j + 3): global byte offsets relative to this wave's first one are compile-time constants
+    const gbyte* strm = to_global(up + (size_t)((2 * w + 1) * S2 + 1) * 64);       // (wave-uniform; + lane * 16)
+
+    const int ub0 = w * 32 + q * 4;
+    unsigned lane8 = (unsigned)l * 8u, lane16 = (unsigned)l * 16u;
+    // da tile (row stride 2048 B): this lane's 4 values of (gate g, tile n) at (da_w0 ^ (n << 5)) + g * 512; B fragment of k-group
+    // ks at b_row + (b_ch ^ (ks << 6))
+    unsigned da_w0 = (unsigned)r * (GH * 2) + ((((unsigned)w * 4u + ((unsigned)q >> 1)) ^ (unsigned)r) << 4) + ((unsigned)q & 1u) * 8u;
+    unsigned b_row = (unsigned)r * (GH * 2), b_ch = ((unsigned)q ^ (unsigned)r) << 4;
+    // row-major copy of the da tile: one 16-byte chunk per lane and gate (row 2w + l/32, chunk l%32 of the gate's 32)
+    const unsigned row0 = 2u * (unsigned)w + ((unsigned)l >> 5), ch0 = (unsigned)l & 31u;
+    unsigned cl0 = row0 * (GH * 2) + ((ch0 ^ row0) << 4), cg0 = row0 * (GH * 2) + ch0 * 16u;
+
+    f32x4 dhv[2], dc[2];
+    const int ldl = a.dh_last_ld ? a.dh_last_ld : RH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        dhv[n] = a.dh_last ? *reinterpret_cast<const f32x4*>(a.dh_last + (size_t)b * ldl + ub0 + 16 * n) : z4;
+        dc[n] = a.dc_last ? *reinterpret_cast<const f32x4*>(a.dc_last + (size_t)b * ldl + ub0 + 16 * n) : z4;
+    }
+    gbyte *acts_p[G], *cs_p, *dx_p, *da_p;
+    const size_t acts_step = tps * (GH / 16) * 512, cs_step = tps * (RH / 16) * 512, dx_step = cs_step, da_step = (size_t)B * GH * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        acts_p[g] = to_global(a.acts) + (((size_t)(T - 1) * tps + bx) * (GH / 32) + g * (RH / 32) + w) * 1024;
+    cs_p = to_global(a.cs) + (((size_t)(T - 1) * tps + bx) * (RH / 32) + w) * 1024;        // c_{t-1} of step T-1 (slot T-1)
+    dx_p = to_global(a.dhs_ext) + (((size_t)(T - 1) * tps + bx) * (RH / 16) + 2 * w) * 512;
+    da_p = to_global(a.da) + ((size_t)(T - 1) * B + bx * 16) * (GH * 2);
+
+    const int cs_steps = a.chunk_steps;
+    const unsigned wait_value = a.wait_value ? a.wait_value : 1u;
+    int pk = __builtin_amdgcn_readfirstlane(cs_steps ? (T - 1) / cs_steps : 0), plo = pk * cs_steps;
+    if (HAS_EXT && cs_steps && a.wait_ready) wave_wait_ge(a.wait_ready + pk, wait_value, a.status, 2u);
+    int pwait = (cs_steps && a.wait_ready && plo > 0) ? plo : -1;
+    int psig = (cs_steps && a.signal_done) ? plo : -1;
+
+    // saved values as TILE16P pairs (elements 0..3 tile 2w, 4..7 tile 2w + 1): gates i f g o, c_{t-1}; `carry` = c_t (the previous
+    // step's c_{t-1}); the upstream gradient per tile (TILE16)
+    u16x8 qa[G], qs, carry;
+    u16x4 qd[2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) qa[g] = *reinterpret_cast<const g_u16x8*>(acts_p[g] + lane16);
+    qs = *reinterpret_cast<const g_u16x8*>(cs_p + lane16);
+    carry = *reinterpret_cast<const g_u16x8*>(cs_p + cs_step + lane16);
+    if (HAS_EXT) {
+        qd[0] = *reinterpret_cast<const g_u16x4*>(dx_p + lane8);
+        qd[1] = *reinterpret_cast<const g_u16x4*>(dx_p + 512 + lane8);
+    }
+    // the ring of streamed fragments: slots 3, 7, 11, 15 of the first step
+    frag ring[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ring[j] = *reinterpret_cast<const g_u16x8*>(strm + (size_t)j * 2 * 64 * 16 + lane16);
+    vm_drain();
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < G; ++g) acts_p[g] -= (T > 1 ? acts_step : 0);
+    cs_p -= (T > 1 ? cs_step : 0);
+    dx_p -= (T > 1 ? dx_step : 0);
+
+    auto lo4 = [&](const u16x8& v) __attribute__((always_inline)) { return unpack4(__builtin_shufflevector(v, v, 0, 1, 2, 3)); };
+    auto hi4 = [&](const u16x8& v) __attribute__((always_inline)) { return unpack4(__builtin_shufflevector(v, v, 4, 5, 6, 7)); };
+    auto dhs = [&](float y) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f((y - y * y) * 0x1p100f, 0.0f, 0.2f); };
+    // factors of d of the step about to be processed: ko = tanh(c_t) hs'(o), kc = o (1 - tanh(c_t)^2); in 4 pieces per tile
+    f32x4 ko[2], kc[2], t_c;
+    constexpr float K2 = 2.8853900817779268f;
+    auto precompute = [&](int n, int piece) __attribute__((always_inline)) {
+        if (W8_ABL_NOMATH) return;
+        if (piece == 0) {
+            t_c = n ? hi4(carry) : lo4(carry);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t_c[e] = __builtin_amdgcn_exp2f(t_c[e] * K2);
+        } else if (piece == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t_c[e] = __builtin_fmaf(__builtin_amdgcn_rcpf(t_c[e] + 1.0f), -2.0f, 1.0f);      // tanh(c_t)
+        } else if (piece == 2) {
+            const f32x4 o = n ? hi4(qa[3]) : lo4(qa[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kc[n][e] = o[e] * __builtin_fmaf(-t_c[e], t_c[e], 1.0f);
+                ko[n][e] = (o[e] - o[e] * o[e]) * 0x1p100f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ko[n][e] = t_c[e] * __builtin_amdgcn_fmed3f(ko[n][e], 0.0f, 0.2f);
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) precompute(n, pc);
+
+    frag bq[3], lt, cp;          // (one staging register for the LDS-resident fragments: requested 4 slots before its use)
+    f32x4 acc[2];
+    acc[0] = dhv[0];
+    acc[1] = dhv[1];
+    auto step = [&](const int t) __attribute__((always_inline)) {
+        pins(acts_p[0]); pins(acts_p[1]); pins(acts_p[2]); pins(acts_p[3]); pins(cs_p); pins(da_p);
+        if (HAS_EXT) pins(dx_p);
+        if (HAS_EXT) wave_wait_ge_if(t, __builtin_amdgcn_readfirstlane(pwait), uniform_ptr(a.wait_ready + (pk - 1)), wait_value, a.status, 2u);
+        // ---- E (exposed) ------------------------------------------------------------------------------------------------
+        // this step's i, f, g, c_{t-1} and upstream gradient: requests 0..2, 4, 6.. of the previous step's M phase; behind the last of
+        // them (slot 25) that phase issued what lbw_vm_before(64) - lbw_vm_before(26) counts
+        vm_wait<V_STEP - lbw_vm_before(HAS_EXT ? 26 : 18, HAS_EXT)>();
+        pin8(qa[0]); pin8(qa[1]); pin8(qa[2]); pin8(qs);
+        if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const f32x4 ig = n ? hi4(qa[0]) : lo4(qa[0]), fg = n ? hi4(qa[1]) : lo4(qa[1]), gg = n ? hi4(qa[2]) : lo4(qa[2]);
+            const f32x4 cpv = n ? hi4(qs) : lo4(qs);
+            f32x4 d = acc[n], di, df, dg, dO;
+            if (HAS_EXT) {
+                const f32x4 dx = unpack4(qd[n]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] += dx[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (W8_ABL_NOMATH) { di[e] = df[e] = dg[e] = dO[e] = d[e]; continue; }
+                const float dct = __builtin_fmaf(d[e], kc[n][e], dc[n][e]);
+                dO[e] = d[e] * ko[n][e];
+                di[e] = dct * gg[e] * dhs(ig[e]);
+                df[e] = dct * cpv[e] * dhs(fg[e]);
+                dg[e] = dct * ig[e] * __builtin_fmaf(-gg[e], gg[e], 1.0f);
+                dc[n][e] = dct * fg[e];
+            }
+            unsigned char* dan = dabuf + (da_w0 ^ (unsigned)(n << 5));
+            *reinterpret_cast<u16x4*>(dan + 0 * 512) = pack4(di);
+            *reinterpret_cast<u16x4*>(dan + 1 * 512) = pack4(df);
+            *reinterpret_cast<u16x4*>(dan + 2 * 512) = pack4(dg);
+            *reinterpret_cast<u16x4*>(dan + 3 * 512) = pack4(dO);
+        }
+        carry = qs;                                       // c_{t-1} is the next step's c_t
+        w8_barrier();                                     // ---- the da tile is complete
+        bq[0] = *reinterpret_cast<const frag*>(dabuf + b_row + b_ch);
+        bq[1] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ (1u << 6)));
+        lt = myl[0];
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]));
+        static_for<0, 64>(SF_LAMBDA(slc) {
+            constexpr int sl = decltype(slc)::value, kq = sl >> 1, n = sl & 1, j4 = sl >> 2;
+            if constexpr (n == 0 && kq + 2 < 32)
+                bq[(kq + 2) % 3] = *reinterpret_cast<const frag*>(dabuf + b_row + (b_ch ^ ((unsigned)(kq + 2) << 6)));
+            if constexpr (lbw_class(sl) == 0) {
+                mfma1<true>(acc[n], ua[j4 * 2 + n], bq[kq % 3]);
+            } else if constexpr (lbw_class(sl) == 1 && W8_ABL_NOL) {
+                mfma1<true>(acc[n], ua[j4 * 2], bq[kq % 3]);
+            } else if constexpr (lbw_class(sl) == 1) {
+                mfma1<false>(acc[n], lt, bq[kq % 3]);
+                lt = myl[(size_t)((j4 + 1) & 15) * 64];
+            } else if constexpr (W8_ABL_NOSTREAM) {
+                mfma1<true>(acc[n], ua[j4 * 2 + 1], bq[kq % 3]);
+            } else {
+                // the streamed fragment of this slot was requested 16 slots ago (4 ring entries); behind it: what those slots issued
+                vm_wait<lbw_ring_younger(sl, HAS_EXT)>();
+                pin8(ring[lbw_ring_entry(sl)]);
+                mfma1<false>(acc[n], ring[lbw_ring_entry(sl)], bq[kq % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fillers (memory instructions exactly as lbw_vm_ops lists them, in this order) ---------------------------------
+            // streamed fragments (lbw_vm_ops): fragment j sits 2j fragments behind the first one
+            if constexpr (sl == 0 && !W8_ABL_NOSTREAM) {
+                pinu(lane16);
+                static_for<4, 8>(SF_LAMBDA(jc) {
+                    constexpr int j = decltype(jc)::value;
+                    xload16(ring[lbw_ring_entry(4 * j + 3)], strm + (size_t)(j * 2) * 64 * 16, lane16);
+                });
+            }
+            if constexpr ((sl & 3) == 3 && sl <= 31 && !W8_ABL_NOSTREAM) {          // for slot sl + 32, into the entry just consumed
+                pinu(lane16);
+                xload16(ring[lbw_ring_entry(sl + 32)], strm + (size_t)(((sl + 32) >> 2) * 2) * 64 * 16, lane16);
+            }
+            if constexpr ((sl & 3) == 3 && sl >= 51 && !W8_ABL_NOSTREAM) {          // for slot sl - 48 of the next step
+                pinu(lane16);
+                xload16(ring[lbw_ring_entry(sl - 48)], strm + (size_t)(((sl - 48) >> 2) * 2) * 64 * 16, lane16);
+            }
+            // (W8_ABL_NOLOADS: the same instructions on ONE hot line - they stay in the count, their latency is an L2 hit's)
+            if constexpr ((sl & 3) == 1 && sl < 16) { pinu(lane16); xload16(qa[sl >> 2], W8_ABL_NOLOADS ? strm : acts_p[sl >> 2], lane16); }     // i f g o of step t-1
+            if constexpr (sl == 17) { pinu(lane16); xload16(qs, W8_ABL_NOLOADS ? strm : cs_p, lane16); }                                       // c_{t-2}
+            if constexpr (sl == 21 && HAS_EXT) { pinu(lane8); xload8(qd[0], W8_ABL_NOLOADS ? strm : dx_p, lane8); }
+            if constexpr (sl == 25 && HAS_EXT) { pinu(lane8); xload8(qd[1], W8_ABL_NOLOADS ? strm : dx_p + 512, lane8); }
+            // the next step's factors: tanh(c_t) from `carry` (registers), o from request 3 (slot 13)
+            // (slots 48 .. 55: four of the eight ring entries are dead between slot 47 and the next step - the registers the factors use)
+            if constexpr (sl == 47) { vm_wait<lbw_vm_before(48, HAS_EXT) - lbw_vm_before(14, HAS_EXT)>(); pin8(qa[3]); }
+            if constexpr (sl >= 48 && sl < 56) precompute((sl - 48) >> 2, (sl - 48) & 3);
+            // row-major copy of the da tile (final since the barrier): gate (sl - 43) / 4
+            if constexpr (sl >= 4 && sl <= 10 && (sl & 1) == 0) {
+                pinu(cg0);
+                store16_wt(da_p, cg0 + ((sl - 4) >> 1) * 512, cp);
+            }
+            if constexpr (sl >= 2 && sl <= 8 && (sl & 1) == 0) cp = *reinterpret_cast<const frag*>(dabuf + (cl0 + ((sl - 2) >> 1) * 512));
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_nop 9" : "+v"(acc[0]), "+v"(acc[1]));
+        da_p -= da_step;
+        wave_signal_done_if<false>(t, __builtin_amdgcn_readfirstlane(psig), uniform_ptr(a.signal_done + pk));
+        {
+            const bool adv = cs_steps && t == plo;
+            pk -= adv ? 1 : 0;
+            plo -= adv ? cs_steps : 0;
+            pwait = (a.wait_ready && plo > 0) ? plo : -1;
+            psig = a.signal_done ? plo : -1;
+        }
+    };
+    for (int t = T - 1; t >= 0; --t) {
+        step(t);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acts_p[g] -= (t > 1 ? acts_step : 0);
+        cs_p -= (t > 1 ? cs_step : 0);
+        if (HAS_EXT) dx_p -= (t > 1 ? dx_step : 0);
+    }
+    const int ldd = a.dh0_ld ? a.dh0_ld : RH;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        if (a.dh0) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)b * ldd + ub0 + 16 * n) = acc[n];
+        if (a.dc0) *reinterpret_cast<f32x4*>(a.dc0 + (size_t)b * ldd + ub0 + 16 * n) = dc[n];
+    }
+    vm_drain();
+    pin8(qa[0]); pin8(qa[1]); pin8(qa[2]); pin8(qa[3]); pin8(qs);
+    if (HAS_EXT) { pin1(qd[0]); pin1(qd[1]); }
+    pin8(ring[0]); pin8(ring[1]); pin8(ring[2]); pin8(ring[3]); pin8(ring[4]); pin8(ring[5]); pin8(ring[6]); pin8(ring[7]);
+}
+template <bool HAS_EXT>
+__global__ __launch_bounds__(512, 1) void lstm_bwd_w8_k(const mvae_rnn_bwd_args a) {
+    lstm_bwd_w8_body<HAS_EXT>(a, blockIdx.x);
+}
+template <bool HAS_EXT>
+int launch_lstm_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
+    const size_t lds = (size_t)16 * 4 * RH * sizeof(bf16_t) + (size_t)8 * 16 * 64 * sizeof(frag);
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_w8_k<HAS_EXT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return MVAE_E_LAUNCH;
+        raised = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_w8_k<HAS_EXT>), dim3(a.B / 16), dim3(512), lds, s, a);
+    MVAE_CHECK_LAUNCH();
+    return MVAE_OK;
+}
+
 constexpr int GRU_W8_NLDS = 16;
 template <int XMODE, int SAVE>
 __global__ __launch_bounds__(512, 1) void gru_fwd_w8_k(const mvae_rnn_fwd_args a) {
@@ -946,8 +1289,12 @@ int launch_fwd_multi_w8(const rnn_fwd_multi& m, int total, hipStream_t s) {
 }  // namespace
 
 int mvae_rnn_bwd_w8(const mvae_rnn_bwd_args& a, hipStream_t s) {
-    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0 || a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU)
-        return MVAE_E_UNSUPPORTED;
+    if (a.H != RH || a.dtype != MVAE_BF16 || (a.B % 16) != 0) return MVAE_E_UNSUPPORTED;
+    if (a.cell == MVAE_LSTM && a.seq_layout == MVAE_TILE16P) {       // (the data of lstm_bwd_il_k: a drop-in for it)
+        if (!a.cs) return MVAE_E_ARG;
+        return a.dhs_ext ? launch_lstm_bwd_w8<true>(a, s) : launch_lstm_bwd_w8<false>(a, s);
+    }
+    if (a.seq_layout != MVAE_TILE16Q || a.cell != MVAE_GRU) return MVAE_E_UNSUPPORTED;
     return a.dhs_ext ? launch_gru_bwd_w8<true>(a, s) : launch_gru_bwd_w8<false>(a, s);
 }
 // Entry points used by rnn_resident.hip's dispatch.  MVAE_E_UNSUPPORTED: not a shape of this file.

@@ -270,6 +270,14 @@ def test_rnn_backward_resident_kernels_short_and_odd_lengths(cellname, cell, T):
         _rnn_backward_case(cellname, cell, hl.BF16, dict(DTYPES)[hl.BF16], 256, 32, ext, T=T)
 
 
+@pytest.mark.parametrize("T,ext", [(1, True), (2, False), (7, True), (8, False)])
+def test_lstm_backward_two_waves_per_simd_experiment_keeps_parity(T, ext, monkeypatch):
+    """MVAE_LSTM_BWD_W8=1: the LSTM BPTT on 8 waves per workgroup with a quarter of U^T streamed from L2 (rnn_w8.hip) - slower than
+    the 4-wave kernel (in-order vmcnt) and off by default, but the same function of the same data"""
+    monkeypatch.setenv("MVAE_LSTM_BWD_W8", "1")
+    _rnn_backward_case("LSTM", hl.LSTM, hl.BF16, dict(DTYPES)[hl.BF16], 256, 32, ext, T=T)
+
+
 def _rnn_backward_case(cellname, cell, dtype, tol, H, B, ext, T):
     rng, G, U, W, b, h0, c0 = _rnn_problem(cellname, H, T, B, seed=11 + H)
     GH = G * H
