@@ -83,7 +83,9 @@ def host_onehot_to_index(a, what="input"):
                                                 C.byref(bad))
     if rc == hl.E_FORMAT:
         raise NotImplementedError("%s must be one-hot rows of width <= 255 (reference layout, import_midi.py:255-262): row %d of "
-                                  "window %d is not; dense / multi-hot rows need the dense input projection, which is not built"
+                                  "window %d is not; dense / multi-hot rows need the dense input projection, which is not built.  (A DECODED song - "
+                                  "process_decoder_outputs: no silent column, all-zero rows where the model chose silence - becomes windows "
+                                  "again through import_midi.windows_from_unrolled_rolls, as in the reference.)"
                                   % (what, bad.value % T, bad.value // T))
     hl.check(rc, "mvae_host_onehot_to_index_tm")
     return np.ascontiguousarray(out[:, :n].T)

@@ -42,3 +42,90 @@ def test_midi_parsing_is_refused_not_faked(monkeypatch):
     monkeypatch.setattr(settings, "load_from_pickle_instead_of_midi", False)
     with pytest.raises(NotImplementedError):
         import_midi.import_midi_from_folder("data/original/")
+
+
+def _loop_windows(Y, V, D, s):
+    """the reference's statements of import_midi.py:256-265, :296-345, one after the other, on one song (test-side restatement)"""
+    Y = np.array(Y, dtype=float)
+    if s["include_silent_note"]:
+        Y = np.append(Y, np.zeros((Y.shape[0], 1)), axis=1)
+        for step in range(Y.shape[0]):
+            if np.sum(Y[step]) == 0:
+                Y[step, -1] = 1
+    X = Y[::s["max_voices"], :] if s["song_completion"] else Y
+    V, D = np.array(V, dtype=float), np.array(D, dtype=float)
+    if s["input_length"] > 0:
+        pad = s["input_length"] - (X.shape[0] % s["input_length"])
+        if pad == s["input_length"]:
+            pad = 0
+        X = np.pad(X, ((0, pad), (0, 0)), "constant", constant_values=(0, 0))
+        if s["include_silent_note"]:
+            X[-pad:, -1] = 1
+        X = np.asarray(np.split(X, X.shape[0] // s["input_length"]))
+    if s["output_length"] > 0:
+        pad = s["output_length"] - (Y.shape[0] % s["output_length"])
+        if pad == s["output_length"]:
+            pad = 0
+        Y = np.pad(Y, ((0, pad), (0, 0)), "constant", constant_values=(0, 0))
+        if s["include_silent_note"]:
+            Y[-pad:, -1] = 1
+        Y = np.asarray(np.split(Y, Y.shape[0] // s["output_length"]))
+        V = np.asarray(np.split(np.pad(V, (0, pad), "constant", constant_values=0), (V.shape[0] + pad) // s["output_length"]))
+        D = np.asarray(np.split(np.pad(D, (0, pad), "constant", constant_values=0), (D.shape[0] + pad) // s["output_length"]))
+    return X, Y, V, D
+
+
+def _unrolled_song(rng, steps, width=60):
+    Y = np.zeros((steps, width))
+    sounding = rng.random(steps) < 0.7
+    Y[np.nonzero(sounding)[0], rng.integers(0, width, int(sounding.sum()))] = 1
+    return Y, rng.random(steps) * sounding, (rng.random(steps) < 0.3).astype(float)
+
+
+@pytest.mark.parametrize("steps", [1, 37, 63, 65, 200])
+@pytest.mark.parametrize("completion", [False, True])
+def test_windows_from_unrolled_rolls_equal_the_references_statements(steps, completion):
+    s = dict(include_silent_note=True, max_voices=4, song_completion=completion, input_length=16 if completion else 64,
+             output_length=64, high_crop=84, low_crop=24)
+    Y, V, D = _unrolled_song(np.random.default_rng(steps), steps)
+    want = _loop_windows(Y, V, D, s)
+    for a, b in zip(import_midi.windows_from_unrolled_rolls(Y, V, D, s, as_written=True), want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    got = import_midi.windows_from_unrolled_rolls(Y, V, D, s)
+    whole = [((steps + 3) // 4 if completion else steps) % s["input_length"] == 0, steps % 64 == 0, False, False]   # (the next test)
+    for a, b, w in zip(got, want, whole):
+        assert a.shape == b.shape and (w or np.array_equal(a, b))
+    assert np.all(got[0].sum(-1) == 1) and np.all(got[1].sum(-1) == 1)          # one-hot rows: what the engine's staging takes
+    assert got[0].shape[-1] == 61 and got[1].shape[1:] == (64, 61) and got[2].shape == got[1].shape[:2] == got[3].shape
+
+
+def test_a_song_of_whole_windows_gets_every_silent_bit_in_the_reference_and_not_here_by_default():
+    """``X[-padding_length:, -1] = 1`` with padding_length 0 is ``X[0:, -1] = 1`` (reference import_midi.py:313-314, 327-328)"""
+    s = dict(include_silent_note=True, max_voices=4, song_completion=False, input_length=64, output_length=64, high_crop=84, low_crop=24)
+    Y, V, D = _unrolled_song(np.random.default_rng(1), 128)
+    want = _loop_windows(Y, V, D, s)
+    assert np.all(want[0][..., -1] == 1) and np.any(want[0].sum(-1) == 2)       # the quirk: two-hot rows
+    got = import_midi.windows_from_unrolled_rolls(Y, V, D, s, as_written=True)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    sane = import_midi.windows_from_unrolled_rolls(Y, V, D, s)
+    assert np.all(sane[0].sum(-1) == 1) and np.array_equal(sane[0][..., :60].reshape(-1, 60), Y)
+    assert np.array_equal(sane[2], want[2]) and np.array_equal(sane[3], want[3])
+
+
+def test_a_decoded_song_goes_back_into_windows_the_staging_accepts():
+    """process_decoder_outputs leaves silent steps as all-zero rows without the silent column (vae_definition.py:1084-1093): fed to the
+    one-hot validator as they are they are refused with a pointer to the way back; through the windowing they are valid input"""
+    from midi_vae_amd import packers, staging
+    from midi_vae_amd.config import build_settings
+    s = build_settings(input_length=4, output_length=4)                           # (x max_voices = 16 rows per window)
+    rng = np.random.default_rng(2)
+    P = rng.random((3, s["output_length"], s["output_dim"]))
+    P[:, ::3, -1] = 5.0                                                           # every third step: silence wins
+    song = packers.sample_notes_prediction(s, P, "argmax")
+    assert song.shape == (3 * s["output_length"], 60) and np.any(song.sum(1) == 0)
+    with pytest.raises(NotImplementedError, match="windows_from_unrolled_rolls"):
+        staging.host_onehot_to_index(song.reshape(3, s["output_length"], 60))
+    X, Y, V, D = import_midi.windows_from_unrolled_rolls(song, np.zeros(len(song)), np.zeros(len(song)), s)
+    idx = staging.host_onehot_to_index(X)
+    assert idx.shape == (3, s["input_length"]) and np.array_equal(idx, packers.note_indices(s, P, "argmax").reshape(3, -1))
