@@ -10,7 +10,7 @@ make -s -C $SRC
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DMVAE_VARIANT_BUILD $flags -c $SRC/rnn_resident.hip -o $OUT/rr_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$name.so $SRC/rnn.o $OUT/rr_$name.o $SRC/gemm.o $SRC/heads.o $SRC/misc.o $SRC/latent.o $SRC/hostpack.o $SRC/plan.o -pthread &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$name.so $SRC/rnn.o $OUT/rr_$name.o $SRC/rnn_w8.o $SRC/gemm.o $SRC/heads.o $SRC/misc.o $SRC/latent.o $SRC/hostpack.o $SRC/plan.o -pthread &&
     echo built $name ) &
 done
 wait
