@@ -187,6 +187,9 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         #  <= 10: a workgroup owns two tiles and streams the second one after the BPTT: 6.13.  LSTM: 16 / 24 / 32 all 6.53, <= 12: 7.27)
         self.kstream_wgs = 16 if spec.cell == "GRU" else 32
         self.kstream_max_B = 256
+        # k rows per workgroup and chunk of a K-streaming GEMM (0: the round-2 rule, kstream_wgs workgroups per GEMM whatever its tile
+        # count).  Round 6, same box: GRU 4.84 -> 4.69 ms per step, LSTM 6.29 -> 6.28; 1024 rows: GRU 4.94 (profiles/r06_k_kstream_rows.txt)
+        self.kstream_rows = 2048
         self.dec_kstream = True           # the decoder notes stack's too (engine_phases._notes_backward_multi, _dec_kstream_ok)
         self.hold_side_heads, self._hold_side = True, False
         self.kstream_singles = True      # (settled r02: LSTM 7.60 -> 7.50 ms, GRU 6.55 -> 6.38)    # ... and the dU GEMM of a full-length single-layer encoder branch
