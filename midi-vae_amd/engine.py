@@ -187,6 +187,7 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         #  <= 10: a workgroup owns two tiles and streams the second one after the BPTT: 6.13.  LSTM: 16 / 24 / 32 all 6.53, <= 12: 7.27)
         self.kstream_wgs = 16 if spec.cell == "GRU" else 32
         self.kstream_max_B = 256
+        self.flush_before_join = True     # (engine.backward: the encoder's collected GEMMs in front of the gradient queues' joins)
         # k rows per workgroup and chunk of a K-streaming GEMM (0: the round-2 rule, kstream_wgs workgroups per GEMM whatever its tile
         # count).  Round 6, same box: GRU 4.84 -> 4.69 ms per step, LSTM 6.29 -> 6.28; 1024 rows: GRU 4.94 (profiles/r06_k_kstream_rows.txt)
         self.kstream_rows = 2048
@@ -1233,7 +1234,8 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
                 self._host_call("early", lambda: hook.early(self.grads[self.layout.dec_begin:self.layout.total]))
         # ---- encoder recurrences: the notes stack and the meta rolls, independent branches ---------------------------
         self._cur_B, self._n_side = B, len(self.enc_meta)
-        if not (enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads)):      # (one launch: engine_phases.py)
+        enc_one_launch = bool(enc_multi and self._encoder_backward_multi(B, dcat, ldc, latent_grads))      # (one launch: engine_phases.py)
+        if not enc_one_launch:
             assert not latent_grads
             if self.grad_portions:
                 self._grad_portion_jobs, self._single_slot, self._single_slot_end = [], 3, 5      # (encoder: 14..15 - disjoint: the counters are cumulative per slot)
@@ -1266,9 +1268,17 @@ class Engine(Buffers, ArrayStaging, OptionalGraph, PhaseLaunches, PlannedSteps, 
         # in this join is one more cross-queue hop (40-60 us each, in series) in front of the optimizer.
         tail = self._tail_streams if enc_multi else [st for _, st, _ in self.enc_meta]
         self._tail_streams = []
+        # Round 6: a step that collects its weight-gradient GEMMs (defer_grads_rows) and ran every encoder recurrence as ONE launch on
+        # this queue has everything its collected GEMMs read right here - they go out BEFORE the joins, beside what the gradient
+        # queues still have to do (the decoder side's early launch and its small reductions), instead of behind two cross-queue hops
+        # (reference shape: the critical queue sat 0.16 ms in those waits with 0.09 ms of its own work still to come).
+        flush_first = self.flush_before_join and enc_one_launch and self._deferred_gemms is not None
+        if flush_first:
+            self._flush_deferred_gemms()
         self._join(*tail, self.s_grad, word=1)
         self._join(self.s_grad2, word=2)
-        self._flush_deferred_gemms()
+        if not flush_first:
+            self._flush_deferred_gemms()
 
     def _defers_grads(self, B):
         """does a step of B (padded) windows collect its weight-gradient GEMMs for one launch behind the last recurrence?"""

@@ -32,7 +32,7 @@ class PlannedSteps(object):
     # schedule knobs a caller (a test, an A/B script) may change on a LIVE engine: part of the plan key, so that a change selects
     # other plans instead of replaying the launch list recorded under the old value
     _PLAN_CONFIG = ("head_slices", "grad_portions", "index_dense",
-                    "index_dense_blocks", "xpand_blocks", "pipe_chunk", "phase_max_B", "kstream_grads", "kstream_wgs", "kstream_rows", "kstream_max_B", "dec_kstream", "hold_side_heads",
+                    "index_dense_blocks", "xpand_blocks", "pipe_chunk", "phase_max_B", "kstream_grads", "kstream_wgs", "kstream_rows", "kstream_max_B", "flush_before_join", "dec_kstream", "hold_side_heads",
                     "kstream_singles", "pipe_gemm_blocks", "pipe_proj_blocks", "time_chunks", "fuse_head_bwd", "fuse_bias_grad",
                     "fused_latent", "gate_side_heads", "_hold_dec_grads", "_diag_no_param_grads", "use_plans", "defer_grads_rows", "defer_early", "defer_early_rows", "defer_split_wgs", "gate_pipe_gemms", "pace_mask", "pace_mask_split", "_pace_mask_now", "pace_early")
     # ... and the spec's floats that reach kernel arguments as immediates of the recorded launches
