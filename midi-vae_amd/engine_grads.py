@@ -12,6 +12,24 @@ from . import ops
 from .slots import X_EXT, X_GATHER2
 
 
+
+def kstream_parts(tiles, chunk_rows, kstream_rows, kstream_wgs):
+    """K partitions (a power of two) of one chunk of a K-streaming weight-gradient GEMM with ``tiles`` 128 x 128 output tiles; its launch
+    gets tiles * partitions workgroups, each a whole number of 64-row k tiles per chunk.
+    ``kstream_rows`` > 0 (round 6): every workgroup of the launch gets about that many k rows per chunk, whatever its GEMM's tile count
+    - never more than 1.5 x ``kstream_wgs`` workgroups for one GEMM (the launch's workgroups all wait resident).  With ``kstream_wgs``
+    workgroups per GEMM (the round-2 rule, ``kstream_rows`` = 0) the 12-tile dW of a dense GRU layer ran one tile and a whole chunk per
+    workgroup (4 of 16 idle) beside 4-tile GEMMs split four ways: that problem paced the launch, which ended 0.23 ms behind the encoder
+    BPTT once the two-waves-per-SIMD kernels had made the BPTT faster."""
+    P = 1
+    if kstream_rows:
+        while (chunk_rows // (P * 2) >= kstream_rows and chunk_rows % (P * 2 * 64) == 0 and tiles * P * 2 <= kstream_wgs * 3 // 2):
+            P *= 2
+        return P
+    while P * 2 * tiles <= kstream_wgs and chunk_rows % (P * 2 * 64) == 0:
+        P *= 2
+    return P
+
 class _NullCtx(object):
     def __enter__(self):
         return self
@@ -240,21 +258,7 @@ class ParamGradients(object):
         kw = dict(k_wait=ks["counters"], k_wait_value=ks["target"], k_chunk_rows=ks["rows"], k_reverse=True, chunk_status=ks["status"],
                   trans_a=True, accumulate=True, build_only=True)
         def parts(M, N):        # K partitions per chunk, whole 64-row k tiles each
-            tiles = -(-M // 128) * -(-N // 128)
-            P = 1
-            if self.kstream_rows:
-                # Round 6: every workgroup of the launch gets the SAME number of k rows per chunk (kstream_rows), whatever its
-                # GEMM's tile count.  With kstream_wgs workgroups per GEMM the 12-tile dW of a dense GRU layer ran one tile and a
-                # whole chunk per workgroup (4 of 16 idle) beside 4-tile GEMMs split four ways: that problem paced the launch, which
-                # ended 0.23 ms behind the encoder BPTT once the two-waves-per-SIMD kernels had made the BPTT faster.
-                # (never more than 1.5 x kstream_wgs workgroups for one GEMM: the launch's workgroups all wait resident)
-                while (ks["rows"] // (P * 2) >= self.kstream_rows and ks["rows"] % (P * 2 * 64) == 0 and
-                       tiles * P * 2 <= self.kstream_wgs * 3 // 2):
-                    P *= 2
-                return P
-            while P * 2 * tiles <= self.kstream_wgs and ks["rows"] % (P * 2 * 64) == 0:
-                P *= 2
-            return P
+            return kstream_parts(-(-M // 128) * -(-N // 128), ks["rows"], self.kstream_rows, self.kstream_wgs)
         gb = G[p + ".b"]
         out = []
         if s.cell == "GRU":
