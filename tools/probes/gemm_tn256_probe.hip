@@ -4,6 +4,9 @@
 // the swizzle on the SOURCE address), ds_read_b64_tr_b16 fragments, one barrier per K tile, split-K with f32 atomics.
 //   hipcc --offload-arch=gfx950 -O3 -o gemm_tn256_probe gemm_tn256_probe.hip && ./gemm_tn256_probe [M N K splits]
 #include <hip/hip_runtime.h>
+#ifndef PIPE_FRAGS
+#define PIPE_FRAGS 0
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -81,6 +84,38 @@ __global__ __launch_bounds__(512) void gemm_tn256_k(const bf16_t* __restrict__ A
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
+#if PIPE_FRAGS
+    // register double buffering at k-group granularity: the fragments of k-group g+1 are requested before the MFMAs of k-group g,
+    // across the K-tile boundary too (the next tile's image is complete behind the barrier at the end of the iteration)
+    u16x8 fa[2][8], fb[2][4];
+    auto load = [&](int set, const unsigned char* Ai, const unsigned char* Bi, int kg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = frag(Bi, wn * 64 + j * 16, kg, q, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[set][i] = frag(Ai, wm * 128 + i * 16, kg, q, r);
+    };
+    auto mma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma(fb[set][j], fa[set][i], acc[i][j]);
+    };
+    load(0, smem, smem + IMG, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage(cur ^ 1, hot ? kbeg : kbeg + (t + 1) * BK);
+        const unsigned char* Ai = smem + cur * (2 * IMG);
+        const unsigned char* Bi = Ai + IMG;
+        load(1, Ai, Bi, 1);
+        mma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // the next tile's image is complete (and nobody reads k-group 0 of this one any more)
+        cur ^= 1;
+        if (t + 1 < ntiles) load(0, smem + cur * (2 * IMG), smem + cur * (2 * IMG) + IMG, 0);
+        mma(1);
+        // (k-group 1 of the old image was read before the barrier: the NEXT iteration's stage() may overwrite it - but only after
+        //  every wave has passed this point's ... the barrier above already separates those reads from the next stage())
+    }
+#else
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage(cur ^ 1, hot ? kbeg : kbeg + (t + 1) * BK);     // hot: every tile re-reads the first one (L2 hits)
         const unsigned char* Ai = smem + cur * (2 * IMG);
@@ -101,6 +136,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_k(const bf16_t* __restrict__ A
         __syncthreads();
         cur ^= 1;
     }
+#endif
     // lane holds C[m = .. + r][n = .. + q*4 + 0..3]
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
