@@ -7,6 +7,18 @@
 #ifndef PIPE_FRAGS
 #define PIPE_FRAGS 0
 #endif
+#ifndef STAGGER
+#define STAGGER 0
+#endif
+#ifndef NO_RD
+#define NO_RD 0
+#endif
+#ifndef NO_MM
+#define NO_MM 0
+#endif
+#ifndef FAST_ADDR
+#define FAST_ADDR 1
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -39,6 +51,23 @@ __device__ __forceinline__ u16x8 frag(const unsigned char* img, int rbase, int k
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
     return u16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
 }
+
+// The same read from a PRECOMPUTED per-lane offset: kr & 3 and (kr >> 3) & 1 - the swizzle's inputs - do not depend on the k-group or on
+// the half (kr = kg*32 + q*8 + h*4 + (r >> 2)), so the offset of fragment g is (lane part ^ (g << 5)) + kg*16384 + h*2048: one register
+// per fragment row block, computed once per launch (frag() above costs ~20 VALU instructions per call: 1000 per K tile and wave)
+__device__ __forceinline__ unsigned lane_off(int q, int r) {
+    const int kr = q * 8 + (r >> 2);
+    return (unsigned)(kr * 512 + (sw(kr) << 5) + (r & 3) * 8);
+}
+__device__ __forceinline__ u16x8 frag_at(const unsigned char* img, unsigned off, int kg) {
+    const unsigned char* p0 = img + off + kg * 16384;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 2048));
+    return u16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+}
+
+// (__syncthreads() drains vmcnt(0) - every global_load_lds in flight; the staggered loop's barriers order LDS reads only)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool ATOMIC>
 __global__ __launch_bounds__(512) void gemm_tn256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
@@ -80,19 +109,63 @@ __global__ __launch_bounds__(512) void gemm_tn256_k(const bf16_t* __restrict__ A
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    unsigned offA[8], offB[4];
+    {
+        const unsigned lo = lane_off(q, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) offA[i] = lo ^ (unsigned)((wm * 8 + i) << 5);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) offB[j] = lo ^ (unsigned)((wn * 4 + j) << 5);
+    }
     stage(0, kbeg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-#if PIPE_FRAGS
+#if STAGGER
+    // The two waves of a SIMD (w and w + 4: wave groups G0 = rows 0..127, G1 = rows 128..255 of the tile) run ONE barrier interval apart
+    // - the same code, G1 behind one extra barrier at the start (G0 one at the end): while one group reads its fragments from LDS the
+    // other issues its 32 MFMAs.  Intervals of K tile t:   G0:  R(t,0) | M | R(t,1) | M        G1:  - | R(t,0) | M | R(t,1) | M
+    // A wave waits for its share of the next image behind its R(t,1): G0's first read of tile t+1 comes two barriers later.
+    u16x8 fa[8], fb[4];
+    const bool g1 = w >= 4;
+    auto rd = [&](const unsigned char* Ai, const unsigned char* Bi, int kg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = FAST_ADDR ? frag_at(Bi, offB[j], kg) : frag(Bi, wn * 64 + j * 16, kg, q, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = FAST_ADDR ? frag_at(Ai, offA[i], kg) : frag(Ai, wm * 128 + i * 16, kg, q, r);
+    };
+    auto mm = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma(fb[j], fa[i], acc[i][j]);
+    };
+    if (g1) lds_barrier();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage(cur ^ 1, hot ? kbeg : kbeg + (t + 1) * BK);
+        const unsigned char* Ai = smem + cur * (2 * IMG);
+        const unsigned char* Bi = Ai + IMG;
+        if (!NO_RD || t == 0) rd(Ai, Bi, 0);
+        lds_barrier();
+        if (!NO_MM) mm();
+        lds_barrier();
+        if (!NO_RD) rd(Ai, Bi, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (!NO_MM || t == ntiles - 1) mm();
+        lds_barrier();
+        cur ^= 1;
+    }
+    if (!g1) lds_barrier();
+#elif PIPE_FRAGS
     // register double buffering at k-group granularity: the fragments of k-group g+1 are requested before the MFMAs of k-group g,
     // across the K-tile boundary too (the next tile's image is complete behind the barrier at the end of the iteration)
     u16x8 fa[2][8], fb[2][4];
     auto load = [&](int set, const unsigned char* Ai, const unsigned char* Bi, int kg) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[set][j] = frag(Bi, wn * 64 + j * 16, kg, q, r);
+        for (int j = 0; j < 4; ++j) fb[set][j] = FAST_ADDR ? frag_at(Bi, offB[j], kg) : frag(Bi, wn * 64 + j * 16, kg, q, r);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[set][i] = frag(Ai, wm * 128 + i * 16, kg, q, r);
+        for (int i = 0; i < 8; ++i) fa[set][i] = FAST_ADDR ? frag_at(Ai, offA[i], kg) : frag(Ai, wm * 128 + i * 16, kg, q, r);
     };
     auto mma = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
@@ -124,9 +197,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_k(const bf16_t* __restrict__ A
         for (int kg = 0; kg < 2; ++kg) {
             u16x8 fa[8], fb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag(Bi, wn * 64 + j * 16, kg, q, r);
+            for (int j = 0; j < 4; ++j) fb[j] = FAST_ADDR ? frag_at(Bi, offB[j], kg) : frag(Bi, wn * 64 + j * 16, kg, q, r);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = frag(Ai, wm * 128 + i * 16, kg, q, r);
+            for (int i = 0; i < 8; ++i) fa[i] = FAST_ADDR ? frag_at(Ai, offA[i], kg) : frag(Ai, wm * 128 + i * 16, kg, q, r);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
