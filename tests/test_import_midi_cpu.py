@@ -45,34 +45,34 @@ def test_midi_parsing_is_refused_not_faked(monkeypatch):
 
 
 def _loop_windows(Y, V, D, s):
-    """the reference's statements of import_midi.py:256-265, :296-345, one after the other, on one song (test-side restatement)"""
-    Y = np.array(Y, dtype=float)
-    if s["include_silent_note"]:
-        Y = np.append(Y, np.zeros((Y.shape[0], 1)), axis=1)
-        for step in range(Y.shape[0]):
-            if np.sum(Y[step]) == 0:
-                Y[step, -1] = 1
-    X = Y[::s["max_voices"], :] if s["song_completion"] else Y
-    V, D = np.array(V, dtype=float), np.array(D, dtype=float)
-    if s["input_length"] > 0:
-        pad = s["input_length"] - (X.shape[0] % s["input_length"])
-        if pad == s["input_length"]:
-            pad = 0
-        X = np.pad(X, ((0, pad), (0, 0)), "constant", constant_values=(0, 0))
+    """what the reference's load_rolls produces for one song (import_midi.py:256-265, :296-345), row by row in plain Python: a silent
+    column that is set where a row is empty; X = every max_voices-th row under song_completion; rows appended up to whole windows,
+    each a silent note with velocity 0 and not held - and, as written there, the silent bit of EVERY row when no row had to be
+    appended (the slice [-0:] is the whole array)"""
+    def windows(rows, length, make_pad, quirk):
+        rows = [list(r) if hasattr(r, "__len__") else r for r in rows]
+        missing = (-len(rows)) % length
+        if missing == 0 and quirk:
+            for r in rows:
+                r[-1] = 1.0
+        rows = rows + [make_pad() for _ in range(missing)]
+        return np.array([rows[i:i + length] for i in range(0, len(rows), length)], dtype=float)
+
+    width = len(Y[0])
+    notes = []
+    for row in np.asarray(Y, dtype=float):
+        row = list(row)
         if s["include_silent_note"]:
-            X[-pad:, -1] = 1
-        X = np.asarray(np.split(X, X.shape[0] // s["input_length"]))
-    if s["output_length"] > 0:
-        pad = s["output_length"] - (Y.shape[0] % s["output_length"])
-        if pad == s["output_length"]:
-            pad = 0
-        Y = np.pad(Y, ((0, pad), (0, 0)), "constant", constant_values=(0, 0))
-        if s["include_silent_note"]:
-            Y[-pad:, -1] = 1
-        Y = np.asarray(np.split(Y, Y.shape[0] // s["output_length"]))
-        V = np.asarray(np.split(np.pad(V, (0, pad), "constant", constant_values=0), (V.shape[0] + pad) // s["output_length"]))
-        D = np.asarray(np.split(np.pad(D, (0, pad), "constant", constant_values=0), (D.shape[0] + pad) // s["output_length"]))
-    return X, Y, V, D
+            row.append(0.0 if sum(row) else 1.0)
+        notes.append(row)
+    full = width + (1 if s["include_silent_note"] else 0)
+    silent_row = lambda: [0.0] * (full - 1) + [1.0] if s["include_silent_note"] else [0.0] * full
+    inputs = notes[::s["max_voices"]] if s["song_completion"] else notes
+    X = windows(inputs, s["input_length"], silent_row, s["include_silent_note"])
+    Yw = windows(notes, s["output_length"], silent_row, s["include_silent_note"])
+    Vw = windows(list(np.asarray(V, dtype=float)), s["output_length"], lambda: 0.0, False)
+    Dw = windows(list(np.asarray(D, dtype=float)), s["output_length"], lambda: 0.0, False)
+    return X, Yw, Vw, Dw
 
 
 def _unrolled_song(rng, steps, width=60):
