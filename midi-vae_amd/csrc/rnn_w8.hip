@@ -1,16 +1,23 @@
-// Resident-weights recurrent kernels, TWO WAVES PER SIMD (round 6): H = 256, bf16 MFMA operands, gfx950.
+// Resident-weights recurrent kernels, TWO WAVES PER SIMD (round 6): H = 256, bf16 MFMA operands, gfx950.  DESIGN.md section 3.5.
 //
-// Same contract, layouts and numerics as the slot-interleaved kernels of rnn_resident.hip (seq_layout MVAE_TILE16P);
-// different occupancy.  There one wave per SIMD owns 64 hidden units and 512 registers: whatever that wave cannot issue
-// under its own MFMAs (a 16x16x32 MFMA holds the matrix pipe 16 cycles, ~2 other instructions fit underneath) is dead
-// time, and every dependency stall - MFMA result -> gate arithmetic, ds_read -> MFMA, the barrier - stalls the SIMD
-// (round-5 counters: issue active 51 % of the cycles).  Here a workgroup is 8 waves of 256 registers: wave w owns the 32
-// hidden units [32w, 32w+32) for all gates, so two waves share each SIMD's matrix pipe and the hardware issues one wave's
-// gate arithmetic, LDS and memory instructions under the other's MFMAs.
+// Same contract and numerics as the slot-interleaved kernels of rnn_resident.hip; different occupancy.  There one wave per SIMD
+// owns 64 hidden units and 512 registers: whatever that wave cannot issue under its own MFMAs (a 16x16x32 MFMA holds the matrix
+// pipe 16 cycles, ~2 other instructions fit underneath) is dead time, and every dependency stall - MFMA result -> gate
+// arithmetic, ds_read -> MFMA, the barrier - stalls the SIMD (round-5 counters: issue active 51 % of the cycles).  Here a workgroup
+// is 8 waves of 256 registers (hipcc: 128 VGPRs + 128 AGPRs): two waves share each SIMD's matrix pipe and VALU port, and the
+// hardware issues one wave's gate arithmetic, LDS and memory instructions under the other's MFMAs (tools/probes/issue2_probe.hip).
 //
-// What the split costs: every wave needs ALL of h (and r*h) as MFMA B operand, so the workgroup reads its LDS tiles
-// twice as often (16 ds_read_b128 per wave and step), and a wave has 256 registers for 48 weight fragments (192
-// registers) plus its state: NLDS of the z / r fragments live in a private LDS slab (read back one per MFMA slot).
+// GRU (the product; seq_layout MVAE_TILE16Q, one-hot tables MVAE_TABLE_PAIRED8): U^T is 384 KiB = 48 fragments per wave, 32 of them
+// in AGPRs, 16 in a private LDS slab (every third MFMA slot), nothing streamed.  Wave w owns unit tiles a = w and b = 8 + w of
+// every gate - tiles a of all waves are k-groups 0..3 of h, tiles b k-groups 4..7 - so that a step is a software pipeline: the
+// tile-b half of step t-1 (tanh, h update, LDS write) runs under the first MFMAs of step t, and THREE half exchanges of h / r*h
+// (barriers 2b, 1, 2a) replace two full ones and hide behind the z gate's MFMAs.  Every request of sequence data is an un-tracked
+// asm load waited for by COUNT (vmcnt retires in issue order, loads and stores alike; hipcc's own bookkeeping gives up at loop
+// headers), with the three pitfalls of that noted where they bit: xload8 / pin* below, the epilogues, the unconditional requests.
+//
+// LSTM BPTT (lstm_bwd_w8_k, MVAE_LSTM_BWD_W8=1, NOT the product): U^T is 512 KiB = the whole register file; a quarter of it streams
+// from L2 every step and queues behind the HBM requests of the next step's saved activations: 3.9 vs 2.7 us per step
+// (profiles/r06_g_lstm_bptt_w8.txt).  Kept with its parity test because the finding is the kernel.
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
