@@ -117,6 +117,39 @@ def test_resident_pipelined_path_gradients_match_oracle(cell, B, T):
     assert _rel_l2(da[:8], da_o[:8]) < 8e-2, _rel_l2(da[:8], da_o[:8])
 
 
+def test_gru_one_wave_per_simd_kernels_stay_a_working_partner(monkeypatch):
+    """MVAE_GRU_W8=0: the engine on the slot-interleaved GRU kernels of rounds 1-5 (seq_layout TILE16P, 4 producer waves per workgroup)
+    - the A/B partner of the two-waves-per-SIMD kernels must keep passing what they pass: losses, every
+    parameter gradient and the top layer's d(pre-activation) sequence against the float64 oracle, on the same step the default
+    engine is checked on (and the default engine really is on the other layout)."""
+    from midi_vae_amd import hiplib as hl
+    B, T = 32, 128
+    spec, params, w, batch = _setup("GRU", B, T, 4, 64, 2, seed=100 + T)
+    e0 = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+    assert e0._seq_layout(e0.enc_notes[0]) == hl.TILE16Q and e0._rnn_waves(e0.enc_notes[0]) == 8
+    del e0
+    monkeypatch.setenv("MVAE_GRU_W8", "0")
+    orc = OracleVAE(make_cfg(**spec.oracle_cfg()))
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    m_o, cache = orc.forward(p64, batch, w["eps"].astype(np.float64))
+    g_o = orc.backward(p64, cache)
+    eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+    assert eng._seq_layout(eng.enc_notes[0]) == hl.TILE16P and eng._rnn_waves(eng.enc_notes[0]) == 4
+    assert eng._pipelined(eng.enc_notes) and eng._pipelined(eng.dec_notes)
+    eng.set_params(params)
+    _stage(eng, w, B)
+    eng.forward_backward(B)
+    eng.check_pipeline()
+    m, g = eng.metrics(B), eng.get_grads()
+    for k in m_o:
+        if not k.endswith("_acc"):
+            assert abs(m[k] - m_o[k]) <= 3e-2 * (1 + abs(m_o[k])), (k, m[k], m_o[k])
+    _check_grads(g, g_o, 6e-2)
+    top = eng.dec_notes[-1].prefix
+    da = eng._v(top + ".da", T, B, spec.GH).float().cpu().numpy()
+    assert _rel_l2(da, _oracle_top_da(orc, p64, cache, batch)) < 5e-2
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # (c): BASELINE configs[2] / [3] - 4-style, seq_len 256 x 8 voices (T=2048), z=128, 512 windows per GPU
 # ----------------------------------------------------------------------------------------------------------------------
