@@ -556,6 +556,40 @@ def test_batches_on_both_sides_of_the_kstream_gate_on_one_engine(cell):
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_kstream_partition_rules_accumulate_the_same_gradients_at_full_batch(cell, monkeypatch):
+    """Round 6 (Engine.kstream_rows): at 256 windows a published chunk is 4096 k rows and every K-streaming GEMM splits it so that a
+    workgroup gets 2048 of them (the 12-tile dW of a dense GRU layer: 24 workgroups) instead of kstream_wgs workgroups per GEMM.  The
+    partition only changes who adds what to the f32 accumulators: the gradients of one forward_backward must equal - to accumulation
+    order - those of the round-2 rule and of the ordinary gradient GEMMs (K-streaming off), on the same engine inputs."""
+    from midi_vae_amd import ops
+    B, T = 256, 256                      # (T * B above Engine.defer_grads_rows: the gradient GEMMs run beside the recurrences)
+    spec, params, batch, raw = _problem(cell, B, seed=41, H=256, Z=64, T=T)
+    launches, real = [], ops.gemm_kstream_multi
+    monkeypatch.setattr(ops, "gemm_kstream_multi", lambda problems: (launches.append([max(1, g.split_k) for g in problems]), real(problems))[1])
+    grads, parts = {}, {}
+    for name, knobs in (("rows", dict(kstream_rows=2048)), ("wgs", dict(kstream_rows=0)), ("off", dict(kstream_grads=False))):
+        eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+        for k, v in knobs.items():
+            setattr(eng, k, v)
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        del launches[:]
+        eng.forward_backward(B)
+        eng.check_pipeline()
+        grads[name], parts[name] = eng.get_grads(), [list(p) for p in launches]
+        del eng
+    assert len(parts["rows"]) == 2 and len(parts["wgs"]) == 2 and parts["off"] == [], parts      # (decoder stack, encoder stack)
+    assert all(p == 2 for launch in parts["rows"] for p in launch), parts["rows"]                  # 4096-row chunks in halves
+    if cell == "GRU":
+        assert parts["wgs"] != parts["rows"], parts                                                # (the round-2 rule: 1, 2 and 4)
+    for other in ("wgs", "off"):
+        for k, g in grads["rows"].items():
+            n = np.linalg.norm(grads[other][k])
+            if n > 1e-9:
+                assert _rel_l2(g, grads[other][k]) < 2e-4, (other, k, _rel_l2(g, grads[other][k]))
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 def test_elbo_trajectory_fresh_epsilon_on_the_benched_schedule(cell):
     """north_star: 'ELBO within 1e-3 of reference after equal steps'.  The schedule bench.py times - H=256 bf16, resident
     slot-interleaved kernels, time-pipelined stacks, K-streaming gradient launch, fused latent chain - at its sequence length
