@@ -590,6 +590,41 @@ def test_kstream_partition_rules_accumulate_the_same_gradients_at_full_batch(cel
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_collected_gemms_in_front_of_the_joins_change_no_gradient(cell):
+    """Round 6 (Engine.flush_before_join): at short sequences the encoder's collected weight-gradient GEMMs go out BEFORE the critical
+    queue joins the gradient queues - they read only what the encoder's BPTT launch wrote on that queue.  Same gradients (to f32
+    accumulation order) and, over three optimizer steps, the same parameters as with the GEMMs behind the joins."""
+    B, T = 256, 64                       # the reference's shipped shape: T * B = 16384 rows, a step that collects its GEMMs
+    spec, params, batch, raw = _problem(cell, B, seed=43, H=256, Z=256 if cell == "GRU" else 64, T=T)
+    out = {}
+    for flag in (True, False):
+        eng = Engine(spec, max_batch=B, dtype="bf16", seed=0)
+        eng.flush_before_join = flag
+        assert eng._defers_grads(B)
+        eng.set_params(params)
+        _stage(eng, raw, B)
+        eng.forward_backward(B)
+        eng.check_pipeline()
+        g = eng.get_grads()
+        for _ in range(3):
+            eng.train_step(B)
+        eng.check_pipeline()
+        out[flag] = (g, eng.get_params(), eng.metrics(B)["loss"])
+        del eng
+    for k, g in out[True][0].items():
+        n = np.linalg.norm(out[False][0][k])
+        if n > 1e-9:
+            assert _rel_l2(g, out[False][0][k]) < 2e-4, (k, _rel_l2(g, out[False][0][k]))
+    # (f32 atomics make the accumulation order - and with Adam's m / sqrt(v) the update of an element whose gradient is rounding noise -
+    #  differ from run to run whatever the flag: the three steps' UPDATE is compared, not the parameters element by element)
+    for k, v in out[True][1].items():
+        upd_t, upd_f = v - params[k], out[False][1][k] - params[k]
+        if np.linalg.norm(upd_f) > 1e-9:
+            assert _rel_l2(upd_t, upd_f) < 5e-2, (k, _rel_l2(upd_t, upd_f))
+    assert abs(out[True][2] - out[False][2]) < 1e-3 * (1 + abs(out[False][2]))
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 def test_elbo_trajectory_fresh_epsilon_on_the_benched_schedule(cell):
     """north_star: 'ELBO within 1e-3 of reference after equal steps'.  The schedule bench.py times - H=256 bf16, resident
     slot-interleaved kernels, time-pipelined stacks, K-streaming gradient launch, fused latent chain - at its sequence length
