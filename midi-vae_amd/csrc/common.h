@@ -159,9 +159,11 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 template <int SLEEP = 8>        // (64: a throughput consumer that polls for most of its producer's run time)
 __device__ __forceinline__ void wave_wait_ge(const uint32_t* flag, uint32_t value, uint32_t* status, uint32_t code = 1u) {
-    // the spin bound scales with the pause between two looks, so that every waiter gives up after the SAME ~2-4 s whatever its
-    // SLEEP (the GEMMs' SLEEP = 32 used to wait four times as long as the recurrent kernels they follow)
-    constexpr unsigned LIMIT = 0x200000u * 8u / (SLEEP > 0 ? SLEEP : 1);
+    // One give-up time (~3 s) for every waiter whatever its SLEEP: a look costs its system-scope load (~1.2 us) PLUS the
+    // pause (SLEEP x 64 clocks), so the bound is 0x200000 x 53 / (45 + SLEEP) looks - 2.1 M at SLEEP 8, 1.4 M at 32, 1.0 M at 64.
+    // (Round 6 first scaled it by 8 / SLEEP as if the pause were all of a look: the K-streaming GEMMs' SLEEP = 64 waiter then gave
+    //  up after 0.8 s, and the live-producer test (tests/test_ops_gpu.py) lost a run now and then to a slow first enqueue on a fresh box.)
+    constexpr unsigned LIMIT = (unsigned)(0x200000ull * 53ull / (45ull + (unsigned long long)(SLEEP > 0 ? SLEEP : 1)));
     unsigned tmp, spins, val;
     asm volatile(
         "s_mov_b32 %1, 0\n"
